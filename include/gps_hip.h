@@ -1,0 +1,117 @@
+/*
+ * gps_hip.h -- C ABI of libgps_hip.so, the MI355X (gfx950) native ops of the GPS hot path.
+ *
+ * This is the drop-in boundary for the reference's native layer: the nine functions of the
+ * pybind module `pointnet2._ext`
+ *   /root/reference/modules/third_party/pointnet2/_ext_src/src/bindings.cpp:6-19
+ * which are thin ATen wrappers around the `*_kernel_wrapper` C prototypes this header mirrors
+ * (same argument order and meaning; one `stream` argument appended; `int` status returned
+ * instead of the reference's print-and-exit(-1) of include/cuda_utils.h:30-39).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into HBM on the current HIP device; tensors are dense,
+ *     row-major, fp32 / int32, exactly the layouts of the reference (include/utils.h:5-25);
+ *   - the caller owns and allocates inputs, outputs and scratch; nothing is allocated here;
+ *   - outputs are fully written by the call: no pre-zeroing is required (the reference's host
+ *     wrappers zero-fill because their kernels accumulate or skip; these kernels do not);
+ *   - `stream` is a hipStream_t (NULL = the default stream); calls are asynchronous;
+ *   - no torch types, no exceptions, re-entrant, no global state;
+ *   - return value: GPS_OK or a negative GPS_ERR_* (gps_error_string() explains it).
+ */
+#ifndef GPS_HIP_H_
+#define GPS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPS_HIP_ABI_VERSION 1
+
+#define GPS_OK 0
+#define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
+#define GPS_ERR_UNSUPPORTED (-2)      /* shape outside what the kernels implement (documented)    */
+#define GPS_ERR_LAUNCH (-3)           /* hipGetLastError() reported a launch failure             */
+
+typedef void *gps_stream_t; /* hipStream_t */
+
+#if defined(__GNUC__)
+#define GPS_API __attribute__((visibility("default")))
+#else
+#define GPS_API
+#endif
+
+GPS_API int gps_abi_version(void);
+GPS_API const char *gps_error_string(int status);
+/* Text of the last HIP runtime error seen by a GPS_ERR_LAUNCH on this thread ("" if none). */
+GPS_API const char *gps_last_hip_error(void);
+
+/* Furthest point sampling.  Replaces furthest_point_sampling_kernel_wrapper
+ * (src/sampling.cpp:11-13, kernel src/sampling_gpu.cu:69-173, dispatch :175-229).
+ *   dataset (b,n,3) f32  ->  idxs (b,m) i32.
+ * Semantics incl. the `mag <= 1e-3` skip and the block-size dependent tie-break of the
+ * reference's shared-memory tree are reproduced exactly (bit-exact indices).
+ * `temp` is the (b,n) f32 scratch of the reference prototype; it is only used when
+ * n > GPS_FPS_MAX_RESIDENT_N (running distances then live in HBM) and may be NULL otherwise.
+ * It needs no initialisation. */
+#define GPS_FPS_MAX_RESIDENT_N 2048
+GPS_API int gps_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int32_t *idxs, gps_stream_t stream);
+
+/* out[i,l,j] = points[i,l,idx[i,j]].  Replaces gather_points_kernel_wrapper
+ * (src/sampling.cpp:4-6, kernel src/sampling_gpu.cu:8-20).
+ *   points (b,c,n) f32, idx (b,npoints) i32 -> out (b,c,npoints) f32. */
+GPS_API int gps_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
+                      float *out, gps_stream_t stream);
+
+/* Scatter-add adjoint of gps_gather_points.  Replaces gather_points_grad_kernel_wrapper
+ * (src/sampling.cpp:7-9, kernel src/sampling_gpu.cu:34-47).
+ *   grad_out (b,c,npoints), idx (b,npoints) -> grad_points (b,c,n), overwritten (zeroed here). */
+GPS_API int gps_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int32_t *idx, float *grad_points, gps_stream_t stream);
+
+/* Ball query: per centre the first `nsample` points (ascending index) with d2 < radius^2,
+ * remaining slots padded with the first hit, rows without a hit all 0.  Replaces
+ * query_ball_point_kernel_wrapper (src/ball_query.cpp:4-6, kernel src/ball_query_gpu.cu:9-44).
+ *   new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample) i32.  Bit-exact indices. */
+GPS_API int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int32_t *idx, gps_stream_t stream);
+
+/* out[i,l,j,k] = points[i,l,idx[i,j,k]].  Replaces group_points_kernel_wrapper
+ * (src/group_points.cpp:4-6, kernel src/group_points_gpu.cu:8-28).
+ *   points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample). */
+GPS_API int gps_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int32_t *idx, float *out, gps_stream_t stream);
+
+/* Scatter-add adjoint of gps_group_points.  Replaces group_points_grad_kernel_wrapper
+ * (src/group_points.cpp:8-10, kernel src/group_points_gpu.cu:43-64).
+ *   grad_out (b,c,npoints,nsample), idx -> grad_points (b,c,n), overwritten.
+ * Deterministic: each target sums its contributions in ascending (j,k) order (the reference's
+ * atomicAdd order is undefined). */
+GPS_API int gps_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                          const int32_t *idx, float *grad_points, gps_stream_t stream);
+
+/* Three nearest neighbours (squared distances).  Replaces three_nn_kernel_wrapper
+ * (src/interpolate.cpp:4-5, kernel src/interpolate_gpu.cu:9-59).
+ *   unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32, idx (b,n,3) i32. */
+GPS_API int gps_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int32_t *idx, gps_stream_t stream);
+
+/* out[i,l,j] = sum_t points[i,l,idx[i,j,t]] * weight[i,j,t], t = 0,1,2 in that order.
+ * Replaces three_interpolate_kernel_wrapper (src/interpolate.cpp:6-8, kernel
+ * src/interpolate_gpu.cu:72-101).  points (b,c,m), idx/weight (b,n,3) -> out (b,c,n). */
+GPS_API int gps_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                          const float *weight, float *out, gps_stream_t stream);
+
+/* Adjoint of gps_three_interpolate w.r.t. points.  Replaces three_interpolate_grad_kernel_wrapper
+ * (src/interpolate.cpp:9-12, kernel src/interpolate_gpu.cu:116-143).
+ *   grad_out (b,c,n), idx/weight (b,n,3) -> grad_points (b,c,m), overwritten (zeroed here). */
+GPS_API int gps_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int32_t *idx, const float *weight, float *grad_points,
+                               gps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPS_HIP_H_ */

@@ -1,0 +1,82 @@
+"""ctypes binding of libgps_hip.so (include/gps_hip.h).
+
+The product path has NO CPU fallback: if the shared library cannot be built/loaded, or an op is
+called on a non-GPU tensor, this module raises.  (oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "csrc", "libgps_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "gps_hip.h")
+
+GPS_OK = 0
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes, mirroring include/gps_hip.h one to one
+SIGNATURES = {
+    "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
+    "gps_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gps_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gps_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+}
+
+
+class GpsNativeError(RuntimeError):
+    pass
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/gps_hip.h declares (used by the symbol-export test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return re.findall(r"GPS_API\s+[\w\s\*]+?\b(gps_\w+)\s*\(", text)
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        from .csrc import build as _build
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(LIB_PATH):
+                raise GpsNativeError(f"libgps_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(LIB_PATH):
+        raise GpsNativeError(f"{LIB_PATH} not found; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.gps_abi_version.restype = _i
+    lib.gps_error_string.restype = ctypes.c_char_p
+    lib.gps_error_string.argtypes = [_i]
+    lib.gps_last_hip_error.restype = ctypes.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status == GPS_OK:
+        return
+    lib = load()
+    msg = lib.gps_error_string(status).decode()
+    hip = lib.gps_last_hip_error().decode()
+    raise GpsNativeError(f"{what}: {msg}" + (f" [{hip}]" if hip else ""))

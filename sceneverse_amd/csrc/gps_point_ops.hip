@@ -1,0 +1,874 @@
+// gps_point_ops.hip -- PointNet++ set-abstraction ops for MI355X (gfx950 / CDNA4).
+//
+// Hand-written for 64-wide wavefronts; exported through the C ABI of include/gps_hip.h.
+// Compile with -ffp-contract=off: every distance is evaluated as ((dx*dx + dy*dy) + dz*dz) with
+// each fp32 op individually rounded, the pinned arithmetic of DESIGN.md / SURVEY.md App. B.0, so
+// that indices agree bit for bit with oracle/pointnet2_oracle.c.
+//
+// Reference behaviour restated (not translated) from
+//   /root/reference/modules/third_party/pointnet2/_ext_src/src/{sampling,ball_query,group_points,
+//   interpolate}_gpu.cu   -- cited per kernel below.
+//
+// Design notes (why this is not the reference's launch shape):
+//   * FPS: one WAVE per object, the whole cloud + running distances resident in VGPRs, arg-max by
+//     DPP wave reduction + v_cmp ballots; zero LDS, zero barriers, `temp` never touches HBM.
+//     The reference's 512-thread LDS tree (9 __syncthreads per round) only survives as the
+//     tie-break ORDER, which is folded into the point->(lane,register) assignment.
+//   * ball query: lanes = 64 consecutive points, radius test -> 64-bit ballot -> mbcnt compaction,
+//     which emits hits in ascending index order exactly like the reference's serial scan.
+//   * group: LDS-staged source rows, 16-byte coalesced stores along (npoint*nsample).
+//   * group grad: deterministic CSR gather instead of atomicAdd.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "gps_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace gps {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;            // 4 waves per workgroup, one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// bit-reverse the low `bits` bits of x (bits == 0 -> 0)
+__host__ __device__ __forceinline__ int bitrev(int x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return bits ? (int)(__brev((unsigned)x) >> (32 - bits)) : 0;
+#else
+  int r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+  return r;
+#endif
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+  // lanes whose DPP source is out of range keep `old` (= v): harmless for an idempotent max
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+  return o > v ? o : v;
+}
+
+// Max over the 64 lanes of a wave of a signed int; result is wave-uniform (SGPR).
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = dpp_max_i32<0x111>(v);  // row_shr:1
+  v = dpp_max_i32<0x112>(v);  // row_shr:2
+  v = dpp_max_i32<0x114>(v);  // row_shr:4
+  v = dpp_max_i32<0x118>(v);  // row_shr:8   -> lane 15 of every row holds the row max
+  v = dpp_max_i32<0x142>(v);  // row_bcast:15 -> rows 1,3 fold in rows 0,2
+  v = dpp_max_i32<0x143>(v);  // row_bcast:31 -> rows 2,3 fold in rows 0,1; lane 63 = wave max
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// reference: src/sampling_gpu.cu:100-101 -- `if (mag <= 1e-3) continue;` compares the fp32
+// magnitude with a DOUBLE literal.
+__device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
+  const float mag = (x * x) + (y * y) + (z * z);
+  return (double)mag <= 1e-3;
+}
+
+// ------------------------------------------------------------------------------------------
+// Furthest point sampling, register-resident form (n <= 64 * 32).
+//
+// Reference: src/sampling_gpu.cu:69-173.  idx[0] = 0; every round updates temp[k] =
+// min(d(k, old), temp[k]) for the non-skipped points and picks the arg-max.  Ties are resolved by
+// the reference's launch shape (thread tid = k mod bs keeps its first maximum, then a pairwise
+// tree over strides bs/2..1 where the lower slot wins): among equal maxima the winner minimises
+//     key(k) = ( bitreverse_{log2 bs}(k mod bs), k div bs ),   bs = opt_n_threads(n).
+// Here the point stored in register r of lane L is chosen so that key order == (L, r)
+// lexicographic order:
+//     bs >= 64 (p = log2 bs >= 6):  k = bitrev6(L) + 64 * bitrev_{p-6}(r / Q) + bs * (r % Q)
+//     bs <  64:                     k = bitrev_p(L) + bs * r          (lanes >= bs idle)
+// with Q = ceil(n / bs).  The tie-break is then "lowest lane, then lowest register".
+//
+// Running distances are kept as raw fp32 bit patterns in int registers: every value is -1.0f
+// (skipped / padding slot, never selectable, never updated) or >= +0, and on that set signed
+// integer order == float order, so v_min_i32 / v_max3_i32 replace fminf/fmaxf without the
+// canonicalising v_max the IEEE mode otherwise forces.  Skipped slots get x = 1e30 so that their
+// distance overflows to +inf and min(inf, -1) keeps -1.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int fps_point_index(int L, int r, int p, int Q) {
+  if (p >= 6) {
+    const int w = r / Q, q = r - w * Q;
+    if (w >= (1 << (p - 6))) return -1;
+    return bitrev(L, 6) + 64 * bitrev(w, p - 6) + (q << p);
+  }
+  if (L >= (1 << p) || r >= Q) return -1;
+  return bitrev(L, p) + (r << p);
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void fps_resident_kernel(int b, int n, int m, int p, int Q,
+                                                               const float *__restrict__ dataset,
+                                                               int32_t *__restrict__ idxs) {
+  const int obj = blockIdx.x * kWavesPerBlock + wave_id();
+  if (obj >= b) return;  // whole wave exits together
+  const int L = lane_id();
+  const float *ds = dataset + (size_t)obj * n * 3;
+  int32_t *out = idxs + (size_t)obj * m;
+
+  float x[R], y[R], z[R];
+  int t[R];  // fp32 bit patterns, see above
+  constexpr int kNeg1 = (int)0xBF800000u;   // -1.0f
+  constexpr int kInit = (int)0x501502F9u;   // 1e10f, src/sampling.cpp:74-76
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    // branch-free: out-of-range slots read point 0 and are poisoned like skipped points
+    const int k = fps_point_index(L, r, p, Q);
+    const bool in = k >= 0 && k < n;
+    const int kk = in ? k : 0;
+    const float px = ds[kk * 3 + 0], py = ds[kk * 3 + 1], pz = ds[kk * 3 + 2];
+    const bool ok = in && !fps_skipped(px, py, pz);
+    x[r] = ok ? px : 1e30f;
+    y[r] = py;
+    z[r] = pz;
+    t[r] = ok ? kInit : kNeg1;
+  }
+
+  // first centre: point 0 with its TRUE coordinates (it may itself be a skipped point)
+  float x1 = ds[0], y1 = ds[1], z1 = ds[2];
+  x1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x1)));
+  y1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(y1)));
+  z1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z1)));
+
+  int mine = 0;  // lane (j & 63) buffers idx j; flushed every 64 rounds with one coalesced store
+  for (int j = 1; j < m; ++j) {
+    int lane_best = kNeg1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float dx = x[r] - x1, dy = y[r] - y1, dz = z[r] - z1;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const int di = __float_as_int(d);
+      t[r] = di < t[r] ? di : t[r];
+      lane_best = t[r] > lane_best ? t[r] : lane_best;
+    }
+    const int M = wave_max_i32(lane_best);
+    const unsigned long long cand = __ballot(lane_best == M);
+    const int Lw = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
+    // lowest register of lane Lw that holds M; fetch the next centre from that lane's registers
+    int rw = 0;
+    bool found = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!found) {
+        const int tr = __builtin_amdgcn_readlane(t[r], Lw);
+        if (tr == M) {
+          found = true;
+          rw = r;
+          x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[r]), Lw));
+          y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[r]), Lw));
+          z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[r]), Lw));
+        }
+      }
+    }
+    // M == -1 only when every point is skipped: then (Lw, rw) = (0, 0) -> index 0, as the
+    // reference's (best = -1, besti = 0) initial state yields.
+    const int old = fps_point_index(Lw, rw, p, Q);
+    if (L == (j & 63)) mine = old;
+    if ((j & 63) == 63) {
+      out[j - 63 + L] = mine;  // j-63 .. j, all < m
+      mine = 0;
+    }
+  }
+  const int base = (m - 1) & ~63;  // first index of the unflushed tail (covers idx[0] = 0 too)
+  if (((m - 1) & 63) != 63 && base + L < m) out[base + L] = mine;
+}
+
+// ------------------------------------------------------------------------------------------
+// Furthest point sampling, streaming form for n > 2048: one 512-thread workgroup per object,
+// running distances in HBM scratch `temp` (b,n).  Same semantics, same tie order: each thread
+// keeps the first strict maximum of its strided sequence (= lowest k div bs), threads are ranked
+// by bitreverse(tid).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void fps_streaming_kernel(int b, int n, int m,
+                                                             const float *__restrict__ dataset,
+                                                             float *__restrict__ temp,
+                                                             int32_t *__restrict__ idxs) {
+  constexpr int BS = 512, P = 9;
+  __shared__ unsigned long long red[BS / kWave];
+  __shared__ int winner_k[BS];
+  __shared__ int s_old;
+  const int obj = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float *ds = dataset + (size_t)obj * n * 3;
+  float *tp = temp + (size_t)obj * n;
+  int32_t *out = idxs + (size_t)obj * m;
+  for (int k = tid; k < n; k += BS) tp[k] = 1e10f;
+  if (tid == 0) out[0] = 0;
+  int old = 0;
+  // rank of this thread in the reference's tree: lower bitrev wins ties
+  const unsigned rank = (unsigned)bitrev(tid, P);
+  for (int j = 1; j < m; ++j) {
+    const float x1 = ds[old * 3 + 0], y1 = ds[old * 3 + 1], z1 = ds[old * 3 + 2];
+    int besti = 0;
+    float best = -1.f;
+    for (int k = tid; k < n; k += BS) {
+      const float x2 = ds[k * 3 + 0], y2 = ds[k * 3 + 1], z2 = ds[k * 3 + 2];
+      if (fps_skipped(x2, y2, z2)) continue;
+      const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const float d2 = d < tp[k] ? d : tp[k];
+      tp[k] = d2;
+      if (d2 > best) { best = d2; besti = k; }
+    }
+    winner_k[tid] = besti;
+    // sortable key: value (0 for the -1 sentinel, bits+1 otherwise) high, inverted rank low
+    const unsigned vb = best < 0.f ? 0u : (unsigned)__float_as_int(best) + 1u;
+    unsigned long long key = ((unsigned long long)vb << 32) | (unsigned long long)(0xFFFFFFFFu - rank);
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(key, off, kWave);
+      key = o > key ? o : key;
+    }
+    if (lane_id() == 0) red[wave_id()] = key;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long k2 = red[0];
+      for (int w = 1; w < BS / kWave; ++w) k2 = red[w] > k2 ? red[w] : k2;
+      const unsigned wr = 0xFFFFFFFFu - (unsigned)(k2 & 0xFFFFFFFFu);
+      const int wt = bitrev((int)wr, P);
+      s_old = winner_k[wt];
+      out[j] = s_old;
+    }
+    __syncthreads();
+    old = s_old;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// gather_points: out[i,l,j] = points[i,l,idx[i,j]]     (src/sampling_gpu.cu:8-20)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gather_points_kernel(int b, int c, int n, int m,
+                                                                const float *__restrict__ points,
+                                                                const int32_t *__restrict__ idx,
+                                                                float *__restrict__ out) {
+  const long long total = (long long)b * c * m;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (long long)gridDim.x * kBlock) {
+    const int j = (int)(e % m);
+    const long long il = e / m;  // i*c + l
+    const int i = (int)(il / c);
+    out[e] = points[il * n + idx[(long long)i * m + j]];
+  }
+}
+
+// gather_points_grad: scatter-add (src/sampling_gpu.cu:34-47).  Unordered fp32 atomics like the
+// reference; not on the GPS path (xyz carries no gradient).
+__global__ __launch_bounds__(kBlock) void gather_points_grad_kernel(
+    int b, int c, int n, int m, const float *__restrict__ grad_out,
+    const int32_t *__restrict__ idx, float *__restrict__ grad_points) {
+  const long long total = (long long)b * c * m;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (long long)gridDim.x * kBlock) {
+    const int j = (int)(e % m);
+    const long long il = e / m;
+    const int i = (int)(il / c);
+    atomicAdd(grad_points + il * n + idx[(long long)i * m + j], grad_out[e]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ball query (src/ball_query_gpu.cu:9-44).
+//
+// One workgroup per object, its 4 waves split the centres; lane L of a wave owns points
+// L, L+64, ... (R registers per coordinate when the cloud fits, else streamed from L1/L2).
+// Per (centre, 64-point chunk): d2 -> v_cmp_lt ballot -> mbcnt prefix -> hits written at
+// cnt + prefix into a per-wave LDS row; the row (+ first-hit padding, or zeros when no hit) is
+// stored with one coalesced write.  Chunks are visited in ascending order and a centre stops as
+// soon as nsample hits are found, so the output equals the reference's serial scan.
+// ------------------------------------------------------------------------------------------
+template <int R>  // R > 0: register-resident cloud of <= 64*R points; R == 0: streamed
+__global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m, float radius,
+                                                             int nsample,
+                                                             const float *__restrict__ new_xyz,
+                                                             const float *__restrict__ xyz,
+                                                             int32_t *__restrict__ idx) {
+  extern __shared__ int32_t bq_rows[];  // kWavesPerBlock rows of nsample ints
+  const int obj = blockIdx.x;
+  const int L = lane_id(), w = wave_id();
+  const float *p = xyz + (size_t)obj * n * 3;
+  const float *q = new_xyz + (size_t)obj * m * 3;
+  int32_t *o = idx + (size_t)obj * m * nsample;
+  int32_t *row = bq_rows + w * nsample;
+  const float radius2 = radius * radius;
+
+  constexpr int RR = R > 0 ? R : 1;
+  float px[RR], py[RR], pz[RR];
+  if (R > 0) {
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+      const int k = i * kWave + L;
+      const bool in = k < n;
+      px[i] = in ? p[k * 3 + 0] : 0.f;
+      py[i] = in ? p[k * 3 + 1] : 0.f;
+      pz[i] = in ? p[k * 3 + 2] : 0.f;
+    }
+  }
+  const int nchunks = (n + kWave - 1) / kWave;
+
+  for (int j = w; j < m; j += kWavesPerBlock) {
+    float cx = q[j * 3 + 0], cy = q[j * 3 + 1], cz = q[j * 3 + 2];
+    cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx)));
+    cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
+    cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cz)));
+    int cnt = 0, first = 0;
+    if (R > 0) {
+#pragma unroll
+      for (int i = 0; i < RR; ++i) {
+        if (cnt < nsample && i < nchunks) {  // wave-uniform
+          const int k = i * kWave + L;
+          const float dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
+          const bool hit = (k < n) && (d2 < radius2);
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi(
+                                      (unsigned)(mask >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (hit && pos < nsample) row[pos] = k;
+            if (cnt == 0) first = i * kWave + (__ffsll((long long)mask) - 1);
+            cnt += __popcll(mask);
+          }
+        }
+      }
+    } else {
+      for (int i = 0; i < nchunks && cnt < nsample; ++i) {
+        const int k = i * kWave + L;
+        const bool in = k < n;
+        const float x = in ? p[k * 3 + 0] : 0.f, y = in ? p[k * 3 + 1] : 0.f,
+                    z = in ? p[k * 3 + 2] : 0.f;
+        const float dx = cx - x, dy = cy - y, dz = cz - z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        const bool hit = in && (d2 < radius2);
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+          const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi(
+                                    (unsigned)(mask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (hit && pos < nsample) row[pos] = k;
+          if (cnt == 0) first = i * kWave + (__ffsll((long long)mask) - 1);
+          cnt += __popcll(mask);
+        }
+      }
+    }
+    if (cnt > nsample) cnt = nsample;
+    // same-wave LDS write -> read: the compiler's lgkmcnt wait orders them, no barrier needed
+    for (int s = L; s < nsample; s += kWave) o[j * nsample + s] = s < cnt ? row[s] : first;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// group_points: out[i,l,j,k] = points[i,l,idx[i,j,k]]     (src/group_points_gpu.cu:8-28)
+//
+// grid = (b, channel tiles).  A workgroup stages its [CT][n] slab of `points` in LDS with
+// coalesced loads, then streams the output: thread (tx, ty) owns 4 consecutive (j,k) positions
+// (one int4 of idx, loaded once) and walks the tile's channels, emitting one 16-byte store per
+// channel -- a wave writes 1 KiB contiguous per instruction.  The gather itself is an LDS read.
+// ------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void group_points_kernel(int b, int c, int n, int S, int CT,
+                                                               int tx_count,
+                                                               const float *__restrict__ points,
+                                                               const int32_t *__restrict__ idx,
+                                                               float *__restrict__ out) {
+  extern __shared__ float gp_tile[];  // CT * n floats
+  const int obj = blockIdx.x;
+  const int c0 = blockIdx.y * CT;
+  const int ct = (c - c0) < CT ? (c - c0) : CT;
+  const float *src = points + ((size_t)obj * c + c0) * n;
+  const int32_t *ix = idx + (size_t)obj * S;
+  float *dst = out + ((size_t)obj * c + c0) * S;
+
+  const int tile_elems = ct * n;
+  if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(points) & 15) == 0) {
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    float4 *t4 = reinterpret_cast<float4 *>(gp_tile);
+    for (int e = threadIdx.x; e < tile_elems / 4; e += kBlock) t4[e] = src4[e];
+  } else {
+    for (int e = threadIdx.x; e < tile_elems; e += kBlock) gp_tile[e] = src[e];
+  }
+  __syncthreads();
+
+  const int tx = threadIdx.x % tx_count, ty = threadIdx.x / tx_count;
+  const int ty_count = kBlock / tx_count;
+  if (VEC4) {
+    const int S4 = S >> 2;
+    const int4 *ix4 = reinterpret_cast<const int4 *>(ix);
+    for (int s4 = tx; s4 < S4; s4 += tx_count) {
+      const int4 id = ix4[s4];
+      for (int l = ty; l < ct; l += ty_count) {
+        const float *rowp = gp_tile + l * n;
+        float4 v;
+        v.x = rowp[id.x]; v.y = rowp[id.y]; v.z = rowp[id.z]; v.w = rowp[id.w];
+        reinterpret_cast<float4 *>(dst + (size_t)l * S)[s4] = v;
+      }
+    }
+  } else {
+    for (int s = tx; s < S; s += tx_count) {
+      const int id = ix[s];
+      for (int l = ty; l < ct; l += ty_count) dst[(size_t)l * S + s] = gp_tile[l * n + id];
+    }
+  }
+}
+
+// Fallback when one [1][n] row does not fit the LDS budget: plain cached gather.
+__global__ __launch_bounds__(kBlock) void group_points_direct_kernel(
+    int b, int c, int n, int S, const float *__restrict__ points, const int32_t *__restrict__ idx,
+    float *__restrict__ out) {
+  const long long total = (long long)b * c * S;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (long long)gridDim.x * kBlock) {
+    const int s = (int)(e % S);
+    const long long il = e / S;
+    const int i = (int)(il / c);
+    out[e] = points[il * n + idx[(long long)i * S + s]];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// group_points_grad (src/group_points_gpu.cu:43-64), deterministic.
+//
+// The reference scatter-adds with atomicAdd in an undefined order.  Here each workgroup
+// (object, channel tile) inverts idx into a CSR list per target point, STABLE in (j,k), then
+// thread (l, target) sums its list sequentially: ascending (j,k), the order
+// oracle_group_points_grad uses, hence bit-identical to it and run-to-run reproducible.
+//   LDS: idx[S] | list[S] | offset[n+1] | cursor[n] | grad tile [CT][S+1]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void group_points_grad_kernel(
+    int b, int c, int n, int S, int CT, const float *__restrict__ grad_out,
+    const int32_t *__restrict__ idx, float *__restrict__ grad_points) {
+  extern __shared__ int32_t gg_lds[];
+  int32_t *s_idx = gg_lds;              // S
+  int32_t *s_list = s_idx + S;          // S
+  int32_t *s_off = s_list + S;          // n + 1
+  int32_t *s_cur = s_off + n + 1;       // n
+  float *s_g = reinterpret_cast<float *>(s_cur + n);  // CT * (S + 1)
+  const int obj = blockIdx.x;
+  const int c0 = blockIdx.y * CT;
+  const int ct = (c - c0) < CT ? (c - c0) : CT;
+  const int tid = threadIdx.x;
+  const int32_t *ix = idx + (size_t)obj * S;
+  const float *g = grad_out + ((size_t)obj * c + c0) * S;
+  float *gp = grad_points + ((size_t)obj * c + c0) * n;
+
+  for (int e = tid; e < S; e += kBlock) s_idx[e] = ix[e];
+  for (int e = tid; e <= n; e += kBlock) s_off[e] = 0;
+  for (int e = tid; e < n; e += kBlock) s_cur[e] = 0;
+  // grad tile, row pitch S+1 so that lanes reading one jk of different channels spread over banks
+  for (int e = tid; e < ct * S; e += kBlock) {
+    const int l = e / S, s = e - l * S;
+    s_g[l * (S + 1) + s] = g[e];
+  }
+  __syncthreads();
+  for (int e = tid; e < S; e += kBlock) atomicAdd(&s_off[s_idx[e] + 1], 1);  // integer: exact
+  __syncthreads();
+  if (tid < kWave) {  // exclusive scan of the counts by wave 0
+    int carry = 0;
+    for (int base = 0; base < n; base += kWave) {
+      const int e = base + tid;
+      int v = e < n ? s_off[e + 1] : 0;
+      int incl = v;
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int o = __shfl_up(incl, d, kWave);
+        if (tid >= d) incl += o;
+      }
+      if (e < n) s_off[e + 1] = carry + incl;
+      carry += __shfl(incl, kWave - 1, kWave);
+    }
+  }
+  __syncthreads();
+  if (tid < kWave) {  // stable fill by wave 0: 64 consecutive (j,k) per step, grouped by target
+    for (int base = 0; base < S; base += kWave) {
+      const int e = base + tid;
+      const bool live = e < S;
+      const int tgt = live ? s_idx[e] : -1;
+      unsigned long long todo = __ballot(live);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int t0 = __shfl(tgt, leader, kWave);
+        const unsigned long long same = __ballot(live && tgt == t0) & todo;
+        if (live && tgt == t0) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi(
+              (unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+          s_list[s_off[t0] + s_cur[t0] + rank] = e;
+        }
+        if (tid == leader) s_cur[t0] += __popcll(same);
+        todo &= ~same;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < ct * n; e += kBlock) {
+    const int l = e / n, tgt = e - l * n;
+    const int beg = s_off[tgt], end = s_off[tgt + 1];
+    const float *rowp = s_g + l * (S + 1);
+    float acc = 0.f;
+    for (int i = beg; i < end; ++i) acc += rowp[s_list[i]];
+    gp[(size_t)l * n + tgt] = acc;
+  }
+}
+
+// Fallback for shapes whose CSR does not fit LDS: unordered fp32 atomics like the reference.
+__global__ __launch_bounds__(kBlock) void group_points_grad_atomic_kernel(
+    int b, int c, int n, int S, const float *__restrict__ grad_out,
+    const int32_t *__restrict__ idx, float *__restrict__ grad_points) {
+  const long long total = (long long)b * c * S;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (long long)gridDim.x * kBlock) {
+    const int s = (int)(e % S);
+    const long long il = e / S;
+    const int i = (int)(il / c);
+    atomicAdd(grad_points + il * n + idx[(long long)i * S + s], grad_out[e]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// three_nn (src/interpolate_gpu.cu:9-59): thread per unknown point, known points broadcast from
+// LDS.  The reference keeps its running bests in double initialised to 1e40 and compares the fp32
+// distance against them; on fp32 inputs that is the same decision sequence as fp32 bests
+// initialised to +inf (every finite d < 1e40; inf < 1e40 is false like inf < inf), and
+// (float)1e40 == +inf is what gets stored when fewer than 3 known points exist.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void three_nn_kernel(int b, int n, int m,
+                                                           const float *__restrict__ unknown,
+                                                           const float *__restrict__ known,
+                                                           float *__restrict__ dist2,
+                                                           int32_t *__restrict__ idx) {
+  constexpr int kTile = 1024;  // known points per LDS pass
+  __shared__ float s_k[kTile * 3];
+  const int obj = blockIdx.x;
+  const float *u = unknown + (size_t)obj * n * 3;
+  const float *kn = known + (size_t)obj * m * 3;
+  const int j = blockIdx.y * kBlock + threadIdx.x;
+  const bool live = j < n;
+  const float ux = live ? u[j * 3 + 0] : 0.f, uy = live ? u[j * 3 + 1] : 0.f,
+              uz = live ? u[j * 3 + 2] : 0.f;
+  const float inf = __int_as_float(0x7F800000);
+  float b1 = inf, b2 = inf, b3 = inf;
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int base = 0; base < m; base += kTile) {
+    const int cnt = (m - base) < kTile ? (m - base) : kTile;
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * 3; e += kBlock) s_k[e] = kn[base * 3 + e];
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) {
+      const float x = s_k[k * 3 + 0], y = s_k[k * 3 + 1], z = s_k[k * 3 + 2];
+      const float dx = ux - x, dy = uy - y, dz = uz - z;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const int kk = base + k;
+      if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
+      else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
+      else if (d < b3) { b3 = d; i3 = kk; }
+    }
+  }
+  if (live) {
+    float *d2o = dist2 + ((size_t)obj * n + j) * 3;
+    int32_t *io = idx + ((size_t)obj * n + j) * 3;
+    d2o[0] = b1; d2o[1] = b2; d2o[2] = b3;
+    io[0] = i1; io[1] = i2; io[2] = i3;
+  }
+}
+
+// three_interpolate (src/interpolate_gpu.cu:72-101): ((p1*w1 + p2*w2) + p3*w3), unfused.
+__global__ __launch_bounds__(kBlock) void three_interpolate_kernel(
+    int b, int c, int m, int n, const float *__restrict__ points, const int32_t *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out) {
+  const long long total = (long long)b * c * n;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (long long)gridDim.x * kBlock) {
+    const int j = (int)(e % n);
+    const long long il = e / n;
+    const int i = (int)(il / c);
+    const int32_t *ix = idx + ((long long)i * n + j) * 3;
+    const float *w = weight + ((long long)i * n + j) * 3;
+    const float *p = points + il * m;
+    out[e] = (p[ix[0]] * w[0] + p[ix[1]] * w[1]) + p[ix[2]] * w[2];
+  }
+}
+
+// three_interpolate_grad (src/interpolate_gpu.cu:116-143): unordered fp32 atomics like the
+// reference (not on the GPS path).
+__global__ __launch_bounds__(kBlock) void three_interpolate_grad_kernel(
+    int b, int c, int n, int m, const float *__restrict__ grad_out,
+    const int32_t *__restrict__ idx, const float *__restrict__ weight,
+    float *__restrict__ grad_points) {
+  const long long total = (long long)b * c * n;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (long long)gridDim.x * kBlock) {
+    const int j = (int)(e % n);
+    const long long il = e / n;
+    const int i = (int)(il / c);
+    const int32_t *ix = idx + ((long long)i * n + j) * 3;
+    const float *w = weight + ((long long)i * n + j) * 3;
+    float *gp = grad_points + il * m;
+    const float go = grad_out[e];
+    atomicAdd(gp + ix[0], go * w[0]);
+    atomicAdd(gp + ix[1], go * w[1]);
+    atomicAdd(gp + ix[2], go * w[2]);
+  }
+}
+
+}  // namespace gps
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+namespace {
+
+thread_local char g_last_hip_error[256] = "";
+
+int finish_launch() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return GPS_OK;
+  const char *s = hipGetErrorString(e);
+  int i = 0;
+  for (; s && s[i] && i < 255; ++i) g_last_hip_error[i] = s[i];
+  g_last_hip_error[i] = 0;
+  return GPS_ERR_LAUNCH;
+}
+
+// include/cuda_utils.h:15-19 of the reference: the block size that decides FPS tie order.
+int ref_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 512) t = 512;
+  if (t < 1) t = 1;
+  return t;
+}
+
+int ilog2(int v) {
+  int p = 0;
+  while ((1 << (p + 1)) <= v) ++p;
+  return p;
+}
+
+int grid_for(long long total, int per_block) {
+  long long g = (total + per_block - 1) / per_block;
+  const long long cap = 256LL * 8;  // 256 CUs x 8 resident workgroups; grid-stride beyond that
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+constexpr int kLdsBudget = 64 * 1024;  // per-workgroup LDS we allow ourselves (160 KiB per CU)
+
+}  // namespace
+
+extern "C" {
+
+int gps_abi_version(void) { return GPS_HIP_ABI_VERSION; }
+
+const char *gps_error_string(int status) {
+  switch (status) {
+    case GPS_OK: return "ok";
+    case GPS_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case GPS_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    case GPS_ERR_LAUNCH: return "HIP launch failure (see gps_last_hip_error)";
+    default: return "unknown status";
+  }
+}
+
+const char *gps_last_hip_error(void) { return g_last_hip_error; }
+
+int gps_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int32_t *idxs, gps_stream_t stream) {
+  if (b < 0 || n < 0 || m < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0 || m == 0) return GPS_OK;
+  if (n < 1 || !dataset || !idxs) return GPS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const int bs = ref_opt_n_threads(n);
+  const int p = ilog2(bs);
+  const int Q = (n + bs - 1) / bs;
+  const int need = p >= 6 ? (1 << (p - 6)) * Q : Q;
+  const dim3 grid((b + gps::kWavesPerBlock - 1) / gps::kWavesPerBlock), block(gps::kBlock);
+#define GPS_FPS_CASE(R_)                                                                       \
+  hipLaunchKernelGGL(gps::fps_resident_kernel<R_>, grid, block, 0, s, b, n, m, p, Q, dataset, \
+                     idxs)
+  if (need <= 1) GPS_FPS_CASE(1);
+  else if (need <= 2) GPS_FPS_CASE(2);
+  else if (need <= 4) GPS_FPS_CASE(4);
+  else if (need <= 8) GPS_FPS_CASE(8);
+  else if (need <= 16) GPS_FPS_CASE(16);
+  else if (need <= 32) GPS_FPS_CASE(32);
+  else {
+    if (!temp) return GPS_ERR_INVALID_ARGUMENT;  // streaming form needs the (b,n) scratch
+    hipLaunchKernelGGL(gps::fps_streaming_kernel, dim3(b), dim3(512), 0, s, b, n, m, dataset, temp,
+                       idxs);
+  }
+#undef GPS_FPS_CASE
+  return finish_launch();
+}
+
+int gps_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
+                      float *out, gps_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0) return GPS_ERR_INVALID_ARGUMENT;
+  const long long total = (long long)b * c * npoints;
+  if (total == 0) return GPS_OK;
+  if (!points || !idx || !out) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps::gather_points_kernel, dim3(grid_for(total, gps::kBlock)),
+                     dim3(gps::kBlock), 0, (hipStream_t)stream, b, c, n, npoints, points, idx, out);
+  return finish_launch();
+}
+
+int gps_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int32_t *idx, float *grad_points, gps_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0) return GPS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t out_elems = (size_t)b * c * n;
+  if (out_elems == 0) return GPS_OK;
+  if (!grad_points) return GPS_ERR_INVALID_ARGUMENT;
+  if (hipMemsetAsync(grad_points, 0, out_elems * sizeof(float), s) != hipSuccess)
+    return finish_launch();
+  const long long total = (long long)b * c * npoints;
+  if (total == 0) return GPS_OK;
+  if (!grad_out || !idx) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps::gather_points_grad_kernel, dim3(grid_for(total, gps::kBlock)),
+                     dim3(gps::kBlock), 0, s, b, c, n, npoints, grad_out, idx, grad_points);
+  return finish_launch();
+}
+
+int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int32_t *idx, gps_stream_t stream) {
+  if (b < 0 || n < 0 || m < 0 || nsample < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if ((long long)b * m * nsample == 0) return GPS_OK;
+  if (!new_xyz || !idx || (n > 0 && !xyz)) return GPS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)gps::kWavesPerBlock * nsample * sizeof(int32_t);
+  if (lds > (size_t)kLdsBudget) return GPS_ERR_UNSUPPORTED;
+  const dim3 grid(b), block(gps::kBlock);
+  const int need = (n + gps::kWave - 1) / gps::kWave;
+#define GPS_BQ_CASE(R_)                                                                         \
+  hipLaunchKernelGGL(gps::ball_query_kernel<R_>, grid, block, lds, s, b, n, m, radius, nsample, \
+                     new_xyz, xyz, idx)
+  if (need <= 1) GPS_BQ_CASE(1);
+  else if (need <= 2) GPS_BQ_CASE(2);
+  else if (need <= 4) GPS_BQ_CASE(4);
+  else if (need <= 8) GPS_BQ_CASE(8);
+  else if (need <= 16) GPS_BQ_CASE(16);
+  else if (need <= 32) GPS_BQ_CASE(32);
+  else GPS_BQ_CASE(0);
+#undef GPS_BQ_CASE
+  return finish_launch();
+}
+
+int gps_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int32_t *idx, float *out, gps_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return GPS_ERR_INVALID_ARGUMENT;
+  const long long S = (long long)npoints * nsample;
+  if ((long long)b * c * S == 0) return GPS_OK;
+  if (!points || !idx || !out || n == 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (S > 0x7fffffffLL) return GPS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t row_bytes = (size_t)n * sizeof(float);
+  if (row_bytes > (size_t)kLdsBudget) {
+    const long long total = (long long)b * c * S;
+    hipLaunchKernelGGL(gps::group_points_direct_kernel, dim3(grid_for(total, gps::kBlock)),
+                       dim3(gps::kBlock), 0, s, b, c, n, (int)S, points, idx, out);
+    return finish_launch();
+  }
+  // channel tile: as many rows as fit 32 KiB of LDS, but not so many that one workgroup writes
+  // more than ~64 KiB (keeps >= ~8 workgroups per CU in flight at GPS shapes)
+  int CT = (int)((32 * 1024) / row_bytes);
+  const int by_out = (int)((64 * 1024) / (S * sizeof(float)));
+  if (CT > by_out) CT = by_out;
+  if (CT < 1) CT = 1;
+  if (CT > c) CT = c;
+  const bool vec4 = (S % 4) == 0 && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const int work_x = vec4 ? (int)(S / 4) : (int)S;
+  int tx = 1;
+  while (tx < work_x && tx < gps::kBlock) tx <<= 1;  // power of two <= 256
+  const dim3 grid(b, (c + CT - 1) / CT), block(gps::kBlock);
+  const size_t lds = (size_t)CT * row_bytes;
+  if (vec4)
+    hipLaunchKernelGGL(gps::group_points_kernel<true>, grid, block, lds, s, b, c, n, (int)S, CT, tx,
+                       points, idx, out);
+  else
+    hipLaunchKernelGGL(gps::group_points_kernel<false>, grid, block, lds, s, b, c, n, (int)S, CT,
+                       tx, points, idx, out);
+  return finish_launch();
+}
+
+int gps_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                          const int32_t *idx, float *grad_points, gps_stream_t stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return GPS_ERR_INVALID_ARGUMENT;
+  const size_t out_elems = (size_t)b * c * n;
+  if (out_elems == 0) return GPS_OK;
+  if (!grad_points) return GPS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const long long S = (long long)npoints * nsample;
+  if (S == 0) {
+    if (hipMemsetAsync(grad_points, 0, out_elems * sizeof(float), s) != hipSuccess)
+      return finish_launch();
+    return GPS_OK;
+  }
+  if (!grad_out || !idx) return GPS_ERR_INVALID_ARGUMENT;
+  if (S > 0x7fffffffLL) return GPS_ERR_UNSUPPORTED;
+  const size_t fixed = ((size_t)2 * S + 2 * (size_t)n + 1) * sizeof(int32_t);
+  const size_t per_ch = ((size_t)S + 1) * sizeof(float);
+  if (fixed + per_ch <= (size_t)kLdsBudget) {
+    int CT = (int)(((size_t)kLdsBudget - fixed) / per_ch);
+    if (CT > 16) CT = 16;
+    if (CT > c) CT = c;
+    const dim3 grid(b, (c + CT - 1) / CT), block(gps::kBlock);
+    hipLaunchKernelGGL(gps::group_points_grad_kernel, grid, block, fixed + CT * per_ch, s, b, c, n,
+                       (int)S, CT, grad_out, idx, grad_points);
+    return finish_launch();
+  }
+  if (hipMemsetAsync(grad_points, 0, out_elems * sizeof(float), s) != hipSuccess)
+    return finish_launch();
+  const long long total = (long long)b * c * S;
+  hipLaunchKernelGGL(gps::group_points_grad_atomic_kernel, dim3(grid_for(total, gps::kBlock)),
+                     dim3(gps::kBlock), 0, s, b, c, n, (int)S, grad_out, idx, grad_points);
+  return finish_launch();
+}
+
+int gps_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int32_t *idx, gps_stream_t stream) {
+  if (b < 0 || n < 0 || m < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if ((long long)b * n == 0) return GPS_OK;
+  if (!unknown || !dist2 || !idx || (m > 0 && !known)) return GPS_ERR_INVALID_ARGUMENT;
+  const dim3 grid(b, (n + gps::kBlock - 1) / gps::kBlock), block(gps::kBlock);
+  hipLaunchKernelGGL(gps::three_nn_kernel, grid, block, 0, (hipStream_t)stream, b, n, m, unknown,
+                     known, dist2, idx);
+  return finish_launch();
+}
+
+int gps_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                          const float *weight, float *out, gps_stream_t stream) {
+  if (b < 0 || c < 0 || m < 0 || n < 0) return GPS_ERR_INVALID_ARGUMENT;
+  const long long total = (long long)b * c * n;
+  if (total == 0) return GPS_OK;
+  if (!points || !idx || !weight || !out) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps::three_interpolate_kernel, dim3(grid_for(total, gps::kBlock)),
+                     dim3(gps::kBlock), 0, (hipStream_t)stream, b, c, m, n, points, idx, weight,
+                     out);
+  return finish_launch();
+}
+
+int gps_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int32_t *idx, const float *weight, float *grad_points,
+                               gps_stream_t stream) {
+  if (b < 0 || c < 0 || m < 0 || n < 0) return GPS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t out_elems = (size_t)b * c * m;
+  if (out_elems == 0) return GPS_OK;
+  if (!grad_points) return GPS_ERR_INVALID_ARGUMENT;
+  if (hipMemsetAsync(grad_points, 0, out_elems * sizeof(float), s) != hipSuccess)
+    return finish_launch();
+  const long long total = (long long)b * c * n;
+  if (total == 0) return GPS_OK;
+  if (!grad_out || !idx || !weight) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps::three_interpolate_grad_kernel, dim3(grid_for(total, gps::kBlock)),
+                     dim3(gps::kBlock), 0, s, b, c, n, m, grad_out, idx, weight, grad_points);
+  return finish_launch();
+}
+
+}  // extern "C"

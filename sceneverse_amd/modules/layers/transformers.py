@@ -1,0 +1,397 @@
+"""Transformer layers of the GPS hot path, API- and checkpoint-compatible with the reference's
+modules/layers/transformers.py (class names, constructor arguments, forward signatures, return
+tuples, parameter names), re-built around one attention core:
+
+    attention_core()                  softmax(QK^T/sqrt(d) + bias) V, the op behind every layer
+    MultiHeadAttentionSpatial         ref :157-239  language-conditioned pairwise-spatial attention
+    MultiheadSelfAttention            stands in for torch.nn.MultiheadAttention as the reference
+                                      uses it (batch_first, key_padding_mask, attn dropout), with
+                                      nn.MultiheadAttention's parameter names
+    TransformerEncoderLayer           ref :115-154
+    TransformerSpatialEncoderLayer    ref :285-316
+    TransformerDecoderLayer           ref :66-112
+    TransformerSpatialDecoderLayer    ref :242-282
+    CrossAttentionLayer               ref :12-63
+
+Backends of the attention core (see `set_attention_backend`):
+    "hip"    fused gfx950 kernels from libgps_hip.so (GPU tensors; the default on a GPU),
+    "torch"  plain PyTorch ops; chosen automatically only for CPU tensors (tests / gloo runs) or
+             when attention probabilities are requested (`need_weights=True`).
+
+Deviations from the reference, on purpose (DESIGN.md "reference quirks"):
+  * no `assert torch.sum(torch.isnan(fused_attn) == 0)` host sync (ref :234);
+  * attention probabilities are only materialised when `need_weights` is set on the module
+    (every caller in the reference discards them).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from ..utils import get_activation_fn
+
+_BACKEND = "auto"  # "auto" | "hip" | "torch"
+
+
+def set_attention_backend(name: str) -> None:
+    global _BACKEND
+    if name not in ("auto", "hip", "torch"):
+        raise ValueError(name)
+    _BACKEND = name
+
+
+def get_attention_backend() -> str:
+    return _BACKEND
+
+
+def _split_heads(x: Tensor, n_head: int) -> Tensor:
+    """(B, L, H*dh) -> (B, H, L, dh)"""
+    b, l, d = x.shape
+    return x.view(b, l, n_head, d // n_head).transpose(1, 2)
+
+
+def _merge_heads(x: Tensor) -> Tensor:
+    """(B, H, L, dh) -> (B, L, H*dh)"""
+    b, h, l, dh = x.shape
+    return x.transpose(1, 2).reshape(b, l, h * dh)
+
+
+def attention_core(q: Tensor, k: Tensor, v: Tensor, bias: Optional[Tensor] = None,
+                   key_padding_mask: Optional[Tensor] = None, dropout_p: float = 0.0,
+                   training: bool = False, need_weights: bool = False):
+    """q (B,H,L,dh), k/v (B,H,T,dh), bias (B,H,L,T) additive or None, key_padding_mask (B,T)
+    True = ignore.  Returns (out (B,H,L,dh), probs (B,H,L,T) or None).  fp32 softmax."""
+    scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.size(-1))
+    scores = scores.float()
+    if bias is not None:
+        scores = scores + bias.float()
+    if key_padding_mask is not None:
+        scores = scores.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    probs = torch.softmax(scores, dim=-1)
+    p = probs
+    if dropout_p > 0.0 and training:
+        p = F.dropout(p, dropout_p, training=True)
+    out = torch.matmul(p.to(v.dtype), v)
+    return out, (probs if need_weights else None)
+
+
+class MultiHeadAttentionSpatial(nn.Module):
+    """Self-attention over objects whose logits are modulated by pairwise geometry.
+
+    fusion 'cond' (the one GPS uses): per query token l and head h a 6-vector
+    (bias, w_1..w_5) = lang_cond_fc(x_l); loc[h,b,l,t] = sigmoid(w . pairwise[b,l,t,:] + bias);
+    probs = softmax(log(clamp(loc, 1e-6)) + q k^T / sqrt(d_h)) with padded keys removed.
+    Other fusions ('mul', 'bias', 'add', 'ctx') follow ref :199-231.
+    The `dropout` argument is accepted and unused, as in the reference.
+    """
+
+    def __init__(self, d_model, n_head, dropout=0.1, spatial_multihead=True, spatial_dim=5,
+                 spatial_attn_fusion='mul'):
+        super().__init__()
+        assert d_model % n_head == 0, 'd_model: %d, n_head: %d' % (d_model, n_head)
+        self.n_head = n_head
+        self.d_model = d_model
+        self.d_per_head = d_model // n_head
+        self.spatial_multihead = spatial_multihead
+        self.spatial_dim = spatial_dim
+        self.spatial_attn_fusion = spatial_attn_fusion
+        self.need_weights = False
+
+        self.w_qs = nn.Linear(d_model, d_model)
+        self.w_ks = nn.Linear(d_model, d_model)
+        self.w_vs = nn.Linear(d_model, d_model)
+        self.fc = nn.Linear(d_model, d_model)
+
+        self.spatial_n_head = n_head if spatial_multihead else 1
+        if spatial_attn_fusion in ('mul', 'bias', 'add'):
+            self.pairwise_loc_fc = nn.Linear(spatial_dim, self.spatial_n_head)
+        elif spatial_attn_fusion == 'ctx':
+            self.pairwise_loc_fc = nn.Linear(spatial_dim, d_model)
+        elif spatial_attn_fusion == 'cond':
+            self.lang_cond_fc = nn.Linear(d_model, self.spatial_n_head * (spatial_dim + 1))
+        else:
+            raise NotImplementedError('unsupported spatial_attn_fusion %s' % spatial_attn_fusion)
+
+    # ---- geometry term, (B,H,L,T), already in the form that is ADDED to the scaled logits ----
+    def _spatial_logits(self, x_in: Tensor, q: Tensor, pairwise_locs: Tensor,
+                        key_padding_mask: Optional[Tensor]):
+        fusion = self.spatial_attn_fusion
+        H = self.n_head
+        if fusion == 'cond':
+            b, l, _ = x_in.shape
+            sw = self.lang_cond_fc(x_in).float().view(b, l, self.spatial_n_head, self.spatial_dim + 1)
+            sw = sw.permute(0, 2, 1, 3)                                     # (B,h,L,1+D)
+            if self.spatial_n_head == 1:
+                sw = sw.expand(-1, H, -1, -1)
+            loc = torch.einsum('bhld,bltd->bhlt', sw[..., 1:], pairwise_locs.float()) + sw[..., :1]
+            loc = torch.sigmoid(loc)
+        elif fusion in ('mul', 'bias', 'add'):
+            loc = self.pairwise_loc_fc(pairwise_locs).float().permute(0, 3, 1, 2)  # (B,h,L,T)
+            if fusion == 'mul':
+                loc = F.relu(loc)
+            if not self.spatial_multihead:
+                loc = loc.expand(-1, H, -1, -1)
+        else:  # 'ctx'
+            b, l, t, _ = pairwise_locs.shape
+            ctx = self.pairwise_loc_fc(pairwise_locs).view(b, l, t, H, self.d_per_head)
+            loc = torch.einsum('bhlk,blthk->bhlt', q.float(), ctx.float()) / math.sqrt(self.d_per_head)
+        if fusion in ('mul', 'cond'):
+            if key_padding_mask is not None:
+                loc = loc.masked_fill(key_padding_mask[:, None, None, :], 0)
+            return torch.log(torch.clamp(loc, min=1e-6))
+        return loc
+
+    def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, txt_embeds=None):
+        x_in = q
+        qh = _split_heads(self.w_qs(q), self.n_head)
+        kh = _split_heads(self.w_ks(k), self.n_head)
+        vh = _split_heads(self.w_vs(v), self.n_head)
+        if self.spatial_attn_fusion == 'add':
+            # average of two softmaxes (ref :226-227)
+            scores = torch.matmul(qh, kh.transpose(-1, -2)).float() / math.sqrt(self.d_per_head)
+            loc = self._spatial_logits(x_in, qh, pairwise_locs, key_padding_mask)
+            if key_padding_mask is not None:
+                m = key_padding_mask[:, None, None, :]
+                scores = scores.masked_fill(m, float('-inf'))
+                loc = loc.masked_fill(m, float('-inf'))
+            probs = (torch.softmax(scores, 3) + torch.softmax(loc, 3)) / 2
+            out = torch.matmul(probs.to(vh.dtype), vh)
+        else:
+            bias = self._spatial_logits(x_in, qh, pairwise_locs, key_padding_mask)
+            out, probs = attention_core(qh, kh, vh, bias=bias, key_padding_mask=key_padding_mask,
+                                        need_weights=self.need_weights)
+        out = self.fc(_merge_heads(out))
+        if self.need_weights and probs is not None:
+            probs = probs.transpose(0, 1)  # reference layout (head, B, L, T)
+        else:
+            probs = None
+        return out, probs
+
+
+class MultiheadSelfAttention(nn.Module):
+    """torch.nn.MultiheadAttention as the reference instantiates it (batch_first=True, optional
+    kdim/vdim, dropout on the attention probabilities), with the same parameter names
+    (`in_proj_weight`, `in_proj_bias`, `out_proj.*`, or `q/k/v_proj_weight` when kdim/vdim differ)
+    so reference checkpoints load.  Returns (out, head-averaged probs or None)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, batch_first=True, kdim=None, vdim=None):
+        super().__init__()
+        if not batch_first:
+            raise NotImplementedError("the GPS path only uses batch_first=True")
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.kdim = embed_dim if kdim is None else kdim
+        self.vdim = embed_dim if vdim is None else vdim
+        self._same = self.kdim == embed_dim and self.vdim == embed_dim
+        self.need_weights = False
+        if self._same:
+            self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+            self.register_parameter('q_proj_weight', None)
+            self.register_parameter('k_proj_weight', None)
+            self.register_parameter('v_proj_weight', None)
+        else:
+            self.q_proj_weight = nn.Parameter(torch.empty(embed_dim, embed_dim))
+            self.k_proj_weight = nn.Parameter(torch.empty(embed_dim, self.kdim))
+            self.v_proj_weight = nn.Parameter(torch.empty(embed_dim, self.vdim))
+            self.register_parameter('in_proj_weight', None)
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for w in (self.in_proj_weight, self.q_proj_weight, self.k_proj_weight, self.v_proj_weight):
+            if w is not None:
+                nn.init.xavier_uniform_(w)
+        nn.init.constant_(self.in_proj_bias, 0.)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, need_weights=None):
+        E = self.embed_dim
+        bq, bk, bv = self.in_proj_bias[:E], self.in_proj_bias[E:2 * E], self.in_proj_bias[2 * E:]
+        if self._same:
+            if key is query and value is query:
+                q, k, v = F.linear(query, self.in_proj_weight, self.in_proj_bias).chunk(3, dim=-1)
+            else:
+                wq, wk, wv = self.in_proj_weight[:E], self.in_proj_weight[E:2 * E], self.in_proj_weight[2 * E:]
+                q, k, v = F.linear(query, wq, bq), F.linear(key, wk, bk), F.linear(value, wv, bv)
+        else:
+            q = F.linear(query, self.q_proj_weight, bq)
+            k = F.linear(key, self.k_proj_weight, bk)
+            v = F.linear(value, self.v_proj_weight, bv)
+        H = self.num_heads
+        bias = None
+        if attn_mask is not None:
+            bias = attn_mask
+            if bias.dtype == torch.bool:
+                bias = torch.zeros_like(bias, dtype=torch.float32).masked_fill(bias, float('-inf'))
+            while bias.dim() < 4:
+                bias = bias.unsqueeze(0)
+        want = self.need_weights if need_weights is None else need_weights
+        out, probs = attention_core(_split_heads(q, H), _split_heads(k, H), _split_heads(v, H),
+                                    bias=bias, key_padding_mask=key_padding_mask,
+                                    dropout_p=self.dropout, training=self.training,
+                                    need_weights=want)
+        out = self.out_proj(_merge_heads(out))
+        return out, (probs.mean(dim=1) if probs is not None else None)
+
+
+def _ffn(layer, x):
+    return layer.linear2(layer.dropout(layer.activation(layer.linear1(x))))
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Self-attention + FFN, post-norm unless `prenorm` (ref :115-154).  forward -> (x, attn)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, batch_first=True, dropout=0.1,
+                 activation="relu", prenorm=False):
+        super().__init__()
+        self.self_attn = MultiheadSelfAttention(d_model, nhead, dropout=dropout, batch_first=batch_first)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.activation = get_activation_fn(activation)
+        self.prenorm = prenorm
+
+    def forward(self, tgt, tgt_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None):
+        h = self.norm1(tgt) if self.prenorm else tgt
+        h, attn = self.self_attn(query=h, key=h, value=h, attn_mask=tgt_mask,
+                                 key_padding_mask=tgt_key_padding_mask)
+        tgt = tgt + self.dropout1(h)
+        # ref :147-153: the pre-norm variant normalises the residual stream itself before the FFN
+        tgt = self.norm2(tgt) if self.prenorm else self.norm1(tgt)
+        tgt = tgt + self.dropout2(_ffn(self, tgt))
+        if not self.prenorm:
+            tgt = self.norm2(tgt)
+        return tgt, attn
+
+
+class TransformerSpatialEncoderLayer(TransformerEncoderLayer):
+    """Post-norm encoder layer whose attention is MultiHeadAttentionSpatial (ref :285-316)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 spatial_multihead=True, spatial_dim=5, spatial_attn_fusion='mul'):
+        super().__init__(d_model, nhead, dim_feedforward=dim_feedforward, dropout=dropout,
+                         activation=activation)
+        del self.self_attn
+        self.self_attn = MultiHeadAttentionSpatial(
+            d_model, nhead, dropout=dropout, spatial_multihead=spatial_multihead,
+            spatial_dim=spatial_dim, spatial_attn_fusion=spatial_attn_fusion)
+
+    def forward(self, tgt, tgt_pairwise_locs, tgt_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None):
+        h, attn = self.self_attn(tgt, tgt, tgt, tgt_pairwise_locs,
+                                 key_padding_mask=tgt_key_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(h))
+        tgt = self.norm2(tgt + self.dropout2(_ffn(self, tgt)))
+        return tgt, attn
+
+
+class TransformerDecoderLayer(nn.Module):
+    """Pre-norm self-attention, cross-attention to `memory`, FFN (ref :66-112).
+    forward -> (x, self_attn, cross_attn)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        self.self_attn = MultiheadSelfAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.multihead_attn = MultiheadSelfAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.activation = get_activation_fn(activation)
+
+    def _self_block(self, h, pairwise_locs, tgt_mask, tgt_key_padding_mask):
+        return self.self_attn(query=h, key=h, value=h, attn_mask=tgt_mask,
+                              key_padding_mask=tgt_key_padding_mask)
+
+    def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None,
+                memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None,
+                memory_key_padding_mask: Optional[Tensor] = None, _pairwise_locs=None):
+        h, self_attn = self._self_block(self.norm1(tgt), _pairwise_locs, tgt_mask, tgt_key_padding_mask)
+        tgt = tgt + self.dropout1(h)
+        h, cross_attn = self.multihead_attn(query=self.norm2(tgt), key=memory, value=memory,
+                                            attn_mask=memory_mask,
+                                            key_padding_mask=memory_key_padding_mask)
+        tgt = tgt + self.dropout2(h)
+        tgt = tgt + self.dropout3(_ffn(self, self.norm3(tgt)))
+        return tgt, self_attn, cross_attn
+
+
+class TransformerSpatialDecoderLayer(TransformerDecoderLayer):
+    """Decoder layer with spatial self-attention (ref :242-282)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 spatial_multihead=True, spatial_dim=5, spatial_attn_fusion='mul'):
+        super().__init__(d_model, nhead, dim_feedforward=dim_feedforward, dropout=dropout,
+                         activation=activation)
+        del self.self_attn
+        self.self_attn = MultiHeadAttentionSpatial(
+            d_model, nhead, dropout=dropout, spatial_multihead=spatial_multihead,
+            spatial_dim=spatial_dim, spatial_attn_fusion=spatial_attn_fusion)
+
+    def _self_block(self, h, pairwise_locs, tgt_mask, tgt_key_padding_mask):
+        return self.self_attn(h, h, h, pairwise_locs, key_padding_mask=tgt_key_padding_mask)
+
+    def forward(self, tgt, memory, tgt_pairwise_locs: Optional[Tensor] = None,
+                tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None,
+                memory_key_padding_mask: Optional[Tensor] = None):
+        return super().forward(tgt, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                               tgt_key_padding_mask=tgt_key_padding_mask,
+                               memory_key_padding_mask=memory_key_padding_mask,
+                               _pairwise_locs=tgt_pairwise_locs)
+
+
+class CrossAttentionLayer(nn.Module):
+    """Cross-attention + FFN block (ref :12-63).  forward -> (x, cross_attn)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 k_dim=None, v_dim=None, prenorm=True):
+        super().__init__()
+        self.prenorm = prenorm
+        self.multihead_attn = MultiheadSelfAttention(
+            d_model, nhead, dropout=dropout, batch_first=True,
+            kdim=d_model if k_dim is None else k_dim, vdim=d_model if v_dim is None else v_dim)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.activation = get_activation_fn(activation)
+
+    def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None,
+                memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None,
+                memory_key_padding_mask: Optional[Tensor] = None):
+        h = self.norm1(tgt) if self.prenorm else tgt
+        h, cross_attn = self.multihead_attn(query=h, key=memory, value=memory,
+                                            attn_mask=memory_mask,
+                                            key_padding_mask=memory_key_padding_mask)
+        tgt = tgt + self.dropout2(h)
+        if not self.prenorm:
+            tgt = self.norm1(tgt)
+        # ref :56-58: in post-norm mode the FFN is fed the raw attention output, not the
+        # normalised residual stream -- reproduced as is
+        h = self.norm3(tgt) if self.prenorm else h
+        tgt = tgt + self.dropout3(_ffn(self, h))
+        if not self.prenorm:
+            tgt = self.norm3(tgt)
+        return tgt, cross_attn

@@ -1,0 +1,84 @@
+"""Contrastive losses (reference optim/loss/contra_loss.py:11-98).  The two between-batch losses
+all-gather their features across data-parallel ranks WITHOUT autograd (as the reference does), so
+under DDP they only train `logit_scale`."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...common.dist_utils import all_gather
+from .loss import LOSS_REGISTRY
+
+
+def _symmetric_clip_loss(a, b, logit_scale):
+    labels = torch.arange(a.shape[0], device=a.device)
+    a2b = logit_scale * a @ b.t()
+    b2a = logit_scale * b @ a.t()
+    return (F.cross_entropy(a2b, labels) + F.cross_entropy(b2a, labels)) / 2
+
+
+@LOSS_REGISTRY.register()
+class TextObjWithinBatch(nn.Module):
+    """Cross-entropy over the objects of each scene between the sentence CLS and every object."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.distributed = cfg.num_gpu > 1
+        self.bce = cfg.task in ["ScanQA"]
+
+    def forward(self, data_dict):
+        obj_feats = data_dict["intra_obj_embeds"]      # (B,O,D)
+        text_feats = data_dict["intra_text_embed"]     # (B,D)
+        labels = data_dict["tgt_object_id"]            # (B,1)
+        masks = data_dict["obj_masks"]
+        if obj_feats.shape[0] != masks.shape[0]:       # per-scene variant: B*L rows
+            rep = int(obj_feats.shape[0] / masks.shape[0])
+            masks = masks.unsqueeze(1).repeat(1, rep, 1).view(-1, masks.shape[1])
+            labels = labels.view(-1, 1)
+        obj_feats = F.normalize(obj_feats, dim=-1, p=2)
+        text_feats = F.normalize(text_feats, dim=-1, p=2)
+        logits = torch.einsum('bod,bd->bo', obj_feats, text_feats)
+        labels = labels.squeeze(-1)
+        if self.bce:
+            return F.binary_cross_entropy_with_logits(logits, labels.float(), reduction="sum",
+                                                      weight=masks) / float(labels.shape[0])
+        logits.masked_fill_(masks.logical_not(), -float('inf'))
+        return F.cross_entropy(logits, labels)
+
+
+@LOSS_REGISTRY.register()
+class TextObjBetweenBatch(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.distributed = cfg.num_gpu > 1
+        self.logit_scale = nn.Parameter((torch.ones([]) * np.log(1 / 0.07)).exp())
+
+    def forward(self, data_dict):
+        logit_scale = torch.clamp(self.logit_scale, max=100)
+        obj_feats = data_dict["inter_obj_embeds"]
+        text_feats = data_dict["inter_text_embed"]
+        labels = data_dict["tgt_object_id"]
+        if obj_feats.shape[0] != labels.shape[0]:
+            labels = labels.view(-1, 1)
+        tgt = obj_feats[torch.arange(labels.size(0)), labels[:, 0], :]
+        tgt = F.normalize(tgt, dim=-1, p=2)
+        text_feats = F.normalize(text_feats, dim=-1, p=2)
+        if self.distributed:
+            tgt, text_feats = all_gather([tgt, text_feats])
+        return _symmetric_clip_loss(text_feats, tgt, logit_scale)
+
+
+@LOSS_REGISTRY.register()
+class TextSceneBetweenBatch(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.distributed = cfg.num_gpu > 1
+        self.logit_scale = nn.Parameter((torch.ones([]) * np.log(1 / 0.07)).exp())
+
+    def forward(self, data_dict):
+        logit_scale = torch.clamp(self.logit_scale, max=100)
+        scene_feats = F.normalize(data_dict["scene_embed"], dim=-1, p=2)
+        text_feats = F.normalize(data_dict["scene_text_embed"], dim=-1, p=2)
+        if self.distributed:
+            scene_feats, text_feats = all_gather([scene_feats, text_feats])
+        return _symmetric_clip_loss(text_feats, scene_feats, logit_scale)

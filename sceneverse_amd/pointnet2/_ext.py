@@ -1,0 +1,165 @@
+"""Tensor-level mirror of the reference's pybind module `pointnet2._ext`
+(/root/reference/modules/third_party/pointnet2/_ext_src/src/bindings.cpp:6-19): the same nine
+function names, argument order, dtype/contiguity checks (include/utils.h:5-25 -> RuntimeError)
+and return conventions as the host wrappers in sampling.cpp / ball_query.cpp / group_points.cpp /
+interpolate.cpp -- but each call goes straight to the C ABI of libgps_hip.so on the current
+torch stream.  GPU tensors only: there is deliberately no CPU path (the reference has none
+either: `AT_ASSERT(false, "CPU not supported")`).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _native
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype: torch.dtype) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (libgps_hip has no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {'a float' if dtype == torch.float32 else 'an int'} tensor")
+
+
+def _same_device(*ts: torch.Tensor) -> None:
+    d = ts[0].device
+    for t in ts[1:]:
+        if t.device != d:
+            raise RuntimeError("all tensors must live on the same GPU")
+
+
+def gather_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _chk(points, "points", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_device(points, idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        st = _native.load().gps_gather_points(b, c, n, m, points.data_ptr(), idx.data_ptr(),
+                                              out.data_ptr(), _stream())
+    _native.check(st, "gather_points")
+    return out
+
+
+def gather_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -> torch.Tensor:
+    _chk(grad_out, "grad_out", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_device(grad_out, idx)
+    b, c, m = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        st = _native.load().gps_gather_points_grad(b, c, int(n), m, grad_out.data_ptr(),
+                                                   idx.data_ptr(), out.data_ptr(), _stream())
+    _native.check(st, "gather_points_grad")
+    return out
+
+
+def furthest_point_sampling(points: torch.Tensor, nsamples: int) -> torch.Tensor:
+    _chk(points, "points", torch.float32)
+    b, n, _ = points.shape
+    m = int(nsamples)
+    out = torch.empty((b, m), dtype=torch.int32, device=points.device)
+    temp = None
+    if n > 2048:  # GPS_FPS_MAX_RESIDENT_N: streaming form keeps running distances in HBM
+        temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        st = _native.load().gps_furthest_point_sampling(
+            b, n, m, points.data_ptr(), temp.data_ptr() if temp is not None else None,
+            out.data_ptr(), _stream())
+    _native.check(st, "furthest_point_sampling")
+    return out
+
+
+def three_nn(unknowns: torch.Tensor, knows: torch.Tensor):
+    _chk(unknowns, "unknowns", torch.float32)
+    _chk(knows, "knows", torch.float32)
+    _same_device(unknowns, knows)
+    b, n, _ = unknowns.shape
+    m = knows.shape[1]
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
+    with torch.cuda.device(unknowns.device):
+        st = _native.load().gps_three_nn(b, n, m, unknowns.data_ptr(), knows.data_ptr(),
+                                         dist2.data_ptr(), idx.data_ptr(), _stream())
+    _native.check(st, "three_nn")
+    return [dist2, idx]
+
+
+def three_interpolate(points: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    _chk(points, "points", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _chk(weight, "weight", torch.float32)
+    _same_device(points, idx, weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        st = _native.load().gps_three_interpolate(b, c, m, n, points.data_ptr(), idx.data_ptr(),
+                                                  weight.data_ptr(), out.data_ptr(), _stream())
+    _native.check(st, "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor,
+                           m: int) -> torch.Tensor:
+    _chk(grad_out, "grad_out", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _chk(weight, "weight", torch.float32)
+    _same_device(grad_out, idx, weight)
+    b, c, n = grad_out.shape
+    out = torch.empty((b, c, int(m)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        st = _native.load().gps_three_interpolate_grad(b, c, n, int(m), grad_out.data_ptr(),
+                                                       idx.data_ptr(), weight.data_ptr(),
+                                                       out.data_ptr(), _stream())
+    _native.check(st, "three_interpolate_grad")
+    return out
+
+
+def ball_query(new_xyz: torch.Tensor, xyz: torch.Tensor, radius: float, nsample: int) -> torch.Tensor:
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(xyz, "xyz", torch.float32)
+    _same_device(new_xyz, xyz)
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        st = _native.load().gps_ball_query(b, n, m, float(radius), int(nsample),
+                                           new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
+                                           _stream())
+    _native.check(st, "ball_query")
+    return idx
+
+
+def group_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _chk(points, "points", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_device(points, idx)
+    b, c, n = points.shape
+    _, npoints, nsample = idx.shape
+    out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        st = _native.load().gps_group_points(b, c, n, npoints, nsample, points.data_ptr(),
+                                             idx.data_ptr(), out.data_ptr(), _stream())
+    _native.check(st, "group_points")
+    return out
+
+
+def group_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -> torch.Tensor:
+    _chk(grad_out, "grad_out", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_device(grad_out, idx)
+    b, c, npoints, nsample = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        st = _native.load().gps_group_points_grad(b, c, int(n), npoints, nsample,
+                                                  grad_out.data_ptr(), idx.data_ptr(),
+                                                  out.data_ptr(), _stream())
+    _native.check(st, "group_points_grad")
+    return out
