@@ -1,0 +1,1 @@
+"""empty stub (make_golden.py only)"""
