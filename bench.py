@@ -1,0 +1,230 @@
+"""bench.py -- GPS pre-train pairs/s (forward + loss + backward + AdamW) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: the `all_pretrain.yaml` model (BERT-4L text
+encoder, PointNet++ object encoder on libgps_hip.so, 4 spatial + 4 joint transformer layers,
+OVPretrainHead) with losses lm_cls_loss + TextObjWithinBatch + TextSceneBetweenBatch, B = 64
+scenes per GPU, 80 objects x 1024 points x 6 ch, 50-token sentence + 300-token scene caption
+(BASELINE.json configs[1]; SURVEY.md section 8(d) "config 2").  Synthetic inputs, random-init
+weights; inputs are resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed.
+
+The single JSON line also carries
+  roofline      the dominant native kernel by time, its ALGORITHMIC bytes / measured duration
+                (HIP events on the launch stream, recorded inside the timed steps) vs 8 TB/s
+  kernels       the same for every libgps_hip.so launch shape seen in a step
+  cpu_baseline  the oracle port (oracle/gps_torch_reference.py + C point ops + HF BERT, fp32, all
+                host cores) timed on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+N_CLS = 607
+
+
+def gps_pretrain_cfg(lang_path: str, num_gpu: int = 1):
+    """Model/solver section of configs/final/all_pretrain.yaml:172-258 (reference)."""
+    from sceneverse_amd.common.config import ConfigNode
+    losses = ["lm_cls_loss", "TextObjWithinBatch", "TextSceneBetweenBatch"]
+    return ConfigNode({
+        "num_gpu": num_gpu, "task": "Pretrain",
+        "data": {"args": {"use_scene_cap": True}},
+        "solver": {"lr": 5e-4, "grad_norm": 5.0,
+                   "optim": {"name": "AdamW", "args": {"betas": [0.9, 0.98]}},
+                   "sched": {"name": "warmup_cosine", "args": {"warmup_steps": 500, "minimum_ratio": 0.1}}},
+        "model": {
+            "name": "OpenVocab",
+            "language": {"name": "BERTLanguageEncoder",
+                         "args": {"weights": None, "hidden_size": 768, "num_hidden_layers": 4,
+                                  "num_attention_heads": 12, "type_vocab_size": 2}, "lr": 1e-5},
+            "vision": {"name": "PointOpenVocabEncoder",
+                       "args": {"backbone": "pointnet++", "hidden_size": 768, "freeze": True,
+                                "path": None, "num_attention_heads": 12, "spatial_dim": 5,
+                                "num_layers": 4, "dim_loc": 6, "dim_feedforward": 2048,
+                                "attn_type": "spatial", "pairwise_rel_type": "center",
+                                "use_matmul_label": False, "lang_type": "bert",
+                                "lang_path": lang_path}, "lr": 1e-4},
+            "grounding": {"name": "UnifiedSpatialCrossEncoderV2",
+                          "args": {"hidden_size": 768, "num_attention_heads": 12, "num_layers": 4,
+                                   "dim_feedforward": 2048, "dim_loc": 6}, "lr": 1e-4},
+            "inter": "before",
+            "heads": {"head_list": ["pretrain_head"],
+                      "pretrain_head": {"name": "OVPretrainHead",
+                                        "args": {"hidden_size": 768, "vocab_size": 30522}}},
+            "loss_list": losses, "vis_loss_list": losses,
+        },
+    })
+
+
+def _lang_dir(seed: int = 0) -> str:
+    d = tempfile.mkdtemp(prefix="gps_txt_")
+    g = torch.Generator().manual_seed(1234 + seed)
+    torch.save(0.02 * torch.randn(N_CLS, 768, generator=g),
+               os.path.join(d, "scannet_607_bert-base-uncased_id.pth"))
+    return d
+
+
+def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
+    """The oracle port of the same training step on the host cores: functional fp32 model of
+    oracle/gps_torch_reference.py over leaf parameter tensors, C point ops, HF BERT, AdamW."""
+    from oracle import gps_torch_reference as R
+    from sceneverse_amd.data.synthetic import synth_batch
+    from transformers import BertConfig, BertModel
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    # parameter container with the reference's names, built from shapes only (no product forward)
+    from sceneverse_amd.model.build import build_model
+    cfg = gps_pretrain_cfg(_lang_dir())
+    shapes = build_model(cfg).state_dict()
+    sd = {}
+    for k, v in shapes.items():
+        if k.startswith("lang_encoder."):
+            continue
+        t = v.detach().clone().float() if torch.is_floating_point(v) else v.clone()
+        frozen = k.startswith("point_encoder.point_feature_extractor") or k.endswith("text_features") \
+            or "running_" in k or not torch.is_floating_point(v)
+        sd[k] = t if frozen else t.requires_grad_(True)
+    del shapes
+    bert = BertModel(BertConfig(hidden_size=768, num_hidden_layers=4, num_attention_heads=12,
+                                type_vocab_size=2)).train()
+    for m in bert.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    lang = lambda ids, masks: bert(ids, masks).last_hidden_state  # noqa: E731
+    logit_scale = torch.tensor(1 / 0.07)
+    params = [t for t in sd.values() if t.requires_grad] + [p for p in bert.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.98))
+    data = synth_batch(batch_size, n_obj=n_obj, n_pts=n_pts, seed=123)
+
+    def one_step():
+        out = R.openvocab_forward(sd, data, lang)
+        loss = R.pretrain_losses(out, data, logit_scale)["total_loss"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        return loss.item()
+
+    one_step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    dt = time.perf_counter() - t0
+    return {"value": batch_size * steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the same fwd+loss+bwd+AdamW step at B={batch_size} "
+                      f"({n_obj} obj x {n_pts} pts, 50+300 tokens), fp32, torch {torch.__version__} "
+                      f"on {cores} host threads, after 1 warm-up step; {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="scenes per GPU (all_pretrain.yaml:167)")
+    ap.add_argument("--n-obj", type=int, default=80)
+    ap.add_argument("--n-pts", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
+    args = ap.parse_args()
+
+    from sceneverse_amd.common import dist_utils
+    from sceneverse_amd.data.synthetic import synth_batch
+    from sceneverse_amd.engine import GPSTrainStep
+    from sceneverse_amd.pointnet2 import _ext as hip_ext
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the GPS hot path has no CPU fallback")
+    rank, world, local = dist_utils.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
+    step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16)
+    batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.step(dict(batch))
+    barrier()
+    hip_ext.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step.step(dict(batch))
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = hip_ext.profile_stop()
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        kernels = []
+        for name, k in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]):
+            gbs = k["bytes_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
+            kernels.append({"kernel": name, "launches_per_step": k["launches"] / args.steps,
+                            "avg_us": round(k["avg_us"], 2),
+                            "algorithmic_bytes": int(k["bytes_per_launch"]),
+                            "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        dom = kernels[0] if kernels else None
+        result = {
+            "metric": "GPS pre-train pairs/sec (fwd+bwd)",
+            "value": round(args.batch * world * args.steps / dt, 2),
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "fp32" if args.fp32 else "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"GPS pre-train step (all_pretrain.yaml model, ScanNet-shaped synthetic "
+                                   f"scenes): {args.n_obj} obj x {args.n_pts} pts x 6 ch, 50-token sentence "
+                                   f"+ 300-token scene caption, fwd+loss+bwd+clip+AdamW",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "point_ops": "fp32 (libgps_hip.so)",
+                       "final_loss": round(final_loss, 4)},
+            "roofline": None if dom is None else {
+                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.n_obj, args.n_pts)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

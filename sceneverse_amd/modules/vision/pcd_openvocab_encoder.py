@@ -46,6 +46,9 @@ class PointOpenVocabEncoder(nn.Module):
         self.point_cls_head = lambda x: x @ self.text_features.t()
         self.dropout = nn.Dropout(0.1)
         self.attn_type = attn_type
+        # the reference's point path is fp32-only (its ext rejects anything else); keep PointNet++
+        # out of an enclosing bf16 autocast unless explicitly allowed
+        self.pointnet_autocast = False
 
         self.freeze = freeze
         if freeze:
@@ -95,7 +98,12 @@ class PointOpenVocabEncoder(nn.Module):
         if self.freeze:
             self.freeze_bn(self.point_feature_extractor)
         B, O = obj_pcds.shape[:2]
-        obj_embeds = self.point_feature_extractor(obj_pcds.reshape(B * O, *obj_pcds.shape[2:]))
+        pcs = obj_pcds.reshape(B * O, *obj_pcds.shape[2:])
+        if obj_pcds.is_cuda and not self.pointnet_autocast:
+            with torch.autocast(device_type="cuda", enabled=False):
+                obj_embeds = self.point_feature_extractor(pcs.float())
+        else:
+            obj_embeds = self.point_feature_extractor(pcs)
         obj_embeds = self.dropout(obj_embeds.view(B, O, -1))
         if self.freeze:
             obj_embeds = obj_embeds.detach()

@@ -17,6 +17,48 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-launch timing (bench.py): HIP events on the launch stream ------------------
+_PROFILE = None  # None | {op name: [(start_event, end_event, algorithmic_bytes), ...]}
+
+
+def profile_start() -> None:
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_stop() -> dict:
+    """-> {op: {"launches": n, "avg_us": t, "bytes_per_launch": B}} (synchronises)."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE or {}, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in rec.items():
+        ms = [s.elapsed_time(e) for s, e, _ in evs]
+        out[name] = {"launches": len(evs), "avg_us": 1e3 * sum(ms) / len(ms),
+                     "bytes_per_launch": sum(b for _, _, b in evs) / len(evs)}
+    return out
+
+
+class _timed:
+    """Brackets one native launch with two events on the current (= launch) stream."""
+
+    def __init__(self, name: str, algo_bytes: int):
+        self.name, self.bytes = name, algo_bytes
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.e.record()
+            _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.bytes))
+        return False
+
+
 def _chk(t: torch.Tensor, name: str, dtype: torch.dtype) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a GPU tensor (libgps_hip has no CPU path)")
@@ -40,7 +82,7 @@ def gather_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     b, c, n = points.shape
     m = idx.shape[1]
     out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed("gather_points", 4 * (b * c * n + b * m + b * c * m)):
         st = _native.load().gps_gather_points(b, c, n, m, points.data_ptr(), idx.data_ptr(),
                                               out.data_ptr(), _stream())
     _native.check(st, "gather_points")
@@ -53,7 +95,7 @@ def gather_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -> tor
     _same_device(grad_out, idx)
     b, c, m = grad_out.shape
     out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with torch.cuda.device(grad_out.device), _timed("gather_points_grad", 4 * (b * c * m + b * m + b * c * int(n))):
         st = _native.load().gps_gather_points_grad(b, c, int(n), m, grad_out.data_ptr(),
                                                    idx.data_ptr(), out.data_ptr(), _stream())
     _native.check(st, "gather_points_grad")
@@ -68,7 +110,7 @@ def furthest_point_sampling(points: torch.Tensor, nsamples: int) -> torch.Tensor
     temp = None
     if n > 2048:  # GPS_FPS_MAX_RESIDENT_N: streaming form keeps running distances in HBM
         temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed(f"furthest_point_sampling(n={n},m={m})", 4 * (b * n * 3 + b * m)):
         st = _native.load().gps_furthest_point_sampling(
             b, n, m, points.data_ptr(), temp.data_ptr() if temp is not None else None,
             out.data_ptr(), _stream())
@@ -84,7 +126,7 @@ def three_nn(unknowns: torch.Tensor, knows: torch.Tensor):
     m = knows.shape[1]
     dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
-    with torch.cuda.device(unknowns.device):
+    with torch.cuda.device(unknowns.device), _timed("three_nn", 4 * (b * n * 3 + b * m * 3 + 2 * b * n * 3)):
         st = _native.load().gps_three_nn(b, n, m, unknowns.data_ptr(), knows.data_ptr(),
                                          dist2.data_ptr(), idx.data_ptr(), _stream())
     _native.check(st, "three_nn")
@@ -99,7 +141,7 @@ def three_interpolate(points: torch.Tensor, idx: torch.Tensor, weight: torch.Ten
     b, c, m = points.shape
     n = idx.shape[1]
     out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed("three_interpolate", 4 * (b * c * m + 2 * b * n * 3 + b * c * n)):
         st = _native.load().gps_three_interpolate(b, c, m, n, points.data_ptr(), idx.data_ptr(),
                                                   weight.data_ptr(), out.data_ptr(), _stream())
     _native.check(st, "three_interpolate")
@@ -114,7 +156,7 @@ def three_interpolate_grad(grad_out: torch.Tensor, idx: torch.Tensor, weight: to
     _same_device(grad_out, idx, weight)
     b, c, n = grad_out.shape
     out = torch.empty((b, c, int(m)), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with torch.cuda.device(grad_out.device), _timed("three_interpolate_grad", 4 * (b * c * n + 2 * b * n * 3 + b * c * int(m))):
         st = _native.load().gps_three_interpolate_grad(b, c, n, int(m), grad_out.data_ptr(),
                                                        idx.data_ptr(), weight.data_ptr(),
                                                        out.data_ptr(), _stream())
@@ -129,7 +171,7 @@ def ball_query(new_xyz: torch.Tensor, xyz: torch.Tensor, radius: float, nsample:
     b, m, _ = new_xyz.shape
     n = xyz.shape[1]
     idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
-    with torch.cuda.device(new_xyz.device):
+    with torch.cuda.device(new_xyz.device), _timed(f"ball_query(n={n},m={m},ns={int(nsample)})", 4 * (b * (n + m) * 3 + b * m * int(nsample))):
         st = _native.load().gps_ball_query(b, n, m, float(radius), int(nsample),
                                            new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
                                            _stream())
@@ -144,7 +186,7 @@ def group_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     b, c, n = points.shape
     _, npoints, nsample = idx.shape
     out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with torch.cuda.device(points.device), _timed(f"group_points(c={c},n={n},np={npoints},ns={nsample})", 4 * (b * c * n + b * npoints * nsample + b * c * npoints * nsample)):
         st = _native.load().gps_group_points(b, c, n, npoints, nsample, points.data_ptr(),
                                              idx.data_ptr(), out.data_ptr(), _stream())
     _native.check(st, "group_points")
@@ -157,7 +199,7 @@ def group_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -> torc
     _same_device(grad_out, idx)
     b, c, npoints, nsample = grad_out.shape
     out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with torch.cuda.device(grad_out.device), _timed(f"group_points_grad(c={c},n={int(n)},np={npoints},ns={nsample})", 4 * (b * c * npoints * nsample + b * npoints * nsample + b * c * int(n))):
         st = _native.load().gps_group_points_grad(b, c, int(n), npoints, nsample,
                                                   grad_out.data_ptr(), idx.data_ptr(),
                                                   out.data_ptr(), _stream())

@@ -17,13 +17,20 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+from torch.amp import custom_bwd, custom_fwd
 from torch.autograd import Function
 
 from . import _ext as _ext  # the nine native entry points (C ABI -> HIP)
 
+# The native ops are fp32-only (indices must be bit-exact; the reference asserts fp32 too,
+# include/utils.h:21-25).  Under torch.autocast(bf16) floating inputs are cast back to fp32.
+_fwd = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = custom_bwd(device_type="cuda")
+
 
 class FurthestPointSampling(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
         """xyz (B,N,3) f32 -> (B,npoint) i32 indices; idx[:,0] == 0."""
         inds = _ext.furthest_point_sampling(xyz, npoint)
@@ -40,6 +47,7 @@ furthest_point_sample = FurthestPointSampling.apply
 
 class GatherOperation(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         """features (B,C,N), idx (B,npoint) i32 -> (B,C,npoint)."""
         ctx.n_src = features.size(2)
@@ -47,6 +55,7 @@ class GatherOperation(Function):
         return _ext.gather_points(features, idx)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         return _ext.gather_points_grad(grad_out.contiguous(), ctx.idx, ctx.n_src), None
 
@@ -56,6 +65,7 @@ gather_operation = GatherOperation.apply
 
 class ThreeNN(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, unknown: torch.Tensor, known: torch.Tensor):
         """unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) L2 distances, idx (B,n,3) i32)."""
         dist2, idx = _ext.three_nn(unknown, known)
@@ -73,6 +83,7 @@ three_nn = ThreeNN.apply
 
 class ThreeInterpolate(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         """features (B,c,m), idx/weight (B,n,3) -> (B,c,n)."""
         ctx.m_src = features.size(2)
@@ -80,6 +91,7 @@ class ThreeInterpolate(Function):
         return _ext.three_interpolate(features, idx, weight)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         g = _ext.three_interpolate_grad(grad_out.contiguous(), ctx.idx, ctx.weight, ctx.m_src)
         return g, None, None
@@ -90,6 +102,7 @@ three_interpolate = ThreeInterpolate.apply
 
 class GroupingOperation(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         """features (B,C,N), idx (B,npoint,nsample) i32 -> (B,C,npoint,nsample)."""
         ctx.n_src = features.size(2)
@@ -97,6 +110,7 @@ class GroupingOperation(Function):
         return _ext.group_points(features, idx)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         return _ext.group_points_grad(grad_out.contiguous(), ctx.idx, ctx.n_src), None
 
@@ -106,6 +120,7 @@ grouping_operation = GroupingOperation.apply
 
 class BallQuery(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
         """xyz (B,N,3), new_xyz (B,npoint,3) -> (B,npoint,nsample) i32."""
         inds = _ext.ball_query(new_xyz, xyz, radius, nsample)
