@@ -1,0 +1,111 @@
+"""The whole GPS model on the MI355X (point ops through libgps_hip.so) against the golden outputs
+of the reference's Python (tests/golden/gps_reference_cpu.pt).
+
+Tolerances (stated per north_star "features/logits/loss within a stated fp tolerance"):
+  fp32 run   : |diff| <= 2e-3 + 2e-3*|ref| on embeddings/logits, 1e-3 relative on losses --
+               GPU GEMM/conv summation order vs CPU;
+  bf16 run   : og3d logits within 0.15 absolute (|logits| ~ 5), losses within 3 % -- bf16
+               autocast of every Linear; FPS/ball-query indices are fp32 and stay bit-exact."""
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle.param_fill import fill_params
+from sceneverse_amd.common.config import ConfigNode
+from sceneverse_amd.model.build import MODEL_REGISTRY, build_model
+from sceneverse_amd.optim.loss import Loss
+from sceneverse_amd.optim.loss.loss import obj_cls_loss
+from util import clone_batch, gps_cfg, lang_dir
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(fx, **kw):
+    model = build_model(gps_cfg(lang_dir(fx["seed"]), **kw))
+    fill_params(model, fx["seed"])
+    return model.to(DEV)
+
+
+def test_gps_pretrain_fp32_matches_reference(golden_cpu):
+    fx, g = golden_cpu, golden_cpu["gps_pretrain"]
+    model = _model(fx).eval()
+    loss_mod = Loss(model.cfg).to(DEV)
+    out = model(clone_batch(fx["batch"], DEV))
+    total, losses = loss_mod(out)
+    total.backward()
+    for k in ("og3d_logits", "intra_text_embed", "intra_obj_embeds", "inter_obj_embeds", "scene_embed",
+              "scene_text_embed", "obj_cls_post_logits"):
+        torch.testing.assert_close(out[k].detach().cpu(), g[k], rtol=2e-3, atol=2e-3,
+                                   msg=lambda m, k=k: f"{k}: {m}")
+    for k, v in g["losses"].items():
+        assert abs(losses[k].item() - v) < 1e-3 * max(1.0, abs(v)), (k, losses[k].item(), v)
+    params = dict(model.named_parameters())
+    for name, ref in g["grads"].items():
+        gn = params[name].grad.norm().item()
+        assert abs(gn - ref["norm"]) <= 1e-2 * ref["norm"] + 1e-7, (name, gn, ref["norm"])
+
+
+def test_gps_pretrain_bf16_autocast(golden_cpu):
+    fx, g = golden_cpu, golden_cpu["gps_pretrain"]
+    model = _model(fx).eval()
+    loss_mod = Loss(model.cfg).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(clone_batch(fx["batch"], DEV))
+        _, losses = loss_mod(out)
+    masks = fx["batch"]["obj_masks"]
+    diff = (out["og3d_logits"].float().cpu() - g["og3d_logits"])[masks].abs().max().item()
+    assert diff < 0.15, diff
+    for k, v in g["losses"].items():
+        assert abs(losses[k].item() - v) < 3e-2 * max(1.0, abs(v)), (k, losses[k].item(), v)
+
+
+def test_grounding_finetune_argmax_agrees(golden_cpu):
+    fx, g = golden_cpu, golden_cpu["gps_ground"]
+    model = _model(fx, heads="ground", use_scene_cap=False).eval()
+    with torch.no_grad():
+        out = model(clone_batch(fx["batch"], DEV))
+    torch.testing.assert_close(out["og3d_logits"].cpu(), g["og3d_logits"], rtol=2e-3, atol=2e-3)
+    assert torch.equal(out["og3d_logits"].argmax(-1).cpu(), g["pred"])      # acc@k decisions
+
+
+def test_objcls_train_step_fp32(golden_cpu):
+    g = golden_cpu["objcls"]
+    cfg = ConfigNode({"num_gpu": 1, "solver": {"lr": 1e-3},
+                      "model": {"name": "ObjCls", "model_name": "pointnet++", "language_type": "bert",
+                                "open_vocab": False, "num_classes": 607, "cls_hidden": 1024}})
+    model = MODEL_REGISTRY.get("ObjCls")(cfg).train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    fill_params(model, golden_cpu["seed"])
+    model = model.to(DEV)
+    out = model(clone_batch(g["batch"], DEV))
+    loss = obj_cls_loss(out)
+    loss.backward()
+    torch.testing.assert_close(out["obj_logits"].detach().cpu(), g["obj_logits"], rtol=2e-3, atol=2e-3)
+    assert abs(loss.item() - g["loss"]) < 1e-3
+    params = dict(model.named_parameters())
+    for name, ref in g["grads"].items():
+        torch.testing.assert_close(params[name].grad.cpu(), ref, rtol=2e-2,
+                                   atol=1e-5 + 2e-3 * ref.abs().max().item(),
+                                   msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_train_step_engine_runs_and_learns():
+    from bench import gps_pretrain_cfg, _lang_dir
+    from sceneverse_amd.data.synthetic import synth_batch
+    from sceneverse_amd.engine import GPSTrainStep
+    step = GPSTrainStep(gps_pretrain_cfg(_lang_dir()), device=DEV, ddp=False)
+    for g in step.optimizer.param_groups:      # skip the 500-step warm-up for this check
+        g["lr"] = g["initial_lr"] = 1e-4
+    step.scheduler.base_lrs = [1e-4 for _ in step.scheduler.base_lrs]
+    step.scheduler.lr_lambdas = [lambda s: 1.0 for _ in step.scheduler.lr_lambdas]
+    batch = synth_batch(4, n_obj=16, seed=3, min_real=5, device=DEV)
+    first = None
+    for i in range(8):
+        loss, _ = step.step(dict(batch))
+        if i == 0:
+            first = loss.item()
+    last = loss.item()
+    assert last == last and last < first, (first, last)

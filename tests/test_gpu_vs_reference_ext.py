@@ -8,6 +8,7 @@ from oracle import build_ref
 from oracle.pointnet2_oracle import OracleExt
 from point_cases import BQ_SHAPES, FPS_SHAPES, generic_cloud, sa1_cloud
 from sceneverse_amd.pointnet2 import _ext as hip
+from util import fps_divergence_is_rounding_tie
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(build_ref.built_path() is None, reason="oracle/_ref not built")]
@@ -22,9 +23,14 @@ def ref():
 def test_sa_chain_three_way(ref):
     x = sa1_cloud()
     xd = x.to(DEV)
-    f_ref, f_hip, f_cpu = ref.furthest_point_sampling(xd, 32), hip.furthest_point_sampling(xd, 32), \
+    f_ref, f_hip, f_cpu = ref.furthest_point_sampling(xd, 32).cpu(), hip.furthest_point_sampling(xd, 32).cpu(), \
         OracleExt.furthest_point_sampling(x, 32)
-    assert torch.equal(f_ref.cpu(), f_cpu) and torch.equal(f_hip.cpu(), f_cpu)
+    assert torch.equal(f_hip, f_cpu)
+    # the hipcc-built reference contracts its distance into FMAs: on the exact-tie lattice object
+    # it may resolve a <= 2 ulp tie differently from the pinned arithmetic
+    diverged = [i for i in range(x.shape[0]) if not torch.equal(f_ref[i], f_cpu[i])]
+    assert len(diverged) <= 1 and all(fps_divergence_is_rounding_tie(x[i], f_cpu[i], f_ref[i]) for i in diverged)
+    f_hip = f_hip.to(DEV)
     new_xyz = hip.gather_points(xd.transpose(1, 2).contiguous(), f_hip).transpose(1, 2).contiguous()
     i_ref, i_hip = ref.ball_query(new_xyz, xd, 0.2, 32), hip.ball_query(new_xyz, xd, 0.2, 32)
     assert torch.equal(i_ref, i_hip)

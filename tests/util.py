@@ -2,6 +2,7 @@
 import os
 import tempfile
 
+import numpy as np
 import torch
 
 from sceneverse_amd.common.config import ConfigNode
@@ -80,3 +81,21 @@ class use_oracle_ext:
 
 def clone_batch(batch, device="cpu"):
     return {k: (v.clone().to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def _ulp_diff(a, b):
+    return abs(int(np.float32(a).view(np.int32)) - int(np.float32(b).view(np.int32)))
+
+
+def fps_divergence_is_rounding_tie(cloud, mine, theirs):
+    """First round where two FPS index sequences differ: replay the pinned (individually rounded)
+    running distances up to there and check that both candidates are within 2 ulp -- i.e. the
+    disagreement is an FMA-contraction artefact on a geometrically exact tie."""
+    j = int((mine != theirs).nonzero()[0])
+    p = cloud.cpu().numpy()
+    temp = np.full(p.shape[0], 1e10, dtype=np.float32)
+    for old in mine[:j].tolist():
+        d = p - p[old]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        temp = np.minimum(temp, d2)
+    return _ulp_diff(temp[int(mine[j])], temp[int(theirs[j])]) <= 2

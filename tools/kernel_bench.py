@@ -1,0 +1,99 @@
+"""Per-kernel timing of libgps_hip.so at the GPS workload shapes (B=64 scenes x 80 objects),
+with the reference's own kernels (oracle/_ref, if built) timed beside them for context.
+Prints one line per op: avg us, algorithmic GB/s, fraction of the 8 TB/s HBM roofline."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from sceneverse_amd.data.synthetic import synth_batch  # noqa: E402
+from sceneverse_amd.pointnet2 import _ext as hip  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    dev = "cuda"
+    d = synth_batch(args.batch, seed=42)
+    pcs = d["obj_fts"].reshape(-1, 1024, 6).to(dev)
+    xyz = pcs[..., :3].contiguous()
+    rgb = pcs[..., 3:].transpose(1, 2).contiguous()
+    b = xyz.shape[0]
+    ref = None
+    try:
+        from oracle import build_ref
+        if build_ref.built_path():
+            ref = build_ref.load_ext()
+    except Exception as ex:  # noqa: BLE001
+        print("reference ext unavailable:", ex)
+
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    fps = hip.furthest_point_sampling(xyz, 32)
+    new_xyz = hip.gather_points(xyz_t, fps).transpose(1, 2).contiguous()
+    idx = hip.ball_query(new_xyz, xyz, 0.2, 32)
+    fps2 = hip.furthest_point_sampling(new_xyz, 16)
+    nx2 = hip.gather_points(new_xyz.transpose(1, 2).contiguous(), fps2).transpose(1, 2).contiguous()
+    idx2 = hip.ball_query(nx2, new_xyz, 0.4, 32)
+    feats = torch.randn(b, 128, 32, device=dev)
+    gout = torch.randn(b, 128, 16, 32, device=dev)
+    nx_t = new_xyz.transpose(1, 2).contiguous()
+
+    ops = [
+        ("fps SA1 (n=1024,m=32)", lambda m: m.furthest_point_sampling(xyz, 32), b * (1024 * 12 + 32 * 4)),
+        ("fps SA2 (n=32,m=16)", lambda m: m.furthest_point_sampling(new_xyz, 16), b * (32 * 12 + 16 * 4)),
+        ("gather SA1 (c=3)", lambda m: m.gather_points(xyz_t, fps), b * (3 * 1024 * 4 + 32 * 4 + 3 * 32 * 4)),
+        ("ball_query SA1", lambda m: m.ball_query(new_xyz, xyz, 0.2, 32), b * ((1024 + 32) * 12 + 32 * 32 * 4)),
+        ("ball_query SA2", lambda m: m.ball_query(nx2, new_xyz, 0.4, 32), b * ((32 + 16) * 12 + 16 * 32 * 4)),
+        ("group SA1 xyz (c=3,n=1024)", lambda m: m.group_points(xyz_t, idx), b * (3 * 1024 * 4 + 1024 * 4 + 3 * 1024 * 4)),
+        ("group SA1 rgb (c=3,n=1024)", lambda m: m.group_points(rgb, idx), b * (3 * 1024 * 4 + 1024 * 4 + 3 * 1024 * 4)),
+        ("group SA2 xyz (c=3,n=32)", lambda m: m.group_points(nx_t, idx2), b * (3 * 32 * 4 + 512 * 4 + 3 * 512 * 4)),
+        ("group SA2 feats (c=128,n=32)", lambda m: m.group_points(feats, idx2), b * (128 * 32 * 4 + 512 * 4 + 128 * 512 * 4)),
+        ("group_grad SA2 feats", lambda m: m.group_points_grad(gout, idx2, 32), b * (128 * 512 * 4 + 512 * 4 + 128 * 32 * 4)),
+    ]
+    rows = []
+    total_bq_group_us = 0.0
+    total_bq_group_bytes = 0
+    for name, fn, nbytes in ops:
+        us = timeit(lambda: fn(hip))
+        row = {"op": name, "us": round(us, 2), "algorithmic_bytes": nbytes,
+               "GBps": round(nbytes / us / 1e3, 1), "frac_8TBps": round(nbytes / us / 1e3 / 8000, 4)}
+        if ref is not None:
+            row["reference_kernel_us"] = round(timeit(lambda: fn(ref)), 2)
+        rows.append(row)
+        if name.startswith(("ball_query", "group SA")):
+            total_bq_group_us += us
+            total_bq_group_bytes += nbytes
+        print(row, flush=True)
+    agg = {"op": "ball_query+group (SA1+SA2, 6 launches)", "us": round(total_bq_group_us, 2),
+           "algorithmic_bytes": total_bq_group_bytes,
+           "GBps": round(total_bq_group_bytes / total_bq_group_us / 1e3, 1),
+           "frac_8TBps": round(total_bq_group_bytes / total_bq_group_us / 1e3 / 8000, 4)}
+    print(agg)
+    rows.append(agg)
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump({"batch": args.batch, "objects": b, "rows": rows}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
