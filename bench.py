@@ -86,7 +86,11 @@ def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
     from sceneverse_amd.data.synthetic import synth_batch
     from transformers import BertConfig, BertModel
 
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("GPS_CPU_BASELINE_THREADS", "64"))))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     # parameter container with the reference's names, built from shapes only (no product forward)
@@ -124,8 +128,13 @@ def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
 
     one_step()  # warm-up
     t0 = time.perf_counter()
-    for _ in range(steps):
+    done = 0
+    for _ in range(steps):     # bounded sample: stop early once ~30 s of CPU work are spent
         one_step()
+        done += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    steps = done
     dt = time.perf_counter() - t0
     return {"value": batch_size * steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps of the same fwd+loss+bwd+AdamW step at B={batch_size} "

@@ -1,0 +1,143 @@
+"""The N>1 path on CPU: two processes, `gloo` backend, world_size 2 (the GPU path is the same code
+with backend "nccl" = RCCL).  Checks, on a down-sized GPS configuration (same model classes, fewer
+layers/objects so two replicas fit the CPU suite's time budget):
+
+  * `dist_utils.all_gather` returns rank-ordered concatenations without autograd history
+    (reference common/dist_utils.py:131-149);
+  * `TextSceneBetweenBatch` sees world_size x B rows when cfg.num_gpu > 1;
+  * after DDP steps on DIFFERENT per-rank shards the replicas hold identical parameters, and the
+    gradient DDP leaves on each rank is the mean of the two single-process gradients;
+  * the 13 never-used trainable tensors do not deadlock the reducer (find_unused_parameters).
+
+Point ops are routed to the CPU oracle (tests only): libgps_hip.so has no CPU path by design.
+"""
+import os
+import socket
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _small_cfg(lang_path, num_gpu, between_batch=True):
+    from util import gps_cfg
+    cfg = gps_cfg(lang_path, num_gpu=num_gpu)
+    if not between_batch:       # per-sample losses only: DDP gradient == mean of shard gradients
+        cfg.model.loss_list = ["lm_cls_loss", "TextObjWithinBatch"]
+        cfg.model.vis_loss_list = list(cfg.model.loss_list)
+    cfg.model.language.args.num_hidden_layers = 1
+    cfg.model.vision.args.num_layers = 1
+    cfg.model.grounding.args.num_layers = 1
+    cfg.solver["grad_norm"] = 5.0
+    return cfg
+
+
+def _worker(rank, world, port, tmp):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from util import lang_dir, use_oracle_ext
+    from sceneverse_amd.common import dist_utils
+    from sceneverse_amd.data.synthetic import synth_batch
+    from sceneverse_amd.engine import GPSTrainStep
+
+    r, w, _ = dist_utils.init_from_env("gloo")
+    assert (r, w) == (rank, world) and dist_utils.get_world_size() == world
+    result = {}
+
+    # -- all_gather helper: rank order, no autograd history
+    t = torch.full((2, 3), float(rank), requires_grad=True)
+    (g,) = dist_utils.all_gather([t])
+    result["gather_ok"] = bool(g.shape == (2 * world, 3) and not g.requires_grad and
+                               all(float(g[2 * i, 0]) == i for i in range(world)))
+
+    lp = lang_dir(0)
+    with use_oracle_ext():
+        # single-process gradients of BOTH shards, same initial weights (seeded inside GPSTrainStep)
+        solo = GPSTrainStep(_small_cfg(lp, world, between_batch=False), device="cpu", ddp=False, seed=5)
+        shards = [synth_batch(2, n_obj=6, n_pts=1024, scene_txt_len=40, seed=100 + i, min_real=3)
+                  for i in range(world)]
+        solo.net.eval()                       # dropout off: gradients must be comparable
+        grads = []
+        for b in shards:
+            solo.model.zero_grad(set_to_none=True)
+            _, total, _ = solo.forward_loss(dict(b, cur_step=0, total_steps=10))
+            total.backward()
+            grads.append({n: p.grad.clone() for n, p in solo.model.named_parameters()
+                          if p.grad is not None})
+
+        ddp = GPSTrainStep(_small_cfg(lp, world, between_batch=False), device="cpu", ddp=True, seed=5)
+        ddp.net.eval()
+        ddp.model.zero_grad(set_to_none=True)
+        out, total, losses = ddp.forward_loss(dict(shards[rank], cur_step=0, total_steps=10))
+        total.backward()
+        worst = 0.0
+        for n, p in ddp.model.named_parameters():
+            if p.grad is None or n not in grads[0]:
+                continue
+            want = sum(g[n] for g in grads) / world
+            denom = want.abs().max().item() + 1e-12
+            worst = max(worst, (p.grad - want).abs().max().item() / denom)
+        result["grad_mean_rel_err"] = worst
+        result["n_unused"] = sum(1 for p in ddp.model.parameters() if p.requires_grad and p.grad is None)
+
+        # -- the between-batch contrastive loss sees world x B rows (features of the other rank
+        #    arrive through all_gather, without gradient)
+        from sceneverse_amd.optim.loss.contra_loss import TextSceneBetweenBatch, _symmetric_clip_loss
+        import torch.nn.functional as F
+        crit = TextSceneBetweenBatch(_small_cfg(lp, world))
+        feats = {"scene_embed": out["scene_embed"].detach(), "scene_text_embed": out["scene_text_embed"].detach()}
+        got = crit(feats)
+        sc = [torch.empty_like(feats["scene_embed"]) for _ in range(world)]
+        tx = [torch.empty_like(feats["scene_text_embed"]) for _ in range(world)]
+        dist.all_gather(sc, feats["scene_embed"].contiguous())
+        dist.all_gather(tx, feats["scene_text_embed"].contiguous())
+        want = _symmetric_clip_loss(F.normalize(torch.cat(tx), dim=-1), F.normalize(torch.cat(sc), dim=-1),
+                                    torch.clamp(crit.logit_scale, max=100))
+        result["between_batch_err"] = abs(float(got) - float(want))
+
+        # -- two optimisation steps (full loss list) on different shards keep the replicas identical
+        ddp = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=True, seed=5)
+        for i in range(2):
+            ddp.step(dict(synth_batch(2, n_obj=6, n_pts=1024, scene_txt_len=40,
+                                      seed=200 + 10 * i + rank, min_real=3)))
+        flat = torch.cat([p.detach().flatten()[:64] for p in ddp.model.parameters()])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        result["replicas_equal"] = bool(torch.equal(both[0], both[1]))
+        result["loss_finite"] = bool(torch.isfinite(total).item())
+    torch.save(result, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_world_size_2_gloo():
+    world = 2
+    tmp = tempfile.mkdtemp()
+    mp.spawn(_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+    for rank in range(world):
+        r = torch.load(os.path.join(tmp, f"rank{rank}.pt"))
+        assert r["gather_ok"], r
+        assert r["replicas_equal"], r
+        assert r["loss_finite"], r
+        assert r["grad_mean_rel_err"] < 1e-4, r
+        assert r["between_batch_err"] < 1e-6, r
+        assert r["n_unused"] >= 13, r
