@@ -111,6 +111,40 @@ GPS_API int gps_three_interpolate_grad(int b, int c, int n, int m, const float *
                                const int32_t *idx, const float *weight, float *grad_points,
                                gps_stream_t stream);
 
+/* ---- fused set-abstraction level (frozen encoder) --------------------------------------------
+ * Additions to the nine reference entry points: one launch for what the reference runs as
+ * QueryAndGroup's gathers + `-=` + `cat` (modules/third_party/pointnet2/pointnet2_utils.py:345-356),
+ * SharedMLP's 3 x (conv1x1 no-bias, BatchNorm2d in eval mode, ReLU) (pytorch_utils.py:11-36) and
+ * max_pool2d over nsample (pointnet2_modules.py:65-71).  Valid when the encoder is frozen (BN on
+ * running statistics, no gradient) -- pcd_openvocab_encoder.py:54-57,121-129, 35 of 37 configs.
+ * The caller folds BN into the conv: w' = diag(gamma / sqrt(var + eps)) w,
+ * shift = beta - mean * gamma / sqrt(var + eps), and packs each layer once with
+ * gps_sa_mlp_pack_layer into one buffer [layer 1 | layer 2 | layer 3].
+ * Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), i.e. fp32 products and sums like the
+ * reference's fp32 conv, in a different summation order (tolerance stated in the tests). */
+
+/* floats of the packed weight buffer of an MLP c_in -> c1 -> c2 -> c3 (-1: unsupported widths;
+ * c1, c2, c3 must be multiples of 32). */
+GPS_API long long gps_sa_mlp_wpack_floats(int c_in, int c1, int c2, int c3);
+
+/* floats of one packed layer c_in -> c_out (-1 unless c_out is a multiple of 32). */
+GPS_API long long gps_sa_mlp_layer_floats(int c_in, int c_out);
+
+/* Pack one layer.  w (c_out, c_in) row-major, BN-folded; shift (c_out); dst = the layer's slice of
+ * the packed buffer ((c_out/32) * tile floats, see gps_sa_mlp_wpack_floats).  Device pointers. */
+GPS_API int gps_sa_mlp_pack_layer(int c_in, int c_out, const float *w, const float *shift, float *dst,
+                                  gps_stream_t stream);
+
+/* xyz (b,n,3), new_xyz (b,npoint,3), features (b,c_feat,n), idx (b,npoint,nsample) from
+ * gps_ball_query  ->  out (b,c3,npoint) = max_k relu(mlp([xyz[idx]-new_xyz ; features[idx]])).
+ * Implemented shapes: nsample == 32 and (c_feat,c1,c2,c3) in {(3,64,64,128), (128,128,128,256)}
+ * (the GPS encoder, modules/layers/pointnet.py:22-63); anything else returns GPS_ERR_UNSUPPORTED
+ * and the host mirror runs the level unfused. */
+GPS_API int gps_sa_mlp_forward(int b, int n, int npoint, int nsample, int c_feat, int c1, int c2, int c3,
+                               const float *xyz, const float *new_xyz, const float *features,
+                               const int32_t *idx, const float *wpack, float *out,
+                               gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

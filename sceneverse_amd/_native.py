@@ -33,6 +33,8 @@ SIGNATURES = {
     "gps_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gps_sa_mlp_pack_layer": [_i, _i, _vp, _vp, _vp, _vp],
+    "gps_sa_mlp_forward": [_i] * 8 + [_vp] * 7,
 }
 
 
@@ -65,6 +67,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_error_string.restype = ctypes.c_char_p
     lib.gps_error_string.argtypes = [_i]
     lib.gps_last_hip_error.restype = ctypes.c_char_p
+    lib.gps_sa_mlp_wpack_floats.restype = ctypes.c_longlong
+    lib.gps_sa_mlp_wpack_floats.argtypes = [_i, _i, _i, _i]
+    lib.gps_sa_mlp_layer_floats.restype = ctypes.c_longlong
+    lib.gps_sa_mlp_layer_floats.argtypes = [_i, _i]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -14,6 +14,7 @@ LIB = os.path.join(HERE, "libgps_hip.so")
 # the transformer kernels want FMA contraction and are compiled separately.
 SOURCES = [
     ("gps_point_ops.hip", ["-ffp-contract=off"]),
+    ("gps_sa_mlp.hip", []),
     ("gps_attention.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",

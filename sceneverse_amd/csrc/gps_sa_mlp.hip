@@ -1,0 +1,354 @@
+// gps_sa_mlp.hip -- fused set-abstraction level for a FROZEN PointNet++ encoder on MI355X (gfx950).
+//
+// One launch replaces, for one SA level of the reference
+//   modules/third_party/pointnet2/pointnet2_utils.py:345-356   group xyz, subtract centre, group feats, cat
+//   modules/third_party/pointnet2/pytorch_utils.py:11-36       SharedMLP = 3 x (conv1x1 no-bias, BN, ReLU)
+//   modules/third_party/pointnet2/pointnet2_modules.py:65-71   max_pool2d over nsample
+// i.e. 2 group_points launches, `-=`, `cat`, 3 x (GEMM, batch-norm, ReLU) and a max-pool -- about
+// half of the GPS training step in the first rocprof trace (profiles/r1/bench_b_kernel_stats.csv).
+// In 35 of the reference's 37 configs the encoder is frozen: BN runs on its running statistics and
+// nothing needs a gradient, so conv+BN folds into W' = diag(gamma/sqrt(var+eps)) W and a shift.
+//
+// Design (CDNA4):
+//   * one 256-thread workgroup per object; the object's points/features/indices are staged once in
+//     LDS (coalesced 16-byte loads), so the grouped (3+C, npoint, nsample) tensor -- 268 KB per
+//     object at SA2, the largest HBM stream of the point path -- never exists in HBM;
+//   * a wave owns one group = one 32-column tile (nsample == 32) through ALL three layers.  Layers
+//     run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bitwise an fmaf chain, so results
+//     stay within fp32 summation-order noise of the reference's fp32 conv).  The D fragment of one
+//     layer (lane = column, registers = rows) IS the B fragment of the next layer's MFMAs once the
+//     K index is permuted to the D row order -- the permutation is applied to the packed weights
+//     instead, so activations never leave the VGPRs between layers;
+//   * weights stream through LDS one 32-row output tile at a time (double buffered, one barrier per
+//     tile); folded BN shift initialises the accumulator, ReLU is one v_max per register;
+//   * max over the 32 samples = DPP row reduction + row_bcast15; pooled rows are collected in LDS
+//     and written with coalesced stores.
+//
+// K-slot order.  For v_mfma_f32_32x32x2_f32 lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
+// and D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] in register r.  Input channels are therefore
+// consumed in "slots" (it, r): the step for slot (it, r) multiplies channel it*32 + (r&3) + 8*(r>>2)
+// (lanes 0-31) and that + 4 (lanes 32-63).  gps_sa_mlp_pack_layer() writes the weights in that
+// order, zero where the channel is >= c_in.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gps_hip.h"
+
+namespace gps_sa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBlock = 256;
+constexpr int kWaves = 4;
+constexpr int kNS = 32;  // samples per group == MFMA N
+
+__host__ __device__ constexpr int slot_channel(int it, int r, int h) {
+  return it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+// number of K steps of a layer with c_in input channels (slots whose lower channel exists)
+__host__ __device__ constexpr int layer_steps(int c_in) {
+  int s = 0;
+  for (int it = 0; it < (c_in + 31) / 32; ++it)
+    for (int r = 0; r < 16; ++r)
+      if (slot_channel(it, r, 0) < c_in) ++s;
+  return s;
+}
+// floats of one packed 32-row output tile: steps x 64 weights + 32 shifts, padded to whole
+// 1 KiB pieces (one global_load_lds_dwordx4 wave-instruction each)
+__host__ __device__ constexpr int tile_floats(int c_in) {
+  return (layer_steps(c_in) * 64 + 32 + 255) / 256 * 256;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: w (c_out, c_in) row-major (already BN-folded), shift (c_out) ->
+//   dst[mt][step][h*32 + i] = w[mt*32 + i][channel(step, h)]   (0 beyond c_in)
+//   dst[mt][steps*64 + i]   = shift[mt*32 + i]
+// ------------------------------------------------------------------------------------------
+__global__ void pack_layer_kernel(int c_in, int c_out, const float *__restrict__ w,
+                                  const float *__restrict__ shift, float *__restrict__ dst) {
+  const int steps = layer_steps(c_in);
+  const int tf = tile_floats(c_in);
+  const int total = (c_out / 32) * tf;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int mt = e / tf, o = e - mt * tf;
+    if (o >= steps * 64) {
+      dst[e] = o < steps * 64 + 32 ? shift[mt * 32 + (o - steps * 64)] : 0.f;
+      continue;
+    }
+    const int s = o >> 6, h = (o >> 5) & 1, i = o & 31;
+    // s-th valid slot
+    int it = 0, r = 0, cnt = 0;
+    for (int a = 0; a < (c_in + 31) / 32; ++a)
+      for (int q = 0; q < 16; ++q)
+        if (slot_channel(a, q, 0) < c_in) {
+          if (cnt == s) { it = a; r = q; }
+          ++cnt;
+        }
+    const int k = slot_channel(it, r, h);
+    dst[e] = k < c_in ? w[(size_t)(mt * 32 + i) * c_in + k] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_f32(float v) {
+  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK,
+                                            0xf, false);
+  return fmaxf(v, __int_as_float(o));
+}
+// max over lanes 0-31 -> lane 31, over lanes 32-63 -> lane 63
+__device__ __forceinline__ float half_wave_max(float v) {
+  v = dpp_max_f32<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_max_f32<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_max_f32<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_max_f32<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each 16-lane row = row max
+  v = dpp_max_f32<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63
+  return v;
+}
+
+// One 32-row output tile: acc = shift; acc += sum_s A[s] (LDS) x B[s] (registers).
+template <int STEPS>
+__device__ __forceinline__ f32x16 mfma_tile(const float *__restrict__ tile, const float (&B)[STEPS],
+                                            int lane) {
+  f32x16 acc;
+  const float *sh = tile + STEPS * 64 + 4 * (lane >> 5);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = sh[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[s * 64 + lane], B[s], acc, 0, 0, 0);
+  return acc;
+}
+
+// Cooperative asynchronous copy of one packed tile (len floats, a multiple of 256) from global
+// memory straight into LDS: each wave-instruction moves 1 KiB (64 lanes x 16 B) to
+// wave-uniform base + lane * 16, no VGPRs held while the MFMAs run.  Completion = the issuing
+// wave's vmcnt(0), then the workgroup barrier.
+__device__ __forceinline__ void tile_copy_async(const float *__restrict__ src, float *dst, int len,
+                                                int wave, int lane) {
+  for (int c = wave; c * 256 < len; c += kWaves)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(src + c * 256 + lane * 4),
+        (__attribute__((address_space(3))) void *)(dst + c * 256), 16, 0, 0);
+}
+__device__ __forceinline__ void tile_copy_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------
+// fused SA level: ball-query indices in, pooled features out.
+//   xyz (b,n,3), new_xyz (b,npoint,3), feats (b,CF,n), idx (b,npoint,32) -> out (b,C3,npoint)
+//   wpack = [layer 1 tiles | layer 2 tiles | layer 3 tiles]
+// ------------------------------------------------------------------------------------------
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(kBlock, 2) void sa_mlp_kernel(
+    int b, int n, int npoint, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int32_t *__restrict__ idx,
+    const float *__restrict__ wpack, float *__restrict__ out) {
+  constexpr int CIN = 3 + CF;
+  constexpr int S1 = layer_steps(CIN), S2 = C1 / 2, S3 = C2 / 2;
+  constexpr int T1 = tile_floats(CIN), T2 = tile_floats(C1), T3 = tile_floats(C2);
+  constexpr int M1 = C1 / 32, M2 = C2 / 32, M3 = C3 / 32;
+  constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+  constexpr int G = M1 + M2 + M3;            // weight tiles (stages) per round
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *s_w0 = lds;                         // TMAX
+  float *s_w1 = s_w0 + TMAX;                 // TMAX
+  float *s_out = s_w1 + TMAX;                // C3 * npoint
+  float *s_feat = s_out + C3 * npoint;       // CF * n   (channel-major, as in HBM)
+  float *s_xyz = s_feat + CF * n;            // n * 3
+  float *s_ctr = s_xyz + n * 3;              // npoint * 3
+  int32_t *s_idx = reinterpret_cast<int32_t *>(s_ctr + npoint * 3);  // npoint * 32
+
+  const int obj = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+
+  // ---- stage the object ------------------------------------------------------------------
+  {
+    const float *gf = feats + (size_t)obj * CF * n;
+    const float *gx = xyz + (size_t)obj * n * 3;
+    const float *gc = new_xyz + (size_t)obj * npoint * 3;
+    const int32_t *gi = idx + (size_t)obj * npoint * kNS;
+    if (((CF * n) & 3) == 0) {
+      const float4 *g4 = reinterpret_cast<const float4 *>(gf);
+      float4 *l4 = reinterpret_cast<float4 *>(s_feat);
+      for (int e = tid; e < (CF * n) >> 2; e += kBlock) l4[e] = g4[e];
+    } else {
+      for (int e = tid; e < CF * n; e += kBlock) s_feat[e] = gf[e];
+    }
+    for (int e = tid; e < n * 3; e += kBlock) s_xyz[e] = gx[e];
+    for (int e = tid; e < npoint * 3; e += kBlock) s_ctr[e] = gc[e];
+    for (int e = tid; e < npoint * kNS; e += kBlock) s_idx[e] = gi[e];
+  }
+  tile_copy_async(wpack, s_w0, T1, wave, lane);
+  tile_copy_wait();
+  __syncthreads();
+
+  auto tile_src = [&](int g, int &len) -> const float * {  // packed tile of stage g (mod G)
+    if (g >= G) g -= G;
+    if (g < M1) { len = T1; return wpack + (size_t)g * T1; }
+    if (g < M1 + M2) { len = T2; return wpack + (size_t)M1 * T1 + (size_t)(g - M1) * T2; }
+    len = T3;
+    return wpack + (size_t)M1 * T1 + (size_t)M2 * T2 + (size_t)(g - M1 - M2) * T3;
+  };
+
+  const int rounds = (npoint + kWaves - 1) / kWaves;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int tile = rd * kWaves + wave;
+    const bool live = tile < npoint;
+    const int j = live ? tile : npoint - 1;
+
+    // ---- layer-1 B operand: X0[channel][sample] gathered from LDS ------------------------
+    float a0[S1];
+    {
+      const int p = s_idx[j * kNS + col];
+      int s = 0;
+#pragma unroll
+      for (int it = 0; it < (CIN + 31) / 32; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (slot_channel(it, r, 0) < CIN) {
+            const int k = slot_channel(it, r, h);          // this lane's channel of the slot
+            float v = 0.f;
+            if (slot_channel(it, r, 1) < 3) {              // both halves are xyz rows
+              v = s_xyz[p * 3 + k] - s_ctr[j * 3 + k];
+            } else if (slot_channel(it, r, 0) >= 3 && slot_channel(it, r, 1) < CIN) {
+              v = s_feat[(k - 3) * n + p];                 // both halves are feature rows
+            } else {                                       // mixed slot: decide per lane
+              if (k < 3) v = s_xyz[p * 3 + k] - s_ctr[j * 3 + k];
+              else if (k < CIN) v = s_feat[(k - 3) * n + p];
+            }
+            a0[s++] = v;
+          }
+    }
+
+    float a1[M1 * 16], a2[M2 * 16];
+    // g = stage within the round; gg = running stage count.  Tile gg sits in buffer gg & 1 and the
+    // next tile is prefetched into the other one (G may be odd, so the parity carries over rounds).
+    int g = 0;
+    // ---- layer 1 ----------------------------------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < M1; ++mt, ++g) {
+      const int gg = rd * G + g;
+      int len;
+      const float *src = tile_src(g + 1, len);
+      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
+      const f32x16 acc = mfma_tile<S1>((gg & 1) ? s_w1 : s_w0, a0, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[mt * 16 + r] = fmaxf(acc[r], 0.f);
+      tile_copy_wait();
+      __syncthreads();
+    }
+    // ---- layer 2 ----------------------------------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < M2; ++mt, ++g) {
+      const int gg = rd * G + g;
+      int len;
+      const float *src = tile_src(g + 1, len);
+      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
+      const f32x16 acc = mfma_tile<S2>((gg & 1) ? s_w1 : s_w0, a1, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[mt * 16 + r] = fmaxf(acc[r], 0.f);
+      tile_copy_wait();
+      __syncthreads();
+    }
+    // ---- layer 3 + max over the 32 samples ---------------------------------------------------
+    for (int mt = 0; mt < M3; ++mt, ++g) {
+      const int gg = rd * G + g;
+      int len;
+      const float *src = tile_src(g + 1, len);
+      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
+      const f32x16 acc = mfma_tile<S3>((gg & 1) ? s_w1 : s_w0, a2, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m = half_wave_max(acc[r]);
+        if (col == 31 && live)
+          s_out[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * npoint + tile] = fmaxf(m, 0.f);
+      }
+      tile_copy_wait();
+      __syncthreads();
+    }
+  }
+  // ---- pooled features out, coalesced -----------------------------------------------------------
+  float *go = out + (size_t)obj * C3 * npoint;
+  const int total = C3 * npoint;
+  if ((total & 3) == 0) {
+    const float4 *l4 = reinterpret_cast<const float4 *>(s_out);
+    float4 *g4 = reinterpret_cast<float4 *>(go);
+    for (int e = tid; e < total >> 2; e += kBlock) g4[e] = l4[e];
+  } else {
+    for (int e = tid; e < total; e += kBlock) go[e] = s_out[e];
+  }
+}
+
+template <int CF, int C1, int C2, int C3>
+size_t sa_lds_bytes(int n, int npoint) {
+  constexpr int CIN = 3 + CF;
+  constexpr int T1 = tile_floats(CIN), T2 = tile_floats(C1), T3 = tile_floats(C2);
+  constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+  return sizeof(float) * ((size_t)2 * TMAX + (size_t)C3 * npoint + (size_t)CF * n + (size_t)n * 3 +
+                          (size_t)npoint * 3 + (size_t)npoint * kNS);
+}
+
+template <int CF, int C1, int C2, int C3>
+int launch_sa(int b, int n, int npoint, const float *xyz, const float *new_xyz, const float *feats,
+              const int32_t *idx, const float *wpack, float *out, hipStream_t s) {
+  const size_t lds = sa_lds_bytes<CF, C1, C2, C3>(n, npoint);
+  if (lds > 80 * 1024) return GPS_ERR_UNSUPPORTED;   // keep two workgroups per CU
+  static bool attr_set = false;                      // dynamic LDS above 64 KiB needs opting in
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_kernel<CF, C1, C2, C3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+      return GPS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3(b), dim3(kBlock), lds, s, b, n, npoint, xyz,
+                     new_xyz, feats, idx, wpack, out);
+  return GPS_OK;
+}
+
+}  // namespace gps_sa
+
+extern "C" {
+
+long long gps_sa_mlp_wpack_floats(int c_in, int c1, int c2, int c3) {
+  if (c_in < 1 || c1 < 32 || c2 < 32 || c3 < 32 || (c1 & 31) || (c2 & 31) || (c3 & 31)) return -1;
+  return (long long)(c1 / 32) * gps_sa::tile_floats(c_in) + (long long)(c2 / 32) * gps_sa::tile_floats(c1) +
+         (long long)(c3 / 32) * gps_sa::tile_floats(c2);
+}
+
+long long gps_sa_mlp_layer_floats(int c_in, int c_out) {
+  if (c_in < 1 || c_out < 32 || (c_out & 31)) return -1;
+  return (long long)(c_out / 32) * gps_sa::tile_floats(c_in);
+}
+
+int gps_sa_mlp_pack_layer(int c_in, int c_out, const float *w, const float *shift, float *dst,
+                          gps_stream_t stream) {
+  if (c_in < 1 || c_out < 32 || (c_out & 31) || !w || !shift || !dst) return GPS_ERR_INVALID_ARGUMENT;
+  const int total = (c_out / 32) * gps_sa::tile_floats(c_in);
+  hipLaunchKernelGGL(gps_sa::pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, c_in, c_out, w, shift, dst);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_sa_mlp_forward(int b, int n, int npoint, int nsample, int c_feat, int c1, int c2, int c3,
+                       const float *xyz, const float *new_xyz, const float *features,
+                       const int32_t *idx, const float *wpack, float *out, gps_stream_t stream) {
+  if (b < 0 || n < 1 || npoint < 1 || nsample < 1 || c_feat < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0) return GPS_OK;
+  if (!xyz || !new_xyz || !idx || !wpack || !out || (c_feat > 0 && !features))
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (nsample != gps_sa::kNS) return GPS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  int st = GPS_ERR_UNSUPPORTED;
+  if (c_feat == 3 && c1 == 64 && c2 == 64 && c3 == 128)
+    st = gps_sa::launch_sa<3, 64, 64, 128>(b, n, npoint, xyz, new_xyz, features, idx, wpack, out, s);
+  else if (c_feat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
+    st = gps_sa::launch_sa<128, 128, 128, 256>(b, n, npoint, xyz, new_xyz, features, idx, wpack, out, s);
+  if (st != GPS_OK) return st;
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -205,3 +205,63 @@ def group_points_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -> torc
                                                   out.data_ptr(), _stream())
     _native.check(st, "group_points_grad")
     return out
+
+
+
+# ---- fused set-abstraction level (additions to the nine reference names; include/gps_hip.h) ----
+def sa_mlp_supported(c_feat: int, channels, nsample: int) -> bool:
+    """True when libgps_hip.so implements the fused level for this MLP (c_feat+3 -> channels)."""
+    if nsample != 32 or len(channels) != 3:
+        return False
+    return (c_feat, *channels) in ((3, 64, 64, 128), (128, 128, 128, 256))
+
+
+def sa_mlp_pack(weights, shifts) -> torch.Tensor:
+    """weights[i] (c_out_i, c_in_i) BN-folded fp32 GPU tensors, shifts[i] (c_out_i) -> the packed
+    buffer gps_sa_mlp_forward reads ([layer 1 | layer 2 | layer 3], K-slot order of the MFMA)."""
+    lib = _native.load()
+    sizes = []
+    for w in weights:
+        n = int(lib.gps_sa_mlp_layer_floats(w.shape[1], w.shape[0]))
+        if n < 0:
+            raise RuntimeError(f"sa_mlp_pack: unsupported layer {w.shape[1]}->{w.shape[0]}")
+        sizes.append(n)
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=weights[0].device)
+    off = 0
+    with torch.cuda.device(buf.device):
+        for w, sft, n in zip(weights, shifts, sizes):
+            w, sft = w.contiguous(), sft.contiguous()
+            _chk(w, "weight", torch.float32)
+            _chk(sft, "shift", torch.float32)
+            st = lib.gps_sa_mlp_pack_layer(w.shape[1], w.shape[0], w.data_ptr(), sft.data_ptr(),
+                                           buf.data_ptr() + 4 * off, _stream())
+            _native.check(st, "sa_mlp_pack_layer")
+            off += n
+    return buf
+
+
+def sa_mlp_forward(xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor,
+                   idx: torch.Tensor, wpack: torch.Tensor, channels) -> torch.Tensor:
+    """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N), idx (B,npoint,32) i32, packed folded
+    MLP C+3 -> channels  ->  (B, channels[-1], npoint) pooled features (one launch)."""
+    _chk(xyz, "xyz", torch.float32)
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(features, "features", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _chk(wpack, "wpack", torch.float32)
+    _same_device(xyz, new_xyz, features, idx, wpack)
+    b, n, _ = xyz.shape
+    c_feat = features.shape[1]
+    _, npoint, nsample = idx.shape
+    c1, c2, c3 = (int(c) for c in channels)
+    out = torch.empty((b, c3, npoint), dtype=torch.float32, device=xyz.device)
+    # algorithmic bytes of the UNFUSED reference API for the same work (SURVEY.md 8(d)): two
+    # group_points calls (xyz, features) -- what this launch absorbs on the gather side
+    algo = 4 * (b * 3 * n + b * npoint * nsample + b * 3 * npoint * nsample) + \
+        4 * (b * c_feat * n + b * npoint * nsample + b * c_feat * npoint * nsample)
+    with torch.cuda.device(xyz.device), _timed(f"sa_mlp_forward(c={c_feat},n={n},np={npoint},mlp={c1}-{c2}-{c3})", algo):
+        st = _native.load().gps_sa_mlp_forward(b, n, npoint, nsample, c_feat, c1, c2, c3,
+                                               xyz.data_ptr(), new_xyz.data_ptr(), features.data_ptr(),
+                                               idx.data_ptr(), wpack.data_ptr(), out.data_ptr(), _stream())
+    _native.check(st, "sa_mlp_forward")
+    return out

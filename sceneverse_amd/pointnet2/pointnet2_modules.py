@@ -20,6 +20,53 @@ import torch.nn.functional as F
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
+# Fused frozen-encoder path (libgps_hip.so gps_sa_mlp_forward): on by default on GPU tensors,
+# `set_fused_sa(False)` restores the op-by-op path (used by the A/B parity tests).
+_FUSED_SA = True
+
+
+def set_fused_sa(flag: bool) -> None:
+    global _FUSED_SA
+    _FUSED_SA = bool(flag)
+
+
+def fold_shared_mlp(mlp: "pt_utils.SharedMLP"):
+    """SharedMLP of (conv1x1 [bias], BatchNorm2d, ReLU) layers -> ([W' (c_out,c_in)], [shift (c_out)])
+    with the batch-norm's RUNNING statistics folded in (valid in eval mode only):
+        y = relu(W' x + shift),  W' = diag(g / sqrt(var + eps)) W,  shift = beta + (bias - mean) g / sqrt(var + eps)
+    Returns None when the module is not of that form."""
+    ws, shifts = [], []
+    for layer in mlp.children():
+        kids = dict(layer.named_children())
+        conv, bnw, act = kids.get("conv"), kids.get("bn"), kids.get("activation")
+        if conv is None or not isinstance(act, nn.ReLU) or list(kids) != ["conv"] + (["bn"] if bnw is not None else []) + ["activation"]:
+            return None
+        if not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.groups != 1:
+            return None
+        w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
+        shift = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(w[:, 0])
+        if bnw is not None:
+            bn = bnw.bn
+            if bn.training or not bn.track_running_stats:
+                return None
+            scale = (bn.weight.detach() if bn.affine else 1.0) / torch.sqrt(bn.running_var + bn.eps)
+            w = w * scale[:, None]
+            shift = (shift - bn.running_mean) * scale + (bn.bias.detach() if bn.affine else 0.0)
+        ws.append(w.contiguous())
+        shifts.append(shift.contiguous())
+    return ws, shifts
+
+
+def _frozen_key(mlp: nn.Module):
+    return tuple((t.data_ptr(), t._version) for t in list(mlp.parameters()) + list(mlp.buffers()))
+
+
+def _is_frozen(mlp: nn.Module) -> bool:
+    """No parameter needs a gradient (or autograd is off) and every batch-norm is in eval mode."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in mlp.parameters()):
+        return False
+    return not any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training for m in mlp.modules())
+
 
 class _PointnetSAModuleBase(nn.Module):
     def __init__(self):
@@ -41,11 +88,68 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = self._sample_centres(xyz)
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
+            fused = self._forward_frozen(grouper, mlp, xyz, new_xyz, features)
+            if fused is not None:
+                pooled.append(fused)
+                continue
             grouped = grouper(xyz, new_xyz, features)          # (B, C', npoint, nsample)
             grouped = mlp(grouped)                             # (B, mlp[-1], npoint, nsample)
             # max over nsample (max_pool2d like ref :68-71, so tie routing in backward matches)
             pooled.append(F.max_pool2d(grouped, kernel_size=[1, grouped.size(3)]).squeeze(-1))
         return new_xyz, torch.cat(pooled, dim=1)
+
+
+    # ---- frozen encoder: one native launch per level -------------------------------------------
+    def _folded(self, mlp, pack: bool):
+        """(weights, shifts[, packed buffer]) of `mlp`, cached until a parameter/buffer changes."""
+        key = (_frozen_key(mlp), pack)
+        cache = mlp.__dict__.get("_gps_folded")
+        if cache is None or cache[0] != key:
+            folded = fold_shared_mlp(mlp)
+            if folded is None:
+                cache = (key, None)
+            else:
+                ws, shifts = folded
+                packed = pointnet2_utils._ext.sa_mlp_pack(ws, shifts) if pack else None
+                cache = (key, (ws, shifts, packed))
+            mlp.__dict__["_gps_folded"] = cache
+        return cache[1]
+
+    def _forward_frozen(self, grouper, mlp, xyz, new_xyz, features):
+        """Pooled features (B, C_out, npoint) of one (grouper, mlp) pair when the encoder is frozen
+        and the tensors live on the GPU, else None (the caller runs the op-by-op path)."""
+        if not (_FUSED_SA and xyz.is_cuda and _is_frozen(mlp)):
+            return None
+        ext = pointnet2_utils._ext
+        if isinstance(grouper, pointnet2_utils.QueryAndGroup):
+            plain = not (grouper.sample_uniformly or grouper.normalize_xyz or grouper.ret_grouped_xyz
+                         or grouper.ret_unique_cnt) and grouper.use_xyz and features is not None
+            chans = [l.conv.out_channels for l in mlp.children() if hasattr(l, "conv")]
+            if not plain or not hasattr(ext, "sa_mlp_supported") or \
+                    not ext.sa_mlp_supported(features.shape[1], chans, grouper.nsample):
+                return None
+            folded = self._folded(mlp, pack=True)
+            if folded is None:
+                return None
+            with torch.no_grad():
+                idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+                return ext.sa_mlp_forward(xyz.float().contiguous(), new_xyz.float().contiguous(),
+                                          features.float().contiguous(), idx, folded[2], chans)
+        if isinstance(grouper, pointnet2_utils.GroupAll) and features is not None and grouper.use_xyz:
+            # group-all level: every object is one 16-column group -> three plain GEMMs over
+            # (B * N) rows with the folded weights (hipBLASLt), ReLU, max over N
+            folded = self._folded(mlp, pack=False)
+            if folded is None:
+                return None
+            ws, shifts, _ = folded
+            with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
+                x = torch.cat([xyz.float(), features.float().transpose(1, 2)], dim=2)   # (B, N, 3 + C)
+                b, n, _ = x.shape
+                x = x.reshape(b * n, -1)
+                for w, sft in zip(ws, shifts):
+                    x = torch.relu_(torch.addmm(sft, x, w.t()))
+                return x.view(b, n, -1).amax(dim=1).unsqueeze(-1)
+        return None
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

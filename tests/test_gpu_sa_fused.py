@@ -1,0 +1,108 @@
+"""The fused frozen set-abstraction level (gps_sa_mlp_forward: gather + centre subtraction + 3 x
+(1x1 conv, folded BN, ReLU) on fp32 MFMA + max-pool, one launch) against
+
+  * the op-by-op path of the same modules (group_points -> torch conv/BN/ReLU/max_pool2d), and
+  * the CPU oracle (oracle/gps_torch_reference.pointnetpp, pinned to the reference's Python),
+
+on the GPS encoder (modules/layers/pointnet.py:22-63 shapes) with non-trivial BN statistics.
+Tolerance: the fused kernel sums fp32 products in MFMA K-slot order with BN folded into the
+weights, the reference sums in GEMM order and applies BN afterwards -- |diff| <= 1e-4 * max|ref|
+per tensor (activations are O(1); measured ~1e-6)."""
+import pytest
+import torch
+
+from oracle.param_fill import fill_params
+from sceneverse_amd.data.synthetic import adversarial_objects, synth_batch
+from sceneverse_amd.modules.layers.pointnet import PointNetPP
+from sceneverse_amd.pointnet2 import pointnet2_modules as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _encoder(seed=0):
+    net = PointNetPP(sa_n_points=[32, 16, None], sa_n_samples=[32, 32, None], sa_radii=[0.2, 0.4, None],
+                     sa_mlps=[[3, 64, 64, 128], [128, 128, 128, 256], [256, 256, 512, 768]])
+    fill_params(net, seed)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    return net.to(DEV).eval()
+
+
+def _clouds():
+    adv = adversarial_objects(1024)
+    rgb = torch.rand(adv.shape[0], 1024, 3) * 2 - 1
+    d = synth_batch(2, n_obj=12, seed=11, min_real=6)
+    return torch.cat([torch.cat([adv, rgb], 2), d["obj_fts"].reshape(-1, 1024, 6)], 0)
+
+
+def _close(a, b, what):
+    tol = 1e-4 * b.abs().max().item()
+    err = (a - b).abs().max().item()
+    assert err <= tol, (what, err, tol)
+
+
+def test_fused_levels_match_unfused_ops():
+    net, pcs = _encoder(), _clouds().to(DEV)
+    xyz = pcs[..., :3].contiguous()
+    feats = pcs[..., 3:].transpose(1, 2).contiguous()
+    with torch.no_grad():
+        for lvl, sa in enumerate(net.encoder):
+            M.set_fused_sa(True)
+            nx_f, f_f = sa(xyz, feats)
+            M.set_fused_sa(False)
+            nx_u, f_u = sa(xyz, feats)
+            M.set_fused_sa(True)
+            assert f_f.shape == f_u.shape, (lvl, f_f.shape, f_u.shape)
+            if nx_u is not None:
+                assert torch.equal(nx_f, nx_u)
+            _close(f_f, f_u, f"SA{lvl + 1}")
+            xyz, feats = nx_u, f_u
+
+
+def test_fused_encoder_matches_cpu_oracle():
+    from oracle import gps_torch_reference as R
+    net, pcs = _encoder(seed=3), _clouds()
+    with torch.no_grad():
+        got = net(pcs.to(DEV)).cpu()
+    sd = {"pn." + k: v.cpu() for k, v in net.state_dict().items()}
+    want = R.pointnetpp(sd, "pn", pcs)
+    _close(got, want, "PointNetPP")
+
+
+def test_fused_path_is_taken_and_cached():
+    net, pcs = _encoder(), _clouds().to(DEV)[:4]
+    from sceneverse_amd.pointnet2 import _ext
+    _ext.profile_start()
+    with torch.no_grad():
+        net(pcs)
+        net(pcs)
+    rec = _ext.profile_stop()
+    names = [k for k in rec if k.startswith("sa_mlp_forward")]
+    assert len(names) == 2 and all(rec[k]["launches"] == 2 for k in names), rec.keys()
+    assert not any(k.startswith("group_points") for k in rec), rec.keys()
+    mlp = net.encoder[0].mlps[0]
+    key0 = mlp.__dict__["_gps_folded"][0]
+    with torch.no_grad():
+        mlp.layer0.bn.bn.running_mean.add_(0.5)        # weights change -> repack
+        out2 = net(pcs)
+    assert mlp.__dict__["_gps_folded"][0] != key0
+    M.set_fused_sa(False)
+    with torch.no_grad():
+        ref2 = net(pcs)
+    M.set_fused_sa(True)
+    _close(out2, ref2, "after BN update")
+
+
+def test_unfrozen_encoder_keeps_the_differentiable_path():
+    net = _encoder()
+    for p in net.parameters():
+        p.requires_grad_(True)
+    net.train()
+    pcs = _clouds().to(DEV)[:4]
+    from sceneverse_amd.pointnet2 import _ext
+    _ext.profile_start()
+    net(pcs).sum().backward()
+    rec = _ext.profile_stop()
+    assert not any(k.startswith("sa_mlp_forward") for k in rec)
+    assert any(k.startswith("group_points_grad") for k in rec)

@@ -70,7 +70,36 @@ def main():
         ("group SA2 feats (c=128,n=32)", lambda m: m.group_points(feats, idx2), b * (128 * 32 * 4 + 512 * 4 + 128 * 512 * 4)),
         ("group_grad SA2 feats", lambda m: m.group_points_grad(gout, idx2, 32), b * (128 * 512 * 4 + 512 * 4 + 128 * 32 * 4)),
     ]
+    # fused frozen SA levels (gps_sa_mlp_forward); algorithmic bytes = the two group_points calls
+    # each launch absorbs (unfused reference API), FLOPs = the three 1x1 convs
+    from sceneverse_amd.pointnet2 import pointnet2_modules as M
+    torch.manual_seed(0)
+
+    def _packed(cin, chans):
+        ws, ss, c = [], [], cin
+        for co in chans:
+            ws.append(torch.randn(co, c, device=dev) * (2.0 / c) ** 0.5)
+            ss.append(torch.randn(co, device=dev) * 0.05)
+            c = co
+        return hip.sa_mlp_pack(ws, ss)
+
+    wp1, wp2 = _packed(6, [64, 64, 128]), _packed(131, [128, 128, 256])
+    f1 = hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1, [64, 64, 128])
+    fused = [
+        ("sa_mlp SA1 fused (6-64-64-128)", lambda: hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1, [64, 64, 128]),
+         2 * b * (3 * 1024 * 4 + 1024 * 4 + 3 * 1024 * 4), 2 * b * 1024 * (6 * 64 + 64 * 64 + 64 * 128)),
+        ("sa_mlp SA2 fused (131-128-128-256)", lambda: hip.sa_mlp_forward(new_xyz, nx2, f1, idx2, wp2, [128, 128, 256]),
+         b * (3 * 32 * 4 + 512 * 4 + 3 * 512 * 4) + b * (128 * 32 * 4 + 512 * 4 + 128 * 512 * 4),
+         2 * b * 512 * (131 * 128 + 128 * 128 + 128 * 256)),
+    ]
     rows = []
+    for name, fn, nbytes, flops in fused:
+        us = timeit(fn)
+        row = {"op": name, "us": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1),
+               "frac_8TBps": round(nbytes / us / 1e3 / 8000, 4), "TFLOPs_fp32": round(flops / us / 1e6, 1),
+               "frac_fp32_mfma_157TF": round(flops / us / 1e6 / 157.3, 4)}
+        rows.append(row)
+        print(row, flush=True)
     total_bq_group_us = 0.0
     total_bq_group_bytes = 0
     for name, fn, nbytes in ops:
