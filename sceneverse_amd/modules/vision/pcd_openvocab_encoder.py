@@ -99,8 +99,8 @@ class PointOpenVocabEncoder(nn.Module):
             self.freeze_bn(self.point_feature_extractor)
         B, O = obj_pcds.shape[:2]
         pcs = obj_pcds.reshape(B * O, *obj_pcds.shape[2:])
-        if obj_pcds.is_cuda and not self.pointnet_autocast:
-            with torch.autocast(device_type="cuda", enabled=False):
+        if not self.pointnet_autocast:
+            with torch.autocast(device_type=obj_pcds.device.type, enabled=False):
                 obj_embeds = self.point_feature_extractor(pcs.float())
         else:
             obj_embeds = self.point_feature_extractor(pcs)
