@@ -4,8 +4,11 @@ of the reference's Python (tests/golden/gps_reference_cpu.pt).
 Tolerances (stated per north_star "features/logits/loss within a stated fp tolerance"):
   fp32 run   : |diff| <= 2e-3 + 2e-3*|ref| on embeddings/logits, 1e-3 relative on losses --
                GPU GEMM/conv summation order vs CPU;
-  bf16 run   : og3d logits within 0.15 absolute (|logits| ~ 5), losses within 3 % -- bf16
-               autocast of every Linear; FPS/ball-query indices are fp32 and stay bit-exact."""
+  bf16 run   : LayerNorm-ed embeddings (O(1)) within 0.08 absolute; og3d logits (a 768-term dot
+               product of two such embeddings: |ref| up to ~450, std ~15 with the test weights)
+               within 1 % of max|ref|; losses within 3 % -- bf16 autocast of every Linear (CPU
+               bf16 autocast of the same model lands at 0.044 / 0.2 % of max, so these bounds
+               are ~2-5x the bf16 floor); FPS/ball-query indices are fp32 and stay bit-exact."""
 import pytest
 import torch
 import torch.nn as nn
@@ -54,8 +57,12 @@ def test_gps_pretrain_bf16_autocast(golden_cpu):
         out = model(clone_batch(fx["batch"], DEV))
         _, losses = loss_mod(out)
     masks = fx["batch"]["obj_masks"]
-    diff = (out["og3d_logits"].float().cpu() - g["og3d_logits"])[masks].abs().max().item()
-    assert diff < 0.15, diff
+    ref = g["og3d_logits"][masks]
+    diff = (out["og3d_logits"].float().cpu()[masks] - ref).abs().max().item()
+    assert diff < 1e-2 * ref.abs().max().item(), (diff, ref.abs().max().item())
+    for k in ("intra_text_embed", "intra_obj_embeds", "inter_obj_embeds", "scene_embed"):
+        d = (out[k].float().cpu() - g[k]).abs().max().item()
+        assert d < 0.08, (k, d)
     for k, v in g["losses"].items():
         assert abs(losses[k].item() - v) < 3e-2 * max(1.0, abs(v)), (k, losses[k].item(), v)
 
