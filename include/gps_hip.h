@@ -145,6 +145,34 @@ GPS_API int gps_sa_mlp_forward(int b, int n, int npoint, int nsample, int c_feat
                                const int32_t *idx, const float *wpack, float *out,
                                gps_stream_t stream);
 
+/* ---- fused self-attention core (object-level spatial transformer, joint text+object transformer) --
+ * One launch for what the reference runs between the QKV projections and the output projection:
+ *   modules/layers/transformers.py:193-239  MultiHeadAttentionSpatial.forward, fusion 'cond':
+ *       probs = softmax(log(clamp(sigmoid(w . pairwise + b), 1e-6)) + q k^T / sqrt(64)), masked keys
+ *       get probability 0; out = probs v     (w, b = lang_cond_fc(x) per token and head)
+ *   modules/layers/transformers.py:141 (torch.nn.MultiheadAttention, key_padding_mask, dropout on
+ *       the probabilities) -- the same core without the spatial term (sw == pl == NULL).
+ * q, k, v: bf16 (B, L, ld_qkv) views, head h in columns [64 h, 64 h + 64) -- three column blocks of
+ * one packed projection output are fine (ld_qkv = its row pitch, a multiple of 8).  sw (B,L,H*6)
+ * fp32: per token and head [b, w_1..w_5].  pl (B,L,L,5) fp32 (calc_pairwise_locs,
+ * modules/utils.py:38-87).  mask (B,L) bytes, 1 = padded key.  p_drop/seed: dropout on the
+ * probabilities (counter-based, reproducible between forward and backward).
+ * out (B, L, ld_o) bf16; lse (B,H,L) fp32 log-sum-exp of the logits (saved for backward).
+ * bf16 MFMA with fp32 accumulation; softmax in fp32.  head_dim must be 64, L <= 256. */
+GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
+                             int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
+                             float p_drop, unsigned long long seed, void *out, int ld_o, float *lse,
+                             gps_stream_t stream);
+
+/* Gradients of gps_attn_forward: dout (B,L,ld_o) bf16 -> dq, dk, dv (bf16, same layout/pitch as
+ * q, k, v) and dsw (B,L,H*6) fp32 (when sw != NULL).  pl and mask carry no gradient (inputs of the
+ * data pipeline).  Probabilities are recomputed from lse. */
+GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
+                              int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
+                              float p_drop, unsigned long long seed, const void *dout, int ld_o,
+                              const float *lse, void *dq, void *dk, void *dv, float *dsw,
+                              gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,8 @@ SIGNATURES = {
     "gps_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_sa_mlp_pack_layer": [_i, _i, _vp, _vp, _vp, _vp],
     "gps_sa_mlp_forward": [_i] * 8 + [_vp] * 7,
+    "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _i, _vp, _vp],
+    "gps_attn_backward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _i] + [_vp] * 6,
 }
 
 

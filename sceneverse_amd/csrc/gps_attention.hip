@@ -1,0 +1,641 @@
+// gps_attention.hip -- fused multi-head self-attention core for the GPS object/joint transformers on
+// MI355X (gfx950): QK^T, language-conditioned pairwise-spatial bias, key-padding mask, softmax,
+// attention dropout and PV in one launch; backward in one launch.  bf16 in/out, fp32 accumulate on
+// v_mfma_f32_16x16x32_bf16.
+//
+// Reference behaviour restated:
+//   modules/layers/transformers.py:193-239  MultiHeadAttentionSpatial.forward, fusion 'cond':
+//       attn = q k^T / sqrt(d_h);  w = lang_cond_fc(x) -> per (token, head): bias b, weights w_1..5
+//       loc = sigmoid(w . pairwise[b,l,t,:] + b);  masked keys: attn = -inf, loc = 0
+//       probs = softmax(log(clamp(loc, 1e-6)) + attn);  out = probs v
+//   modules/layers/transformers.py:141 (nn.MultiheadAttention with key_padding_mask, dropout on the
+//       probabilities) -- the same core without the spatial term.
+// The reference materialises ~12 (B,H,L,L) fp32 tensors per layer for this;
+// here nothing of size L x L ever reaches HBM.
+//
+// Tiny-sequence design (L = 80 objects, 130 joint tokens; d_h = 64): one workgroup per (batch, head),
+// one wave per 16-row strip.  K (row-major) and V^T live in LDS; scores are computed TRANSPOSED
+// (S^T = K Q^T) so that a lane owns one query column: the softmax row reduction is in-lane plus two
+// cross-row shuffles, and the D fragments of S^T are directly the A fragments of the P V product
+// (the K index of that product is permuted to the D row order, and V^T is read in the same order).
+// The pairwise tensor (B,L,L,5) is shared by the 12 heads of a scene: the block -> (b,h) map sends
+// all heads of a scene to the same XCD so that it is served from that XCD's L2.
+//
+// Backward, two passes in one launch: pass 1 (query strips, transposed scores) produces dQ, the
+// gradient of the conditioning vector (lang_cond_fc output) and delta = rowsum(P dP); pass 2 (key
+// strips, plain orientation so that a lane owns one key) recomputes the probabilities and produces
+// dK and dV.  Probabilities are recomputed from the saved log-sum-exp, never stored.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gps_hip.h"
+
+namespace gps_attn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int DH = 64;        // head width (the only one the GPS configs use)
+constexpr int KS = DH + 8;    // LDS row pitch of row-major tiles, bf16 elements (144 B: conflict-free b128)
+constexpr int SD = 6;         // conditioning vector per (token, head): bias + 5 weights
+
+struct Params {
+  int B, H, L, nt;            // nt = ceil(L / 16)
+  int ld_qkv, ld_o;           // row pitches in elements
+  const uint16_t *q, *k, *v;  // (B, L, ld_qkv) views, head h at column h * 64
+  const float *sw;            // (B, L, H * 6) or null
+  const float *pl;            // (B, L, L, 5)  or null
+  const uint8_t *mask;        // (B, L), 1 = padded key, or null
+  uint16_t *out;              // (B, L, ld_o)
+  float *lse;                 // (B, H, L)
+  // backward only
+  const uint16_t *dout;       // (B, L, ld_o)
+  uint16_t *dq, *dk, *dv;     // (B, L, ld_qkv) views
+  float *dsw;                 // (B, L, H * 6)
+  float p_drop;
+  unsigned int drop_thr;      // keep iff rng >= drop_thr
+  unsigned long long seed;
+};
+
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even
+  unsigned int u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ u32x4 zero4() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
+
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// counter-based RNG for attention dropout (splitmix64 finaliser): the same (seed, element) gives the
+// same keep decision in forward and backward
+__device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned int)((z ^ (z >> 31)) >> 32);
+}
+
+__device__ __forceinline__ void block_to_bh(const Params &P, int &b, int &h) {
+  const int id = blockIdx.x;
+  if ((P.B & 7) == 0) {       // heads of one scene on one XCD (block id mod 8), scenes spread over XCDs
+    const int xcd = id & 7, slot = id >> 3;
+    b = (slot / P.H) * 8 + xcd;
+    h = slot % P.H;
+  } else {
+    b = id / P.H;
+    h = id % P.H;
+  }
+}
+
+// rows [0, rows_total) of a (.., ld) bf16 matrix (64 columns of head h) -> LDS [rows_total][KS];
+// rows >= rows_valid are zero
+__device__ __forceinline__ void stage_rows(uint16_t *dst, const uint16_t *src, int ld, int rows_valid,
+                                           int rows_total) {
+  for (int e = threadIdx.x; e < rows_total * 8; e += blockDim.x) {
+    const int r = e >> 3, ch = e & 7;
+    u32x4 v = zero4();
+    if (r < rows_valid) v = *reinterpret_cast<const u32x4 *>(src + (size_t)r * ld + ch * 8);
+    *reinterpret_cast<u32x4 *>(dst + r * KS + ch * 8) = v;
+  }
+}
+// the same rows transposed -> LDS [64][ts] (column t of row d), zero for t >= rows_valid
+__device__ __forceinline__ void stage_transposed(uint16_t *dst, const uint16_t *src, int ld,
+                                                 int rows_valid, int rows_total, int ts) {
+  for (int e = threadIdx.x; e < rows_total * 8; e += blockDim.x) {
+    const int r = e >> 3, ch = e & 7;
+    u32x4 v = zero4();
+    if (r < rows_valid) v = *reinterpret_cast<const u32x4 *>(src + (size_t)r * ld + ch * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dst[(ch * 8 + 2 * i) * ts + r] = (uint16_t)(v[i] & 0xFFFFu);
+      dst[(ch * 8 + 2 * i + 1) * ts + r] = (uint16_t)(v[i] >> 16);
+    }
+  }
+}
+// B fragment of a product whose K index runs over rows of the transposed LDS tile `t` (pitch ts):
+// lane (n = lane & 15, g = lane >> 4) gets rows {32c + 4g + 0..3, 32c + 16 + 4g + 0..3} of column
+// 16 * ntile + n -- the K order in which the D fragments of two adjacent 16-row tiles are packed.
+__device__ __forceinline__ bf16x8 frag_from_transposed(const uint16_t *t, int ts, int ntile, int c,
+                                                       int lane) {
+  const uint16_t *p = t + (16 * ntile + (lane & 15)) * ts + 32 * c + 4 * (lane >> 4);
+  const u32x2 lo = *reinterpret_cast<const u32x2 *>(p);
+  const u32x2 hi = *reinterpret_cast<const u32x2 *>(p + 16);
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return as_frag(v);
+}
+// pack the D fragments of two adjacent 16-row tiles into one A fragment (same K order as above)
+__device__ __forceinline__ bf16x8 pack_tiles(const f32x4 &a, const f32x4 &b) {
+  u32x4 v = {pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])};
+  return as_frag(v);
+}
+
+__device__ __forceinline__ float xor_reduce_max_rows(float v) {   // across the 4 lane groups
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor_reduce_sum_rows(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ror_reduce_sum_16(float v) {     // within each 16-lane row, all lanes
+  v += dpp_ror<0x128>(v);  // row_ror:8
+  v += dpp_ror<0x124>(v);  // row_ror:4
+  v += dpp_ror<0x122>(v);  // row_ror:2
+  v += dpp_ror<0x121>(v);  // row_ror:1
+  return v;
+}
+
+// spatial term of one (query, key) pair: z = w0 + sum_d w_d pl_d; sig = sigmoid(z);
+// returns log(clamp(sig, 1e-6)) (masked keys: log(1e-6)), and sig through `sig`.
+__device__ __forceinline__ float spatial_bias(const float *__restrict__ plp, const float (&w)[SD],
+                                              bool key_masked, float &sig) {
+  float z = w[0];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) z = fmaf(w[1 + d], plp[d], z);
+  sig = key_masked ? 0.f : 1.f / (1.f + __expf(-z));
+  return __logf(fmaxf(sig, 1e-6f));
+}
+
+// ==========================================================================================
+// forward
+// ==========================================================================================
+template <int NT, bool SPATIAL>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const Params P) {
+  constexpr int NC = (NT + 1) / 2;          // 32-key chunks of the P V product
+  constexpr int TS = NC * 32 + 8;           // pitch of the transposed V tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);   // [NT*16][KS]
+  uint16_t *Vt = Ks + NT * 16 * KS;                     // [64][TS]
+
+  int b, h;
+  block_to_bh(P, b, h);
+  const int L = P.L, nt = P.nt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)b * L;
+  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
+  const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
+  stage_rows(Ks, kb, P.ld_qkv, L, NT * 16);
+  stage_transposed(Vt, vb, P.ld_qkv, L, NC * 32, TS);
+  __syncthreads();
+
+  const bool dropout = P.drop_thr != 0u;
+  const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+
+  for (int s = wave; s < nt; s += nwaves) {
+    const int qi = 16 * s + m;              // this lane's query
+    const bool q_ok = qi < L;
+    bf16x8 bq[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 v = zero4();
+      if (q_ok) v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_qkv + 32 * c + 8 * g);
+      bq[c] = as_frag(v);
+    }
+    // S^T tiles: acc[j][r] = <q_qi, k_t>, t = 16 j + 4 g + r
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j < nt) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
+          acc[j] = mfma(as_frag(a), bq[c], acc[j]);
+        }
+      }
+    }
+    float w[SD];
+    if (SPATIAL) {
+#pragma unroll
+      for (int d = 0; d < SD; ++d)
+        w[d] = q_ok ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
+    }
+    // logits, row max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 16 * j + 4 * g + r;
+        const bool t_ok = (j < nt) && t < L;
+        const bool km = t_ok && P.mask && P.mask[row0 + t];
+        float x = acc[j][r] * 0.125f;
+        if (SPATIAL && t_ok && q_ok) {
+          float sig;
+          x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+        }
+        if (!t_ok || km) x = -INFINITY;
+        acc[j][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = xor_reduce_max_rows(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(acc[j][r] - mx);   // exp(-inf - mx) = 0; all keys masked -> NaN like torch
+        acc[j][r] = p;
+        sum += p;
+      }
+    sum = xor_reduce_sum_rows(sum);
+    const float inv = 1.f / sum;
+    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * L + qi] = mx + __logf(sum);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = acc[j][r] * inv;
+        if (dropout) {
+          const int t = 16 * j + 4 * g + r;
+          const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
+          p = rng_u32(P.seed, idx) >= P.drop_thr ? p * keep_scale : 0.f;
+        }
+        acc[j][r] = p;
+      }
+    // O strip = P V
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (2 * c < nt) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8 pa = pack_tiles(acc[2 * c], (2 * c + 1 < NT) ? acc[(2 * c + 1 < NT) ? 2 * c + 1 : 0] : z);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[n] = mfma(pa, frag_from_transposed(Vt, TS, n, c, lane), o[n]);
+      }
+    }
+    // o[n][r] = O[query 16 s + 4 g + r][d = 16 n + m]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qr = 16 * s + 4 * g + r;
+      if (qr < L) {
+        uint16_t *op = P.out + (row0 + qr) * P.ld_o + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r]);
+      }
+    }
+  }
+}
+
+// ==========================================================================================
+// backward
+// ==========================================================================================
+template <int NT, bool SPATIAL>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
+  constexpr int NC = (NT + 1) / 2;
+  constexpr int TS = NC * 32 + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // pass 1: Ks [NT*16][KS] | Vs [NT*16][KS] | Kt [64][TS];  pass 2 (aliased): Qt [64][TS] | dOt [64][TS]
+  uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *Vs = Ks + NT * 16 * KS;
+  uint16_t *Kt = Vs + NT * 16 * KS;
+  uint16_t *Qt = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *dOt = Qt + 64 * TS;
+  constexpr int kBig = (2 * NT * 16 * KS + 64 * TS) * 2;   // bytes of the aliased region
+  float *delta_s = reinterpret_cast<float *>(smem + kBig);   // [NT*16]
+
+  int b, h;
+  block_to_bh(P, b, h);
+  const int L = P.L, nt = P.nt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)b * L;
+  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
+  const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
+  const uint16_t *dob = P.dout + row0 * P.ld_o + h * DH;
+  const float *lse = P.lse + ((size_t)b * P.H + h) * L;
+  const bool dropout = P.drop_thr != 0u;
+  const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+
+  stage_rows(Ks, kb, P.ld_qkv, L, NT * 16);
+  stage_rows(Vs, vb, P.ld_qkv, L, NT * 16);
+  stage_transposed(Kt, kb, P.ld_qkv, L, NC * 32, TS);
+  __syncthreads();
+
+  // ---------------- pass 1: query strips, transposed scores -> dQ, dsw, delta ----------------
+  for (int s = wave; s < nt; s += nwaves) {
+    const int qi = 16 * s + m;
+    const bool q_ok = qi < L;
+    bf16x8 bq[2], bdo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 v = zero4(), u = zero4();
+      if (q_ok) {
+        v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_qkv + 32 * c + 8 * g);
+        u = *reinterpret_cast<const u32x4 *>(dob + (size_t)qi * P.ld_o + 32 * c + 8 * g);
+      }
+      bq[c] = as_frag(v);
+      bdo[c] = as_frag(u);
+    }
+    f32x4 acc[NT], dacc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j < nt) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
+          const u32x4 av = *reinterpret_cast<const u32x4 *>(Vs + (16 * j + m) * KS + 32 * c + 8 * g);
+          acc[j] = mfma(as_frag(a), bq[c], acc[j]);       // S^T
+          dacc[j] = mfma(as_frag(av), bdo[c], dacc[j]);   // (dO V^T)^T
+        }
+      }
+    }
+    float w[SD];
+    if (SPATIAL) {
+#pragma unroll
+      for (int d = 0; d < SD; ++d) w[d] = q_ok ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
+    }
+    const float lse_q = q_ok ? lse[qi] : 0.f;
+    // p, gate (1 - sig where the spatial term has a gradient), dP
+    f32x4 gate[SPATIAL ? NT : 1];
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 16 * j + 4 * g + r;
+        const bool t_ok = (j < nt) && t < L && q_ok;
+        const bool km = t_ok && P.mask && P.mask[row0 + t];
+        float x = acc[j][r] * 0.125f;
+        float gt = 0.f;
+        if (SPATIAL && t_ok) {
+          float sig;
+          x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+          gt = sig > 1e-6f ? 1.f - sig : 0.f;     // d/dz log(clamp(sigmoid(z), 1e-6))
+        }
+        if (SPATIAL) gate[SPATIAL ? j : 0][r] = gt;
+        const float p = (t_ok && !km) ? __expf(x - lse_q) : 0.f;
+        float dp = dacc[j][r];
+        if (dropout) {
+          const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
+          dp = rng_u32(P.seed, idx) >= P.drop_thr ? dp * keep_scale : 0.f;
+        }
+        acc[j][r] = p;
+        dacc[j][r] = dp;
+        delta += p * dp;
+      }
+    delta = xor_reduce_sum_rows(delta);
+    if (g == 0) delta_s[16 * s + m] = delta;
+    float dw[SD];
+#pragma unroll
+    for (int d = 0; d < SD; ++d) dw[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dlogit = acc[j][r] * (dacc[j][r] - delta);
+        if (SPATIAL) {
+          const int t = 16 * j + 4 * g + r;
+          const float dz = dlogit * gate[SPATIAL ? j : 0][r];
+          if (dz != 0.f) {
+            const float *plp = P.pl + ((row0 + qi) * L + t) * 5;
+            dw[0] += dz;
+#pragma unroll
+            for (int d = 0; d < 5; ++d) dw[1 + d] = fmaf(dz, plp[d], dw[1 + d]);
+          }
+        }
+        acc[j][r] = dlogit * 0.125f;            // dS
+      }
+    if (SPATIAL) {
+#pragma unroll
+      for (int d = 0; d < SD; ++d) dw[d] = xor_reduce_sum_rows(dw[d]);
+      if (g == 0 && q_ok) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) P.dsw[((row0 + qi) * P.H + h) * SD + d] = dw[d];
+      }
+    }
+    // dQ strip = dS K
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (2 * c < nt) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8 da = pack_tiles(acc[2 * c], (2 * c + 1 < NT) ? acc[(2 * c + 1 < NT) ? 2 * c + 1 : 0] : z);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[n] = mfma(da, frag_from_transposed(Kt, TS, n, c, lane), o[n]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qr = 16 * s + 4 * g + r;
+      if (qr < L) {
+        uint16_t *op = P.dq + (row0 + qr) * P.ld_qkv + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r]);
+      }
+    }
+  }
+  __syncthreads();   // every strip's delta is in LDS; K/V tiles no longer needed
+  stage_transposed(Qt, qb, P.ld_qkv, L, NC * 32, TS);
+  stage_transposed(dOt, dob, P.ld_o, L, NC * 32, TS);
+  __syncthreads();
+
+  // ---------------- pass 2: key strips, plain orientation -> dK, dV ----------------
+  for (int js = wave; js < nt; js += nwaves) {
+    const int t = 16 * js + m;            // this lane's key
+    const bool t_ok = t < L;
+    const bool km = t_ok && P.mask && P.mask[row0 + t];
+    bf16x8 bk[2], bv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 v = zero4(), u = zero4();
+      if (t_ok) {
+        v = *reinterpret_cast<const u32x4 *>(kb + (size_t)t * P.ld_qkv + 32 * c + 8 * g);
+        u = *reinterpret_cast<const u32x4 *>(vb + (size_t)t * P.ld_qkv + 32 * c + 8 * g);
+      }
+      bk[c] = as_frag(v);
+      bv[c] = as_frag(u);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = 0; c < NC; ++c) {        // 32-query chunks
+      f32x4 pt[2], ds[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int i = 2 * c + hh;          // query tile
+        pt[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < nt) {
+          const int qa = 16 * i + m;       // A-fragment row of this lane
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            u32x4 v = zero4(), u = zero4();
+            if (qa < L) {
+              v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qa * P.ld_qkv + 32 * cc + 8 * g);
+              u = *reinterpret_cast<const u32x4 *>(dob + (size_t)qa * P.ld_o + 32 * cc + 8 * g);
+            }
+            sacc = mfma(as_frag(v), bk[cc], sacc);    // S[query 16 i + 4 g + r][key t]
+            dacc = mfma(as_frag(u), bv[cc], dacc);    // dO V^T
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = 16 * i + 4 * g + r;
+            const bool ok = t_ok && qi < L;
+            float x = sacc[r] * 0.125f;
+            if (SPATIAL && ok) {
+              float w[SD];
+#pragma unroll
+              for (int d = 0; d < SD; ++d) w[d] = P.sw[((row0 + qi) * P.H + h) * SD + d];
+              float sig;
+              x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+            }
+            const float p = (ok && !km) ? __expf(x - lse[qi]) : 0.f;
+            float dp = dacc[r], pd = p;
+            if (dropout) {
+              const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
+              const bool keep = rng_u32(P.seed, idx) >= P.drop_thr;
+              dp = keep ? dp * keep_scale : 0.f;
+              pd = keep ? p * keep_scale : 0.f;
+            }
+            const float dl = ok ? p * (dp - delta_s[qi]) : 0.f;
+            pt[hh][r] = pd;
+            ds[hh][r] = dl * 0.125f;
+          }
+        }
+      }
+      const bf16x8 pa = pack_tiles(pt[0], pt[1]);
+      const bf16x8 da = pack_tiles(ds[0], ds[1]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        dv[n] = mfma(pa, frag_from_transposed(dOt, TS, n, c, lane), dv[n]);
+        dk[n] = mfma(da, frag_from_transposed(Qt, TS, n, c, lane), dk[n]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tr = 16 * js + 4 * g + r;
+      if (tr < L) {
+        uint16_t *pk = P.dk + (row0 + tr) * P.ld_qkv + h * DH + m;
+        uint16_t *pv = P.dv + (row0 + tr) * P.ld_qkv + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          pk[16 * n] = f2bf(dk[n][r]);
+          pv[16 * n] = f2bf(dv[n][r]);
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+size_t fwd_lds() {
+  constexpr int NC = (NT + 1) / 2;
+  return (size_t)2 * (NT * 16 * KS + 64 * (NC * 32 + 8));
+}
+template <int NT>
+size_t bwd_lds() {
+  constexpr int NC = (NT + 1) / 2;
+  return (size_t)2 * (2 * NT * 16 * KS + 64 * (NC * 32 + 8)) + (size_t)4 * NT * 16;
+}
+inline int pick_waves(int nt) {
+  const int rounds = (nt + 7) / 8;
+  return (nt + rounds - 1) / rounds;
+}
+
+template <int NT>
+int launch(const Params &P, bool backward, hipStream_t s) {
+  const int nw = pick_waves(P.nt);
+  const dim3 grid(P.B * P.H), block(64 * nw);
+  const bool spatial = P.sw != nullptr;
+  const size_t lds = backward ? bwd_lds<NT>() : fwd_lds<NT>();
+  if (lds > 64 * 1024) {
+    static bool done[4] = {false, false, false, false};
+    const int slot = (backward ? 2 : 0) + (spatial ? 1 : 0);
+    if (!done[slot]) {
+      const void *fn = backward ? (spatial ? (const void *)&attn_bwd_kernel<NT, true> : (const void *)&attn_bwd_kernel<NT, false>)
+                                : (spatial ? (const void *)&attn_fwd_kernel<NT, true> : (const void *)&attn_fwd_kernel<NT, false>);
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return GPS_ERR_LAUNCH;
+      done[slot] = true;
+    }
+  }
+  if (backward) {
+    if (spatial) hipLaunchKernelGGL((attn_bwd_kernel<NT, true>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((attn_bwd_kernel<NT, false>), grid, block, lds, s, P);
+  } else {
+    if (spatial) hipLaunchKernelGGL((attn_fwd_kernel<NT, true>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((attn_fwd_kernel<NT, false>), grid, block, lds, s, P);
+  }
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int dispatch(Params &P, bool backward, hipStream_t s) {
+  P.nt = (P.L + 15) / 16;
+  if (P.nt <= 5) return launch<5>(P, backward, s);
+  if (P.nt <= 9) return launch<9>(P, backward, s);
+  if (P.nt <= 16) return launch<16>(P, backward, s);
+  return GPS_ERR_UNSUPPORTED;
+}
+
+}  // namespace gps_attn
+
+extern "C" {
+
+int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
+                     int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
+                     float p_drop, unsigned long long seed, void *out, int ld_o, float *lse,
+                     gps_stream_t stream) {
+  if (B < 0 || H < 1 || L < 0 || ld_qkv < H * 64 || ld_o < H * 64 || p_drop < 0.f || p_drop >= 1.f)
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (head_dim != gps_attn::DH || (ld_qkv & 7) || (ld_o & 7)) return GPS_ERR_UNSUPPORTED;
+  if (B == 0 || L == 0) return GPS_OK;
+  if (!q || !k || !v || !out || !lse || ((sw == nullptr) != (pl == nullptr))) return GPS_ERR_INVALID_ARGUMENT;
+  gps_attn::Params P = {};
+  P.B = B; P.H = H; P.L = L; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
+  P.q = (const uint16_t *)q; P.k = (const uint16_t *)k; P.v = (const uint16_t *)v;
+  P.sw = sw; P.pl = pl; P.mask = mask; P.out = (uint16_t *)out; P.lse = lse;
+  P.p_drop = p_drop; P.seed = seed;
+  P.drop_thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  return gps_attn::dispatch(P, false, (hipStream_t)stream);
+}
+
+int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
+                      int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
+                      float p_drop, unsigned long long seed, const void *dout, int ld_o,
+                      const float *lse, void *dq, void *dk, void *dv, float *dsw,
+                      gps_stream_t stream) {
+  if (B < 0 || H < 1 || L < 0 || ld_qkv < H * 64 || ld_o < H * 64 || p_drop < 0.f || p_drop >= 1.f)
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (head_dim != gps_attn::DH || (ld_qkv & 7) || (ld_o & 7)) return GPS_ERR_UNSUPPORTED;
+  if (B == 0 || L == 0) return GPS_OK;
+  if (!q || !k || !v || !dout || !lse || !dq || !dk || !dv || ((sw == nullptr) != (pl == nullptr)) ||
+      (sw && !dsw))
+    return GPS_ERR_INVALID_ARGUMENT;
+  gps_attn::Params P = {};
+  P.B = B; P.H = H; P.L = L; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
+  P.q = (const uint16_t *)q; P.k = (const uint16_t *)k; P.v = (const uint16_t *)v;
+  P.sw = sw; P.pl = pl; P.mask = mask; P.lse = const_cast<float *>(lse);
+  P.dout = (const uint16_t *)dout; P.dq = (uint16_t *)dq; P.dk = (uint16_t *)dk; P.dv = (uint16_t *)dv;
+  P.dsw = dsw; P.p_drop = p_drop; P.seed = seed;
+  P.drop_thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  return gps_attn::dispatch(P, true, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -48,6 +48,26 @@ def get_attention_backend() -> str:
     return _BACKEND
 
 
+def _bf16_mode(x: Tensor) -> bool:
+    """True when this op would run in bf16: a bf16 tensor, or fp32 under torch.autocast(bf16)."""
+    if x.dtype == torch.bfloat16:
+        return True
+    return x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled() and \
+        torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
+def _use_hip(x: Tensor, d_model: int, n_head: int) -> bool:
+    """The fused gfx950 attention core (libgps_hip.so) serves GPU self-attention in bf16."""
+    if _BACKEND == "torch" or not x.is_cuda:
+        return False
+    from . import fused_attention
+    ok = x.dim() == 3 and fused_attention.supported(d_model, n_head, x.shape[1]) and _bf16_mode(x)
+    if _BACKEND == "hip" and not ok:
+        raise RuntimeError("attention backend 'hip' requested for an unsupported call "
+                           f"(shape {tuple(x.shape)}, dtype {x.dtype}, d_model {d_model}, heads {n_head})")
+    return ok
+
+
 def _split_heads(x: Tensor, n_head: int) -> Tensor:
     """(B, L, H*dh) -> (B, H, L, dh)"""
     b, l, d = x.shape
@@ -145,7 +165,22 @@ class MultiHeadAttentionSpatial(nn.Module):
             return torch.log(torch.clamp(loc, min=1e-6))
         return loc
 
+    def _forward_fused(self, x, pairwise_locs, key_padding_mask):
+        """fusion 'cond', self-attention, bf16 on the GPU: ONE projection GEMM producing
+        [q | k | v | per-head (bias, w_1..w_5)] and one fused attention launch."""
+        from .fused_attention import fused_self_attention
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.lang_cond_fc.weight], 0)
+        bias = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias, self.lang_cond_fc.bias], 0)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            packed = F.linear(x, w, bias)
+        out = fused_self_attention(packed, self.n_head, pairwise_locs, key_padding_mask)
+        return self.fc(out), None
+
     def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, txt_embeds=None):
+        if (self.spatial_attn_fusion == 'cond' and k is q and v is q and not self.need_weights
+                and self.spatial_n_head == self.n_head and self.spatial_dim == 5
+                and _use_hip(q, self.d_model, self.n_head)):
+            return self._forward_fused(q, pairwise_locs, key_padding_mask)
         x_in = q
         qh = _split_heads(self.w_qs(q), self.n_head)
         kh = _split_heads(self.w_ks(k), self.n_head)
@@ -209,6 +244,15 @@ class MultiheadSelfAttention(nn.Module):
         nn.init.constant_(self.out_proj.bias, 0.)
 
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, need_weights=None):
+        want = self.need_weights if need_weights is None else need_weights
+        if (self._same and key is query and value is query and attn_mask is None and not want
+                and _use_hip(query, self.embed_dim, self.num_heads)):
+            from .fused_attention import fused_self_attention
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                packed = F.linear(query, self.in_proj_weight, self.in_proj_bias)
+            out = fused_self_attention(packed, self.num_heads, None, key_padding_mask,
+                                       dropout_p=self.dropout, training=self.training)
+            return self.out_proj(out), None
         E = self.embed_dim
         bq, bk, bv = self.in_proj_bias[:E], self.in_proj_bias[E:2 * E], self.in_proj_bias[2 * E:]
         if self._same:
