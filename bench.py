@@ -34,6 +34,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, same guide
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")   # rocprofv3 --pmc, see tools/pmc_traffic.py
 N_CLS = 607
 
 
@@ -197,12 +199,28 @@ def main() -> None:
     if rank == 0:
         kernels = []
         for name, k in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]):
-            gbs = k["bytes_per_launch"] / (k["avg_us"] * 1e-6) / 1e9
-            kernels.append({"kernel": name, "launches_per_step": k["launches"] / args.steps,
-                            "avg_us": round(k["avg_us"], 2),
-                            "algorithmic_bytes": int(k["bytes_per_launch"]),
-                            "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            sec = k["avg_us"] * 1e-6
+            gbs = k["bytes_per_launch"] / sec / 1e9
+            row = {"kernel": name, "launches_per_step": k["launches"] / args.steps,
+                   "avg_us": round(k["avg_us"], 2), "algorithmic_bytes": int(k["bytes_per_launch"]),
+                   "achieved_GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+            # which roof bounds the kernel: the one its algorithmic work would take longer on
+            t_hbm = k["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
+            peak_tf = MFMA_PEAK_TFLOPS.get(k.get("mfma_dtype") or "", 0.0)
+            t_mfma = k["flops_per_launch"] / (peak_tf * 1e12) if peak_tf else 0.0
+            if t_mfma > t_hbm:
+                tf = k["flops_per_launch"] / sec / 1e12
+                row.update({"bound": "mfma", "algorithmic_flops": int(k["flops_per_launch"]),
+                            "mfma_dtype": k["mfma_dtype"], "achieved_TFLOPs": round(tf, 1),
+                            "frac": round(tf / peak_tf, 4)})
+            else:
+                row.update({"bound": "hbm", "frac": row["frac_hbm"]})
+            kernels.append(row)
         dom = kernels[0] if kernels else None
+        traffic = None
+        if dom is not None and os.path.exists(PMC_TRAFFIC):
+            with open(PMC_TRAFFIC) as f:
+                traffic = json.load(f).get("per_launch_hbm_bytes", {}).get(dom["kernel"])
         result = {
             "metric": "GPS pre-train pairs/sec (fwd+bwd)",
             "value": round(args.batch * world * args.steps / dt, 2),
@@ -222,9 +240,13 @@ def main() -> None:
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "point_ops": "fp32 (libgps_hip.so)",
                        "final_loss": round(final_loss, 4)},
-            "roofline": None if dom is None else {
-                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": None},
+            "roofline": None if dom is None else (
+                {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],
+                 "peak": MFMA_PEAK_TFLOPS[dom["mfma_dtype"]], "unit": "TFLOP/s", "frac": dom["frac"],
+                 "dtype": dom["mfma_dtype"], "traffic": traffic}
+                if dom["bound"] == "mfma" else
+                {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic}),
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

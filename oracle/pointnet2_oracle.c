@@ -15,8 +15,9 @@
  *
  * Parity pin status: the reference ships no golden vectors for these ops
  * (SURVEY.md 8c).  The oracle is pinned against the reference itself run on the
- * MI355X (oracle/_ref, the reference sources compiled unmodified) -- see
- * tests/golden/README.md and tests/test_golden_ref.py.
+ * MI355X (oracle/_ref, the reference sources compiled unmodified): committed fixtures
+ * tests/golden/point_ops_ref_gpu.pt (made by tests/golden/make_golden_gpu.py), checked on CPU by
+ * tests/test_oracle_vs_golden_gpu.py and live on the GPU by tests/test_gpu_vs_reference_ext.py.
  */
 #include <math.h>
 #include <stdint.h>

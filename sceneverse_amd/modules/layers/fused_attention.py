@@ -56,7 +56,11 @@ class _FusedSelfAttention(torch.autograd.Function):
         out = torch.empty((B, L, D), dtype=torch.bfloat16, device=packed.device)
         lse = torch.empty((B, n_head, L), dtype=torch.float32, device=packed.device)
         base, esz = packed.data_ptr(), packed.element_size()
-        with torch.cuda.device(packed.device):
+        from ...pointnet2._ext import _timed
+        # algorithmic work: q,k,v,out once (+ pairwise/cond vector), 2 x L x L x 64 MACs per head
+        nbytes = 2 * B * L * 4 * D + (B * L * L * 5 * 4 + B * L * n_head * 6 * 4 if spatial else 0)
+        with torch.cuda.device(packed.device), _timed(f"attn_forward(L={L},spatial={int(spatial)})", nbytes,
+                                                      4 * B * n_head * L * L * HEAD_DIM, "bf16"):
             st = _native.load().gps_attn_forward(
                 B, n_head, L, HEAD_DIM, base, base + D * esz, base + 2 * D * esz, W,
                 _ptr(sw), _ptr(pl), _ptr(m8), float(p_drop), int(seed), out.data_ptr(), D,
@@ -77,7 +81,10 @@ class _FusedSelfAttention(torch.autograd.Function):
         dsw = torch.empty_like(sw) if spatial else None
         base, esz = packed.data_ptr(), packed.element_size()
         gbase = dpacked.data_ptr()
-        with torch.cuda.device(packed.device):
+        from ...pointnet2._ext import _timed
+        nbytes = 2 * B * L * 8 * D + (B * L * L * 5 * 4 + 2 * B * L * n_head * 6 * 4 if spatial else 0)
+        with torch.cuda.device(packed.device), _timed(f"attn_backward(L={L},spatial={int(spatial)})", nbytes,
+                                                      10 * B * n_head * L * L * HEAD_DIM, "bf16"):
             st = _native.load().gps_attn_backward(
                 B, n_head, L, HEAD_DIM, base, base + D * esz, base + 2 * D * esz, W,
                 _ptr(sw), _ptr(pl), _ptr(m8), p_drop, seed, dout.data_ptr(), D, lse.data_ptr(),

@@ -27,23 +27,26 @@ def profile_start() -> None:
 
 
 def profile_stop() -> dict:
-    """-> {op: {"launches": n, "avg_us": t, "bytes_per_launch": B}} (synchronises)."""
+    """-> {op: {"launches": n, "avg_us": t, "bytes_per_launch": B, "flops_per_launch": F,
+    "mfma_dtype": "fp32"|"bf16"|None}} (synchronises)."""
     global _PROFILE
     rec, _PROFILE = _PROFILE or {}, None
     torch.cuda.synchronize()
     out = {}
     for name, evs in rec.items():
-        ms = [s.elapsed_time(e) for s, e, _ in evs]
+        ms = [s.elapsed_time(e) for s, e, *_ in evs]
         out[name] = {"launches": len(evs), "avg_us": 1e3 * sum(ms) / len(ms),
-                     "bytes_per_launch": sum(b for _, _, b in evs) / len(evs)}
+                     "bytes_per_launch": sum(ev[2] for ev in evs) / len(evs),
+                     "flops_per_launch": sum(ev[3] for ev in evs) / len(evs),
+                     "mfma_dtype": evs[0][4]}
     return out
 
 
 class _timed:
     """Brackets one native launch with two events on the current (= launch) stream."""
 
-    def __init__(self, name: str, algo_bytes: int):
-        self.name, self.bytes = name, algo_bytes
+    def __init__(self, name: str, algo_bytes: int, algo_flops: int = 0, mfma_dtype=None):
+        self.name, self.bytes, self.flops, self.mfma = name, algo_bytes, algo_flops, mfma_dtype
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -55,7 +58,7 @@ class _timed:
     def __exit__(self, *exc):
         if _PROFILE is not None:
             self.e.record()
-            _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.bytes))
+            _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.bytes, self.flops, self.mfma))
         return False
 
 

@@ -32,4 +32,14 @@ if [[ $WHAT == all || $WHAT == *prof* ]]; then
   f=$(ls $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -45 "$f"
   tail -3 $OUT/prof_bench.log
 fi
+if [[ $WHAT == *pmc* ]]; then
+  ts pmc
+  rm -rf /tmp/pmc && mkdir -p /tmp/pmc
+  (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc -o fetch --output-format csv -- python $REPO/tools/pmc_workload.py > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?")
+  (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc -o write --output-format csv -- python $REPO/tools/pmc_workload.py > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?")
+  ls -la /tmp/pmc | head
+  mkdir -p $OUT/pmc
+  cp /tmp/pmc/*counter_collection.csv $OUT/pmc/ 2>/dev/null
+  python tools/pmc_traffic.py /tmp/pmc/fetch_counter_collection.csv /tmp/pmc/write_counter_collection.csv $OUT/pmc/pmc_traffic.json | tail -60
+fi
 ts done; du -sh $REPO/gpurun_out

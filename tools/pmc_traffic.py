@@ -1,0 +1,66 @@
+"""Turn the two rocprofv3 --pmc passes of tools/pmc_workload.py into HBM bytes per launch.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json
+
+Correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB-like units derived from
+the L2's fabric request counters and are NOT byte-exact on gfx950 (FETCH_SIZE = 1/2 of a wide coalesced
+read; WRITE_SIZE uncalibrated) -> both are calibrated on the 512 MiB device copy at the head of the
+workload (known bytes / counter), and the factors are recorded in the output."""
+import collections
+import csv
+import json
+import re
+import sys
+
+CAL_BYTES = 512 << 20
+
+# HIP symbol -> the kernel names bench.py reports
+NAMES = [
+    (r"sa_mlp_kernel<128, 128, 128, 256>", "sa_mlp_forward(c=128,n=32,np=16,mlp=128-128-256)"),
+    (r"sa_mlp_kernel<3, 64, 64, 128>", "sa_mlp_forward(c=3,n=1024,np=32,mlp=64-64-128)"),
+    (r"fps_resident_kernel<16>", "furthest_point_sampling(n=1024,m=32)"),
+    (r"fps_resident_kernel<1>", "furthest_point_sampling(n=32,m=16)"),
+    (r"ball_query_kernel<16>", "ball_query(n=1024,m=32,ns=32)"),
+    (r"ball_query_kernel<1>", "ball_query(n=32,m=16,ns=32)"),
+    (r"group_points_kernel", "group_points"),
+    (r"gather_points_kernel", "gather_points"),
+]
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != counter:
+                continue
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main(fetch_csv, write_csv, out):
+    fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    cal = [k for k in fetch if "copy" in k.lower() and max(fetch[k]) > 0]
+    cal_k = max(cal, key=lambda k: max(fetch[k]))
+    f_unit = CAL_BYTES / (sum(fetch[cal_k]) / len(fetch[cal_k]))
+    w_unit = CAL_BYTES / (sum(write[cal_k]) / len(write[cal_k]))
+    res = {"calibration": {"kernel": cal_k[:80], "known_bytes_each_way": CAL_BYTES,
+                           "bytes_per_FETCH_SIZE_unit": f_unit, "bytes_per_WRITE_SIZE_unit": w_unit},
+           "per_launch_hbm_bytes": {}, "per_launch_detail": {}}
+    for k in fetch:
+        for pat, name in NAMES:
+            if re.search(re.escape(pat), k):
+                fb = f_unit * sum(fetch[k]) / len(fetch[k])
+                wb = w_unit * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
+                if name in ("group_points", "gather_points"):
+                    name = f"{name}#{len(res['per_launch_detail'])}"
+                res["per_launch_hbm_bytes"][name] = int(fb + wb)
+                res["per_launch_detail"][name] = {"symbol": k[:100], "read_bytes": int(fb), "write_bytes": int(wb),
+                                                  "launches": len(fetch[k])}
+                break
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

@@ -1,0 +1,63 @@
+"""Workload for the rocprofv3 --pmc passes (HBM traffic per launch of the native point-path kernels).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d <dir> -o fetch --output-format csv -- python tools/pmc_workload.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d <dir> -o write --output-format csv -- python tools/pmc_workload.py
+
+A plain 512 MiB device copy runs first: its byte count is known, so tools/pmc_traffic.py can calibrate
+the two counters in this environment (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half of a wide
+coalesced read; WRITE_SIZE is uncalibrated) before converting the kernels' counters to bytes."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from sceneverse_amd.data.synthetic import synth_batch  # noqa: E402
+from sceneverse_amd.pointnet2 import _ext as hip  # noqa: E402
+
+CAL_BYTES = 512 << 20
+
+
+def main():
+    dev = "cuda"
+    src = torch.randn(CAL_BYTES // 4, device=dev)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)                      # calibration: CAL_BYTES read + CAL_BYTES written
+    torch.cuda.synchronize()
+
+    d = synth_batch(64, seed=42)
+    pcs = d["obj_fts"].reshape(-1, 1024, 6).to(dev)
+    xyz = pcs[..., :3].contiguous()
+    rgb = pcs[..., 3:].transpose(1, 2).contiguous()
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    torch.manual_seed(0)
+
+    def packed(cin, chans):
+        ws, ss, c = [], [], cin
+        for co in chans:
+            ws.append(torch.randn(co, c, device=dev) * (2.0 / c) ** 0.5)
+            ss.append(torch.randn(co, device=dev) * 0.05)
+            c = co
+        return hip.sa_mlp_pack(ws, ss)
+
+    wp1, wp2 = packed(6, [64, 64, 128]), packed(131, [128, 128, 256])
+    for _ in range(3):
+        fps = hip.furthest_point_sampling(xyz, 32)
+        new_xyz = hip.gather_points(xyz_t, fps).transpose(1, 2).contiguous()
+        idx = hip.ball_query(new_xyz, xyz, 0.2, 32)
+        f1 = hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1, [64, 64, 128])
+        fps2 = hip.furthest_point_sampling(new_xyz, 16)
+        nx2 = hip.gather_points(new_xyz.transpose(1, 2).contiguous(), fps2).transpose(1, 2).contiguous()
+        idx2 = hip.ball_query(nx2, new_xyz, 0.4, 32)
+        hip.sa_mlp_forward(new_xyz, nx2, f1, idx2, wp2, [128, 128, 256])
+        # the unfused reference API on the same data (what the fused launches absorb)
+        hip.group_points(xyz_t, idx)
+        hip.group_points(f1, idx2)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
