@@ -173,6 +173,22 @@ GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, 
                               const float *lse, void *dq, void *dk, void *dv, float *dsw,
                               gps_stream_t stream);
 
+/* ---- row-sparse cross-entropy (masked-LM head) ----------------------------------------------------
+ * Replaces the F.cross_entropy(..., ignore_index=-1) of lm_cls_loss (optim/loss/loss.py:56-61) over
+ * txt_lm_cls_logits (modules/heads/pretrain_head.py:22-56).  logits (n_rows, ld >= vocab) bf16
+ * (logits_bf16 != 0) or fp32; labels int64; rows whose label == ignore_index (or is out of range)
+ * contribute loss 0 and gradient 0 and are never read.  loss_rows[n] = lse[n] - logits[n][label];
+ * the caller takes sum(loss_rows) / count(valid) (the reference's mean over non-ignored targets). */
+GPS_API int gps_masked_ce_forward(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
+                                  const long long *labels, long long ignore_index, float *loss_rows,
+                                  float *lse, gps_stream_t stream);
+/* dlogits[n][v] = (softmax(logits[n])[v] - [v == label]) * grad_rows[n], 0 for ignored rows; same
+ * dtype as logits, row pitch ldd. */
+GPS_API int gps_masked_ce_backward(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
+                                   const long long *labels, long long ignore_index, const float *lse,
+                                   const float *grad_rows, void *dlogits, long long ldd,
+                                   gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

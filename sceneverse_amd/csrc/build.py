@@ -16,6 +16,7 @@ SOURCES = [
     ("gps_point_ops.hip", ["-ffp-contract=off"]),
     ("gps_sa_mlp.hip", []),
     ("gps_attention.hip", []),
+    ("gps_losses.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-I" + os.path.join(ROOT, "include")]

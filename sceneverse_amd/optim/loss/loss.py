@@ -1,6 +1,7 @@
 """Loss functions over `data_dict` and the list-of-losses container (reference
 optim/loss/loss.py).  Module-level functions are looked up by name exactly like the reference's
 `globals()` dispatch (:121-129); registered nn.Module losses come from LOSS_REGISTRY."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -66,7 +67,12 @@ def lm_cls_loss(data_dict):                                 # ref :56-61
     labels = data_dict["masked_lm_labels"]
     if labels.dim() == 3:
         labels = labels.view(-1, labels.size(-1))
-    return F.cross_entropy(data_dict["txt_lm_cls_logits"].permute(0, 2, 1), labels, ignore_index=-1)
+    logits = data_dict["txt_lm_cls_logits"]
+    if logits.is_cuda and logits.dtype in (torch.bfloat16, torch.float32):
+        # row-sparse kernel: ignored positions (> 90 % of the rows) are never read
+        from .masked_ce import masked_cross_entropy
+        return masked_cross_entropy(logits, labels, ignore_index=-1)
+    return F.cross_entropy(logits.permute(0, 2, 1), labels, ignore_index=-1)
 
 
 def obj_cls_pre_loss_mask(data_dict):                       # ref :64-69

@@ -1,0 +1,48 @@
+"""Row-sparse cross-entropy kernel (gps_masked_ce_*) against F.cross_entropy(ignore_index=-1), the
+call the reference makes in lm_cls_loss (optim/loss/loss.py:56-61).
+fp32 logits: loss within 1e-5 relative, gradient within 1e-6 absolute (exp/log intrinsics).
+bf16 logits: both sides read the same bf16 values; the kernel rounds its gradient to bf16 once
+(torch computes in fp32 from the up-cast): gradient within 2^-8 relative of the largest entry."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sceneverse_amd.optim.loss.masked_ce import masked_cross_entropy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("n,v,dtype", [(3200, 30522, torch.bfloat16), (257, 30522, torch.float32),
+                                       (64, 607, torch.float32), (5, 7, torch.bfloat16)])
+def test_matches_torch_cross_entropy(n, v, dtype):
+    g = torch.Generator().manual_seed(n + v)
+    logits = (torch.randn(n, v, generator=g) * 3).to(dtype)
+    labels = torch.randint(0, v, (n,), generator=g)
+    labels[torch.rand(n, generator=g) < 0.85] = -1
+    labels[0] = 3 % v                                     # at least one labelled row
+    ref_in = logits.float().requires_grad_(True)
+    ref = F.cross_entropy(ref_in, labels, ignore_index=-1)
+    ref.backward()
+    x = logits.to(DEV).requires_grad_(True)
+    got = masked_cross_entropy(x, labels.to(DEV), ignore_index=-1)
+    got.backward()
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-6, (got.item(), ref.item())
+    gd, gr = x.grad.float().cpu(), ref_in.grad
+    tol = 1e-6 if dtype == torch.float32 else 2 ** -8 * gr.abs().max().item()
+    assert (gd - gr).abs().max().item() <= tol, ((gd - gr).abs().max().item(), tol)
+    assert gd[labels == -1].abs().max().item() == 0.0      # ignored rows: exact zeros
+
+
+def test_lm_cls_loss_uses_it_and_handles_3d_labels():
+    from sceneverse_amd.optim.loss.loss import lm_cls_loss
+    from sceneverse_amd.pointnet2 import _ext
+    logits = torch.randn(4, 50, 30522, device=DEV, dtype=torch.bfloat16)
+    labels = torch.full((4, 50), -1, dtype=torch.long, device=DEV)
+    labels[:, 3] = 17
+    _ext.profile_start()
+    val = lm_cls_loss({"txt_lm_cls_logits": logits, "masked_lm_labels": labels})
+    rec = _ext.profile_stop()
+    assert "masked_ce_forward" in rec
+    ref = F.cross_entropy(logits.float().permute(0, 2, 1), labels, ignore_index=-1)
+    assert abs(val.item() - ref.item()) < 1e-4
