@@ -145,6 +145,18 @@ GPS_API int gps_sa_mlp_forward(int b, int n, int npoint, int nsample, int c_feat
                                const int32_t *idx, const float *wpack, float *out,
                                gps_stream_t stream);
 
+/* Split-bf16 variant of the three calls above: each fp32 operand is carried as bf16 (hi, lo) and each
+ * product as W_hi X_hi + W_hi X_lo + W_lo X_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (~2^-16 relative error per product, ~5x fewer matrix-pipe cycles than the fp32 MFMA form).  The
+ * packed buffer has its own format: pack with gps_sa_mlp_pack_layer_bf16x3. */
+GPS_API long long gps_sa_mlp_layer_floats_bf16x3(int c_in, int c_out);
+GPS_API int gps_sa_mlp_pack_layer_bf16x3(int c_in, int c_out, const float *w, const float *shift, float *dst,
+                                         gps_stream_t stream);
+GPS_API int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int c_feat, int c1, int c2,
+                                      int c3, const float *xyz, const float *new_xyz, const float *features,
+                                      const int32_t *idx, const float *wpack, float *out,
+                                      gps_stream_t stream);
+
 /* ---- fused self-attention core (object-level spatial transformer, joint text+object transformer) --
  * One launch for what the reference runs between the QKV projections and the output projection:
  *   modules/layers/transformers.py:193-239  MultiHeadAttentionSpatial.forward, fusion 'cond':

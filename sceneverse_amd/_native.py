@@ -35,6 +35,8 @@ SIGNATURES = {
     "gps_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_sa_mlp_pack_layer": [_i, _i, _vp, _vp, _vp, _vp],
     "gps_sa_mlp_forward": [_i] * 8 + [_vp] * 7,
+    "gps_sa_mlp_pack_layer_bf16x3": [_i, _i, _vp, _vp, _vp, _vp],
+    "gps_sa_mlp_forward_bf16x3": [_i] * 8 + [_vp] * 7,
     "gps_masked_ce_forward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_masked_ce_backward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp],
@@ -76,6 +78,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_sa_mlp_wpack_floats.argtypes = [_i, _i, _i, _i]
     lib.gps_sa_mlp_layer_floats.restype = ctypes.c_longlong
     lib.gps_sa_mlp_layer_floats.argtypes = [_i, _i]
+    lib.gps_sa_mlp_layer_floats_bf16x3.restype = ctypes.c_longlong
+    lib.gps_sa_mlp_layer_floats_bf16x3.argtypes = [_i, _i]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -309,6 +309,255 @@ int launch_sa(int b, int n, int npoint, const float *xyz, const float *new_xyz, 
   return GPS_OK;
 }
 
+
+// ==========================================================================================
+// split-bf16 variant: every fp32 operand x is carried as (hi, lo) = (bf16(x), bf16(x - hi)) and each
+// product as  W_hi X_hi + W_hi X_lo + W_lo X_hi  on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+// 3 MFMAs at the bf16 rate (16x the fp32 MFMA rate) instead of 8, i.e. ~5.3x fewer matrix-pipe
+// cycles, for a relative error ~2^-16 per product (the dropped W_lo X_lo term and the 2^-17
+// representation residuals) -- inside the 1e-4 tolerance of the parity tests.
+//
+// Same chaining trick: D regs [8u, 8u+8) of a 32-row tile are the B fragment (K = 16) of step
+// (tile, u) of the next layer; K-slot (half h, element e) <-> channel 32 it + 16 u + 8 (e>>2) + 4 h + (e&3).
+// Packed tile (bytes): step s: [hi: 64 lanes x 16 B][lo: 64 lanes x 16 B]; then 32 fp32 shifts;
+// padded to 1 KiB.
+// ==========================================================================================
+namespace x3 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int steps16(int c_in) { return (c_in + 15) / 16; }
+__host__ __device__ constexpr int slot_channel16(int it_u, int e, int h) {   // it_u = 2 * it + u
+  return 16 * it_u + 8 * (e >> 2) + 4 * h + (e & 3);
+}
+// floats (4-byte units) of one packed 32-row tile
+__host__ __device__ constexpr int tile_floats16(int c_in) {
+  return (steps16(c_in) * 512 + 32 + 255) / 256 * 256;
+}
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__global__ void pack_layer16_kernel(int c_in, int c_out, const float *__restrict__ w,
+                                    const float *__restrict__ shift, float *__restrict__ dst) {
+  const int steps = steps16(c_in);
+  const int tf = tile_floats16(c_in);
+  const int total = (c_out / 32) * tf;
+  for (int e4 = blockIdx.x * blockDim.x + threadIdx.x; e4 < total; e4 += gridDim.x * blockDim.x) {
+    const int mt = e4 / tf, o = e4 - mt * tf;   // o: 4-byte unit inside the tile
+    if (o >= steps * 512) {
+      dst[e4] = o < steps * 512 + 32 ? shift[mt * 32 + (o - steps * 512)] : 0.f;
+      continue;
+    }
+    const int s = o >> 9, part = (o >> 8) & 1, lane = (o >> 2) & 63, pair = o & 3;   // 2 bf16 per unit
+    const int i = lane & 31, h = lane >> 5;
+    unsigned int packed = 0;
+    for (int q = 0; q < 2; ++q) {
+      const int e = 2 * pair + q;
+      const int k = slot_channel16(s, e, h);
+      const float x = k < c_in ? w[(size_t)(mt * 32 + i) * c_in + k] : 0.f;
+      const uint16_t hi = f2bf(x);
+      const float back = __uint_as_float((unsigned int)hi << 16);
+      const uint16_t v = part == 0 ? hi : f2bf(x - back);
+      packed |= (unsigned int)v << (16 * q);
+    }
+    dst[e4] = __uint_as_float(packed);
+  }
+}
+
+__device__ __forceinline__ void split8(const f32x8 &v, bf16x8 &hi, bf16x8 &lo) {
+  hi = __builtin_convertvector(v, bf16x8);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+
+template <int STEPS>
+__device__ __forceinline__ f32x16 mfma_tile16(const float *__restrict__ tile, const bf16x8 (&Bhi)[STEPS],
+                                              const bf16x8 (&Blo)[STEPS], int lane) {
+  f32x16 acc;
+  const float *sh = tile + STEPS * 512 + 4 * (lane >> 5);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = sh[(r & 3) + 8 * (r >> 2)];
+  const bf16x8 *frag = reinterpret_cast<const bf16x8 *>(tile) + lane;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const bf16x8 ahi = frag[s * 128], alo = frag[s * 128 + 64];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, Bhi[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, Blo[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, Bhi[s], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(kBlock, 2) void sa_mlp_x3_kernel(
+    int b, int n, int npoint, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int32_t *__restrict__ idx,
+    const float *__restrict__ wpack, float *__restrict__ out) {
+  constexpr int CIN = 3 + CF;
+  constexpr int S1 = steps16(CIN), S2 = C1 / 16, S3 = C2 / 16;
+  constexpr int T1 = tile_floats16(CIN), T2 = tile_floats16(C1), T3 = tile_floats16(C2);
+  constexpr int M1 = C1 / 32, M2 = C2 / 32, M3 = C3 / 32;
+  constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+  constexpr int G = M1 + M2 + M3;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *s_w0 = lds;
+  float *s_w1 = s_w0 + TMAX;
+  float *s_out = s_w1 + TMAX;                // C3 * npoint
+  float *s_feat = s_out + C3 * npoint;       // CF * n
+  float *s_xyz = s_feat + CF * n;            // n * 3
+  float *s_ctr = s_xyz + n * 3;              // npoint * 3
+  int32_t *s_idx = reinterpret_cast<int32_t *>(s_ctr + npoint * 3);
+
+  const int obj = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  {
+    const float *gf = feats + (size_t)obj * CF * n;
+    const float *gx = xyz + (size_t)obj * n * 3;
+    const float *gc = new_xyz + (size_t)obj * npoint * 3;
+    const int32_t *gi = idx + (size_t)obj * npoint * kNS;
+    if (((CF * n) & 3) == 0) {
+      const float4 *g4 = reinterpret_cast<const float4 *>(gf);
+      float4 *l4 = reinterpret_cast<float4 *>(s_feat);
+      for (int e = tid; e < (CF * n) >> 2; e += kBlock) l4[e] = g4[e];
+    } else {
+      for (int e = tid; e < CF * n; e += kBlock) s_feat[e] = gf[e];
+    }
+    for (int e = tid; e < n * 3; e += kBlock) s_xyz[e] = gx[e];
+    for (int e = tid; e < npoint * 3; e += kBlock) s_ctr[e] = gc[e];
+    for (int e = tid; e < npoint * kNS; e += kBlock) s_idx[e] = gi[e];
+  }
+  tile_copy_async(wpack, s_w0, T1, wave, lane);
+  tile_copy_wait();
+  __syncthreads();
+
+  auto tile_src = [&](int g, int &len) -> const float * {
+    if (g >= G) g -= G;
+    if (g < M1) { len = T1; return wpack + (size_t)g * T1; }
+    if (g < M1 + M2) { len = T2; return wpack + (size_t)M1 * T1 + (size_t)(g - M1) * T2; }
+    len = T3;
+    return wpack + (size_t)M1 * T1 + (size_t)M2 * T2 + (size_t)(g - M1 - M2) * T3;
+  };
+
+  const int rounds = (npoint + kWaves - 1) / kWaves;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int tile = rd * kWaves + wave;
+    const bool live = tile < npoint;
+    const int j = live ? tile : npoint - 1;
+
+    bf16x8 a0h[S1], a0l[S1];
+    {
+      const int p = s_idx[j * kNS + col];
+#pragma unroll
+      for (int s = 0; s < S1; ++s) {
+        f32x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = slot_channel16(s, e, h);
+          float x;
+          if (slot_channel16(s, e, 0) >= 3 && slot_channel16(s, e, 1) < CIN) {
+            x = s_feat[(k - 3) * n + p];
+          } else {
+            x = 0.f;
+            if (k < 3) x = s_xyz[p * 3 + k] - s_ctr[j * 3 + k];
+            else if (k < CIN) x = s_feat[(k - 3) * n + p];
+          }
+          v[e] = x;
+        }
+        split8(v, a0h[s], a0l[s]);
+      }
+    }
+    bf16x8 a1h[S2], a1l[S2], a2h[S3], a2l[S3];
+    int g = 0;
+#pragma unroll
+    for (int mt = 0; mt < M1; ++mt, ++g) {
+      const int gg = rd * G + g;
+      int len;
+      const float *src = tile_src(g + 1, len);
+      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
+      const f32x16 acc = mfma_tile16<S1>((gg & 1) ? s_w1 : s_w0, a0h, a0l, lane);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc[8 * u + e], 0.f);
+        split8(v, a1h[2 * mt + u], a1l[2 * mt + u]);
+      }
+      tile_copy_wait();
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < M2; ++mt, ++g) {
+      const int gg = rd * G + g;
+      int len;
+      const float *src = tile_src(g + 1, len);
+      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
+      const f32x16 acc = mfma_tile16<S2>((gg & 1) ? s_w1 : s_w0, a1h, a1l, lane);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc[8 * u + e], 0.f);
+        split8(v, a2h[2 * mt + u], a2l[2 * mt + u]);
+      }
+      tile_copy_wait();
+      __syncthreads();
+    }
+    for (int mt = 0; mt < M3; ++mt, ++g) {
+      const int gg = rd * G + g;
+      int len;
+      const float *src = tile_src(g + 1, len);
+      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
+      const f32x16 acc = mfma_tile16<S3>((gg & 1) ? s_w1 : s_w0, a2h, a2l, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m = half_wave_max(acc[r]);
+        if (col == 31 && live)
+          s_out[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * npoint + tile] = fmaxf(m, 0.f);
+      }
+      tile_copy_wait();
+      __syncthreads();
+    }
+  }
+  float *go = out + (size_t)obj * C3 * npoint;
+  const int total = C3 * npoint;
+  if ((total & 3) == 0) {
+    const float4 *l4 = reinterpret_cast<const float4 *>(s_out);
+    float4 *g4 = reinterpret_cast<float4 *>(go);
+    for (int e = tid; e < total >> 2; e += kBlock) g4[e] = l4[e];
+  } else {
+    for (int e = tid; e < total; e += kBlock) go[e] = s_out[e];
+  }
+}
+
+template <int CF, int C1, int C2, int C3>
+int launch_sa_x3(int b, int n, int npoint, const float *xyz, const float *new_xyz, const float *feats,
+                 const int32_t *idx, const float *wpack, float *out, hipStream_t s) {
+  constexpr int CIN = 3 + CF;
+  constexpr int T1 = tile_floats16(CIN), T2 = tile_floats16(C1), T3 = tile_floats16(C2);
+  constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+  const size_t lds = sizeof(float) * ((size_t)2 * TMAX + (size_t)C3 * npoint + (size_t)CF * n + (size_t)n * 3 +
+                                      (size_t)npoint * 3 + (size_t)npoint * kNS);
+  if (lds > 80 * 1024) return GPS_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_x3_kernel<CF, C1, C2, C3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+      return GPS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3>), dim3(b), dim3(kBlock), lds, s, b, n, npoint, xyz,
+                     new_xyz, feats, idx, wpack, out);
+  return GPS_OK;
+}
+
+}  // namespace x3
+
 }  // namespace gps_sa
 
 extern "C" {
@@ -330,6 +579,38 @@ int gps_sa_mlp_pack_layer(int c_in, int c_out, const float *w, const float *shif
   const int total = (c_out / 32) * gps_sa::tile_floats(c_in);
   hipLaunchKernelGGL(gps_sa::pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, c_in, c_out, w, shift, dst);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+long long gps_sa_mlp_layer_floats_bf16x3(int c_in, int c_out) {
+  if (c_in < 1 || c_out < 32 || (c_out & 31)) return -1;
+  return (long long)(c_out / 32) * gps_sa::x3::tile_floats16(c_in);
+}
+
+int gps_sa_mlp_pack_layer_bf16x3(int c_in, int c_out, const float *w, const float *shift, float *dst,
+                                 gps_stream_t stream) {
+  if (c_in < 1 || c_out < 32 || (c_out & 31) || !w || !shift || !dst) return GPS_ERR_INVALID_ARGUMENT;
+  const int total = (c_out / 32) * gps_sa::x3::tile_floats16(c_in);
+  hipLaunchKernelGGL(gps_sa::x3::pack_layer16_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, c_in, c_out, w, shift, dst);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int c_feat, int c1, int c2, int c3,
+                              const float *xyz, const float *new_xyz, const float *features,
+                              const int32_t *idx, const float *wpack, float *out, gps_stream_t stream) {
+  if (b < 0 || n < 1 || npoint < 1 || nsample < 1 || c_feat < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0) return GPS_OK;
+  if (!xyz || !new_xyz || !idx || !wpack || !out || (c_feat > 0 && !features))
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (nsample != gps_sa::kNS) return GPS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  int st = GPS_ERR_UNSUPPORTED;
+  if (c_feat == 3 && c1 == 64 && c2 == 64 && c3 == 128)
+    st = gps_sa::x3::launch_sa_x3<3, 64, 64, 128>(b, n, npoint, xyz, new_xyz, features, idx, wpack, out, s);
+  else if (c_feat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
+    st = gps_sa::x3::launch_sa_x3<128, 128, 128, 256>(b, n, npoint, xyz, new_xyz, features, idx, wpack, out, s);
+  if (st != GPS_OK) return st;
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

@@ -219,13 +219,20 @@ def sa_mlp_supported(c_feat: int, channels, nsample: int) -> bool:
     return (c_feat, *channels) in ((3, 64, 64, 128), (128, 128, 128, 256))
 
 
-def sa_mlp_pack(weights, shifts) -> torch.Tensor:
+SA_PRECISIONS = ("fp32", "bf16x3")
+
+
+def sa_mlp_pack(weights, shifts, precision: str = "fp32") -> torch.Tensor:
     """weights[i] (c_out_i, c_in_i) BN-folded fp32 GPU tensors, shifts[i] (c_out_i) -> the packed
-    buffer gps_sa_mlp_forward reads ([layer 1 | layer 2 | layer 3], K-slot order of the MFMA)."""
+    buffer gps_sa_mlp_forward[_bf16x3] reads ([layer 1 | layer 2 | layer 3], K-slot order of the MFMA)."""
     lib = _native.load()
+    assert precision in SA_PRECISIONS, precision
+    x3 = precision == "bf16x3"
+    layer_floats = lib.gps_sa_mlp_layer_floats_bf16x3 if x3 else lib.gps_sa_mlp_layer_floats
+    pack_layer = lib.gps_sa_mlp_pack_layer_bf16x3 if x3 else lib.gps_sa_mlp_pack_layer
     sizes = []
     for w in weights:
-        n = int(lib.gps_sa_mlp_layer_floats(w.shape[1], w.shape[0]))
+        n = int(layer_floats(w.shape[1], w.shape[0]))
         if n < 0:
             raise RuntimeError(f"sa_mlp_pack: unsupported layer {w.shape[1]}->{w.shape[0]}")
         sizes.append(n)
@@ -236,15 +243,15 @@ def sa_mlp_pack(weights, shifts) -> torch.Tensor:
             w, sft = w.contiguous(), sft.contiguous()
             _chk(w, "weight", torch.float32)
             _chk(sft, "shift", torch.float32)
-            st = lib.gps_sa_mlp_pack_layer(w.shape[1], w.shape[0], w.data_ptr(), sft.data_ptr(),
-                                           buf.data_ptr() + 4 * off, _stream())
+            st = pack_layer(w.shape[1], w.shape[0], w.data_ptr(), sft.data_ptr(),
+                            buf.data_ptr() + 4 * off, _stream())
             _native.check(st, "sa_mlp_pack_layer")
             off += n
     return buf
 
 
 def sa_mlp_forward(xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor,
-                   idx: torch.Tensor, wpack: torch.Tensor, channels) -> torch.Tensor:
+                   idx: torch.Tensor, wpack: torch.Tensor, channels, precision: str = "fp32") -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N), idx (B,npoint,32) i32, packed folded
     MLP C+3 -> channels  ->  (B, channels[-1], npoint) pooled features (one launch)."""
     _chk(xyz, "xyz", torch.float32)
@@ -262,8 +269,12 @@ def sa_mlp_forward(xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Ten
     # group_points calls (xyz, features) -- what this launch absorbs on the gather side
     algo = 4 * (b * 3 * n + b * npoint * nsample + b * 3 * npoint * nsample) + \
         4 * (b * c_feat * n + b * npoint * nsample + b * c_feat * npoint * nsample)
-    with torch.cuda.device(xyz.device), _timed(f"sa_mlp_forward(c={c_feat},n={n},np={npoint},mlp={c1}-{c2}-{c3})", algo):
-        st = _native.load().gps_sa_mlp_forward(b, n, npoint, nsample, c_feat, c1, c2, c3,
+    flops = 2 * b * npoint * nsample * ((3 + c_feat) * c1 + c1 * c2 + c2 * c3)
+    x3 = precision == "bf16x3"
+    fn = _native.load().gps_sa_mlp_forward_bf16x3 if x3 else _native.load().gps_sa_mlp_forward
+    with torch.cuda.device(xyz.device), _timed(f"sa_mlp_forward(c={c_feat},n={n},np={npoint},mlp={c1}-{c2}-{c3},{precision})",
+                                                algo, 3 * flops if x3 else flops, "bf16" if x3 else "fp32"):
+        st = fn(b, n, npoint, nsample, c_feat, c1, c2, c3,
                                                xyz.data_ptr(), new_xyz.data_ptr(), features.data_ptr(),
                                                idx.data_ptr(), wpack.data_ptr(), out.data_ptr(), _stream())
     _native.check(st, "sa_mlp_forward")

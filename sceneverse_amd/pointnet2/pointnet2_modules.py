@@ -30,6 +30,18 @@ def set_fused_sa(flag: bool) -> None:
     _FUSED_SA = bool(flag)
 
 
+# Arithmetic of the fused level: "bf16x3" = split-bf16 products on the bf16 MFMA (~2^-16 relative
+# error per product, default), "fp32" = v_mfma_f32_32x32x2_f32 (bitwise an fp32 fmaf chain).
+_SA_PRECISION = "bf16x3"
+
+
+def set_sa_precision(name: str) -> None:
+    global _SA_PRECISION
+    if name not in ("fp32", "bf16x3"):
+        raise ValueError(name)
+    _SA_PRECISION = name
+
+
 def fold_shared_mlp(mlp: "pt_utils.SharedMLP"):
     """SharedMLP of (conv1x1 [bias], BatchNorm2d, ReLU) layers -> ([W' (c_out,c_in)], [shift (c_out)])
     with the batch-norm's RUNNING statistics folded in (valid in eval mode only):
@@ -102,7 +114,7 @@ class _PointnetSAModuleBase(nn.Module):
     # ---- frozen encoder: one native launch per level -------------------------------------------
     def _folded(self, mlp, pack: bool):
         """(weights, shifts[, packed buffer]) of `mlp`, cached until a parameter/buffer changes."""
-        key = (_frozen_key(mlp), pack)
+        key = (_frozen_key(mlp), pack, _SA_PRECISION)
         cache = mlp.__dict__.get("_gps_folded")
         if cache is None or cache[0] != key:
             folded = fold_shared_mlp(mlp)
@@ -110,7 +122,7 @@ class _PointnetSAModuleBase(nn.Module):
                 cache = (key, None)
             else:
                 ws, shifts = folded
-                packed = pointnet2_utils._ext.sa_mlp_pack(ws, shifts) if pack else None
+                packed = pointnet2_utils._ext.sa_mlp_pack(ws, shifts, _SA_PRECISION) if pack else None
                 cache = (key, (ws, shifts, packed))
             mlp.__dict__["_gps_folded"] = cache
         return cache[1]
@@ -134,7 +146,7 @@ class _PointnetSAModuleBase(nn.Module):
             with torch.no_grad():
                 idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
                 return ext.sa_mlp_forward(xyz.float().contiguous(), new_xyz.float().contiguous(),
-                                          features.float().contiguous(), idx, folded[2], chans)
+                                          features.float().contiguous(), idx, folded[2], chans, _SA_PRECISION)
         if isinstance(grouper, pointnet2_utils.GroupAll) and features is not None and grouper.use_xyz:
             # group-all level: every object is one 16-column group -> three plain GEMMs over
             # (B * N) rows with the folded weights (hipBLASLt), ReLU, max over N

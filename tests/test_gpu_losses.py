@@ -21,7 +21,7 @@ def test_matches_torch_cross_entropy(n, v, dtype):
     labels = torch.randint(0, v, (n,), generator=g)
     labels[torch.rand(n, generator=g) < 0.85] = -1
     labels[0] = 3 % v                                     # at least one labelled row
-    ref_in = logits.float().requires_grad_(True)
+    ref_in = logits.float().clone().requires_grad_(True)
     ref = F.cross_entropy(ref_in, labels, ignore_index=-1)
     ref.backward()
     x = logits.to(DEV).requires_grad_(True)

@@ -5,9 +5,11 @@
   * the CPU oracle (oracle/gps_torch_reference.pointnetpp, pinned to the reference's Python),
 
 on the GPS encoder (modules/layers/pointnet.py:22-63 shapes) with non-trivial BN statistics.
-Tolerance: the fused kernel sums fp32 products in MFMA K-slot order with BN folded into the
-weights, the reference sums in GEMM order and applies BN afterwards -- |diff| <= 1e-4 * max|ref|
-per tensor (activations are O(1); measured ~1e-6)."""
+Both arithmetic modes of the fused level are run: "fp32" (fp32 MFMA, bitwise an fmaf chain) and
+"bf16x3" (split-bf16 products, ~2^-16 relative per product; the shipped default).
+Tolerance: the fused kernel sums products in MFMA K-slot order with BN folded into the weights,
+the reference sums in GEMM order and applies BN afterwards -- |diff| <= 1e-4 * max|ref| per tensor
+(activations are O(1))."""
 import pytest
 import torch
 
@@ -40,6 +42,13 @@ def _close(a, b, what):
     tol = 1e-4 * b.abs().max().item()
     err = (a - b).abs().max().item()
     assert err <= tol, (what, err, tol)
+
+
+@pytest.fixture(params=["bf16x3", "fp32"], autouse=True)
+def precision(request):
+    M.set_sa_precision(request.param)
+    yield request.param
+    M.set_sa_precision("bf16x3")
 
 
 def test_fused_levels_match_unfused_ops():

@@ -75,23 +75,28 @@ def main():
     from sceneverse_amd.pointnet2 import pointnet2_modules as M
     torch.manual_seed(0)
 
-    def _packed(cin, chans):
+    def _packed_pair(cin, chans):
         ws, ss, c = [], [], cin
         for co in chans:
             ws.append(torch.randn(co, c, device=dev) * (2.0 / c) ** 0.5)
             ss.append(torch.randn(co, device=dev) * 0.05)
             c = co
-        return hip.sa_mlp_pack(ws, ss)
+        return {p: hip.sa_mlp_pack(ws, ss, p) for p in ("fp32", "bf16x3")}
 
-    wp1, wp2 = _packed(6, [64, 64, 128]), _packed(131, [128, 128, 256])
-    f1 = hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1, [64, 64, 128])
-    fused = [
-        ("sa_mlp SA1 fused (6-64-64-128)", lambda: hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1, [64, 64, 128]),
-         2 * b * (3 * 1024 * 4 + 1024 * 4 + 3 * 1024 * 4), 2 * b * 1024 * (6 * 64 + 64 * 64 + 64 * 128)),
-        ("sa_mlp SA2 fused (131-128-128-256)", lambda: hip.sa_mlp_forward(new_xyz, nx2, f1, idx2, wp2, [128, 128, 256]),
-         b * (3 * 32 * 4 + 512 * 4 + 3 * 512 * 4) + b * (128 * 32 * 4 + 512 * 4 + 128 * 512 * 4),
-         2 * b * 512 * (131 * 128 + 128 * 128 + 128 * 256)),
-    ]
+    wp1, wp2 = _packed_pair(6, [64, 64, 128]), _packed_pair(131, [128, 128, 256])
+    f1 = hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1["fp32"], [64, 64, 128])
+    by1 = 2 * b * (3 * 1024 * 4 + 1024 * 4 + 3 * 1024 * 4)
+    by2 = b * (3 * 32 * 4 + 512 * 4 + 3 * 512 * 4) + b * (128 * 32 * 4 + 512 * 4 + 128 * 512 * 4)
+    fl1 = 2 * b * 1024 * (6 * 64 + 64 * 64 + 64 * 128)
+    fl2 = 2 * b * 512 * (131 * 128 + 128 * 128 + 128 * 256)
+    fused = []
+    for prec in ("fp32", "bf16x3"):
+        fused.append((f"sa_mlp SA1 fused (6-64-64-128) {prec}",
+                      lambda prec=prec: hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1[prec], [64, 64, 128], prec),
+                      by1, fl1))
+        fused.append((f"sa_mlp SA2 fused (131-128-128-256) {prec}",
+                      lambda prec=prec: hip.sa_mlp_forward(new_xyz, nx2, f1, idx2, wp2[prec], [128, 128, 256], prec),
+                      by2, fl2))
     rows = []
     for name, fn, nbytes, flops in fused:
         us = timeit(fn)

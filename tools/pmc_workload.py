@@ -41,18 +41,18 @@ def main():
             ws.append(torch.randn(co, c, device=dev) * (2.0 / c) ** 0.5)
             ss.append(torch.randn(co, device=dev) * 0.05)
             c = co
-        return hip.sa_mlp_pack(ws, ss)
+        return hip.sa_mlp_pack(ws, ss, 'bf16x3')
 
     wp1, wp2 = packed(6, [64, 64, 128]), packed(131, [128, 128, 256])
     for _ in range(3):
         fps = hip.furthest_point_sampling(xyz, 32)
         new_xyz = hip.gather_points(xyz_t, fps).transpose(1, 2).contiguous()
         idx = hip.ball_query(new_xyz, xyz, 0.2, 32)
-        f1 = hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1, [64, 64, 128])
+        f1 = hip.sa_mlp_forward(xyz, new_xyz, rgb, idx, wp1, [64, 64, 128], 'bf16x3')
         fps2 = hip.furthest_point_sampling(new_xyz, 16)
         nx2 = hip.gather_points(new_xyz.transpose(1, 2).contiguous(), fps2).transpose(1, 2).contiguous()
         idx2 = hip.ball_query(nx2, new_xyz, 0.4, 32)
-        hip.sa_mlp_forward(new_xyz, nx2, f1, idx2, wp2, [128, 128, 256])
+        hip.sa_mlp_forward(new_xyz, nx2, f1, idx2, wp2, [128, 128, 256], 'bf16x3')
         # the unfused reference API on the same data (what the fused launches absorb)
         hip.group_points(xyz_t, idx)
         hip.group_points(f1, idx2)
