@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const Params P) {
 // backward
 // ==========================================================================================
 template <int NT, bool SPATIAL>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
+__global__ __launch_bounds__(512) void attn_bwd_recompute_kernel(const Params P) {
   constexpr int NC = (NT + 1) / 2;
   constexpr int TS = NC * 32 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -544,16 +544,233 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
   }
 }
 
+
+// ==========================================================================================
+// backward, LDS-resident probabilities (L <= 144): pass 1 as above, but it also leaves the dropped
+// probabilities P^T and dS^T (bf16, [key][query]) in LDS; pass 2 is then pure MFMA --
+//   dV[t][d] = sum_m P^T[t][m] dO[m][d],   dK[t][d] = sum_m dS^T[t][m] Q[m][d]
+// with A fragments read row-wise from those tiles and B fragments from the transposed dO / Q tiles:
+// no recomputation, no global loads, standard K order.
+// LDS: region A = Ks | Vs | Kt (pass 1), aliased by Qt | dOt (pass 2); region B = PT | dST.
+// ==========================================================================================
+template <int NT, bool SPATIAL>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
+  constexpr int NC = (NT + 1) / 2;
+  constexpr int TS = NC * 32 + 8;             // pitch of transposed tiles and of PT / dST
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *Vs = Ks + NT * 16 * KS;
+  uint16_t *Kt = Vs + NT * 16 * KS;
+  uint16_t *Qt = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *dOt = Qt + 64 * TS;
+  constexpr int kRegionA = 2 * NT * 16 * KS + 64 * TS;       // elements
+  uint16_t *PT = reinterpret_cast<uint16_t *>(smem) + kRegionA;   // [NT*16][TS]
+  uint16_t *dST = PT + NT * 16 * TS;
+
+  int b, h;
+  block_to_bh(P, b, h);
+  const int L = P.L, nt = P.nt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)b * L;
+  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
+  const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
+  const uint16_t *dob = P.dout + row0 * P.ld_o + h * DH;
+  const float *lse = P.lse + ((size_t)b * P.H + h) * L;
+  const bool dropout = P.drop_thr != 0u;
+  const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+
+  stage_rows(Ks, kb, P.ld_qkv, L, NT * 16);
+  stage_rows(Vs, vb, P.ld_qkv, L, NT * 16);
+  stage_transposed(Kt, kb, P.ld_qkv, L, NC * 32, TS);
+  {  // pad columns [nt*16, NC*32) of PT / dST are read by the last chunk but written by no strip
+    u32x4 *z = reinterpret_cast<u32x4 *>(PT);
+    for (int e = threadIdx.x; e < (2 * NT * 16 * TS) / 8; e += blockDim.x) z[e] = zero4();
+  }
+  __syncthreads();
+
+  // ---------------- pass 1: query strips -> dQ, d cond-vector, P^T and dS^T tiles ----------------
+  for (int s = wave; s < nt; s += nwaves) {
+    const int qi = 16 * s + m;
+    const bool q_ok = qi < L;
+    bf16x8 bq[2], bdo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 v = zero4(), u = zero4();
+      if (q_ok) {
+        v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_qkv + 32 * c + 8 * g);
+        u = *reinterpret_cast<const u32x4 *>(dob + (size_t)qi * P.ld_o + 32 * c + 8 * g);
+      }
+      bq[c] = as_frag(v);
+      bdo[c] = as_frag(u);
+    }
+    f32x4 acc[NT], dacc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j < nt) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
+          const u32x4 av = *reinterpret_cast<const u32x4 *>(Vs + (16 * j + m) * KS + 32 * c + 8 * g);
+          acc[j] = mfma(as_frag(a), bq[c], acc[j]);
+          dacc[j] = mfma(as_frag(av), bdo[c], dacc[j]);
+        }
+      }
+    }
+    float w[SD];
+    if (SPATIAL) {
+#pragma unroll
+      for (int d = 0; d < SD; ++d) w[d] = q_ok ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
+    }
+    const float lse_q = q_ok ? lse[qi] : 0.f;
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 16 * j + 4 * g + r;
+        const bool t_ok = (j < nt) && t < L && q_ok;
+        const bool km = t_ok && P.mask && P.mask[row0 + t];
+        float x = acc[j][r] * 0.125f;
+        if (SPATIAL && t_ok) {
+          float sig;
+          x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+        }
+        const float p = (t_ok && !km) ? __expf(x - lse_q) : 0.f;
+        float dp = dacc[j][r], pd = p;
+        if (dropout) {
+          const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
+          const bool keep = rng_u32(P.seed, idx) >= P.drop_thr;
+          dp = keep ? dp * keep_scale : 0.f;
+          pd = keep ? p * keep_scale : 0.f;
+        }
+        if (j < nt) PT[t * TS + 16 * s + m] = f2bf(pd);
+        acc[j][r] = p;
+        dacc[j][r] = dp;
+        delta += p * dp;
+      }
+    delta = xor_reduce_sum_rows(delta);
+    float dw[SD];
+#pragma unroll
+    for (int d = 0; d < SD; ++d) dw[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 16 * j + 4 * g + r;
+        const float dlogit = acc[j][r] * (dacc[j][r] - delta);
+        if (SPATIAL) {
+          if (dlogit != 0.f) {          // p > 0: key is real and not masked
+            const float *plp = P.pl + ((row0 + qi) * L + t) * 5;
+            float z = w[0];
+#pragma unroll
+            for (int d = 0; d < 5; ++d) z = fmaf(w[1 + d], plp[d], z);
+            const float sig = 1.f / (1.f + __expf(-z));
+            const float dz = sig > 1e-6f ? dlogit * (1.f - sig) : 0.f;   // d/dz log(clamp(sigmoid z, 1e-6))
+            dw[0] += dz;
+#pragma unroll
+            for (int d = 0; d < 5; ++d) dw[1 + d] = fmaf(dz, plp[d], dw[1 + d]);
+          }
+        }
+        const float dsv = dlogit * 0.125f;
+        if (j < nt) dST[t * TS + 16 * s + m] = f2bf(dsv);
+        acc[j][r] = dsv;
+      }
+    if (SPATIAL) {
+#pragma unroll
+      for (int d = 0; d < SD; ++d) dw[d] = xor_reduce_sum_rows(dw[d]);
+      if (g == 0 && q_ok) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) P.dsw[((row0 + qi) * P.H + h) * SD + d] = dw[d];
+      }
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (2 * c < nt) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8 da = pack_tiles(acc[2 * c], (2 * c + 1 < NT) ? acc[(2 * c + 1 < NT) ? 2 * c + 1 : 0] : z);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[n] = mfma(da, frag_from_transposed(Kt, TS, n, c, lane), o[n]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qr = 16 * s + 4 * g + r;
+      if (qr < L) {
+        uint16_t *op = P.dq + (row0 + qr) * P.ld_qkv + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r]);
+      }
+    }
+  }
+  __syncthreads();   // PT / dST complete; K / V tiles dead
+  stage_transposed(Qt, qb, P.ld_qkv, L, NC * 32, TS);
+  stage_transposed(dOt, dob, P.ld_o, L, NC * 32, TS);
+  __syncthreads();
+
+  // ---------------- pass 2: key strips, MFMA only ----------------
+  for (int js = wave; js < nt; js += nwaves) {
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint16_t *prow = PT + (16 * js + m) * TS + 8 * g;
+    const uint16_t *drow = dST + (16 * js + m) * TS + 8 * g;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (2 * c < nt) {
+        const bf16x8 pa = as_frag(*reinterpret_cast<const u32x4 *>(prow + 32 * c));
+        const bf16x8 da = as_frag(*reinterpret_cast<const u32x4 *>(drow + 32 * c));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const bf16x8 bo = as_frag(*reinterpret_cast<const u32x4 *>(dOt + (16 * n + m) * TS + 32 * c + 8 * g));
+          const bf16x8 bqf = as_frag(*reinterpret_cast<const u32x4 *>(Qt + (16 * n + m) * TS + 32 * c + 8 * g));
+          dv[n] = mfma(pa, bo, dv[n]);
+          dk[n] = mfma(da, bqf, dk[n]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tr = 16 * js + 4 * g + r;
+      if (tr < L) {
+        uint16_t *pk = P.dk + (row0 + tr) * P.ld_qkv + h * DH + m;
+        uint16_t *pv = P.dv + (row0 + tr) * P.ld_qkv + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          pk[16 * n] = f2bf(dk[n][r]);
+          pv[16 * n] = f2bf(dv[n][r]);
+        }
+      }
+    }
+  }
+}
+
 template <int NT>
 size_t fwd_lds() {
   constexpr int NC = (NT + 1) / 2;
   return (size_t)2 * (NT * 16 * KS + 64 * (NC * 32 + 8));
 }
 template <int NT>
-size_t bwd_lds() {
+size_t bwd_recompute_lds() {
   constexpr int NC = (NT + 1) / 2;
   return (size_t)2 * (2 * NT * 16 * KS + 64 * (NC * 32 + 8)) + (size_t)4 * NT * 16;
 }
+template <int NT>
+size_t bwd_lds() {                      // region A + PT + dST
+  constexpr int NC = (NT + 1) / 2;
+  constexpr int TS = NC * 32 + 8;
+  return (size_t)2 * (2 * NT * 16 * KS + 64 * TS + 2 * NT * 16 * TS);
+}
+constexpr size_t kLdsMax = 160 * 1024;
 inline int pick_waves(int nt) {
   const int rounds = (nt + 7) / 8;
   return (nt + rounds - 1) / rounds;
@@ -564,21 +781,28 @@ int launch(const Params &P, bool backward, hipStream_t s) {
   const int nw = pick_waves(P.nt);
   const dim3 grid(P.B * P.H), block(64 * nw);
   const bool spatial = P.sw != nullptr;
-  const size_t lds = backward ? bwd_lds<NT>() : fwd_lds<NT>();
+  const bool resident = bwd_lds<NT>() <= kLdsMax;     // P^T / dS^T fit LDS
+  const size_t lds = backward ? (resident ? bwd_lds<NT>() : bwd_recompute_lds<NT>()) : fwd_lds<NT>();
   if (lds > 64 * 1024) {
     static bool done[4] = {false, false, false, false};
     const int slot = (backward ? 2 : 0) + (spatial ? 1 : 0);
     if (!done[slot]) {
-      const void *fn = backward ? (spatial ? (const void *)&attn_bwd_kernel<NT, true> : (const void *)&attn_bwd_kernel<NT, false>)
-                                : (spatial ? (const void *)&attn_fwd_kernel<NT, true> : (const void *)&attn_fwd_kernel<NT, false>);
+      const void *fn =
+          backward ? (resident ? (spatial ? (const void *)&attn_bwd_kernel<NT, true> : (const void *)&attn_bwd_kernel<NT, false>)
+                               : (spatial ? (const void *)&attn_bwd_recompute_kernel<NT, true>
+                                          : (const void *)&attn_bwd_recompute_kernel<NT, false>))
+                   : (spatial ? (const void *)&attn_fwd_kernel<NT, true> : (const void *)&attn_fwd_kernel<NT, false>);
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return GPS_ERR_LAUNCH;
       done[slot] = true;
     }
   }
-  if (backward) {
+  if (backward && resident) {
     if (spatial) hipLaunchKernelGGL((attn_bwd_kernel<NT, true>), grid, block, lds, s, P);
     else hipLaunchKernelGGL((attn_bwd_kernel<NT, false>), grid, block, lds, s, P);
+  } else if (backward) {
+    if (spatial) hipLaunchKernelGGL((attn_bwd_recompute_kernel<NT, true>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((attn_bwd_recompute_kernel<NT, false>), grid, block, lds, s, P);
   } else {
     if (spatial) hipLaunchKernelGGL((attn_fwd_kernel<NT, true>), grid, block, lds, s, P);
     else hipLaunchKernelGGL((attn_fwd_kernel<NT, false>), grid, block, lds, s, P);
