@@ -34,6 +34,13 @@
 
 #include "gps_hip.h"
 
+#ifndef GPS_SA1_WAVES
+#define GPS_SA1_WAVES 8   // weights resident in LDS: waves only share the object
+#endif
+#ifndef GPS_SA2_WAVES
+#define GPS_SA2_WAVES 8   // streamed weights: 8 groups per weight tile
+#endif
+
 namespace gps_sa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -126,9 +133,10 @@ __device__ __forceinline__ f32x16 mfma_tile(const float *__restrict__ tile, cons
 // memory straight into LDS: each wave-instruction moves 1 KiB (64 lanes x 16 B) to
 // wave-uniform base + lane * 16, no VGPRs held while the MFMAs run.  Completion = the issuing
 // wave's vmcnt(0), then the workgroup barrier.
+template <int NWAVES = kWaves>
 __device__ __forceinline__ void tile_copy_async(const float *__restrict__ src, float *dst, int len,
                                                 int wave, int lane) {
-  for (int c = wave; c * 256 < len; c += kWaves)
+  for (int c = wave; c * 256 < len; c += NWAVES)
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void *)(src + c * 256 + lane * 4),
         (__attribute__((address_space(3))) void *)(dst + c * 256), 16, 0, 0);
@@ -369,9 +377,66 @@ __global__ void pack_layer16_kernel(int c_in, int c_out, const float *__restrict
   }
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// two fp32 -> one dword of two bf16 (round to nearest even); hipcc's vector convert emits one
+// single-element v_cvt_pk per value plus shifts/ors, so the instruction is named explicitly
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {
+  unsigned int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max(x, 0) as ONE compiler-visible instruction: on the raw bits, signed-integer max with 0 maps
+// every negative float (and -0) to +0 and keeps every non-negative one (v_max_i32).  fmaxf() would
+// cost a canonicalising v_max first; an inline-asm v_max_f32 must NOT be used here: hipcc's hazard
+// recogniser does not see inline-asm readers of MFMA results and would not pad the XDL-write ->
+// VALU-read wait states (observed: stale accumulators).
+__device__ __forceinline__ float relu1(float x) {
+  const int i = __float_as_int(x);
+  return __int_as_float(i > 0 ? i : 0);
+}
+// v -> (hi, lo) bf16 fragments with v ~= hi + lo:  3 VALU per element
 __device__ __forceinline__ void split8(const f32x8 &v, bf16x8 &hi, bf16x8 &lo) {
-  hi = __builtin_convertvector(v, bf16x8);
-  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), bf16x8);
+  u32x4 h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float b0 = __uint_as_float(h[i] << 16), b1 = __uint_as_float(h[i] & 0xFFFF0000u);
+    l[i] = cvt_pk_bf16(v[2 * i] - b0, v[2 * i + 1] - b1);
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+// In-place max over lanes 0-31 -> lane 31 and lanes 32-63 -> lane 63 of all 16 registers of a D
+// fragment, one v_max_f32_dpp per register and step (the DPP shift is a modifier of the max itself;
+// lanes without a source lane keep their value).  Steps run register-major so that a register is
+// re-read 16 instructions after it was written (DPP needs 2 wait states after a VALU write).
+__device__ __forceinline__ void half_wave_max16(f32x16 &a) {
+  float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], x5 = a[5], x6 = a[6], x7 = a[7];
+  float x8 = a[8], x9 = a[9], xa = a[10], xb = a[11], xc = a[12], xd = a[13], xe = a[14], xf = a[15];
+  // One asm block per step: the 16 instructions of a step touch 16 different registers, so inside
+  // a block a register is re-read 16 instructions after its write; `s_nop 1` at the head of every
+  // block covers the 2 wait states a DPP read needs after whatever VALU wrote the inputs (the
+  // compiler does not see DPP inside inline asm and pads nothing).
+#define GPS_DPP16(CTRL)                                                                               \
+  asm volatile("s_nop 1\n\t"                                                                          \
+               "v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\t"           \
+               "v_max_f32_dpp %2, %2, %2 " CTRL "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\t"           \
+               "v_max_f32_dpp %4, %4, %4 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL "\n\t"           \
+               "v_max_f32_dpp %6, %6, %6 " CTRL "\n\tv_max_f32_dpp %7, %7, %7 " CTRL "\n\t"           \
+               "v_max_f32_dpp %8, %8, %8 " CTRL "\n\tv_max_f32_dpp %9, %9, %9 " CTRL "\n\t"           \
+               "v_max_f32_dpp %10, %10, %10 " CTRL "\n\tv_max_f32_dpp %11, %11, %11 " CTRL "\n\t"     \
+               "v_max_f32_dpp %12, %12, %12 " CTRL "\n\tv_max_f32_dpp %13, %13, %13 " CTRL "\n\t"     \
+               "v_max_f32_dpp %14, %14, %14 " CTRL "\n\tv_max_f32_dpp %15, %15, %15 " CTRL               \
+               : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),      \
+                 "+v"(x8), "+v"(x9), "+v"(xa), "+v"(xb), "+v"(xc), "+v"(xd), "+v"(xe), "+v"(xf))
+  GPS_DPP16("row_shr:1 row_mask:0xf bank_mask:0xf");
+  GPS_DPP16("row_shr:2 row_mask:0xf bank_mask:0xf");
+  GPS_DPP16("row_shr:4 row_mask:0xf bank_mask:0xf");
+  GPS_DPP16("row_shr:8 row_mask:0xf bank_mask:0xf");
+  GPS_DPP16("row_bcast:15 row_mask:0xa bank_mask:0xf");
+#undef GPS_DPP16
+  a[0] = x0; a[1] = x1; a[2] = x2; a[3] = x3; a[4] = x4; a[5] = x5; a[6] = x6; a[7] = x7;
+  a[8] = x8; a[9] = x9; a[10] = xa; a[11] = xb; a[12] = xc; a[13] = xd; a[14] = xe; a[15] = xf;
 }
 
 template <int STEPS>
@@ -392,22 +457,30 @@ __device__ __forceinline__ f32x16 mfma_tile16(const float *__restrict__ tile, co
   return acc;
 }
 
-template <int CF, int C1, int C2, int C3>
-__global__ __launch_bounds__(kBlock, 2) void sa_mlp_x3_kernel(
+// WAVES waves per workgroup (each owns one 32-sample group per round).  RESIDENT: the whole packed
+// MLP fits in LDS next to the object -> loaded once per workgroup, no per-tile barriers; otherwise
+// the 32-row weight tiles stream through a double buffer (one barrier per tile).  More waves per
+// workgroup = more columns per streamed weight byte (the LDS-DMA weight stream, not the matrix pipe,
+// bounds the streaming form: profiles/r1).
+template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT>
+__global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
     int b, int n, int npoint, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ feats, const int32_t *__restrict__ idx,
     const float *__restrict__ wpack, float *__restrict__ out) {
+  constexpr int BLOCK = WAVES * 64;
   constexpr int CIN = 3 + CF;
   constexpr int S1 = steps16(CIN), S2 = C1 / 16, S3 = C2 / 16;
   constexpr int T1 = tile_floats16(CIN), T2 = tile_floats16(C1), T3 = tile_floats16(C2);
   constexpr int M1 = C1 / 32, M2 = C2 / 32, M3 = C3 / 32;
   constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+  constexpr int TOTAL = M1 * T1 + M2 * T2 + M3 * T3;
   constexpr int G = M1 + M2 + M3;
+  constexpr int WBUF = RESIDENT ? TOTAL : 2 * TMAX;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *s_w0 = lds;
-  float *s_w1 = s_w0 + TMAX;
-  float *s_out = s_w1 + TMAX;                // C3 * npoint
+  float *s_w1 = s_w0 + TMAX;                 // streaming form only
+  float *s_out = lds + WBUF;                 // C3 * npoint
   float *s_feat = s_out + C3 * npoint;       // CF * n
   float *s_xyz = s_feat + CF * n;            // n * 3
   float *s_ctr = s_xyz + n * 3;              // npoint * 3
@@ -424,29 +497,45 @@ __global__ __launch_bounds__(kBlock, 2) void sa_mlp_x3_kernel(
     if (((CF * n) & 3) == 0) {
       const float4 *g4 = reinterpret_cast<const float4 *>(gf);
       float4 *l4 = reinterpret_cast<float4 *>(s_feat);
-      for (int e = tid; e < (CF * n) >> 2; e += kBlock) l4[e] = g4[e];
+      for (int e = tid; e < (CF * n) >> 2; e += BLOCK) l4[e] = g4[e];
     } else {
-      for (int e = tid; e < CF * n; e += kBlock) s_feat[e] = gf[e];
+      for (int e = tid; e < CF * n; e += BLOCK) s_feat[e] = gf[e];
     }
-    for (int e = tid; e < n * 3; e += kBlock) s_xyz[e] = gx[e];
-    for (int e = tid; e < npoint * 3; e += kBlock) s_ctr[e] = gc[e];
-    for (int e = tid; e < npoint * kNS; e += kBlock) s_idx[e] = gi[e];
+    for (int e = tid; e < n * 3; e += BLOCK) s_xyz[e] = gx[e];
+    for (int e = tid; e < npoint * 3; e += BLOCK) s_ctr[e] = gc[e];
+    for (int e = tid; e < npoint * kNS; e += BLOCK) s_idx[e] = gi[e];
   }
-  tile_copy_async(wpack, s_w0, T1, wave, lane);
+  tile_copy_async<WAVES>(wpack, s_w0, RESIDENT ? TOTAL : T1, wave, lane);
   tile_copy_wait();
   __syncthreads();
 
-  auto tile_src = [&](int g, int &len) -> const float * {
+  auto tile_off = [&](int g, int &len) -> int {      // offset (floats) of weight tile g (mod G)
     if (g >= G) g -= G;
-    if (g < M1) { len = T1; return wpack + (size_t)g * T1; }
-    if (g < M1 + M2) { len = T2; return wpack + (size_t)M1 * T1 + (size_t)(g - M1) * T2; }
+    if (g < M1) { len = T1; return g * T1; }
+    if (g < M1 + M2) { len = T2; return M1 * T1 + (g - M1) * T2; }
     len = T3;
-    return wpack + (size_t)M1 * T1 + (size_t)M2 * T2 + (size_t)(g - M1 - M2) * T3;
+    return M1 * T1 + M2 * T2 + (g - M1 - M2) * T3;
+  };
+  // begin stage g of round rd: returns the LDS tile to compute on; streaming form also starts the
+  // copy of the next tile into the other buffer
+  auto stage_begin = [&](int rd, int g) -> const float * {
+    int len;
+    if (RESIDENT) return s_w0 + tile_off(g, len);
+    const int gg = rd * G + g;
+    const int off = tile_off(g + 1, len);
+    tile_copy_async<WAVES>(wpack + off, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
+    return (gg & 1) ? s_w1 : s_w0;
+  };
+  auto stage_end = [&]() {
+    if (!RESIDENT) {
+      tile_copy_wait();
+      __syncthreads();
+    }
   };
 
-  const int rounds = (npoint + kWaves - 1) / kWaves;
+  const int rounds = (npoint + WAVES - 1) / WAVES;
   for (int rd = 0; rd < rounds; ++rd) {
-    const int tile = rd * kWaves + wave;
+    const int tile = rd * WAVES + wave;
     const bool live = tile < npoint;
     const int j = live ? tile : npoint - 1;
 
@@ -473,86 +562,88 @@ __global__ __launch_bounds__(kBlock, 2) void sa_mlp_x3_kernel(
       }
     }
     bf16x8 a1h[S2], a1l[S2], a2h[S3], a2l[S3];
+    // Software pipeline: the post-processing (ReLU + hi/lo split, or ReLU + max-pool) of output tile
+    // mt-1 is issued after the MFMAs of tile mt, in the same scheduling region, so that its VALU work
+    // runs in the shadow of the matrix pipe (independent registers).  Only the last tile of a layer
+    // is post-processed in the open (the next layer needs all of it).
+    auto split_tile = [&](const f32x16 &acc, bf16x8 &h0, bf16x8 &l0, bf16x8 &h1, bf16x8 &l1) {
+      f32x8 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v0[e] = relu1(acc[e]); v1[e] = relu1(acc[8 + e]); }
+      split8(v0, h0, l0);
+      split8(v1, h1, l1);
+    };
+    auto pool_tile = [&](f32x16 acc, int mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);          // ReLU commutes with the max
+      half_wave_max16(acc);
+      if (col == 31 && live) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          s_out[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * npoint + tile] = acc[r];
+      }
+    };
     int g = 0;
+    f32x16 prev;
 #pragma unroll
     for (int mt = 0; mt < M1; ++mt, ++g) {
-      const int gg = rd * G + g;
-      int len;
-      const float *src = tile_src(g + 1, len);
-      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
-      const f32x16 acc = mfma_tile16<S1>((gg & 1) ? s_w1 : s_w0, a0h, a0l, lane);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f32x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc[8 * u + e], 0.f);
-        split8(v, a1h[2 * mt + u], a1l[2 * mt + u]);
-      }
-      tile_copy_wait();
-      __syncthreads();
+      const float *wt = stage_begin(rd, g);
+      const f32x16 acc = mfma_tile16<S1>(wt, a0h, a0l, lane);
+      if (mt > 0) split_tile(prev, a1h[2 * mt - 2], a1l[2 * mt - 2], a1h[2 * mt - 1], a1l[2 * mt - 1]);
+      prev = acc;
+      stage_end();
     }
+    split_tile(prev, a1h[2 * M1 - 2], a1l[2 * M1 - 2], a1h[2 * M1 - 1], a1l[2 * M1 - 1]);
 #pragma unroll
     for (int mt = 0; mt < M2; ++mt, ++g) {
-      const int gg = rd * G + g;
-      int len;
-      const float *src = tile_src(g + 1, len);
-      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
-      const f32x16 acc = mfma_tile16<S2>((gg & 1) ? s_w1 : s_w0, a1h, a1l, lane);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f32x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc[8 * u + e], 0.f);
-        split8(v, a2h[2 * mt + u], a2l[2 * mt + u]);
-      }
-      tile_copy_wait();
-      __syncthreads();
+      const float *wt = stage_begin(rd, g);
+      const f32x16 acc = mfma_tile16<S2>(wt, a1h, a1l, lane);
+      if (mt > 0) split_tile(prev, a2h[2 * mt - 2], a2l[2 * mt - 2], a2h[2 * mt - 1], a2l[2 * mt - 1]);
+      prev = acc;
+      stage_end();
     }
+    split_tile(prev, a2h[2 * M2 - 2], a2l[2 * M2 - 2], a2h[2 * M2 - 1], a2l[2 * M2 - 1]);
     for (int mt = 0; mt < M3; ++mt, ++g) {
-      const int gg = rd * G + g;
-      int len;
-      const float *src = tile_src(g + 1, len);
-      tile_copy_async(src, (gg & 1) ? s_w0 : s_w1, len, wave, lane);
-      const f32x16 acc = mfma_tile16<S3>((gg & 1) ? s_w1 : s_w0, a2h, a2l, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m = half_wave_max(acc[r]);
-        if (col == 31 && live)
-          s_out[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * npoint + tile] = fmaxf(m, 0.f);
-      }
-      tile_copy_wait();
-      __syncthreads();
+      const float *wt = stage_begin(rd, g);
+      const f32x16 acc = mfma_tile16<S3>(wt, a2h, a2l, lane);
+      if (mt > 0) pool_tile(prev, mt - 1);
+      prev = acc;
+      stage_end();
     }
+    pool_tile(prev, M3 - 1);
   }
+  if (RESIDENT) __syncthreads();
   float *go = out + (size_t)obj * C3 * npoint;
   const int total = C3 * npoint;
   if ((total & 3) == 0) {
     const float4 *l4 = reinterpret_cast<const float4 *>(s_out);
     float4 *g4 = reinterpret_cast<float4 *>(go);
-    for (int e = tid; e < total >> 2; e += kBlock) g4[e] = l4[e];
+    for (int e = tid; e < total >> 2; e += BLOCK) g4[e] = l4[e];
   } else {
-    for (int e = tid; e < total; e += kBlock) go[e] = s_out[e];
+    for (int e = tid; e < total; e += BLOCK) go[e] = s_out[e];
   }
 }
 
-template <int CF, int C1, int C2, int C3>
+template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT>
 int launch_sa_x3(int b, int n, int npoint, const float *xyz, const float *new_xyz, const float *feats,
                  const int32_t *idx, const float *wpack, float *out, hipStream_t s) {
   constexpr int CIN = 3 + CF;
   constexpr int T1 = tile_floats16(CIN), T2 = tile_floats16(C1), T3 = tile_floats16(C2);
   constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
-  const size_t lds = sizeof(float) * ((size_t)2 * TMAX + (size_t)C3 * npoint + (size_t)CF * n + (size_t)n * 3 +
+  constexpr int TOTAL = (C1 / 32) * T1 + (C2 / 32) * T2 + (C3 / 32) * T3;
+  constexpr int WBUF = RESIDENT ? TOTAL : 2 * TMAX;
+  const size_t lds = sizeof(float) * ((size_t)WBUF + (size_t)C3 * npoint + (size_t)CF * n + (size_t)n * 3 +
                                       (size_t)npoint * 3 + (size_t)npoint * kNS);
-  if (lds > 80 * 1024) return GPS_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_x3_kernel<CF, C1, C2, C3>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+  if (lds > 160 * 1024) return GPS_ERR_UNSUPPORTED;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GPS_ERR_LAUNCH;
-    attr_set = true;
+    attr_lds = lds;
   }
-  hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3>), dim3(b), dim3(kBlock), lds, s, b, n, npoint, xyz,
-                     new_xyz, feats, idx, wpack, out);
+  hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT>), dim3(b), dim3(WAVES * 64), lds, s, b, n,
+                     npoint, xyz, new_xyz, feats, idx, wpack, out);
   return GPS_OK;
 }
 
@@ -607,9 +698,11 @@ int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int c_feat,
   hipStream_t s = (hipStream_t)stream;
   int st = GPS_ERR_UNSUPPORTED;
   if (c_feat == 3 && c1 == 64 && c2 == 64 && c3 == 128)
-    st = gps_sa::x3::launch_sa_x3<3, 64, 64, 128>(b, n, npoint, xyz, new_xyz, features, idx, wpack, out, s);
+    st = gps_sa::x3::launch_sa_x3<3, 64, 64, 128, GPS_SA1_WAVES, true>(b, n, npoint, xyz, new_xyz, features, idx,
+                                                                      wpack, out, s);
   else if (c_feat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
-    st = gps_sa::x3::launch_sa_x3<128, 128, 128, 256>(b, n, npoint, xyz, new_xyz, features, idx, wpack, out, s);
+    st = gps_sa::x3::launch_sa_x3<128, 128, 128, 256, GPS_SA2_WAVES, false>(b, n, npoint, xyz, new_xyz, features,
+                                                                            idx, wpack, out, s);
   if (st != GPS_OK) return st;
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
