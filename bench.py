@@ -156,6 +156,8 @@ def main() -> None:
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     args = ap.parse_args()
 
     from sceneverse_amd.common import dist_utils
@@ -172,7 +174,8 @@ def main() -> None:
     torch.cuda.set_device(dev)
 
     cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
-    step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16)
+    use_graph = world == 1 and not args.no_graph
+    step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=use_graph)
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
 
     def barrier():
@@ -180,16 +183,47 @@ def main() -> None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graph_note = None
+    if use_graph:
+        # engine preparation (untimed, before the W warm-up steps): eager steps + one capture
+        try:
+            for _ in range(step.graph_warmup + 1):
+                step.step(dict(batch))
+            torch.cuda.synchronize()
+            graph_note = "whole step replayed as one HIP graph"
+        except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a requirement
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            del step
+            torch.cuda.empty_cache()
+            use_graph = False
+            cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
+            step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=False)
+            graph_note = f"eager (graph capture failed: {type(e).__name__})"
     for _ in range(args.warmup):
         step.step(dict(batch))
     barrier()
-    hip_ext.profile_start()
+    if not use_graph:
+        hip_ext.profile_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step.step(dict(batch))
     barrier()
     dt = time.perf_counter() - t0
-    kern = hip_ext.profile_stop()
+    if use_graph:
+        # a replayed graph cannot host per-launch event pairs: the per-kernel durations come from
+        # eager steps of the same workload run right after the timed region (not part of `value`)
+        step.graph = False
+        step.step(dict(batch))
+        hip_ext.profile_start()
+        for _ in range(3):
+            step.step(dict(batch))
+        kern = hip_ext.profile_stop()
+        for k in kern.values():
+            k["launches"] = k["launches"] * args.steps / 3.0
+        step.graph = True
+    else:
+        kern = hip_ext.profile_stop()
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -238,7 +272,11 @@ def main() -> None:
                                    f"scenes): {args.n_obj} obj x {args.n_pts} pts x 6 ch, 50-token sentence "
                                    f"+ 300-token scene caption, fwd+loss+bwd+clip+AdamW",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "point_ops": "fp32 (libgps_hip.so)",
+                       "parallelism": f"dp{world}", "point_ops": "fp32-accurate split-bf16 MFMA (libgps_hip.so)",
+                       "launch": graph_note or "eager",
+                       "kernel_timing": ("HIP events around each native launch, eager steps right after the "
+                                         "timed graph replays" if use_graph else
+                                         "HIP events around each native launch inside the timed steps"),
                        "final_loss": round(final_loss, 4)},
             "roofline": None if dom is None else (
                 {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],

@@ -168,22 +168,24 @@ GPS_API int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int
  * one packed projection output are fine (ld_qkv = its row pitch, a multiple of 8).  sw (B,L,H*6)
  * fp32: per token and head [b, w_1..w_5].  pl (B,L,L,5) fp32 (calc_pairwise_locs,
  * modules/utils.py:38-87).  mask (B,L) bytes, 1 = padded key.  p_drop/seed: dropout on the
- * probabilities (counter-based, reproducible between forward and backward).
+ * probabilities (counter-based, reproducible between forward and backward); seed_dev: optional
+ * device pointer to one uint64 that is added to `seed` when the kernel runs (lets a captured HIP
+ * graph draw a fresh mask on every replay), NULL to use `seed` alone.
  * out (B, L, ld_o) bf16; lse (B,H,L) fp32 log-sum-exp of the logits (saved for backward).
  * bf16 MFMA with fp32 accumulation; softmax in fp32.  head_dim must be 64, L <= 256. */
 GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                              int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
-                             float p_drop, unsigned long long seed, void *out, int ld_o, float *lse,
-                             gps_stream_t stream);
+                             float p_drop, unsigned long long seed, const void *seed_dev, void *out,
+                             int ld_o, float *lse, gps_stream_t stream);
 
 /* Gradients of gps_attn_forward: dout (B,L,ld_o) bf16 -> dq, dk, dv (bf16, same layout/pitch as
  * q, k, v) and dsw (B,L,H*6) fp32 (when sw != NULL).  pl and mask carry no gradient (inputs of the
  * data pipeline).  Probabilities are recomputed from lse. */
 GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                               int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
-                              float p_drop, unsigned long long seed, const void *dout, int ld_o,
-                              const float *lse, void *dq, void *dk, void *dv, float *dsw,
-                              gps_stream_t stream);
+                              float p_drop, unsigned long long seed, const void *seed_dev,
+                              const void *dout, int ld_o, const float *lse, void *dq, void *dk, void *dv,
+                              float *dsw, gps_stream_t stream);
 
 /* ---- row-sparse cross-entropy (masked-LM head) ----------------------------------------------------
  * Replaces the F.cross_entropy(..., ignore_index=-1) of lm_cls_loss (optim/loss/loss.py:56-61) over

@@ -57,7 +57,13 @@ struct Params {
   float p_drop;
   unsigned int drop_thr;      // keep iff rng >= drop_thr
   unsigned long long seed;
+  const unsigned long long *seed_dev;   // optional device word added to `seed` (HIP-graph replays
+                                        // get fresh dropout masks by advancing it on the device)
 };
+
+__device__ __forceinline__ unsigned long long effective_seed(const Params &P) {
+  return P.seed + (P.seed_dev ? *P.seed_dev : 0ull);
+}
 
 __device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even
   unsigned int u = __float_as_uint(f);
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const Params P) {
 
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+  const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
 
   for (int s = wave; s < nt; s += nwaves) {
     const int qi = 16 * s + m;              // this lane's query
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const Params P) {
         if (dropout) {
           const int t = 16 * j + 4 * g + r;
           const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
-          p = rng_u32(P.seed, idx) >= P.drop_thr ? p * keep_scale : 0.f;
+          p = rng_u32(seed, idx) >= P.drop_thr ? p * keep_scale : 0.f;
         }
         acc[j][r] = p;
       }
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(512) void attn_bwd_recompute_kernel(const Params P)
   const float *lse = P.lse + ((size_t)b * P.H + h) * L;
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+  const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
 
   stage_rows(Ks, kb, P.ld_qkv, L, NT * 16);
   stage_rows(Vs, vb, P.ld_qkv, L, NT * 16);
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(512) void attn_bwd_recompute_kernel(const Params P)
         float dp = dacc[j][r];
         if (dropout) {
           const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
-          dp = rng_u32(P.seed, idx) >= P.drop_thr ? dp * keep_scale : 0.f;
+          dp = rng_u32(seed, idx) >= P.drop_thr ? dp * keep_scale : 0.f;
         }
         acc[j][r] = p;
         dacc[j][r] = dp;
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(512) void attn_bwd_recompute_kernel(const Params P)
             float dp = dacc[r], pd = p;
             if (dropout) {
               const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
-              const bool keep = rng_u32(P.seed, idx) >= P.drop_thr;
+              const bool keep = rng_u32(seed, idx) >= P.drop_thr;
               dp = keep ? dp * keep_scale : 0.f;
               pd = keep ? p * keep_scale : 0.f;
             }
@@ -580,6 +588,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
   const float *lse = P.lse + ((size_t)b * P.H + h) * L;
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+  const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
 
   stage_rows(Ks, kb, P.ld_qkv, L, NT * 16);
   stage_rows(Vs, vb, P.ld_qkv, L, NT * 16);
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
         float dp = dacc[j][r], pd = p;
         if (dropout) {
           const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
-          const bool keep = rng_u32(P.seed, idx) >= P.drop_thr;
+          const bool keep = rng_u32(seed, idx) >= P.drop_thr;
           dp = keep ? dp * keep_scale : 0.f;
           pd = keep ? p * keep_scale : 0.f;
         }
@@ -824,8 +833,8 @@ extern "C" {
 
 int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                      int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
-                     float p_drop, unsigned long long seed, void *out, int ld_o, float *lse,
-                     gps_stream_t stream) {
+                     float p_drop, unsigned long long seed, const void *seed_dev, void *out, int ld_o,
+                     float *lse, gps_stream_t stream) {
   if (B < 0 || H < 1 || L < 0 || ld_qkv < H * 64 || ld_o < H * 64 || p_drop < 0.f || p_drop >= 1.f)
     return GPS_ERR_INVALID_ARGUMENT;
   if (head_dim != gps_attn::DH || (ld_qkv & 7) || (ld_o & 7)) return GPS_ERR_UNSUPPORTED;
@@ -835,15 +844,15 @@ int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const voi
   P.B = B; P.H = H; P.L = L; P.ld_qkv = ld_qkv; P.ld_o = ld_o;
   P.q = (const uint16_t *)q; P.k = (const uint16_t *)k; P.v = (const uint16_t *)v;
   P.sw = sw; P.pl = pl; P.mask = mask; P.out = (uint16_t *)out; P.lse = lse;
-  P.p_drop = p_drop; P.seed = seed;
+  P.p_drop = p_drop; P.seed = seed; P.seed_dev = (const unsigned long long *)seed_dev;
   P.drop_thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
   return gps_attn::dispatch(P, false, (hipStream_t)stream);
 }
 
 int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                       int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
-                      float p_drop, unsigned long long seed, const void *dout, int ld_o,
-                      const float *lse, void *dq, void *dk, void *dv, float *dsw,
+                      float p_drop, unsigned long long seed, const void *seed_dev, const void *dout,
+                      int ld_o, const float *lse, void *dq, void *dk, void *dv, float *dsw,
                       gps_stream_t stream) {
   if (B < 0 || H < 1 || L < 0 || ld_qkv < H * 64 || ld_o < H * 64 || p_drop < 0.f || p_drop >= 1.f)
     return GPS_ERR_INVALID_ARGUMENT;
@@ -857,7 +866,7 @@ int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const vo
   P.q = (const uint16_t *)q; P.k = (const uint16_t *)k; P.v = (const uint16_t *)v;
   P.sw = sw; P.pl = pl; P.mask = mask; P.lse = const_cast<float *>(lse);
   P.dout = (const uint16_t *)dout; P.dq = (uint16_t *)dq; P.dk = (uint16_t *)dk; P.dv = (uint16_t *)dv;
-  P.dsw = dsw; P.p_drop = p_drop; P.seed = seed;
+  P.dsw = dsw; P.p_drop = p_drop; P.seed = seed; P.seed_dev = (const unsigned long long *)seed_dev;
   P.drop_thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
   return gps_attn::dispatch(P, true, (hipStream_t)stream);
 }

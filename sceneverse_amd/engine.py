@@ -11,6 +11,15 @@ tensors never receive a gradient).
 
 bf16: the transformer stack, BERT, heads and losses run under `torch.autocast(bfloat16)`;
 the point ops always compute in fp32 (indices must be bit-exact).
+
+HIP graph (`graph=True`, single process): the step issues ~1 800 launches from ~37 ms of Python
+per step, which is what bounds it once the kernels are fused.  After
+`graph_warmup` eager steps the whole step (forward, losses, backward, clipping, AdamW) is captured
+once into a HIP graph on static input buffers and then replayed: one `hipGraphLaunch` per step.
+The learning rate is a device tensor the scheduler fills in place, attention dropout draws its
+seed from a device word (fused_attention._next_device_seed), torch's own RNG ops are graph-safe,
+so every replay is a fresh, correctly scheduled optimisation step.  Not used under DDP: the
+gradient all-reduce stays in eager mode there.
 """
 from __future__ import annotations
 
@@ -28,18 +37,30 @@ from .optim.build import build_optim
 class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
-                 bucket_cap_mb: int = 64, seed: int = 42):
+                 bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3):
         self.cfg = cfg
         self.device = torch.device(device)
         torch.manual_seed(seed)
         self.model = build_model(cfg).to(self.device)
-        self.loss, self.optimizer, self.scheduler = build_optim(cfg, self.model.get_opt_params(),
-                                                                total_steps)
+        world = dist_utils.get_world_size()
+        use_ddp = (world > 1) if ddp is None else ddp
+        self.graph = bool(graph) and self.device.type == "cuda" and not use_ddp
+        self.graph_warmup = max(1, int(graph_warmup))
+        self._graph = None
+        self._static = None
+        param_groups = self.model.get_opt_params()
+        if self.graph:
+            # capturable optimizer state: step counters and learning rates live on the device
+            cfg.solver.optim.args["capturable"] = True
+            for g in param_groups:
+                # float `initial_lr` keeps LambdaLR's arithmetic on the host (a tensor base lr would
+                # cost one .item() sync per group and step); the live `lr` is filled in place
+                g["initial_lr"] = float(g["lr"])
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
+        self.loss, self.optimizer, self.scheduler = build_optim(cfg, param_groups, total_steps)
         self.loss = self.loss.to(self.device)
         self.grad_norm = cfg.solver.get("grad_norm", None)
         self.amp_dtype = amp_dtype if self.device.type == "cuda" else None
-        world = dist_utils.get_world_size()
-        use_ddp = (world > 1) if ddp is None else ddp
         self.net: nn.Module = self.model
         if use_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
@@ -62,9 +83,55 @@ class GPSTrainStep:
             total, losses = self.loss(out)
         return out, total, losses
 
+    def _eager_body(self, data_dict):
+        out, total, losses = self.forward_loss(data_dict)
+        self.optimizer.zero_grad(set_to_none=True)
+        total.backward()
+        if self.grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+        self.optimizer.step()
+        return total, losses
+
+    def _graph_step(self, data_dict):
+        """Warm-up steps run eagerly on a side stream (torch's capture protocol), then the step is
+        captured once; afterwards: copy the batch into the static buffers, replay."""
+        tensors = {k: v for k, v in data_dict.items() if torch.is_tensor(v)}
+        if self._graph is None and self.global_step < self.graph_warmup:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                total, losses = self._eager_body(data_dict)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            return total.detach(), {k: v.detach() for k, v in losses.items()}
+        if self._graph is None:
+            self._static = {k: v.clone() for k, v in tensors.items()}
+            static_dict = dict(data_dict)
+            static_dict.update(self._static)
+            self.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                total, losses = self._eager_body(static_dict)
+            self._graph, self._graph_out = g, (total, losses)
+        else:
+            for k, v in tensors.items():
+                buf = self._static[k]
+                if buf.data_ptr() != v.data_ptr():
+                    buf.copy_(v, non_blocking=True)
+        self._graph.replay()
+        total, losses = self._graph_out
+        return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
+
     def step(self, data_dict):
         """One optimisation step; returns (total_loss tensor, dict of loss tensors).  No host sync."""
         self.net.train()
+        if self.graph:
+            data_dict['cur_step'] = 0
+            data_dict['total_steps'] = 1 << 30
+            total, losses = self._graph_step(data_dict)
+            self.scheduler.step()
+            self.global_step += 1
+            return total, losses
         data_dict['cur_step'] = self.global_step
         data_dict['total_steps'] = 1 << 30
         out, total, losses = self.forward_loss(data_dict)

@@ -100,9 +100,10 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         txt_len, obj_len = txt_embeds.shape[1], obj_embeds.shape[1]
         joint_pad = torch.cat((txt_masks, obj_masks), dim=1).logical_not()
         type_txt = self.token_type_embeddings.weight[0]
-        type_obj = self.token_type_embeddings.weight[1]
+        # the same deterministic embedding is re-added every layer (ref :154-164): evaluate it once
+        obj_extra = self.loc_layers[0](obj_locs) + self.token_type_embeddings.weight[1]
         for layer in self.unified_encoder:
-            obj_embeds = obj_embeds + self.loc_layers[0](obj_locs) + type_obj
+            obj_embeds = obj_embeds + obj_extra
             txt_embeds = txt_embeds + type_txt
             joint = torch.cat((txt_embeds, obj_embeds), dim=1)
             joint, _ = layer(joint, tgt_key_padding_mask=joint_pad)

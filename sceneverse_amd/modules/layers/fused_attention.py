@@ -42,7 +42,7 @@ def _ptr(t: Optional[torch.Tensor]):
 class _FusedSelfAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, packed: torch.Tensor, pl: Optional[torch.Tensor], mask: Optional[torch.Tensor],
-                n_head: int, p_drop: float, seed: int) -> torch.Tensor:
+                n_head: int, p_drop: float, seed: int, seed_dev: Optional[torch.Tensor]) -> torch.Tensor:
         B, L, W = packed.shape
         D = n_head * HEAD_DIM
         spatial = pl is not None
@@ -63,16 +63,16 @@ class _FusedSelfAttention(torch.autograd.Function):
                                                       4 * B * n_head * L * L * HEAD_DIM, "bf16"):
             st = _native.load().gps_attn_forward(
                 B, n_head, L, HEAD_DIM, base, base + D * esz, base + 2 * D * esz, W,
-                _ptr(sw), _ptr(pl), _ptr(m8), float(p_drop), int(seed), out.data_ptr(), D,
+                _ptr(sw), _ptr(pl), _ptr(m8), float(p_drop), int(seed), _ptr(seed_dev), out.data_ptr(), D,
                 lse.data_ptr(), _stream())
         _native.check(st, "attn_forward")
-        ctx.save_for_backward(packed, sw, pl, m8, lse)
+        ctx.save_for_backward(packed, sw, pl, m8, lse, seed_dev)
         ctx.meta = (n_head, float(p_drop), int(seed), spatial)
         return out
 
     @staticmethod
     def backward(ctx, dout: torch.Tensor):
-        packed, sw, pl, m8, lse = ctx.saved_tensors
+        packed, sw, pl, m8, lse, seed_dev = ctx.saved_tensors
         n_head, p_drop, seed, spatial = ctx.meta
         B, L, W = packed.shape
         D = n_head * HEAD_DIM
@@ -87,12 +87,12 @@ class _FusedSelfAttention(torch.autograd.Function):
                                                       10 * B * n_head * L * L * HEAD_DIM, "bf16"):
             st = _native.load().gps_attn_backward(
                 B, n_head, L, HEAD_DIM, base, base + D * esz, base + 2 * D * esz, W,
-                _ptr(sw), _ptr(pl), _ptr(m8), p_drop, seed, dout.data_ptr(), D, lse.data_ptr(),
+                _ptr(sw), _ptr(pl), _ptr(m8), p_drop, seed, _ptr(seed_dev), dout.data_ptr(), D, lse.data_ptr(),
                 gbase, gbase + D * esz, gbase + 2 * D * esz, _ptr(dsw), _stream())
         _native.check(st, "attn_backward")
         if spatial:
             dpacked[..., 3 * D:] = dsw
-        return dpacked, None, None, None, None, None
+        return dpacked, None, None, None, None, None, None
 
 
 def fused_self_attention(packed: torch.Tensor, n_head: int, pairwise_locs: Optional[torch.Tensor] = None,
@@ -100,5 +100,24 @@ def fused_self_attention(packed: torch.Tensor, n_head: int, pairwise_locs: Optio
                          training: bool = False) -> torch.Tensor:
     """packed (B, L, 3*D [+ H*6]) bf16 -> (B, L, D) bf16 attention output (heads merged)."""
     p = float(dropout_p) if training else 0.0
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0   # CPU generator: no sync
-    return _FusedSelfAttention.apply(packed.contiguous(), pairwise_locs, key_padding_mask, n_head, p, seed)
+    seed, seed_dev = 0, None
+    if p > 0.0:
+        # the dropout stream lives ON THE DEVICE: a per-device uint64 advanced by one tiny kernel per
+        # call and snapshotted for this call's forward+backward.  No host value is baked into the
+        # launch, so a captured HIP graph draws a fresh mask on every replay.
+        seed_dev = _next_device_seed(packed.device)
+    return _FusedSelfAttention.apply(packed.contiguous(), pairwise_locs, key_padding_mask, n_head, p, seed,
+                                     seed_dev)
+
+
+_SEED_STATE = {}
+
+
+def _next_device_seed(device: torch.device) -> torch.Tensor:
+    state = _SEED_STATE.get(device)
+    if state is None:
+        init = int(torch.randint(0, 2 ** 62, (1,)).item())          # honours torch.manual_seed
+        state = torch.tensor([init], dtype=torch.int64, device=device)
+        _SEED_STATE[device] = state
+    state.add_(0x632BE59BD9B4E019)       # odd 63-bit increment; wraps modulo 2^64
+    return state.clone()

@@ -115,7 +115,8 @@ class PointOpenVocabEncoder(nn.Module):
                 obj_locs[:, :, :3], obj_locs[:, :, 3:], pairwise_rel_type=self.pairwise_rel_type,
                 spatial_dist_norm=True, spatial_dim=self.spatial_dim)
             pad = obj_masks.logical_not()
+            loc_embeds = self.loc_layers[0](obj_locs)      # re-added every layer (ref :176-178); evaluated once
             for layer in self.spatial_encoder:
-                obj_embeds = obj_embeds + self.loc_layers[0](obj_locs)
+                obj_embeds = obj_embeds + loc_embeds
                 obj_embeds, _ = layer(obj_embeds, pairwise_locs, tgt_key_padding_mask=pad)
         return obj_embeds, obj_embeds_pre, obj_sem_cls

@@ -75,7 +75,7 @@ def test_forward_backward_match_fp32_formulation(B, L, spatial):
 
     x = packed.to(DEV).requires_grad_(True)
     out = _FusedSelfAttention.apply(x, pl.to(DEV) if pl is not None else None,
-                                    mask.to(DEV) if mask is not None else None, H, 0.0, 0)
+                                    mask.to(DEV) if mask is not None else None, H, 0.0, 0, None)
     out.backward(go.to(DEV))
     _close(out, ref, 2e-2, "out")
     g, gr = x.grad.float().cpu(), ref_in.grad
@@ -95,14 +95,17 @@ def test_dropout_is_reproducible_linear_and_adjoint():
     p, seed = 0.3, 1234567
 
     def run(pk):
-        return _FusedSelfAttention.apply(pk, pl, mask, H, p, seed)
+        return _FusedSelfAttention.apply(pk, pl, mask, H, p, seed, None)
 
     x = packed.to(DEV)
     o1, o2 = run(x), run(x)
     assert torch.equal(o1, o2)                                   # same seed -> same mask
-    o3 = _FusedSelfAttention.apply(x, pl, mask, H, p, seed + 1)
+    o3 = _FusedSelfAttention.apply(x, pl, mask, H, p, seed + 1, None)
     assert not torch.equal(o1, o3)
-    o0 = _FusedSelfAttention.apply(x, pl, mask, H, 0.0, 0)
+    o0 = _FusedSelfAttention.apply(x, pl, mask, H, 0.0, 0, None)
+    # a device-side seed word is added to the host seed: (seed, dev=1) == (seed + 1, dev=None)
+    dev1 = torch.tensor([1], dtype=torch.int64, device=DEV)
+    assert torch.equal(_FusedSelfAttention.apply(x, pl, mask, H, p, seed, dev1), o3)
     # E[dropout(P)] = P: averaged over all outputs the two agree to a few percent
     assert abs(o1.float().mean().item() - o0.float().mean().item()) < 0.05 * o0.float().abs().mean().item() + 1e-3
     # adjoint identity in v (out is linear in v for a fixed keep mask): <out(v), g> == <v, dv>
