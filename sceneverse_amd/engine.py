@@ -45,6 +45,10 @@ class GPSTrainStep:
         world = dist_utils.get_world_size()
         use_ddp = (world > 1) if ddp is None else ddp
         self.graph = bool(graph) and self.device.type == "cuda" and not use_ddp
+        if self.graph:
+            # eager steps after a capture (bench's per-kernel timing pass) meet AccumulateGrad nodes
+            # created on the capture stream; the cross-stream sync torch inserts is what we want
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.graph_warmup = max(1, int(graph_warmup))
         self._graph = None
         self._static = None
