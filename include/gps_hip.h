@@ -203,6 +203,31 @@ GPS_API int gps_masked_ce_backward(int n_rows, int vocab, int logits_bf16, const
                                    const float *grad_rows, void *dlogits, long long ldd,
                                    gps_stream_t stream);
 
+/* ---- fused residual + dropout + LayerNorm (post-norm transformer layers) ---------------------------
+ * y = LayerNorm(x + dropout(h)) * gamma + beta, the pattern of modules/layers/transformers.py:143-153
+ * and :311-315 (`self.norm1(tgt + self.dropout1(tgt2))`), one launch instead of dropout, add,
+ * layer_norm and the fp32->bf16 copy autocast inserts for the next GEMM.
+ * x (n_rows, d) residual stream, fp32 or bf16 (x_bf16); h (n_rows, d) branch output, fp32 or bf16
+ * (h_bf16); y has x's dtype; y_bf16 (optional, may be NULL) receives a bf16 copy of y.
+ * mean/rstd (n_rows) fp32 are saved for backward.  d must be a multiple of 256, d <= 2048.
+ * Dropout: counter-based like gps_attn_forward (p_drop, seed, optional device seed word). */
+GPS_API int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int h_bf16, const void *x,
+                                              const void *h, const float *gamma, const float *beta, float eps,
+                                              float p_drop, unsigned long long seed, const void *seed_dev,
+                                              void *y, void *y_bf16, float *mean, float *rstd,
+                                              gps_stream_t stream);
+/* rows of the partial dgamma/dbeta buffers the backward call fills (one per workgroup). */
+GPS_API int gps_ln_partial_rows(int n_rows);
+/* dy (x's dtype) [+ dy_bf16: gradient that arrived through the bf16 copy, may be NULL] -> dx (x's
+ * dtype), dh (h's dtype), dgamma_part / dbeta_part (gps_ln_partial_rows(n_rows), d) fp32: the caller
+ * sums them over the first axis. */
+GPS_API int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                               const void *dy_bf16, const void *x, const void *h,
+                                               const float *gamma, const float *mean, const float *rstd,
+                                               float p_drop, unsigned long long seed, const void *seed_dev,
+                                               void *dx, void *dh, float *dgamma_part, float *dbeta_part,
+                                               gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

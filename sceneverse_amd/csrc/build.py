@@ -17,6 +17,7 @@ SOURCES = [
     ("gps_sa_mlp.hip", []),
     ("gps_attention.hip", []),
     ("gps_losses.hip", []),
+    ("gps_layernorm.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-I" + os.path.join(ROOT, "include")]

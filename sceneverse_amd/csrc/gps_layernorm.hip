@@ -1,0 +1,272 @@
+// gps_layernorm.hip -- fused  y = LayerNorm(x + dropout(h)) * gamma + beta  (forward and backward)
+// for the post-norm transformer layers of the GPS path on MI355X (gfx950).
+//
+// Reference pattern (every encoder layer, twice): modules/layers/transformers.py:143-153, :311-315
+//     tgt = self.norm1(tgt + self.dropout1(tgt2));  tgt = self.norm2(tgt + self.dropout2(ffn(tgt)))
+// which under bf16 autocast runs as dropout (bf16) -> add (promotes to fp32) -> layer_norm (fp32)
+// -> a separate fp32->bf16 copy for the next GEMM, and three kernels plus casts in backward.
+// Here: one launch forward (optionally also emitting the bf16 copy the next GEMM wants), one launch
+// backward (+ one tiny column reduction for dgamma/dbeta).  HBM-bound: forward moves
+// sizeof(x) + sizeof(h) + sizeof(y) [+2] bytes per element, backward sizeof(dy) + sizeof(x) +
+// sizeof(h) + sizeof(dx) + sizeof(dh).
+//
+// One wave per row, the row (<= 2048 elements, 4 consecutive elements per lane and step, 16-byte
+// loads) stays in VGPRs: mean and variance are computed two-pass from registers, row reductions are
+// wave shuffles, no LDS in forward.  Dropout uses the same counter-based RNG as the attention core
+// (seed + optional device seed word), recomputed in backward.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gps_hip.h"
+
+namespace gps_ln {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxIter = 8;          // D <= 8 * 256
+
+__device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned int)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+// 4 consecutive elements at p (element index e0), as fp32
+__device__ __forceinline__ float4 load4(const float *p, size_t e0) {
+  return *reinterpret_cast<const float4 *>(p + e0);
+}
+__device__ __forceinline__ float4 load4(const uint16_t *p, size_t e0) {
+  const uint2 v = *reinterpret_cast<const uint2 *>(p + e0);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u),
+                     __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void store4(float *p, size_t e0, float4 v) {
+  *reinterpret_cast<float4 *>(p + e0) = v;
+}
+__device__ __forceinline__ void store4(uint16_t *p, size_t e0, float4 v) {
+  uint2 o;
+  o.x = (unsigned int)f2bf(v.x) | ((unsigned int)f2bf(v.y) << 16);
+  o.y = (unsigned int)f2bf(v.z) | ((unsigned int)f2bf(v.w) << 16);
+  *reinterpret_cast<uint2 *>(p + e0) = o;
+}
+
+struct Drop {
+  unsigned int thr;          // keep iff rng >= thr; 0 = no dropout
+  float scale;               // 1 / (1 - p)
+  unsigned long long seed;
+};
+__device__ __forceinline__ float4 drop4(float4 h, const Drop &d, unsigned long long e0) {
+  if (d.thr == 0u) return h;
+  h.x = rng_u32(d.seed, e0 + 0) >= d.thr ? h.x * d.scale : 0.f;
+  h.y = rng_u32(d.seed, e0 + 1) >= d.thr ? h.y * d.scale : 0.f;
+  h.z = rng_u32(d.seed, e0 + 2) >= d.thr ? h.z * d.scale : 0.f;
+  h.w = rng_u32(d.seed, e0 + 3) >= d.thr ? h.w * d.scale : 0.f;
+  return h;
+}
+
+template <typename TX, typename TH>
+__global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
+    int n_rows, int d, const TX *__restrict__ x, const TH *__restrict__ h, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float eps, float p_drop, unsigned int thr, unsigned long long seed,
+    const unsigned long long *__restrict__ seed_dev, TX *__restrict__ y, uint16_t *__restrict__ y16,
+    float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int iters = d >> 8;
+  Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
+  const float inv_d = 1.f / (float)d;
+  for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
+    const size_t base = (size_t)row * d;
+    float4 z[kMaxIter];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i)
+      if (i < iters) {
+        const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+        const float4 xv = load4(x, e0);
+        const float4 hv = drop4(load4(h, e0), dr, e0);
+        z[i] = make_float4(xv.x + hv.x, xv.y + hv.y, xv.z + hv.z, xv.w + hv.w);
+        s += (z[i].x + z[i].y) + (z[i].z + z[i].w);
+      }
+    const float mean = wave_sum(s) * inv_d;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i)
+      if (i < iters) {
+        const float a = z[i].x - mean, b = z[i].y - mean, c = z[i].z - mean, e = z[i].w - mean;
+        v += (a * a + b * b) + (c * c + e * e);
+      }
+    const float rstd = rsqrtf(wave_sum(v) * inv_d + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i)
+      if (i < iters) {
+        const int c0 = (i * 64 + lane) * 4;
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c0);
+        const float4 bt = *reinterpret_cast<const float4 *>(beta + c0);
+        float4 o;
+        o.x = (z[i].x - mean) * rstd * g.x + bt.x;
+        o.y = (z[i].y - mean) * rstd * g.y + bt.y;
+        o.z = (z[i].z - mean) * rstd * g.z + bt.z;
+        o.w = (z[i].w - mean) * rstd * g.w + bt.w;
+        store4(y, base + c0, o);
+        if (y16) store4(y16, base + c0, o);
+      }
+  }
+}
+
+// dx = dz, dh = dz * keep * scale, partial dgamma/dbeta per workgroup ([gridDim.x][d] each)
+template <typename TX, typename TH>
+__global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
+    int n_rows, int d, const TX *__restrict__ dy, const uint16_t *__restrict__ dy16, const TX *__restrict__ x,
+    const TH *__restrict__ h, const float *__restrict__ gamma, const float *__restrict__ mean_in,
+    const float *__restrict__ rstd_in, float p_drop, unsigned int thr, unsigned long long seed,
+    const unsigned long long *__restrict__ seed_dev, TX *__restrict__ dx, TH *__restrict__ dh,
+    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part) {
+  extern __shared__ float red[];      // [kWaves][d] reused for dgamma then dbeta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int iters = d >> 8;
+  Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
+  const float inv_d = 1.f / (float)d;
+  float4 gacc[kMaxIter], bacc[kMaxIter], gm[kMaxIter];
+#pragma unroll
+  for (int i = 0; i < kMaxIter; ++i) {
+    gacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < iters) gm[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
+  }
+  for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
+    const size_t base = (size_t)row * d;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 zh[kMaxIter], a[kMaxIter];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i)
+      if (i < iters) {
+        const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+        const float4 xv = load4(x, e0);
+        const float4 hv = drop4(load4(h, e0), dr, e0);
+        float4 g = load4(dy, e0);
+        if (dy16) {           // gradient that arrived through the bf16 copy of y
+          const float4 g2 = load4(dy16, e0);
+          g = make_float4(g.x + g2.x, g.y + g2.y, g.z + g2.z, g.w + g2.w);
+        }
+        zh[i] = make_float4((xv.x + hv.x - mean) * rstd, (xv.y + hv.y - mean) * rstd,
+                            (xv.z + hv.z - mean) * rstd, (xv.w + hv.w - mean) * rstd);
+        a[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
+        s1 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+        s2 += (a[i].x * zh[i].x + a[i].y * zh[i].y) + (a[i].z * zh[i].z + a[i].w * zh[i].w);
+        gacc[i].x += g.x * zh[i].x; gacc[i].y += g.y * zh[i].y;
+        gacc[i].z += g.z * zh[i].z; gacc[i].w += g.w * zh[i].w;
+        bacc[i].x += g.x; bacc[i].y += g.y; bacc[i].z += g.z; bacc[i].w += g.w;
+      }
+    s1 = wave_sum(s1) * inv_d;
+    s2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i)
+      if (i < iters) {
+        const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+        float4 dz;
+        dz.x = rstd * (a[i].x - s1 - zh[i].x * s2);
+        dz.y = rstd * (a[i].y - s1 - zh[i].y * s2);
+        dz.z = rstd * (a[i].z - s1 - zh[i].z * s2);
+        dz.w = rstd * (a[i].w - s1 - zh[i].w * s2);
+        store4(dx, e0, dz);
+        float4 dhv = dz;
+        if (dr.thr) {
+          const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+          const float4 k = drop4(one, dr, e0);          // keep * scale per element
+          dhv = make_float4(dz.x * k.x, dz.y * k.y, dz.z * k.z, dz.w * k.w);
+        }
+        store4(dh, e0, dhv);
+      }
+  }
+  // cross-wave reduction of the column sums, then one partial row per workgroup
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i)
+      if (i < iters)
+        *reinterpret_cast<float4 *>(red + wave * d + (i * 64 + lane) * 4) = pass == 0 ? gacc[i] : bacc[i];
+    __syncthreads();
+    float *dst = (pass == 0 ? dgamma_part : dbeta_part) + (size_t)blockIdx.x * d;
+    for (int c = threadIdx.x; c < d; c += kBlock) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) t += red[w * d + c];
+      dst[c] = t;
+    }
+  }
+}
+
+inline int grid_rows(int n_rows) {
+  int g = (n_rows + kWaves - 1) / kWaves;
+  return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+
+}  // namespace gps_ln
+
+extern "C" {
+
+int gps_ln_partial_rows(int n_rows) { return gps_ln::grid_rows(n_rows); }
+
+int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int h_bf16, const void *x, const void *h,
+                                      const float *gamma, const float *beta, float eps, float p_drop,
+                                      unsigned long long seed, const void *seed_dev, void *y, void *y_bf16,
+                                      float *mean, float *rstd, gps_stream_t stream) {
+  if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
+  if ((d & 255) || d > 256 * gps_ln::kMaxIter) return GPS_ERR_UNSUPPORTED;
+  if (n_rows == 0) return GPS_OK;
+  if (!x || !h || !gamma || !beta || !y || !mean || !rstd) return GPS_ERR_INVALID_ARGUMENT;
+  const unsigned int thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  const dim3 grid(gps_ln::grid_rows(n_rows)), block(gps_ln::kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned long long *sd = (const unsigned long long *)seed_dev;
+#define GPS_LN_FWD(TX, TH)                                                                                   \
+  hipLaunchKernelGGL((gps_ln::add_dropout_ln_fwd_kernel<TX, TH>), grid, block, 0, s, n_rows, d, (const TX *)x, \
+                     (const TH *)h, gamma, beta, eps, p_drop, thr, seed, sd, (TX *)y, (uint16_t *)y_bf16, mean, rstd)
+  if (x_bf16 && h_bf16) GPS_LN_FWD(uint16_t, uint16_t);
+  else if (x_bf16) GPS_LN_FWD(uint16_t, float);
+  else if (h_bf16) GPS_LN_FWD(float, uint16_t);
+  else GPS_LN_FWD(float, float);
+#undef GPS_LN_FWD
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                       const void *dy_bf16, const void *x, const void *h, const float *gamma,
+                                       const float *mean, const float *rstd, float p_drop,
+                                       unsigned long long seed, const void *seed_dev, void *dx, void *dh,
+                                       float *dgamma_part, float *dbeta_part, gps_stream_t stream) {
+  if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
+  if ((d & 255) || d > 256 * gps_ln::kMaxIter) return GPS_ERR_UNSUPPORTED;
+  if (n_rows == 0) return GPS_OK;
+  if (!dy || !x || !h || !gamma || !mean || !rstd || !dx || !dh || !dgamma_part || !dbeta_part)
+    return GPS_ERR_INVALID_ARGUMENT;
+  const unsigned int thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  const dim3 grid(gps_ln::grid_rows(n_rows)), block(gps_ln::kBlock);
+  const size_t lds = sizeof(float) * gps_ln::kWaves * d;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned long long *sd = (const unsigned long long *)seed_dev;
+#define GPS_LN_BWD(TX, TH)                                                                                     \
+  hipLaunchKernelGGL((gps_ln::add_dropout_ln_bwd_kernel<TX, TH>), grid, block, lds, s, n_rows, d, (const TX *)dy, \
+                     (const uint16_t *)dy_bf16, (const TX *)x, (const TH *)h, gamma, mean, rstd, p_drop, thr,   \
+                     seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part)
+  if (x_bf16 && h_bf16) GPS_LN_BWD(uint16_t, uint16_t);
+  else if (x_bf16) GPS_LN_BWD(uint16_t, float);
+  else if (h_bf16) GPS_LN_BWD(float, uint16_t);
+  else GPS_LN_BWD(float, float);
+#undef GPS_LN_BWD
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

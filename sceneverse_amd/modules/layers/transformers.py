@@ -286,6 +286,12 @@ def _ffn(layer, x):
     return layer.linear2(layer.dropout(layer.activation(layer.linear1(x))))
 
 
+def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout) -> Tensor:
+    """norm(x + drop(h)): one fused launch on the GPU (fused_norm), the plain ops elsewhere."""
+    from .fused_norm import add_dropout_layer_norm
+    return add_dropout_layer_norm(x, h, norm, drop.p, drop.training)
+
+
 class TransformerEncoderLayer(nn.Module):
     """Self-attention + FFN, post-norm unless `prenorm` (ref :115-154).  forward -> (x, attn)."""
 
@@ -308,12 +314,14 @@ class TransformerEncoderLayer(nn.Module):
         h = self.norm1(tgt) if self.prenorm else tgt
         h, attn = self.self_attn(query=h, key=h, value=h, attn_mask=tgt_mask,
                                  key_padding_mask=tgt_key_padding_mask)
+        if not self.prenorm:
+            tgt = _res_norm(self.norm1, tgt, h, self.dropout1)
+            tgt = _res_norm(self.norm2, tgt, _ffn(self, tgt), self.dropout2)
+            return tgt, attn
         tgt = tgt + self.dropout1(h)
         # ref :147-153: the pre-norm variant normalises the residual stream itself before the FFN
-        tgt = self.norm2(tgt) if self.prenorm else self.norm1(tgt)
+        tgt = self.norm2(tgt)
         tgt = tgt + self.dropout2(_ffn(self, tgt))
-        if not self.prenorm:
-            tgt = self.norm2(tgt)
         return tgt, attn
 
 
@@ -333,8 +341,8 @@ class TransformerSpatialEncoderLayer(TransformerEncoderLayer):
                 tgt_key_padding_mask: Optional[Tensor] = None):
         h, attn = self.self_attn(tgt, tgt, tgt, tgt_pairwise_locs,
                                  key_padding_mask=tgt_key_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(h))
-        tgt = self.norm2(tgt + self.dropout2(_ffn(self, tgt)))
+        tgt = _res_norm(self.norm1, tgt, h, self.dropout1)
+        tgt = _res_norm(self.norm2, tgt, _ffn(self, tgt), self.dropout2)
         return tgt, attn
 
 
