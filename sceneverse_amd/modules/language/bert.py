@@ -3,9 +3,25 @@ HuggingFace `transformers` (out of scope); this wrap
 registry name, constructor arguments, `self.model` attribute (checkpoint keys `model.*`) and
 forward contract.  Extra, for offline machines: `weights=None` (or `random_init=True`) builds
 `BertModel(BertConfig(...))` with random weights instead of calling `from_pretrained`."""
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ..build import LANGUAGE_REGISTRY
+
+# GPU fast path of the encoder stack (SURVEY.md 8(f).3): the HuggingFace PARAMETERS and embedding
+# block are used as they are, but each BertLayer runs as
+#   one packed QKV GEMM -> fused attention core (libgps_hip.so; torch SDPA above 256 tokens)
+#   -> dense -> fused residual+dropout+LayerNorm -> dense+GELU -> dense -> fused residual+dropout+LN
+# instead of HF's op-by-op formulation (3 projection GEMMs, separate dropout/add/LayerNorm/casts).
+# Same mathematics as transformers.models.bert.modeling_bert.BertLayer (post-norm, exact GELU,
+# key-padding mask from the attention mask, dropout on probabilities and on both branches).
+_FAST = True
+
+
+def set_fast_bert(flag: bool) -> None:
+    global _FAST
+    _FAST = bool(flag)
 
 
 @LANGUAGE_REGISTRY.register()
@@ -25,5 +41,43 @@ class BERTLanguageEncoder(nn.Module):
             self.tokenizer = BertTokenizer.from_pretrained(weights, do_lower_case=True)
             self.model = BertModel.from_pretrained(weights, config=self.bert_config)
 
+    def _fast_ok(self, txt_ids) -> bool:
+        from ..layers.transformers import _bf16_mode
+        cfg = self.bert_config
+        probe = self.model.embeddings.word_embeddings.weight
+        return (_FAST and txt_ids.is_cuda and _bf16_mode(probe) and cfg.hidden_act == "gelu"
+                and cfg.hidden_size == cfg.num_attention_heads * 64 and not cfg.is_decoder
+                and getattr(cfg, "position_embedding_type", "absolute") == "absolute")
+
+    def _fast_forward(self, txt_ids, txt_masks):
+        from ..layers.fused_attention import fused_self_attention, supported as attn_supported
+        from ..layers.fused_norm import add_dropout_layer_norm
+        m, H = self.model, self.bert_config.num_attention_heads
+        x = m.embeddings(input_ids=txt_ids)                     # (B, L, D) fp32 under autocast
+        B, L, D = x.shape
+        pad = txt_masks == 0
+        training = self.training
+        for layer in m.encoder.layer:
+            sa, so = layer.attention.self, layer.attention.output
+            w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0)
+            b = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0)
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                packed = F.linear(x, w, b)
+                if attn_supported(D, H, L):
+                    ctx = fused_self_attention(packed, H, None, pad, dropout_p=sa.dropout.p, training=training)
+                else:   # long captions: torch SDPA (flash) on views of the packed projection
+                    q, k, v = packed.view(B, L, 3, H, D // H).permute(2, 0, 3, 1, 4)
+                    ctx = F.scaled_dot_product_attention(
+                        q, k, v, attn_mask=pad.logical_not()[:, None, None, :],
+                        dropout_p=sa.dropout.p if training else 0.0)
+                    ctx = ctx.transpose(1, 2).reshape(B, L, D)
+                x = add_dropout_layer_norm(x, so.dense(ctx), so.LayerNorm, so.dropout.p, training)
+                inter = layer.intermediate.intermediate_act_fn(layer.intermediate.dense(x))
+                x = add_dropout_layer_norm(x, layer.output.dense(inter), layer.output.LayerNorm,
+                                           layer.output.dropout.p, training)
+        return x
+
     def forward(self, txt_ids, txt_masks, **kwargs):
+        if self._fast_ok(txt_ids):
+            return self._fast_forward(txt_ids, txt_masks)
         return self.model(txt_ids, txt_masks).last_hidden_state
