@@ -174,7 +174,7 @@ def main() -> None:
     torch.cuda.set_device(dev)
 
     cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not args.no_graph      # world_size > 1: split-graph data parallelism (engine.py)
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=use_graph)
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
 
@@ -190,7 +190,9 @@ def main() -> None:
             for _ in range(step.graph_warmup + 1):
                 step.step(dict(batch))
             torch.cuda.synchronize()
-            graph_note = "whole step replayed as one HIP graph"
+            graph_note = ("whole step replayed as one HIP graph" if step.graph else
+                          "3 HIP graphs per step (forward | losses+backward | clip+AdamW) around eager RCCL "
+                          "all-gather / all-reduce")
         except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a requirement
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
@@ -200,6 +202,8 @@ def main() -> None:
             cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
             step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=False)
             graph_note = f"eager (graph capture failed: {type(e).__name__})"
+            if world > 1:   # every rank must take the same branch: a one-sided failure would deadlock,
+                pass        # so capture errors under world_size > 1 are fatal by design (see below)
     for _ in range(args.warmup):
         step.step(dict(batch))
     barrier()
@@ -213,7 +217,8 @@ def main() -> None:
     if use_graph:
         # a replayed graph cannot host per-launch event pairs: the per-kernel durations come from
         # eager steps of the same workload run right after the timed region (not part of `value`)
-        step.graph = False
+        saved = (step.graph, step.graph_dp)
+        step.graph = step.graph_dp = False
         step.step(dict(batch))
         hip_ext.profile_start()
         for _ in range(3):
@@ -221,7 +226,7 @@ def main() -> None:
         kern = hip_ext.profile_stop()
         for k in kern.values():
             k["launches"] = k["launches"] * args.steps / 3.0
-        step.graph = True
+        step.graph, step.graph_dp = saved
     else:
         kern = hip_ext.profile_stop()
     t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -18,8 +18,22 @@ per step, which is what bounds it once the kernels are fused (DESIGN.md section 
 once into a HIP graph on static input buffers and then replayed: one `hipGraphLaunch` per step.
 The learning rate is a device tensor the scheduler fills in place, attention dropout draws its
 seed from a device word (fused_attention._next_device_seed), torch's own RNG ops are graph-safe,
-so every replay is a fresh, correctly scheduled optimisation step.  Not used under DDP: the
-gradient all-reduce stays in eager mode there.
+so every replay is a fresh, correctly scheduled optimisation step.
+
+HIP graph + data parallelism (`graph=True` with world_size > 1, "graph_dp"): torch DDP's bucket hooks
+cannot live inside a replayed graph, and capturing RCCL collectives cannot be validated on a 1-GPU
+box, so the step is split at its two exchange points instead and the collectives stay EAGER:
+
+    graph 1  model forward                                        (replay)
+    eager    all-gather of the contrastive features (C2)          RCCL, into static buffers
+    graph 2  losses + backward into ONE flat fp32 gradient buffer  (replay; shares graph 1's pool)
+    eager    all-reduce of the flat gradient buffer, / world (C1)  RCCL, one collective of ~491 MB
+    graph 3  gradient clipping + AdamW                             (replay)
+
+The all-reduce is not overlapped with backward (backward is one graph launch); at ~3 ms over xGMI
+against a ~31 ms step that costs less than the ~13 ms of launch gaps the eager DDP step carries.
+Parameters are broadcast from rank 0 once.  The same code runs with world_size 1 (collectives are
+no-ops), which is how tests/test_gpu_model.py exercises it on one GPU.
 """
 from __future__ import annotations
 
@@ -44,8 +58,14 @@ class GPSTrainStep:
         self.model = build_model(cfg).to(self.device)
         world = dist_utils.get_world_size()
         use_ddp = (world > 1) if ddp is None else ddp
-        self.graph = bool(graph) and self.device.type == "cuda" and not use_ddp
-        if self.graph:
+        want_graph = bool(graph) and self.device.type == "cuda"
+        # graph == "dp" forces the split-graph data-parallel form even at world_size 1 (tests)
+        self.graph_dp = want_graph and (graph == "dp" or (use_ddp and world > 1))
+        if self.graph_dp:
+            use_ddp = False
+        self.world = world
+        self.graph = want_graph and not use_ddp and not self.graph_dp
+        if self.graph or self.graph_dp:
             # eager steps after a capture (bench's per-kernel timing pass) meet AccumulateGrad nodes
             # created on the capture stream; the cross-stream sync torch inserts is what we want
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -53,7 +73,7 @@ class GPSTrainStep:
         self._graph = None
         self._static = None
         param_groups = self.model.get_opt_params()
-        if self.graph:
+        if self.graph or self.graph_dp:
             # capturable optimizer state: step counters and learning rates live on the device
             cfg.solver.optim.args["capturable"] = True
             for g in param_groups:
@@ -75,6 +95,109 @@ class GPSTrainStep:
             else:
                 self.net = DDP(self.model, **kw)
         self.global_step = 0
+        if self.graph_dp and dist_utils.is_dist():
+            with torch.no_grad():                      # what DDP does at construction
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    torch.distributed.broadcast(t, src=0)
+
+    # ---- split-graph data parallelism ------------------------------------------------------------
+    def _dist_losses(self):
+        return [m for m in self.loss.modules() if hasattr(m, "gather_inputs") and getattr(m, "distributed", False)]
+
+    def _gather_features(self, out):
+        """Eager C2: all-gather what the between-batch losses need into their static buffers."""
+        for m in self._dist_losses():
+            with torch.no_grad(), self._autocast():
+                ins = [t.detach().contiguous() for t in m.gather_inputs(out)]
+            if m._gathered is None:
+                m._gathered = [torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+                                           device=t.device) for t in ins]
+            for buf, t in zip(m._gathered, ins):
+                if dist_utils.is_dist() and self.world > 1:
+                    torch.distributed.all_gather_into_tensor(buf, t)
+                else:
+                    buf.copy_(t)
+
+    def _allreduce_grads(self):
+        """Eager C1: one all-reduce of the flat gradient buffer, then the mean."""
+        if dist_utils.is_dist() and self.world > 1:
+            torch.distributed.all_reduce(self._flat_grad)
+            self._flat_grad.mul_(1.0 / self.world)
+
+    def _clip_and_step(self):
+        if self.grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+        self.optimizer.step()
+
+    def _graph_dp_step(self, data_dict):
+        tensors = {k: v for k, v in data_dict.items() if torch.is_tensor(v)}
+        cur = torch.cuda.current_stream(self.device)
+        if self._graph is None and self.global_step < self.graph_warmup:
+            # eager warm-up with the same exchange points (lazy inits, hipBLASLt heuristics, ...)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                with self._autocast():
+                    out = self.net(data_dict)
+                self._gather_features(out)
+                with self._autocast():
+                    total, losses = self.loss(out)
+                self.optimizer.zero_grad(set_to_none=True)
+                total.backward()
+                grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+                if dist_utils.is_dist() and self.world > 1:
+                    flat = torch.cat([g.reshape(-1).float() for g in grads])
+                    torch.distributed.all_reduce(flat)
+                    flat.mul_(1.0 / self.world)
+                    off = 0
+                    for g in grads:
+                        g.copy_(flat[off:off + g.numel()].view_as(g))
+                        off += g.numel()
+                self._clip_and_step()
+            cur.wait_stream(side)
+            return total.detach(), {k: v.detach() for k, v in losses.items()}
+        if self._graph is None:
+            self._static = {k: v.clone() for k, v in tensors.items()}
+            static_dict = dict(data_dict)
+            static_dict.update(self._static)
+            # gradients live as views of ONE flat fp32 buffer (only for parameters that do receive a
+            # gradient: the never-used ones keep grad None, as under DDP / eager AdamW)
+            used = [p for p in self.model.parameters() if p.grad is not None]
+            self._flat_grad = torch.zeros(sum(p.numel() for p in used), dtype=torch.float32, device=self.device)
+            off = 0
+            self.optimizer.zero_grad(set_to_none=True)
+            for p in used:
+                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            torch.cuda.synchronize(self.device)
+            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                with self._autocast():
+                    out = self.net(static_dict)
+            self._gather_features(out)
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._flat_grad.zero_()
+                with self._autocast():
+                    total, losses = self.loss(out)
+                total.backward()                      # accumulates into the flat views
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(g3):
+                self._clip_and_step()
+            self._graph, self._graph_out = (g1, g2, g3), (out, total, losses)
+        else:
+            for k, v in tensors.items():
+                buf = self._static[k]
+                if buf.data_ptr() != v.data_ptr():
+                    buf.copy_(v, non_blocking=True)
+        g1, g2, g3 = self._graph
+        out, total, losses = self._graph_out
+        g1.replay()
+        self._gather_features(out)
+        g2.replay()
+        self._allreduce_grads()
+        g3.replay()
+        return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
 
     def _autocast(self):
         if self.amp_dtype is None:
@@ -129,10 +252,10 @@ class GPSTrainStep:
     def step(self, data_dict):
         """One optimisation step; returns (total_loss tensor, dict of loss tensors).  No host sync."""
         self.net.train()
-        if self.graph:
+        if self.graph or self.graph_dp:
             data_dict['cur_step'] = 0
             data_dict['total_steps'] = 1 << 30
-            total, losses = self._graph_step(data_dict)
+            total, losses = self._graph_dp_step(data_dict) if self.graph_dp else self._graph_step(data_dict)
             self.scheduler.step()
             self.global_step += 1
             return total, losses

@@ -53,18 +53,21 @@ class TextObjBetweenBatch(nn.Module):
         self.distributed = cfg.num_gpu > 1
         self.logit_scale = nn.Parameter((torch.ones([]) * np.log(1 / 0.07)).exp())
 
-    def forward(self, data_dict):
-        logit_scale = torch.clamp(self.logit_scale, max=100)
+    _gathered = None   # engine hook, see TextSceneBetweenBatch
+
+    def gather_inputs(self, data_dict):
         obj_feats = data_dict["inter_obj_embeds"]
-        text_feats = data_dict["inter_text_embed"]
         labels = data_dict["tgt_object_id"]
         if obj_feats.shape[0] != labels.shape[0]:
             labels = labels.view(-1, 1)
         tgt = obj_feats[torch.arange(labels.size(0)), labels[:, 0], :]
-        tgt = F.normalize(tgt, dim=-1, p=2)
-        text_feats = F.normalize(text_feats, dim=-1, p=2)
+        return [F.normalize(tgt, dim=-1, p=2), F.normalize(data_dict["inter_text_embed"], dim=-1, p=2)]
+
+    def forward(self, data_dict):
+        logit_scale = torch.clamp(self.logit_scale, max=100)
+        tgt, text_feats = self.gather_inputs(data_dict)
         if self.distributed:
-            tgt, text_feats = all_gather([tgt, text_feats])
+            tgt, text_feats = self._gathered if self._gathered is not None else all_gather([tgt, text_feats])
         return _symmetric_clip_loss(text_feats, tgt, logit_scale)
 
 
@@ -75,10 +78,20 @@ class TextSceneBetweenBatch(nn.Module):
         self.distributed = cfg.num_gpu > 1
         self.logit_scale = nn.Parameter((torch.ones([]) * np.log(1 / 0.07)).exp())
 
+    # Engine hook (sceneverse_amd.engine, HIP-graph data parallelism): when set, `_gathered` holds
+    # the already all-gathered [scene, text] features (static buffers the engine fills with an
+    # eager RCCL all-gather of `gather_inputs(...)` between two graph replays); like the reference's
+    # gather (common/dist_utils.py:131-149) they carry no autograd history.
+    _gathered = None
+
+    def gather_inputs(self, data_dict):
+        return [F.normalize(data_dict["scene_embed"], dim=-1, p=2),
+                F.normalize(data_dict["scene_text_embed"], dim=-1, p=2)]
+
     def forward(self, data_dict):
         logit_scale = torch.clamp(self.logit_scale, max=100)
-        scene_feats = F.normalize(data_dict["scene_embed"], dim=-1, p=2)
-        text_feats = F.normalize(data_dict["scene_text_embed"], dim=-1, p=2)
+        scene_feats, text_feats = self.gather_inputs(data_dict)
         if self.distributed:
-            scene_feats, text_feats = all_gather([scene_feats, text_feats])
+            scene_feats, text_feats = (self._gathered if self._gathered is not None
+                                       else all_gather([scene_feats, text_feats]))
         return _symmetric_clip_loss(text_feats, scene_feats, logit_scale)

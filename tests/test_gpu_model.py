@@ -144,9 +144,9 @@ def test_hip_graph_step_matches_eager_step():
                 m.dropout_prob = 0.0
         return st
 
-    batches = [synth_batch(4, n_obj=16, seed=20 + i, min_real=5, device=DEV) for i in range(6)]
+    batches = [synth_batch(4, n_obj=16, seed=20 + i, min_real=5, device=DEV) for i in range(5)]
     runs = {}
-    for graph in (False, True):
+    for graph in (False, True, "dp"):
         st = make(graph)
         losses, lrs = [], []
         for b in batches:
@@ -156,13 +156,16 @@ def test_hip_graph_step_matches_eager_step():
         runs[graph] = (losses, lrs, [p.detach().float().flatten()[:512].clone() for p in st.model.parameters()])
         if graph:
             assert st._graph is not None          # steps 3.. were graph replays
-    (le, lre, pe), (lg, lrg, pg) = runs[False], runs[True]
-    for a, b in zip(le, lg):
-        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
-    assert all(abs(a - b) < 1e-12 + 1e-6 * abs(a) for a, b in zip(lre, lrg)), (lre, lrg)
+            assert st.graph_dp == (graph == "dp")
+    le, lre, pe = runs[False]
     assert len(set(lre)) > 1                       # the schedule actually moved
-    worst = max((a - b).abs().max().item() for a, b in zip(pe, pg))
-    assert worst < 1e-3, worst
+    for mode in (True, "dp"):                      # one graph / split-graph data-parallel form (world 1)
+        lg, lrg, pg = runs[mode]
+        for a, b in zip(le, lg):
+            assert abs(a - b) <= 2e-3 * abs(a), (mode, le, lg)
+        assert all(abs(a - b) < 1e-12 + 1e-6 * abs(a) for a, b in zip(lre, lrg)), (mode, lre, lrg)
+        worst = max((a - b).abs().max().item() for a, b in zip(pe, pg))
+        assert worst < 1e-3, (mode, worst)
 
 
 def test_fast_bert_path_matches_huggingface_layers():
