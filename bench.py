@@ -202,8 +202,6 @@ def main() -> None:
             cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
             step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=False)
             graph_note = f"eager (graph capture failed: {type(e).__name__})"
-            if world > 1:   # every rank must take the same branch: a one-sided failure would deadlock,
-                pass        # so capture errors under world_size > 1 are fatal by design (see below)
     for _ in range(args.warmup):
         step.step(dict(batch))
     barrier()

@@ -113,6 +113,24 @@ def _worker(rank, world, port, tmp):
                                     torch.clamp(crit.logit_scale, max=100))
         result["between_batch_err"] = abs(float(got) - float(want))
 
+        # -- the eager exchange points of the split-graph data-parallel step (engine.py "graph_dp":
+        #    the graphs themselves need a GPU, the collectives between them are exercised here)
+        eng = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=False, seed=5)
+        eng.world = world
+        fake_out = {"scene_embed": torch.full((2, 768), float(rank + 1)),
+                    "scene_text_embed": torch.full((2, 768), -float(rank + 1))}
+        eng._gather_features(fake_out)
+        (crit2,) = eng._dist_losses()
+        sc_all, tx_all = crit2._gathered
+        n0 = 1.0 / (768 ** 0.5)
+        result["graph_dp_gather_ok"] = bool(
+            sc_all.shape == (2 * world, 768) and not sc_all.requires_grad
+            and torch.allclose(sc_all[::2, 0], torch.full((world,), n0))
+            and torch.allclose(tx_all[::2, 0], torch.full((world,), -n0)))
+        eng._flat_grad = torch.full((10,), float(rank))
+        eng._allreduce_grads()
+        result["graph_dp_allreduce_ok"] = bool(torch.allclose(eng._flat_grad, torch.full((10,), (world - 1) / 2.0)))
+
         # -- two optimisation steps (full loss list) on different shards keep the replicas identical
         ddp = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=True, seed=5)
         for i in range(2):
@@ -141,3 +159,4 @@ def test_ddp_world_size_2_gloo():
         assert r["grad_mean_rel_err"] < 1e-4, r
         assert r["between_batch_err"] < 1e-6, r
         assert r["n_unused"] >= 13, r
+        assert r["graph_dp_gather_ok"] and r["graph_dp_allreduce_ok"], r
