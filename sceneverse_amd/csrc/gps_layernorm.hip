@@ -23,7 +23,7 @@ namespace gps_ln {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxIter = 8;          // D <= 8 * 256
+constexpr int kMaxIter = 8;          // D <= 8 * 256 (ITERS = D / 256 is a template parameter)
 
 __device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
   unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
@@ -74,22 +74,22 @@ __device__ __forceinline__ float4 drop4(float4 h, const Drop &d, unsigned long l
   return h;
 }
 
-template <typename TX, typename TH>
+template <typename TX, typename TH, int ITERS>
 __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
     int n_rows, int d, const TX *__restrict__ x, const TH *__restrict__ h, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, float p_drop, unsigned int thr, unsigned long long seed,
     const unsigned long long *__restrict__ seed_dev, TX *__restrict__ y, uint16_t *__restrict__ y16,
     float *__restrict__ mean_out, float *__restrict__ rstd_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int iters = d >> 8;
+  constexpr int iters = ITERS;
   Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
   const float inv_d = 1.f / (float)d;
   for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
     const size_t base = (size_t)row * d;
-    float4 z[kMaxIter];
+    float4 z[ITERS];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxIter; ++i)
+    for (int i = 0; i < ITERS; ++i)
       if (i < iters) {
         const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
         const float4 xv = load4(x, e0);
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
     const float mean = wave_sum(s) * inv_d;
     float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxIter; ++i)
+    for (int i = 0; i < ITERS; ++i)
       if (i < iters) {
         const float a = z[i].x - mean, b = z[i].y - mean, c = z[i].z - mean, e = z[i].w - mean;
         v += (a * a + b * b) + (c * c + e * e);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
     const float rstd = rsqrtf(wave_sum(v) * inv_d + eps);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
-    for (int i = 0; i < kMaxIter; ++i)
+    for (int i = 0; i < ITERS; ++i)
       if (i < iters) {
         const int c0 = (i * 64 + lane) * 4;
         const float4 g = *reinterpret_cast<const float4 *>(gamma + c0);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
 }
 
 // dx = dz, dh = dz * keep * scale, partial dgamma/dbeta per workgroup ([gridDim.x][d] each)
-template <typename TX, typename TH>
+template <typename TX, typename TH, int ITERS>
 __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
     int n_rows, int d, const TX *__restrict__ dy, const uint16_t *__restrict__ dy16, const TX *__restrict__ x,
     const TH *__restrict__ h, const float *__restrict__ gamma, const float *__restrict__ mean_in,
@@ -134,12 +134,12 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
     float *__restrict__ dgamma_part, float *__restrict__ dbeta_part) {
   extern __shared__ float red[];      // [kWaves][d] reused for dgamma then dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int iters = d >> 8;
+  constexpr int iters = ITERS;
   Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
   const float inv_d = 1.f / (float)d;
-  float4 gacc[kMaxIter], bacc[kMaxIter], gm[kMaxIter];
+  float4 gacc[ITERS], bacc[ITERS], gm[ITERS];
 #pragma unroll
-  for (int i = 0; i < kMaxIter; ++i) {
+  for (int i = 0; i < ITERS; ++i) {
     gacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     bacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < iters) gm[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
   for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
     const size_t base = (size_t)row * d;
     const float mean = mean_in[row], rstd = rstd_in[row];
-    float4 zh[kMaxIter], a[kMaxIter];
+    float4 zh[ITERS], a[ITERS];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxIter; ++i)
+    for (int i = 0; i < ITERS; ++i)
       if (i < iters) {
         const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
         const float4 xv = load4(x, e0);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
     s1 = wave_sum(s1) * inv_d;
     s2 = wave_sum(s2) * inv_d;
 #pragma unroll
-    for (int i = 0; i < kMaxIter; ++i)
+    for (int i = 0; i < ITERS; ++i)
       if (i < iters) {
         const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
         float4 dz;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kMaxIter; ++i)
+    for (int i = 0; i < ITERS; ++i)
       if (i < iters)
         *reinterpret_cast<float4 *>(red + wave * d + (i * 64 + lane) * 4) = pass == 0 ? gacc[i] : bacc[i];
     __syncthreads();
@@ -224,21 +224,31 @@ int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int h_bf16,
                                       unsigned long long seed, const void *seed_dev, void *y, void *y_bf16,
                                       float *mean, float *rstd, gps_stream_t stream) {
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
-  if ((d & 255) || d > 256 * gps_ln::kMaxIter) return GPS_ERR_UNSUPPORTED;
+  if ((d & 255) || d > 256 * gps_ln::kMaxIter || ((d >> 8) > 4 && (d >> 8) != 8)) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
   if (!x || !h || !gamma || !beta || !y || !mean || !rstd) return GPS_ERR_INVALID_ARGUMENT;
   const unsigned int thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
   const dim3 grid(gps_ln::grid_rows(n_rows)), block(gps_ln::kBlock);
   hipStream_t s = (hipStream_t)stream;
   const unsigned long long *sd = (const unsigned long long *)seed_dev;
-#define GPS_LN_FWD(TX, TH)                                                                                   \
-  hipLaunchKernelGGL((gps_ln::add_dropout_ln_fwd_kernel<TX, TH>), grid, block, 0, s, n_rows, d, (const TX *)x, \
+#define GPS_LN_FWD_I(TX, TH, IT)                                                                                  \
+  hipLaunchKernelGGL((gps_ln::add_dropout_ln_fwd_kernel<TX, TH, IT>), grid, block, 0, s, n_rows, d, (const TX *)x, \
                      (const TH *)h, gamma, beta, eps, p_drop, thr, seed, sd, (TX *)y, (uint16_t *)y_bf16, mean, rstd)
+#define GPS_LN_FWD(TX, TH)                          \
+  do { switch (d >> 8) {                            \
+    case 1: GPS_LN_FWD_I(TX, TH, 1); break;         \
+    case 2: GPS_LN_FWD_I(TX, TH, 2); break;         \
+    case 3: GPS_LN_FWD_I(TX, TH, 3); break;         \
+    case 4: GPS_LN_FWD_I(TX, TH, 4); break;         \
+    case 8: GPS_LN_FWD_I(TX, TH, 8); break;         \
+    default: return GPS_ERR_UNSUPPORTED;            \
+  } } while (0)
   if (x_bf16 && h_bf16) GPS_LN_FWD(uint16_t, uint16_t);
   else if (x_bf16) GPS_LN_FWD(uint16_t, float);
   else if (h_bf16) GPS_LN_FWD(float, uint16_t);
   else GPS_LN_FWD(float, float);
 #undef GPS_LN_FWD
+#undef GPS_LN_FWD_I
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
@@ -248,7 +258,7 @@ int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, int h_bf16
                                        unsigned long long seed, const void *seed_dev, void *dx, void *dh,
                                        float *dgamma_part, float *dbeta_part, gps_stream_t stream) {
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
-  if ((d & 255) || d > 256 * gps_ln::kMaxIter) return GPS_ERR_UNSUPPORTED;
+  if ((d & 255) || d > 256 * gps_ln::kMaxIter || ((d >> 8) > 4 && (d >> 8) != 8)) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
   if (!dy || !x || !h || !gamma || !mean || !rstd || !dx || !dh || !dgamma_part || !dbeta_part)
     return GPS_ERR_INVALID_ARGUMENT;
@@ -257,15 +267,25 @@ int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, int h_bf16
   const size_t lds = sizeof(float) * gps_ln::kWaves * d;
   hipStream_t s = (hipStream_t)stream;
   const unsigned long long *sd = (const unsigned long long *)seed_dev;
-#define GPS_LN_BWD(TX, TH)                                                                                     \
-  hipLaunchKernelGGL((gps_ln::add_dropout_ln_bwd_kernel<TX, TH>), grid, block, lds, s, n_rows, d, (const TX *)dy, \
-                     (const uint16_t *)dy_bf16, (const TX *)x, (const TH *)h, gamma, mean, rstd, p_drop, thr,   \
+#define GPS_LN_BWD_I(TX, TH, IT)                                                                                    \
+  hipLaunchKernelGGL((gps_ln::add_dropout_ln_bwd_kernel<TX, TH, IT>), grid, block, lds, s, n_rows, d, (const TX *)dy, \
+                     (const uint16_t *)dy_bf16, (const TX *)x, (const TH *)h, gamma, mean, rstd, p_drop, thr,       \
                      seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part)
+#define GPS_LN_BWD(TX, TH)                          \
+  do { switch (d >> 8) {                            \
+    case 1: GPS_LN_BWD_I(TX, TH, 1); break;         \
+    case 2: GPS_LN_BWD_I(TX, TH, 2); break;         \
+    case 3: GPS_LN_BWD_I(TX, TH, 3); break;         \
+    case 4: GPS_LN_BWD_I(TX, TH, 4); break;         \
+    case 8: GPS_LN_BWD_I(TX, TH, 8); break;         \
+    default: return GPS_ERR_UNSUPPORTED;            \
+  } } while (0)
   if (x_bf16 && h_bf16) GPS_LN_BWD(uint16_t, uint16_t);
   else if (x_bf16) GPS_LN_BWD(uint16_t, float);
   else if (h_bf16) GPS_LN_BWD(float, uint16_t);
   else GPS_LN_BWD(float, float);
 #undef GPS_LN_BWD
+#undef GPS_LN_BWD_I
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

@@ -54,6 +54,7 @@ class BERTLanguageEncoder(nn.Module):
         from ..layers.fused_norm import add_dropout_layer_norm
         m, H = self.model, self.bert_config.num_attention_heads
         x = m.embeddings(input_ids=txt_ids)                     # (B, L, D) fp32 under autocast
+        x16 = x                                                 # bf16 copy of x once a fused LN made one
         B, L, D = x.shape
         pad = txt_masks == 0
         training = self.training
@@ -62,7 +63,7 @@ class BERTLanguageEncoder(nn.Module):
             w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0)
             b = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0)
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-                packed = F.linear(x, w, b)
+                packed = F.linear(x16, w, b)
                 if attn_supported(D, H, L):
                     ctx = fused_self_attention(packed, H, None, pad, dropout_p=sa.dropout.p, training=training)
                 else:   # long captions: torch SDPA (flash) on views of the packed projection
@@ -71,10 +72,11 @@ class BERTLanguageEncoder(nn.Module):
                         q, k, v, attn_mask=pad.logical_not()[:, None, None, :],
                         dropout_p=sa.dropout.p if training else 0.0)
                     ctx = ctx.transpose(1, 2).reshape(B, L, D)
-                x = add_dropout_layer_norm(x, so.dense(ctx), so.LayerNorm, so.dropout.p, training)
-                inter = layer.intermediate.intermediate_act_fn(layer.intermediate.dense(x))
-                x = add_dropout_layer_norm(x, layer.output.dense(inter), layer.output.LayerNorm,
-                                           layer.output.dropout.p, training)
+                x, x16 = add_dropout_layer_norm(x, so.dense(ctx), so.LayerNorm, so.dropout.p, training,
+                                                want_bf16=True)
+                inter = layer.intermediate.intermediate_act_fn(layer.intermediate.dense(x16))
+                x, x16 = add_dropout_layer_norm(x, layer.output.dense(inter), layer.output.LayerNorm,
+                                                layer.output.dropout.p, training, want_bf16=True)
         return x
 
     def forward(self, txt_ids, txt_masks, **kwargs):

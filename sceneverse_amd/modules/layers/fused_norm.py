@@ -26,13 +26,14 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class _AddDropoutLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev):
+    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev, want_bf16: bool):
         d = x.shape[-1]
         x2 = x.reshape(-1, d).contiguous()
         h2 = h.reshape(-1, d).contiguous()
         n = x2.shape[0]
         g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
         y = torch.empty_like(x2)
+        y16 = torch.empty((n, d), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
         mean = torch.empty(n, dtype=torch.float32, device=x.device)
         rstd = torch.empty(n, dtype=torch.float32, device=x.device)
         from ...pointnet2._ext import _timed
@@ -41,18 +42,23 @@ class _AddDropoutLN(torch.autograd.Function):
             st = _native.load().gps_add_dropout_layernorm_forward(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), x2.data_ptr(),
                 h2.data_ptr(), g32.data_ptr(), b32.data_ptr(), float(eps), float(p_drop), 0, _ptr(seed_dev),
-                y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                y.data_ptr(), _ptr(y16), mean.data_ptr(), rstd.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_forward")
         ctx.save_for_backward(x2, h2, g32, mean, rstd, seed_dev)
         ctx.meta = (float(p_drop), x.shape, h.shape, gamma.dtype, beta.dtype)
+        if want_bf16:
+            return y.view(x.shape), y16.view(x.shape)
         return y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy16=None):
         x2, h2, g32, mean, rstd, seed_dev = ctx.saved_tensors
         p_drop, x_shape, h_shape, g_dtype, b_dtype = ctx.meta
         n, d = x2.shape
+        if dy is None:
+            dy = torch.zeros(x_shape, dtype=x2.dtype, device=x2.device)
         dy2 = dy.reshape(n, d).to(x2.dtype).contiguous()
+        dy16_2 = dy16.reshape(n, d).to(torch.bfloat16).contiguous() if dy16 is not None else None
         dx = torch.empty_like(x2)
         dh = torch.empty_like(h2)
         lib = _native.load()
@@ -62,32 +68,35 @@ class _AddDropoutLN(torch.autograd.Function):
         nbytes = n * d * (3 * x2.element_size() + 2 * h2.element_size())
         with torch.cuda.device(x2.device), _timed("add_dropout_layernorm_backward", nbytes):
             st = lib.gps_add_dropout_layernorm_backward(
-                n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), dy2.data_ptr(), None,
-                x2.data_ptr(), h2.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, 0,
+                n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), dy2.data_ptr(),
+                _ptr(dy16_2), x2.data_ptr(), h2.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, 0,
                 _ptr(seed_dev), dx.data_ptr(), dh.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
                 torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_backward")
         sums = part.sum(dim=1)
         return (dx.view(x_shape), dh.view(h_shape), sums[0].to(g_dtype), sums[1].to(b_dtype),
-                None, None, None)
+                None, None, None, None)
 
 
 def supported(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm) -> bool:
     d = x.shape[-1]
-    return (_ENABLED and x.is_cuda and h.is_cuda and x.shape == h.shape and d % 256 == 0 and d <= 2048
+    return (_ENABLED and x.is_cuda and h.is_cuda and x.shape == h.shape and d in (256, 512, 768, 1024, 2048)
             and x.dtype in (torch.float32, torch.bfloat16) and h.dtype in (torch.float32, torch.bfloat16)
             and isinstance(norm, nn.LayerNorm) and tuple(norm.normalized_shape) == (d,)
             and norm.elementwise_affine and norm.bias is not None)
 
 
 def add_dropout_layer_norm(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm, p_drop: float = 0.0,
-                           training: bool = False) -> torch.Tensor:
-    """norm(x + dropout(h, p_drop, training)); y has x's dtype on the fused path."""
+                           training: bool = False, want_bf16: bool = False):
+    """norm(x + dropout(h, p_drop, training)); y has x's dtype on the fused path.
+    want_bf16: also return a bf16 copy of y written by the same launch (what the next GEMM reads
+    under autocast; its gradient is added inside the fused backward) -> (y, y_bf16)."""
     p = float(p_drop) if training else 0.0
     if not supported(x, h, norm):
-        return norm(x + F.dropout(h, p, training=p > 0.0))
+        y = norm(x + F.dropout(h, p, training=p > 0.0))
+        return (y, y) if want_bf16 else y
     seed_dev = None
     if p > 0.0:
         from .fused_attention import _next_device_seed
         seed_dev = _next_device_seed(x.device)
-    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev)
+    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev, bool(want_bf16))

@@ -286,10 +286,11 @@ def _ffn(layer, x):
     return layer.linear2(layer.dropout(layer.activation(layer.linear1(x))))
 
 
-def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout) -> Tensor:
-    """norm(x + drop(h)): one fused launch on the GPU (fused_norm), the plain ops elsewhere."""
+def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout, want_bf16: bool = False):
+    """norm(x + drop(h)): one fused launch on the GPU (fused_norm), the plain ops elsewhere.
+    want_bf16 (only meaningful under bf16 autocast): -> (y, bf16 copy of y for the next GEMM)."""
     from .fused_norm import add_dropout_layer_norm
-    return add_dropout_layer_norm(x, h, norm, drop.p, drop.training)
+    return add_dropout_layer_norm(x, h, norm, drop.p, drop.training, want_bf16=want_bf16)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -315,8 +316,10 @@ class TransformerEncoderLayer(nn.Module):
         h, attn = self.self_attn(query=h, key=h, value=h, attn_mask=tgt_mask,
                                  key_padding_mask=tgt_key_padding_mask)
         if not self.prenorm:
-            tgt = _res_norm(self.norm1, tgt, h, self.dropout1)
-            tgt = _res_norm(self.norm2, tgt, _ffn(self, tgt), self.dropout2)
+            b16 = _bf16_mode(tgt) and tgt.dtype == torch.float32
+            tgt, ffn_in = _res_norm(self.norm1, tgt, h, self.dropout1, want_bf16=True) if b16 else \
+                (lambda t: (t, t))(_res_norm(self.norm1, tgt, h, self.dropout1))
+            tgt = _res_norm(self.norm2, tgt, _ffn(self, ffn_in), self.dropout2)
             return tgt, attn
         tgt = tgt + self.dropout1(h)
         # ref :147-153: the pre-norm variant normalises the residual stream itself before the FFN
@@ -341,8 +344,10 @@ class TransformerSpatialEncoderLayer(TransformerEncoderLayer):
                 tgt_key_padding_mask: Optional[Tensor] = None):
         h, attn = self.self_attn(tgt, tgt, tgt, tgt_pairwise_locs,
                                  key_padding_mask=tgt_key_padding_mask)
-        tgt = _res_norm(self.norm1, tgt, h, self.dropout1)
-        tgt = _res_norm(self.norm2, tgt, _ffn(self, tgt), self.dropout2)
+        b16 = _bf16_mode(tgt) and tgt.dtype == torch.float32
+        tgt, ffn_in = _res_norm(self.norm1, tgt, h, self.dropout1, want_bf16=True) if b16 else \
+            (lambda t: (t, t))(_res_norm(self.norm1, tgt, h, self.dropout1))
+        tgt = _res_norm(self.norm2, tgt, _ffn(self, ffn_in), self.dropout2)
         return tgt, attn
 
 

@@ -60,8 +60,8 @@ def test_dropout_mask_is_consistent_between_forward_and_backward():
     x = torch.zeros(n, d, device=DEV)
     h = torch.ones(n, d, device=DEV, requires_grad=True)
     gamma, beta = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
-    y = _AddDropoutLN.apply(x, h, gamma, beta, 1e-5, p, seed_dev)
-    y2 = _AddDropoutLN.apply(x, h, gamma, beta, 1e-5, p, seed_dev)
+    y = _AddDropoutLN.apply(x, h, gamma, beta, 1e-5, p, seed_dev, False)
+    y2 = _AddDropoutLN.apply(x, h, gamma, beta, 1e-5, p, seed_dev, False)
     assert torch.equal(y, y2)
     # z = keep / (1 - p) in {0, 4/3}: the normalised row takes its minimum exactly at dropped elements
     dropped = y <= y.min(dim=1, keepdim=True).values + 1e-6
@@ -70,7 +70,7 @@ def test_dropout_mask_is_consistent_between_forward_and_backward():
     y.backward(torch.randn_like(y))
     assert (h.grad[dropped] == 0).all()
     assert (h.grad[~dropped] != 0).float().mean().item() > 0.99
-    y3 = _AddDropoutLN.apply(x, h, gamma, beta, 1e-5, p, seed_dev + 1)
+    y3 = _AddDropoutLN.apply(x, h, gamma, beta, 1e-5, p, seed_dev + 1, False)
     assert not torch.equal(y, y3)
 
 
@@ -79,3 +79,21 @@ def test_unsupported_width_takes_the_torch_path():
     x, h = torch.randn(4, 100, device=DEV), torch.randn(4, 100, device=DEV)
     y = add_dropout_layer_norm(x, h, norm, 0.0, False)
     assert torch.allclose(y, norm(x + h))
+
+
+def test_bf16_copy_output_and_its_gradient():
+    n, d = 640, 768
+    g = torch.Generator().manual_seed(3)
+    x, h = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g).to(torch.bfloat16)
+    norm = nn.LayerNorm(d).to(DEV)
+    w = torch.randn(d, 64, generator=g).to(DEV)
+    xg, hg = x.to(DEV).requires_grad_(True), h.to(DEV).requires_grad_(True)
+    y, y16 = add_dropout_layer_norm(xg, hg, norm, 0.0, False, want_bf16=True)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y.to(torch.bfloat16))
+    loss = (y * 0.5).sum() + (y16.float() @ w).square().mean()       # gradient through BOTH outputs
+    loss.backward()
+    xr, hr = x.to(DEV).requires_grad_(True), h.to(DEV).float().requires_grad_(True)
+    yr = F.layer_norm(xr + hr, (d,), norm.weight, norm.bias, norm.eps)
+    ((yr * 0.5).sum() + (yr.to(torch.bfloat16).float() @ w).square().mean()).backward()
+    for a, b in ((xg.grad, xr.grad), (hg.grad.float(), hr.grad)):
+        assert (a - b).abs().max().item() <= 2 ** -6 * b.abs().max().item(), (a - b).abs().max().item()
