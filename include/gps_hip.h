@@ -218,6 +218,8 @@ GPS_API int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int
                                               gps_stream_t stream);
 /* rows of the partial dgamma/dbeta buffers the backward call fills (one per workgroup). */
 GPS_API int gps_ln_partial_rows(int n_rows);
+/* out[2][d] = column sums of part[2][parts][d] ([dgamma | dbeta] partial rows -> their totals). */
+GPS_API int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, gps_stream_t stream);
 /* dy (x's dtype) [+ dy_bf16: gradient that arrived through the bf16 copy, may be NULL] -> dx (x's
  * dtype), dh (h's dtype), dgamma_part / dbeta_part (gps_ln_partial_rows(n_rows), d) fp32: the caller
  * sums them over the first axis. */

@@ -208,6 +208,26 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
   }
 }
 
+// out[c] = sum_r part[r][c] for the 2*d columns of the [dgamma | dbeta] partial rows
+// (part is [2][parts][d]; out is [2][d]).  One thread per column, coalesced across threads.
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int d, const float *__restrict__ part,
+                                                                  float *__restrict__ out) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= 2 * d) return;
+  const int which = c / d, col = c - which * d;
+  const float *p = part + (size_t)which * parts * d + col;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = 0;
+  for (; r + 4 <= parts; r += 4) {
+    a0 += p[(size_t)r * d];
+    a1 += p[(size_t)(r + 1) * d];
+    a2 += p[(size_t)(r + 2) * d];
+    a3 += p[(size_t)(r + 3) * d];
+  }
+  for (; r < parts; ++r) a0 += p[(size_t)r * d];
+  out[c] = (a0 + a1) + (a2 + a3);
+}
+
 inline int grid_rows(int n_rows) {
   int g = (n_rows + kWaves - 1) / kWaves;
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
@@ -218,6 +238,13 @@ inline int grid_rows(int n_rows) {
 extern "C" {
 
 int gps_ln_partial_rows(int n_rows) { return gps_ln::grid_rows(n_rows); }
+
+int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, gps_stream_t stream) {
+  if (parts < 1 || d < 1 || !part || !out) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps_ln::reduce_partials_kernel, dim3((2 * d + gps_ln::kBlock - 1) / gps_ln::kBlock),
+                     dim3(gps_ln::kBlock), 0, (hipStream_t)stream, parts, d, part, out);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
 
 int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int h_bf16, const void *x, const void *h,
                                       const float *gamma, const float *beta, float eps, float p_drop,

@@ -73,7 +73,11 @@ class _AddDropoutLN(torch.autograd.Function):
                 _ptr(seed_dev), dx.data_ptr(), dh.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
                 torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_backward")
-        sums = part.sum(dim=1)
+        sums = torch.empty((2, d), dtype=torch.float32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            st = lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), sums.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        _native.check(st, "ln_reduce_partials")
         return (dx.view(x_shape), dh.view(h_shape), sums[0].to(g_dtype), sums[1].to(b_dtype),
                 None, None, None, None)
 
