@@ -33,6 +33,24 @@ def test_argument_validation_without_gpu():
     assert lib.gps_group_points(0, 3, 8, 2, 2, None, None, None, None) == 0
     assert lib.gps_furthest_point_sampling(0, 8, 4, None, None, None, None) == 0
     assert lib.gps_three_nn(1, 0, 5, None, None, None, None, None) == 0
+    # fused entry points: empty batches are fine, unsupported shapes say so, bad arguments are caught
+    assert lib.gps_sa_mlp_forward(0, 32, 16, 32, 128, 128, 128, 256, None, None, None, None, None, None, None) == 0
+    assert lib.gps_sa_mlp_forward(1, 32, 16, 16, 128, 128, 128, 256, 1, 1, 1, 1, 1, 1, None) == -2   # nsample != 32
+    assert lib.gps_sa_mlp_forward_bf16x3(1, 32, 16, 32, 7, 64, 64, 64, 1, 1, 1, 1, 1, 1, None) == -2  # widths
+    assert lib.gps_sa_mlp_layer_floats(6, 64) == 2 * 512 and lib.gps_sa_mlp_layer_floats(6, 65) == -1
+    assert lib.gps_sa_mlp_wpack_floats(131, 128, 128, 256) == 16 * 4352
+    assert lib.gps_attn_forward(0, 12, 80, 64, None, None, None, 2304, None, None, None, 0.0, 0, None, None, 768,
+                                None, None) == 0
+    assert lib.gps_attn_forward(2, 12, 80, 32, 1, 1, 1, 2304, None, None, None, 0.0, 0, None, 1, 768, 1, None) == -2
+    assert lib.gps_attn_forward(2, 12, 80, 64, 1, 1, 1, 2304, 1, None, None, 0.0, 0, None, 1, 768, 1, None) == -1
+    assert lib.gps_attn_forward(2, 12, 300, 64, 1, 1, 1, 2304, None, None, None, 0.0, 0, None, 1, 768, 1, None) == -2
+    assert lib.gps_masked_ce_forward(0, 30522, 1, None, 30522, None, -1, None, None, None) == 0
+    assert lib.gps_masked_ce_forward(4, 30522, 1, 1, 100, 1, -1, 1, 1, None) == -1                   # ld < vocab
+    assert lib.gps_add_dropout_layernorm_forward(4, 100, 0, 1, 1, 1, 1, 1, 1e-5, 0.0, 0, None, 1, None, 1, 1,
+                                                 None) == -2                                          # width
+    assert lib.gps_add_dropout_layernorm_forward(0, 768, 0, 1, None, None, None, None, 1e-5, 0.0, 0, None, None,
+                                                 None, None, None, None) == 0
+    assert lib.gps_ln_partial_rows(8320) == 1024 and lib.gps_ln_partial_rows(5) == 2
 
 
 def test_no_oracle_import_in_product_code():
