@@ -31,6 +31,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Library-GEMM solution selection: hipBLASLt's default heuristics leave 10-20 % on the table for
+# the (tokens x 768 / 2048 / 3072 / 30522) shapes of this step.  tools/tune_gemm.sh records, once, the
+# fastest solution per shape with PyTorch's TunableOp; the committed CSV is used READ-ONLY here (no
+# tuning inside bench.py).  Must be set before torch is imported.
+_TUNED = os.path.join(ROOT, "profiles", "tunableop_gfx950.csv")
+if os.path.exists(_TUNED) and not os.environ.get("GPS_NO_TUNABLEOP_FILE") \
+        and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
+    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+    os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
+    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = _TUNED
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
