@@ -35,8 +35,8 @@ if ROOT not in sys.path:
 # the (tokens x 768 / 2048 / 3072 / 30522) shapes of this step.  tools/tune_gemm.sh records, once, the
 # fastest solution per shape with PyTorch's TunableOp; the committed CSV is used READ-ONLY here (no
 # tuning inside bench.py).  Must be set before torch is imported.
-_TUNED = os.path.join(ROOT, "profiles", "tunableop_gfx950.csv")
-if os.path.exists(_TUNED) and not os.environ.get("GPS_NO_TUNABLEOP_FILE") \
+_TUNED = os.path.join(ROOT, "profiles", "tunableop_gfx950.csv")   # torch appends the device ordinal: ...9500.csv
+if os.path.exists(_TUNED.replace(".csv", "0.csv")) and not os.environ.get("GPS_NO_TUNABLEOP_FILE") \
         and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
