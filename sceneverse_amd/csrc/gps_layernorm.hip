@@ -209,23 +209,27 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
 }
 
 // out[c] = sum_r part[r][c] for the 2*d columns of the [dgamma | dbeta] partial rows
-// (part is [2][parts][d]; out is [2][d]).  One thread per column, coalesced across threads.
+// (part is [2][parts][d]; out is [2][d]).  A workgroup owns 64 columns: its 4 waves split the rows
+// (each wave reads 256 contiguous bytes per row, 8 rows in flight per thread), then combine in LDS.
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int d, const float *__restrict__ part,
                                                                   float *__restrict__ out) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= 2 * d) return;
-  const int which = c / d, col = c - which * d;
-  const float *p = part + (size_t)which * parts * d + col;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int r = 0;
-  for (; r + 4 <= parts; r += 4) {
-    a0 += p[(size_t)r * d];
-    a1 += p[(size_t)(r + 1) * d];
-    a2 += p[(size_t)(r + 2) * d];
-    a3 += p[(size_t)(r + 3) * d];
+  __shared__ float red[kWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;           // column in [0, 2 d)
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < 2 * d) {
+    const int which = c / d, col = c - which * d;
+    const float *p = part + (size_t)which * parts * d + col;
+    int r = wave;
+    for (; r + 7 * kWaves < parts; r += 8 * kWaves) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += p[(size_t)(r + u * kWaves) * d];
+    }
+    for (; r < parts; r += kWaves) acc[0] += p[(size_t)r * d];
   }
-  for (; r < parts; ++r) a0 += p[(size_t)r * d];
-  out[c] = (a0 + a1) + (a2 + a3);
+  red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && c < 2 * d) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 inline int grid_rows(int n_rows) {
@@ -241,8 +245,8 @@ int gps_ln_partial_rows(int n_rows) { return gps_ln::grid_rows(n_rows); }
 
 int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, gps_stream_t stream) {
   if (parts < 1 || d < 1 || !part || !out) return GPS_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(gps_ln::reduce_partials_kernel, dim3((2 * d + gps_ln::kBlock - 1) / gps_ln::kBlock),
-                     dim3(gps_ln::kBlock), 0, (hipStream_t)stream, parts, d, part, out);
+  hipLaunchKernelGGL(gps_ln::reduce_partials_kernel, dim3((2 * d + 63) / 64), dim3(gps_ln::kBlock), 0,
+                     (hipStream_t)stream, parts, d, part, out);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

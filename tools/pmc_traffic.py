@@ -16,8 +16,8 @@ CAL_BYTES = 512 << 20
 
 # HIP symbol -> the kernel names bench.py reports
 NAMES = [
-    (r"sa_mlp_x3_kernel<128, 128, 128, 256>", "sa_mlp_forward(c=128,n=32,np=16,mlp=128-128-256,bf16x3)"),
-    (r"sa_mlp_x3_kernel<3, 64, 64, 128>", "sa_mlp_forward(c=3,n=1024,np=32,mlp=64-64-128,bf16x3)"),
+    (r"sa_mlp_x3_kernel<128, 128, 128, 256,", "sa_mlp_forward(c=128,n=32,np=16,mlp=128-128-256,bf16x3)"),
+    (r"sa_mlp_x3_kernel<3, 64, 64, 128,", "sa_mlp_forward(c=3,n=1024,np=32,mlp=64-64-128,bf16x3)"),
     (r"sa_mlp_kernel<128, 128, 128, 256>", "sa_mlp_forward(c=128,n=32,np=16,mlp=128-128-256,fp32)"),
     (r"sa_mlp_kernel<3, 64, 64, 128>", "sa_mlp_forward(c=3,n=1024,np=32,mlp=64-64-128,fp32)"),
     (r"fps_resident_kernel<16>", "furthest_point_sampling(n=1024,m=32)"),
