@@ -184,6 +184,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);   // [NT*16][KS]
   uint16_t *Vt = Ks + NT * 16 * KS;                     // [64][TS]
+  uint8_t *s_mask = reinterpret_cast<uint8_t *>(Vt + 64 * TS);   // [NT*16] key-padding flags
 
   int b, h;
   block_to_bh(P, b, h);
@@ -196,6 +197,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const Params P) {
   const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
   stage_rows(Ks, kb, P.ld_qkv, L, NT * 16);
   stage_transposed(Vt, vb, P.ld_qkv, L, NC * 32, TS);
+  for (int t = threadIdx.x; t < NT * 16; t += blockDim.x)
+    s_mask[t] = (t < L && P.mask) ? P.mask[row0 + t] : 0;
   __syncthreads();
 
   const bool dropout = P.drop_thr != 0u;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const Params P) {
       for (int r = 0; r < 4; ++r) {
         const int t = 16 * j + 4 * g + r;
         const bool t_ok = (j < nt) && t < L;
-        const bool km = t_ok && P.mask && P.mask[row0 + t];
+        const bool km = t_ok && s_mask[t];
         float x = acc[j][r] * 0.125f;
         if (SPATIAL && t_ok && q_ok) {
           float sig;
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
   constexpr int kRegionA = 2 * NT * 16 * KS + 64 * TS;       // elements
   uint16_t *PT = reinterpret_cast<uint16_t *>(smem) + kRegionA;   // [NT*16][TS]
   uint16_t *dST = PT + NT * 16 * TS;
+  uint8_t *s_mask = reinterpret_cast<uint8_t *>(dST + NT * 16 * TS);   // [NT*16] key-padding flags
 
   int b, h;
   block_to_bh(P, b, h);
@@ -596,6 +600,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
   {  // pad columns [nt*16, NC*32) of PT / dST are read by the last chunk but written by no strip
     u32x4 *z = reinterpret_cast<u32x4 *>(PT);
     for (int e = threadIdx.x; e < (2 * NT * 16 * TS) / 8; e += blockDim.x) z[e] = zero4();
+    for (int t = threadIdx.x; t < NT * 16; t += blockDim.x)
+      s_mask[t] = (t < L && P.mask) ? P.mask[row0 + t] : 0;
   }
   __syncthreads();
 
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
       for (int r = 0; r < 4; ++r) {
         const int t = 16 * j + 4 * g + r;
         const bool t_ok = (j < nt) && t < L && q_ok;
-        const bool km = t_ok && P.mask && P.mask[row0 + t];
+        const bool km = t_ok && s_mask[t];
         float x = acc[j][r] * 0.125f;
         if (SPATIAL && t_ok) {
           float sig;
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
 template <int NT>
 size_t fwd_lds() {
   constexpr int NC = (NT + 1) / 2;
-  return (size_t)2 * (NT * 16 * KS + 64 * (NC * 32 + 8));
+  return (size_t)2 * (NT * 16 * KS + 64 * (NC * 32 + 8)) + (size_t)NT * 16;
 }
 template <int NT>
 size_t bwd_recompute_lds() {
@@ -777,7 +783,7 @@ template <int NT>
 size_t bwd_lds() {                      // region A + PT + dST
   constexpr int NC = (NT + 1) / 2;
   constexpr int TS = NC * 32 + 8;
-  return (size_t)2 * (2 * NT * 16 * KS + 64 * TS + 2 * NT * 16 * TS);
+  return (size_t)2 * (2 * NT * 16 * KS + 64 * TS + 2 * NT * 16 * TS) + (size_t)NT * 16;
 }
 constexpr size_t kLdsMax = 160 * 1024;
 inline int pick_waves(int nt) {

@@ -153,3 +153,21 @@ def test_fp32_inputs_keep_the_torch_formulation():
     from sceneverse_amd.pointnet2 import _ext
     y, _ = layer(x)             # fp32, no autocast: must not be routed to the bf16 kernel
     assert y.dtype == torch.float32
+
+
+def test_full_bench_shapes_against_reference_on_sampled_scenes():
+    """BASELINE sizes: B = 64, spatial L = 80 and joint L = 130.  The fused kernel runs on the whole
+    batch; two sampled scenes are recomputed with the fp32 formulation.  Batch elements are
+    independent, so evaluating a sub-batch alone must reproduce its rows bit for bit."""
+    for L, spatial in ((80, True), (130, False)):
+        packed, pl, mask = _inputs(64, L, spatial, seed=L)
+        x = packed.to(DEV)
+        plg = pl.to(DEV) if pl is not None else None
+        mg = mask.to(DEV)
+        out = _FusedSelfAttention.apply(x, plg, mg, H, 0.0, 0, None)
+        for b in (3, 41):
+            ref = ref_attention(packed[b:b + 1].float(), pl[b:b + 1] if pl is not None else None, mask[b:b + 1])
+            _close(out[b:b + 1], ref, 2e-2, f"L={L} scene {b}")
+        sub = _FusedSelfAttention.apply(x[8:16].contiguous(), plg[8:16].contiguous() if plg is not None else None,
+                                        mg[8:16].contiguous(), H, 0.0, 0, None)
+        assert torch.equal(sub, out[8:16])

@@ -115,3 +115,23 @@ def test_unfrozen_encoder_keeps_the_differentiable_path():
     rec = _ext.profile_stop()
     assert not any(k.startswith("sa_mlp_forward") for k in rec)
     assert any(k.startswith("group_points_grad") for k in rec)
+
+
+def test_full_bench_batch_fused_equals_unfused_on_a_sample():
+    """BASELINE size: B = 64 scenes x 80 objects (5120 clouds of 1024 points) through the fused encoder;
+    a random sample of objects is re-run op by op (group_points + torch conv/BN/ReLU/max-pool) and
+    must agree.  Also: the encoder is a per-object map, so permuting the objects permutes the output."""
+    net = _encoder(seed=5)
+    d = synth_batch(64, seed=42)
+    pcs = d["obj_fts"].reshape(-1, 1024, 6).to(DEV)
+    assert pcs.shape[0] == 5120
+    with torch.no_grad():
+        full = net(pcs)
+        pick = torch.randperm(5120, generator=torch.Generator().manual_seed(1))[:48].to(DEV)
+        M.set_fused_sa(False)
+        ref = net(pcs[pick])
+        M.set_fused_sa(True)
+        _close(full[pick], ref, "sampled objects")
+        perm = torch.randperm(5120, generator=torch.Generator().manual_seed(2)).to(DEV)
+        assert torch.equal(net(pcs[perm]), full[perm])
+    assert torch.isfinite(full).all()
