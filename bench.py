@@ -167,7 +167,6 @@ def main() -> None:
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
-    ap.add_argument("--no-shadow", action="store_true", help="keep autocast's per-call weight casts (A/B)")
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     args = ap.parse_args()
@@ -187,8 +186,7 @@ def main() -> None:
 
     cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
     use_graph = not args.no_graph      # world_size > 1: split-graph data parallelism (engine.py)
-    step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=use_graph,
-                        shadow_weights=not args.no_shadow)
+    step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=use_graph)
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
 
     def barrier():

@@ -51,11 +51,9 @@ from .optim.build import build_optim
 class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
-                 bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
-                 shadow_weights: bool = True):
+                 bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3):
         self.cfg = cfg
         self.device = torch.device(device)
-        self.shadow_weights = bool(shadow_weights) and self.device.type == "cuda"
         torch.manual_seed(seed)
         self.model = build_model(cfg).to(self.device)
         world = dist_utils.get_world_size()
@@ -139,11 +137,10 @@ class GPSTrainStep:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                self._refresh_shadows()
-                with self._autocast(), self._shadow():
+                with self._autocast():
                     out = self.net(data_dict)
                 self._gather_features(out)
-                with self._autocast(), self._shadow():
+                with self._autocast():
                     total, losses = self.loss(out)
                 self.optimizer.zero_grad(set_to_none=True)
                 total.backward()
@@ -175,14 +172,13 @@ class GPSTrainStep:
             torch.cuda.synchronize(self.device)
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
-                self._refresh_shadows()
-                with self._autocast(), self._shadow():
+                with self._autocast():
                     out = self.net(static_dict)
             self._gather_features(out)
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self._flat_grad.zero_()
-                with self._autocast(), self._shadow():
+                with self._autocast():
                     total, losses = self.loss(out)
                 total.backward()                      # accumulates into the flat views
             torch.cuda.synchronize(self.device)
@@ -208,19 +204,8 @@ class GPSTrainStep:
             return contextlib.nullcontext()
         return torch.autocast(device_type="cuda", dtype=self.amp_dtype)
 
-    def _shadow(self):
-        """bf16 shadow weights for the Linears (common/shadow_linear.py): GPU bf16 steps only."""
-        from .common.shadow_linear import shadow_linear
-        return shadow_linear(self.shadow_weights and self.amp_dtype == torch.bfloat16)
-
-    def _refresh_shadows(self):
-        if self.shadow_weights and self.amp_dtype == torch.bfloat16:
-            from .common.shadow_linear import refresh_all
-            refresh_all()
-
     def forward_loss(self, data_dict):
-        self._refresh_shadows()
-        with self._autocast(), self._shadow():
+        with self._autocast():
             out = self.net(data_dict)
             total, losses = self.loss(out)
         return out, total, losses
