@@ -151,18 +151,6 @@ __device__ __forceinline__ float xor_reduce_sum_rows(float v) {
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
 }
-template <int CTRL>
-__device__ __forceinline__ float dpp_ror(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float ror_reduce_sum_16(float v) {     // within each 16-lane row, all lanes
-  v += dpp_ror<0x128>(v);  // row_ror:8
-  v += dpp_ror<0x124>(v);  // row_ror:4
-  v += dpp_ror<0x122>(v);  // row_ror:2
-  v += dpp_ror<0x121>(v);  // row_ror:1
-  return v;
-}
-
 // spatial term of one (query, key) pair: z = w0 + sum_d w_d pl_d; sig = sigmoid(z);
 // returns log(clamp(sig, 1e-6)) (masked keys: log(1e-6)), and sig through `sig`.
 __device__ __forceinline__ float spatial_bias(const float *__restrict__ plp, const float (&w)[SD],

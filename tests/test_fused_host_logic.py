@@ -1,0 +1,82 @@
+"""Host-side logic of the fused paths that can be checked without a GPU:
+  * BN folding of a SharedMLP (what gps_sa_mlp_pack_layer is fed) reproduces conv+BN(eval)+ReLU;
+  * the frozen/unfrozen decision and the cache key of the folded weights;
+  * CPU tensors never reach the fused GPU-only wrappers (torch formulation is used);
+  * the between-batch losses' gather protocol used by the split-graph data-parallel engine."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from sceneverse_amd.common.config import ConfigNode
+from sceneverse_amd.modules.layers import transformers as T
+from sceneverse_amd.modules.layers.fused_norm import add_dropout_layer_norm, supported as ln_supported
+from sceneverse_amd.optim.loss.contra_loss import TextSceneBetweenBatch
+from sceneverse_amd.pointnet2 import pointnet2_modules as M
+from sceneverse_amd.pointnet2 import pytorch_utils as pt_utils
+
+
+def _mlp(spec, seed=0):
+    torch.manual_seed(seed)
+    mlp = pt_utils.SharedMLP(list(spec), bn=True)
+    for m in mlp.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.normal_(1, 0.1)
+            m.bias.data.normal_(0, 0.1)
+    return mlp
+
+
+def test_fold_shared_mlp_equals_conv_bn_relu_in_eval_mode():
+    mlp = _mlp([131, 128, 128, 256]).eval()
+    x = torch.randn(3, 131, 16, 32)
+    ws, shifts = M.fold_shared_mlp(mlp)
+    assert [tuple(w.shape) for w in ws] == [(128, 131), (128, 128), (256, 128)]
+    y = x
+    for w, s in zip(ws, shifts):
+        y = torch.relu(torch.einsum('oc,bcps->bops', w, y) + s.view(1, -1, 1, 1))
+    torch.testing.assert_close(y, mlp(x), rtol=1e-5, atol=1e-5)
+
+
+def test_fold_refuses_training_mode_and_frozen_detection():
+    mlp = _mlp([6, 64, 64, 128]).train()
+    assert M.fold_shared_mlp(mlp) is None                  # running statistics are not what BN uses
+    assert not M._is_frozen(mlp)
+    mlp.eval()
+    assert not M._is_frozen(mlp)                           # parameters still want gradients
+    with torch.no_grad():
+        assert M._is_frozen(mlp)
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+    assert M._is_frozen(mlp)
+    k0 = M._frozen_key(mlp)
+    with torch.no_grad():
+        mlp.layer0.bn.bn.running_mean.add_(1.0)
+    assert M._frozen_key(mlp) != k0                        # in-place update -> repack
+
+
+def test_cpu_tensors_take_the_torch_formulation():
+    x, h = torch.randn(5, 768), torch.randn(5, 768)
+    norm = nn.LayerNorm(768)
+    assert not ln_supported(x, h, norm)
+    torch.testing.assert_close(add_dropout_layer_norm(x, h, norm, 0.1, False), norm(x + h))
+    y, y2 = add_dropout_layer_norm(x, h, norm, 0.0, False, want_bf16=True)
+    assert y is y2
+    layer = T.TransformerEncoderLayer(768, 12, dropout=0.0).eval()
+    assert not T._use_hip(torch.randn(2, 10, 768), 768, 12)
+    out, attn = layer(torch.randn(2, 10, 768))
+    assert out.shape == (2, 10, 768) and attn is None
+
+
+def test_between_batch_loss_gather_protocol():
+    cfg = ConfigNode({"num_gpu": 2})
+    crit = TextSceneBetweenBatch(cfg)
+    d = {"scene_embed": torch.randn(4, 768), "scene_text_embed": torch.randn(4, 768)}
+    sc, tx = crit.gather_inputs(d)
+    torch.testing.assert_close(sc.norm(dim=-1), torch.ones(4))
+    # engine-provided gathered buffers (2 ranks x 4) replace the collective
+    crit._gathered = [torch.cat([sc, sc.flip(0)]).detach(), torch.cat([tx, tx.flip(0)]).detach()]
+    loss = crit(d)
+    assert loss.shape == () and torch.isfinite(loss)
+    loss.backward()
+    assert crit.logit_scale.grad is not None
