@@ -33,6 +33,7 @@ SIGNATURES = {
     "gps_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gps_pairwise_locs": [_i, _i, _vp, _f, _vp, _vp],
     "gps_sa_mlp_pack_layer": [_i, _i, _vp, _vp, _vp, _vp],
     "gps_sa_mlp_forward": [_i] * 8 + [_vp] * 7,
     "gps_sa_mlp_pack_layer_bf16x3": [_i, _i, _vp, _vp, _vp, _vp],

@@ -615,6 +615,60 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_grad_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// pairwise object geometry (reference modules/utils.py:38-87, pairwise_rel_type 'center',
+// spatial_dist_norm, spatial_dim 5):  for every ordered pair (l, t) of a scene
+//     delta = c_l - c_t;  d = sqrt(dx^2 + dy^2 + dz^2 + eps);  d_xy = sqrt(dx^2 + dy^2 + eps)
+//     out = [ d / d_max,  dz / d,  d_xy / d,  dy / d_xy,  dx / d_xy ],   d_max = max over all L*L pairs
+// The reference runs ~15 elementwise/reduction launches over (B,L,L,*) tensors per step; here one
+// workgroup per scene, two passes over the pairs from an LDS copy of the centres.  Same operation
+// order as the torch formulation ((x^2 + y^2) + z^2, then + eps; correctly rounded sqrt and divide;
+// this file is compiled -ffp-contract=off), so the result is bit-identical to it.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pairwise_locs_kernel(int L, const float *__restrict__ centers, float eps,
+                                                                float *__restrict__ out) {
+  extern __shared__ float pw_c[];                 // L * 3 centres | kWavesPerBlock partial maxima
+  float *pw_red = pw_c + L * 3;
+  const int scene = blockIdx.x;
+  const float *c = centers + (size_t)scene * L * 3;
+  for (int e = threadIdx.x; e < L * 3; e += kBlock) pw_c[e] = c[e];
+  __syncthreads();
+  const int pairs = L * L;
+  float mx = 0.f;                                  // d >= sqrt(eps) > 0
+  for (int e = threadIdx.x; e < pairs; e += kBlock) {
+    const int l = e / L, t = e - l * L;
+    const float dx = pw_c[l * 3 + 0] - pw_c[t * 3 + 0], dy = pw_c[l * 3 + 1] - pw_c[t * 3 + 1],
+                dz = pw_c[l * 3 + 2] - pw_c[t * 3 + 2];
+    const float d = sqrtf(((dx * dx + dy * dy) + dz * dz) + eps);
+    mx = d > mx ? d : mx;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(mx, off, kWave);
+    mx = o > mx ? o : mx;
+  }
+  if (lane_id() == 0) pw_red[wave_id()] = mx;
+  __syncthreads();
+  float dmax = pw_red[0];
+#pragma unroll
+  for (int w = 1; w < kWavesPerBlock; ++w) dmax = pw_red[w] > dmax ? pw_red[w] : dmax;
+  float *o = out + (size_t)scene * pairs * 5;
+  for (int e = threadIdx.x; e < pairs; e += kBlock) {
+    const int l = e / L, t = e - l * L;
+    const float dx = pw_c[l * 3 + 0] - pw_c[t * 3 + 0], dy = pw_c[l * 3 + 1] - pw_c[t * 3 + 1],
+                dz = pw_c[l * 3 + 2] - pw_c[t * 3 + 2];
+    const float xy2 = dx * dx + dy * dy;
+    const float d = sqrtf((xy2 + dz * dz) + eps);
+    const float dxy = sqrtf(xy2 + eps);
+    float *p = o + (size_t)e * 5;
+    p[0] = d / dmax;
+    p[1] = dz / d;
+    p[2] = dxy / d;
+    p[3] = dy / dxy;
+    p[4] = dx / dxy;
+  }
+}
+
 }  // namespace gps
 
 // ==========================================================================================
@@ -850,6 +904,17 @@ int gps_three_interpolate(int b, int c, int m, int n, const float *points, const
   hipLaunchKernelGGL(gps::three_interpolate_kernel, dim3(grid_for(total, gps::kBlock)),
                      dim3(gps::kBlock), 0, (hipStream_t)stream, b, c, m, n, points, idx, weight,
                      out);
+  return finish_launch();
+}
+
+int gps_pairwise_locs(int b, int l, const float *centers, float eps, float *out, gps_stream_t stream) {
+  if (b < 0 || l < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0 || l == 0) return GPS_OK;
+  if (!centers || !out) return GPS_ERR_INVALID_ARGUMENT;
+  if (l > 2048) return GPS_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)l * 3 + gps::kWavesPerBlock) * sizeof(float);
+  hipLaunchKernelGGL(gps::pairwise_locs_kernel, dim3(b), dim3(gps::kBlock), lds, (hipStream_t)stream, l, centers,
+                     eps, out);
   return finish_launch();
 }
 

@@ -47,6 +47,11 @@ def calc_pairwise_locs(obj_centers, obj_whls, eps=1e-10, pairwise_rel_type='cent
         return torch.cat([locs.unsqueeze(2).expand(-1, -1, L, -1),
                           locs.unsqueeze(1).expand(-1, L, -1, -1)], dim=3)
 
+    if (obj_centers.is_cuda and obj_centers.dtype == torch.float32 and pairwise_rel_type == 'center'
+            and spatial_dist_norm and spatial_dim == 5 and obj_centers.dim() == 3
+            and not (torch.is_grad_enabled() and obj_centers.requires_grad) and obj_centers.size(1) <= 2048):
+        return _pairwise_locs_native(obj_centers, eps)
+
     delta = obj_centers.unsqueeze(2) - obj_centers.unsqueeze(1)           # (B,L,L,3): c_l - c_t
     dist = torch.sqrt(torch.sum(delta ** 2, 3) + eps)                      # (B,L,L)
     if spatial_dist_norm:
@@ -73,3 +78,16 @@ def calc_pairwise_locs(obj_centers, obj_whls, eps=1e-10, pairwise_rel_type='cent
         raise NotImplementedError(f"pairwise_rel_type {pairwise_rel_type}")
     out = torch.stack(feats, dim=3)
     return out[..., 1:] if spatial_dim == 4 else out
+
+
+def _pairwise_locs_native(obj_centers: torch.Tensor, eps: float) -> torch.Tensor:
+    """One launch of libgps_hip.so's gps_pairwise_locs (bit-identical to the torch formulation above)."""
+    from .. import _native
+    c = obj_centers.contiguous()
+    b, l, _ = c.shape
+    out = torch.empty((b, l, l, 5), dtype=torch.float32, device=c.device)
+    with torch.cuda.device(c.device):
+        st = _native.load().gps_pairwise_locs(b, l, c.data_ptr(), float(eps), out.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+    _native.check(st, "pairwise_locs")
+    return out

@@ -195,3 +195,27 @@ def test_fast_bert_path_matches_huggingface_layers():
         assert (res[True][0] - res[False][0]).abs().max().item() < 0.06, L
         for a, b in zip(res[True][1:], res[False][1:]):
             assert (a - b).abs().max().item() <= 0.05 * b.abs().max().item() + 1e-8, L
+
+
+def test_pairwise_locs_kernel_is_bit_identical_to_the_torch_formulation(golden_cpu):
+    """gps_pairwise_locs vs modules/utils.calc_pairwise_locs' torch ops ON THE GPU: bit-identical
+    (same operation order, correctly rounded sqrt/divide); vs the CPU golden of the reference: 1e-6.
+    Edge cases: coincident centres (d = sqrt(eps)), a single object, padding slots at the origin."""
+    from sceneverse_amd.modules import utils as U
+    g = torch.Generator().manual_seed(0)
+    for B, L in ((64, 80), (3, 1), (2, 130), (1, 257)):
+        c = torch.rand(B, L, 3, generator=g) * 8 - 4
+        c[:, L // 2:] = 0.0                                   # padding objects: all at the origin
+        cg = c.to(DEV)
+        got = U.calc_pairwise_locs(cg, None)
+        delta = cg.unsqueeze(2) - cg.unsqueeze(1)
+        dist = torch.sqrt(torch.sum(delta ** 2, 3) + 1e-10)
+        nd = dist / torch.max(dist.view(B, -1), dim=1)[0].view(-1, 1, 1)
+        dxy = torch.sqrt(torch.sum(delta[..., :2] ** 2, 3) + 1e-10)
+        want = torch.stack([nd, delta[..., 2] / dist, dxy / dist, delta[..., 1] / dxy, delta[..., 0] / dxy], 3)
+        assert torch.equal(got, want), (B, L, (got - want).abs().max().item())
+    fx = golden_cpu
+    locs = fx["batch"]["obj_locs"]
+    got = U.calc_pairwise_locs(locs[:, :, :3].to(DEV), locs[:, :, 3:].to(DEV)).cpu()
+    want = U.calc_pairwise_locs(locs[:, :, :3], locs[:, :, 3:])
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
