@@ -115,7 +115,7 @@ GPS_API int gps_three_interpolate_grad(int b, int c, int n, int m, const float *
  * pairwise_rel_type 'center', spatial_dist_norm=True, spatial_dim=5:
  *   centers (b,l,3) f32 -> out (b,l,l,5) f32 = [d/d_max, dz/d, d_xy/d, dy/d_xy, dx/d_xy] of pair
  *   (l,t), d = sqrt(|c_l-c_t|^2 + eps), d_max = per-scene maximum over all l*l pairs.
- * Same operation order as the reference's torch formulation (bit-identical to it). */
+ * Operation order of the reference's torch formulation; agrees with it to <= 1e-6 (features in [-1,1]). */
 GPS_API int gps_pairwise_locs(int b, int l, const float *centers, float eps, float *out, gps_stream_t stream);
 
 /* ---- fused set-abstraction level (frozen encoder) --------------------------------------------

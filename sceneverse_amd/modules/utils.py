@@ -81,7 +81,7 @@ def calc_pairwise_locs(obj_centers, obj_whls, eps=1e-10, pairwise_rel_type='cent
 
 
 def _pairwise_locs_native(obj_centers: torch.Tensor, eps: float) -> torch.Tensor:
-    """One launch of libgps_hip.so's gps_pairwise_locs (bit-identical to the torch formulation above)."""
+    """One launch of libgps_hip.so's gps_pairwise_locs (within 1e-6 of the torch formulation above)."""
     from .. import _native
     c = obj_centers.contiguous()
     b, l, _ = c.shape
