@@ -406,53 +406,32 @@ __device__ __forceinline__ void split8(const f32x8 &v, bf16x8 &hi, bf16x8 &lo) {
   hi = __builtin_bit_cast(bf16x8, h);
   lo = __builtin_bit_cast(bf16x8, l);
 }
-// In-place max over lanes 0-31 -> lane 31 and lanes 32-63 -> lane 63 of all 16 registers of a D
-// fragment, one v_max_f32_dpp per register and step (the DPP shift is a modifier of the max itself;
-// lanes without a source lane keep their value).  Steps run register-major so that a register is
-// re-read 16 instructions after it was written (DPP needs 2 wait states after a VALU write).
-__device__ __forceinline__ void half_wave_max16(f32x16 &a) {
-  float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], x5 = a[5], x6 = a[6], x7 = a[7];
-  float x8 = a[8], x9 = a[9], xa = a[10], xb = a[11], xc = a[12], xd = a[13], xe = a[14], xf = a[15];
-  // One asm block per step: the 16 instructions of a step touch 16 different registers, so inside
-  // a block a register is re-read 16 instructions after its write; `s_nop 1` at the head of every
-  // block covers the 2 wait states a DPP read needs after whatever VALU wrote the inputs (the
-  // compiler does not see DPP inside inline asm and pads nothing).
-#define GPS_DPP16(CTRL)                                                                               \
-  asm volatile("s_nop 1\n\t"                                                                          \
-               "v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\t"           \
-               "v_max_f32_dpp %2, %2, %2 " CTRL "\n\tv_max_f32_dpp %3, %3, %3 " CTRL "\n\t"           \
-               "v_max_f32_dpp %4, %4, %4 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL "\n\t"           \
-               "v_max_f32_dpp %6, %6, %6 " CTRL "\n\tv_max_f32_dpp %7, %7, %7 " CTRL "\n\t"           \
-               "v_max_f32_dpp %8, %8, %8 " CTRL "\n\tv_max_f32_dpp %9, %9, %9 " CTRL "\n\t"           \
-               "v_max_f32_dpp %10, %10, %10 " CTRL "\n\tv_max_f32_dpp %11, %11, %11 " CTRL "\n\t"     \
-               "v_max_f32_dpp %12, %12, %12 " CTRL "\n\tv_max_f32_dpp %13, %13, %13 " CTRL "\n\t"     \
-               "v_max_f32_dpp %14, %14, %14 " CTRL "\n\tv_max_f32_dpp %15, %15, %15 " CTRL               \
-               : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),      \
-                 "+v"(x8), "+v"(x9), "+v"(xa), "+v"(xb), "+v"(xc), "+v"(xd), "+v"(xe), "+v"(xf))
-  GPS_DPP16("row_shr:1 row_mask:0xf bank_mask:0xf");
-  GPS_DPP16("row_shr:2 row_mask:0xf bank_mask:0xf");
-  GPS_DPP16("row_shr:4 row_mask:0xf bank_mask:0xf");
-  GPS_DPP16("row_shr:8 row_mask:0xf bank_mask:0xf");
-  GPS_DPP16("row_bcast:15 row_mask:0xa bank_mask:0xf");
-#undef GPS_DPP16
-  a[0] = x0; a[1] = x1; a[2] = x2; a[3] = x3; a[4] = x4; a[5] = x5; a[6] = x6; a[7] = x7;
-  a[8] = x8; a[9] = x9; a[10] = xa; a[11] = xb; a[12] = xc; a[13] = xd; a[14] = xe; a[15] = xf;
-}
-
-template <int STEPS>
+template <int STEPS, bool TRANSPOSED = false>
 __device__ __forceinline__ f32x16 mfma_tile16(const float *__restrict__ tile, const bf16x8 (&Bhi)[STEPS],
                                               const bf16x8 (&Blo)[STEPS], int lane) {
   f32x16 acc;
-  const float *sh = tile + STEPS * 512 + 4 * (lane >> 5);
+  if (TRANSPOSED) {
+    const float shc = tile[STEPS * 512 + (lane & 31)];        // shift of this lane's output channel
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = sh[(r & 3) + 8 * (r >> 2)];
+    for (int r = 0; r < 16; ++r) acc[r] = shc;
+  } else {
+    const float *sh = tile + STEPS * 512 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = sh[(r & 3) + 8 * (r >> 2)];
+  }
   const bf16x8 *frag = reinterpret_cast<const bf16x8 *>(tile) + lane;
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const bf16x8 ahi = frag[s * 128], alo = frag[s * 128 + 64];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, Bhi[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, Blo[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, Bhi[s], acc, 0, 0, 0);
+    if (TRANSPOSED) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bhi[s], alo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Blo[s], ahi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bhi[s], ahi, acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, Bhi[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, Blo[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, Bhi[s], acc, 0, 0, 0);
+    }
   }
   return acc;
 }
@@ -573,15 +552,16 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
       split8(v0, h0, l0);
       split8(v1, h1, l1);
     };
-    auto pool_tile = [&](f32x16 acc, int mt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);          // ReLU commutes with the max
-      half_wave_max16(acc);
-      if (col == 31 && live) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          s_out[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * npoint + tile] = acc[r];
-      }
+    // last layer in the transposed form: lane = output channel, registers (+ the other half of the
+    // wave) = the 32 samples of the group -> max-pool = 15 in-lane max + one cross-half exchange
+    auto pool_tile = [&](const f32x16 &acc, int mt) {
+      float m0 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+      float m1 = fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7]));
+      float m2 = fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11]));
+      float m3 = fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]));
+      float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (lane < 32 && live) s_out[(mt * 32 + lane) * npoint + tile] = fmaxf(m, 0.f);   // ReLU after the max
     };
     int g = 0;
     f32x16 prev;
@@ -605,7 +585,7 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
     split_tile(prev, a2h[2 * M2 - 2], a2l[2 * M2 - 2], a2h[2 * M2 - 1], a2l[2 * M2 - 1]);
     for (int mt = 0; mt < M3; ++mt, ++g) {
       const float *wt = stage_begin(rd, g);
-      const f32x16 acc = mfma_tile16<S3>(wt, a2h, a2l, lane);
+      const f32x16 acc = mfma_tile16<S3, true>(wt, a2h, a2l, lane);
       if (mt > 0) pool_tile(prev, mt - 1);
       prev = acc;
       stage_end();
