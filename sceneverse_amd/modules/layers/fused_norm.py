@@ -38,7 +38,7 @@ class _AddDropoutLN(torch.autograd.Function):
         rstd = torch.empty(n, dtype=torch.float32, device=x.device)
         from ...pointnet2._ext import _timed
         nbytes = n * d * (2 * x2.element_size() + h2.element_size())
-        with torch.cuda.device(x.device), _timed("add_dropout_layernorm_forward", nbytes):
+        with torch.cuda.device(x.device), _timed(f"add_dropout_layernorm_forward(rows={n},d={d})", nbytes):
             st = _native.load().gps_add_dropout_layernorm_forward(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), x2.data_ptr(),
                 h2.data_ptr(), g32.data_ptr(), b32.data_ptr(), float(eps), float(p_drop), 0, _ptr(seed_dev),
@@ -66,7 +66,7 @@ class _AddDropoutLN(torch.autograd.Function):
         part = torch.empty((2, parts, d), dtype=torch.float32, device=x2.device)
         from ...pointnet2._ext import _timed
         nbytes = n * d * (3 * x2.element_size() + 2 * h2.element_size())
-        with torch.cuda.device(x2.device), _timed("add_dropout_layernorm_backward", nbytes):
+        with torch.cuda.device(x2.device), _timed(f"add_dropout_layernorm_backward(rows={n},d={d})", nbytes):
             st = lib.gps_add_dropout_layernorm_backward(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), dy2.data_ptr(),
                 _ptr(dy16_2), x2.data_ptr(), h2.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, 0,

@@ -24,18 +24,26 @@ NAMES = [
     (r"fps_resident_kernel<1>", "furthest_point_sampling(n=32,m=16)"),
     (r"ball_query_kernel<16>", "ball_query(n=1024,m=32,ns=32)"),
     (r"ball_query_kernel<1>", "ball_query(n=32,m=16,ns=32)"),
+    (r"add_dropout_ln_bwd_kernel", "add_dropout_layernorm_backward"),
+    (r"add_dropout_ln_fwd_kernel", "add_dropout_layernorm_forward"),
+    (r"attn_bwd_kernel", "attn_backward"),
+    (r"attn_fwd_kernel", "attn_forward"),
     (r"group_points_kernel", "group_points"),
     (r"gather_points_kernel", "gather_points"),
 ]
 
 
 def per_kernel(path, counter):
+    """kernel symbol [+ grid size for the shape-polymorphic kernels] -> counter values per dispatch"""
     acc = collections.defaultdict(list)
     with open(path) as f:
         for r in csv.DictReader(f):
             if r.get("Counter_Name") != counter:
                 continue
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            k = r["Kernel_Name"]
+            if "add_dropout_ln_" in k or "gps_attn::" in k:
+                k = f"{k} grid={r.get('Grid_Size', '?')}"
+            acc[k].append(float(r["Counter_Value"]))
     return acc
 
 
@@ -53,8 +61,8 @@ def main(fetch_csv, write_csv, out):
             if re.search(re.escape(pat), k):
                 fb = f_unit * sum(fetch[k]) / len(fetch[k])
                 wb = w_unit * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
-                if name in ("group_points", "gather_points"):
-                    name = f"{name}#{len(res['per_launch_detail'])}"
+                if name in ("group_points", "gather_points") or " grid=" in k:
+                    name = f"{name}#{len(res['per_launch_detail'])}" + (k[k.rfind(" grid="):] if " grid=" in k else "")
                 res["per_launch_hbm_bytes"][name] = int(fb + wb)
                 res["per_launch_detail"][name] = {"symbol": k[:100], "read_bytes": int(fb), "write_bytes": int(wb),
                                                   "launches": len(fetch[k])}

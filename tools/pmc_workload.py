@@ -56,6 +56,22 @@ def main():
         # the unfused reference API on the same data (what the fused launches absorb)
         hip.group_points(xyz_t, idx)
         hip.group_points(f1, idx2)
+    # fused residual+LayerNorm and attention at the bench shapes (forward + backward)
+    from sceneverse_amd.modules.layers.fused_attention import _FusedSelfAttention
+    from sceneverse_amd.modules.layers.fused_norm import add_dropout_layer_norm
+    norm = torch.nn.LayerNorm(768).to(dev)
+    for rows in (19200, 8320, 5120, 3200):
+        x = torch.randn(rows, 768, device=dev, requires_grad=True)
+        h = torch.randn(rows, 768, device=dev).to(torch.bfloat16).requires_grad_(True)
+        for _ in range(3):
+            add_dropout_layer_norm(x, h, norm, 0.1, True).sum().backward()
+    for L, spatial in ((80, True), (130, False)):
+        W = 3 * 768 + (72 if spatial else 0)
+        packed = torch.randn(64, L, W, device=dev).to(torch.bfloat16).requires_grad_(True)
+        pl = torch.rand(64, L, L, 5, device=dev) if spatial else None
+        mask = torch.zeros(64, L, dtype=torch.bool, device=dev)
+        for _ in range(3):
+            _FusedSelfAttention.apply(packed, pl, mask, 12, 0.0, 0, None).float().sum().backward()
     torch.cuda.synchronize()
 
 
