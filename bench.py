@@ -167,6 +167,8 @@ def main() -> None:
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
+    ap.add_argument("--graph-dp", action="store_true",
+                    help="force the split-graph data-parallel form at world_size 1 (what N > 1 runs; for A/B)")
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     args = ap.parse_args()
@@ -185,8 +187,14 @@ def main() -> None:
     torch.cuda.set_device(dev)
 
     cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
-    use_graph = not args.no_graph      # world_size > 1: split-graph data parallelism (engine.py)
-    step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=use_graph)
+    # One GPU: the whole step as one HIP graph.  N > 1: torch DDP in eager mode -- since the BERT stack
+    # moved onto the fused kernels the eager step is GPU-bound too (28.6 ms eager vs 28.0 ms graph on one
+    # GPU), and DDP overlaps the 491 MB gradient all-reduce with backward, which the split-graph form
+    # (--graph-dp: 3 graphs around eager RCCL collectives, all-reduce exposed) cannot.
+    use_graph = (world == 1 and not args.no_graph) or args.graph_dp
+    step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
+                        graph=("dp" if args.graph_dp else use_graph))
+    use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
 
     def barrier():

@@ -88,6 +88,9 @@ class GPSTrainStep:
         self.net: nn.Module = self.model
         if use_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
+            # find_unused_parameters like the reference: 13 trainable tensors never receive a gradient
+            # (SURVEY.md 2b C1).  DDP's static_graph=True would avoid the per-iteration traversal but
+            # let the replicas drift apart after the first step in tests/test_dist_gloo.py -- not used.
             kw = dict(find_unused_parameters=True, gradient_as_bucket_view=True,
                       bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
             if self.device.type == "cuda":
