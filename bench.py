@@ -180,9 +180,14 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the GPS hot path has no CPU fallback")
-    rank, world, local = dist_utils.init_from_env("nccl")
+    # GPS_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 and the collectives go over gloo, so
+    # the N > 1 code path can be exercised end to end on a one-GPU box (RCCL refuses two ranks on one GPU)
+    share = os.environ.get("GPS_BENCH_SHARE_GPU") == "1"
+    rank, world, local = dist_utils.init_from_env("gloo" if share else "nccl")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if share:
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -294,7 +299,8 @@ def main() -> None:
                                    f"scenes): {args.n_obj} obj x {args.n_pts} pts x 6 ch, 50-token sentence "
                                    f"+ 300-token scene caption, fwd+loss+bwd+clip+AdamW",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "point_ops": "fp32-accurate split-bf16 MFMA (libgps_hip.so)",
+                       "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
+                       "point_ops": "fp32-accurate split-bf16 MFMA (libgps_hip.so)",
                        "launch": graph_note or "eager",
                        "kernel_timing": ("HIP events around each native launch, eager steps right after the "
                                          "timed graph replays" if use_graph else

@@ -256,3 +256,33 @@ def test_ddp_wrapper_runs_on_the_fused_path_with_rccl():
         assert n_none >= 13
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_n2_code_path_on_one_gpu():
+    """bench.py launched exactly as the driver launches it for N = 2 (torch.distributed.run, one process
+    per rank), except that both ranks share cuda:0 and talk over gloo (GPS_BENCH_SHARE_GPU=1; RCCL refuses
+    two ranks on one GPU).  Checks the N > 1 flow end to end: DDP wrap, between-batch all-gather,
+    max-over-ranks timing, one JSON line from rank 0 with the aggregate over both ranks."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, GPS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) < 0.02 * out["value"]
+    assert "cpu_baseline" not in out and out["roofline"] is not None
+    assert out["config"]["final_loss"] == out["config"]["final_loss"]
