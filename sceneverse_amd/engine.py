@@ -140,6 +140,7 @@ class GPSTrainStep:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
+                self._begin_step()
                 with self._autocast():
                     out = self.net(data_dict)
                 self._gather_features(out)
@@ -175,6 +176,7 @@ class GPSTrainStep:
             torch.cuda.synchronize(self.device)
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
+                self._begin_step()
                 with self._autocast():
                     out = self.net(static_dict)
             self._gather_features(out)
@@ -207,7 +209,15 @@ class GPSTrainStep:
             return contextlib.nullcontext()
         return torch.autocast(device_type="cuda", dtype=self.amp_dtype)
 
+    def _begin_step(self):
+        # one tiny launch that advances the device-side dropout seed block; it sits inside every captured
+        # region that runs the model, so each graph replay draws fresh masks
+        if torch.device(self.device).type == "cuda":
+            from .modules.layers import fused_attention
+            fused_attention.begin_step(self.device)
+
     def forward_loss(self, data_dict):
+        self._begin_step()
         with self._autocast():
             out = self.net(data_dict)
             total, losses = self.loss(out)

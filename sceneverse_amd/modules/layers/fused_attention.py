@@ -102,22 +102,70 @@ def fused_self_attention(packed: torch.Tensor, n_head: int, pairwise_locs: Optio
     p = float(dropout_p) if training else 0.0
     seed, seed_dev = 0, None
     if p > 0.0:
-        # the dropout stream lives ON THE DEVICE: a per-device uint64 advanced by one tiny kernel per
-        # call and snapshotted for this call's forward+backward.  No host value is baked into the
-        # launch, so a captured HIP graph draws a fresh mask on every replay.
+        # the dropout stream lives ON THE DEVICE (_SeedStream): this call's forward+backward read one
+        # word of a per-device block.  No host value is baked into the launch, so a captured HIP graph
+        # draws a fresh mask on every replay.
         seed_dev = _next_device_seed(packed.device)
     return _FusedSelfAttention.apply(packed.contiguous(), pairwise_locs, key_padding_mask, n_head, p, seed,
                                      seed_dev)
 
 
+_SEED_INC = 0x632BE59BD9B4E019        # odd 63-bit increment; the stream wraps modulo 2^64
+_SEED_BLOCK = 256
 _SEED_STATE = {}
 
 
-def _next_device_seed(device: torch.device) -> torch.Tensor:
-    state = _SEED_STATE.get(device)
-    if state is None:
+def _wrap64(v: int) -> int:
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+class _SeedStream:
+    """Per-device stream of dropout seed words kept ON THE DEVICE.  A block of _SEED_BLOCK consecutive
+    stream values lives in one int64 tensor; each call hands out a one-element VIEW of it (no launch).
+    `begin_step` advances the whole block in place with one tiny kernel -- inside a captured HIP graph
+    that kernel is replayed, so every replay draws fresh masks.  Exhausting a block mid-step builds a
+    NEW tensor from the old one's last word (never in place: views of the old block may be saved for a
+    pending backward)."""
+
+    def __init__(self, device: torch.device):
         init = int(torch.randint(0, 2 ** 62, (1,)).item())          # honours torch.manual_seed
-        state = torch.tensor([init], dtype=torch.int64, device=device)
-        _SEED_STATE[device] = state
-    state.add_(0x632BE59BD9B4E019)       # odd 63-bit increment; wraps modulo 2^64
-    return state.clone()
+        steps = [_wrap64(init + _SEED_INC * (i + 1)) for i in range(_SEED_BLOCK)]
+        self.offsets = torch.tensor([_wrap64(_SEED_INC * (i + 1)) for i in range(_SEED_BLOCK)],
+                                    dtype=torch.int64, device=device)
+        self.block = torch.tensor(steps, dtype=torch.int64, device=device)
+        self.pos = 0
+
+    def begin_step(self) -> None:
+        if self.pos:
+            self.block.add_(_wrap64(_SEED_INC * _SEED_BLOCK))
+            self.pos = 0
+
+    def next(self) -> torch.Tensor:
+        if self.pos == _SEED_BLOCK:
+            self.block = self.block[-1] + self.offsets
+            self.pos = 0
+        word = self.block[self.pos:self.pos + 1]
+        self.pos += 1
+        return word
+
+
+def _stream_for(device: torch.device) -> _SeedStream:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = _SEED_STATE.get(device)
+    if st is None:
+        st = _SEED_STATE[device] = _SeedStream(device)
+    return st
+
+
+def begin_step(device) -> None:
+    """Advance the device's dropout seed block.  Call once at the start of every training step, INSIDE the
+    region a HIP graph captures (sceneverse_amd/engine.py does); plain eager use without it stays correct
+    (seeds are never reused), it only costs a block rebuild every _SEED_BLOCK dropout calls."""
+    _stream_for(device).begin_step()
+
+
+def _next_device_seed(device: torch.device) -> torch.Tensor:
+    return _stream_for(device).next()

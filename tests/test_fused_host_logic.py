@@ -80,3 +80,28 @@ def test_between_batch_loss_gather_protocol():
     assert loss.shape == () and torch.isfinite(loss)
     loss.backward()
     assert crit.logit_scale.grad is not None
+
+
+def test_seed_stream_never_repeats_and_keeps_saved_views_stable():
+    """The device-side dropout seed stream (fused_attention._SeedStream): words handed out are views of a
+    block; begin_step advances the block in place (between steps), exhaustion builds a new block (so views
+    saved for a pending backward keep their value); no word is ever handed out twice."""
+    import torch
+    from sceneverse_amd.modules.layers import fused_attention as FA
+    torch.manual_seed(5)
+    st = FA._SeedStream(torch.device("cpu"))
+    seen = set()
+    for step in range(3):
+        st.begin_step()
+        views, vals = [], []
+        for _ in range(FA._SEED_BLOCK + 40):            # crosses one exhaustion inside the step
+            w = st.next()
+            assert w.shape == (1,) and w.dtype == torch.int64
+            views.append(w)
+            vals.append(int(w.item()))
+        assert [int(v.item()) for v in views] == vals    # nothing handed out was modified afterwards
+        assert not (seen & set(vals)) and len(set(vals)) == len(vals)
+        seen |= set(vals)
+    # consecutive words differ by the stream increment modulo 2^64
+    a, b = st.next(), st.next()
+    assert (int(b.item()) - int(a.item())) % (1 << 64) == FA._SEED_INC

@@ -168,6 +168,29 @@ def test_hip_graph_step_matches_eager_step():
         assert worst < 1e-3, (mode, worst)
 
 
+def test_graph_replays_draw_fresh_dropout_masks():
+    """With dropout on and the learning rate at zero the weights never move, so any change of the loss
+    between replays of the SAME batch is the dropout mask changing: every replay must differ from the
+    previous one (device-side seed block advanced by a kernel inside the captured graph), for the whole
+    graph and for the split-graph form."""
+    from bench import gps_pretrain_cfg, _lang_dir
+    from sceneverse_amd.data.synthetic import synth_batch
+    from sceneverse_amd.engine import GPSTrainStep
+    batch = synth_batch(4, n_obj=16, seed=31, min_real=5, device=DEV)
+    for graph in (True, "dp"):
+        cfg = gps_pretrain_cfg(_lang_dir())
+        st = GPSTrainStep(cfg, device=DEV, ddp=False, graph=graph, graph_warmup=2, seed=3)
+        st.scheduler.base_lrs = [0.0] * len(st.scheduler.base_lrs)      # lr = base_lr * lambda(step) = 0
+        for g in st.optimizer.param_groups:
+            g["lr"].zero_()
+        w0 = [p.detach().clone() for p in list(st.model.parameters())[:8]]
+        losses = [st.step(dict(batch))[0].item() for _ in range(8)]
+        assert st._graph is not None
+        replays = losses[3:]                       # steps 0-1 eager warm-up, 2 capture, 3.. replays
+        assert len(set(replays)) == len(replays), (graph, losses)
+        assert all(torch.equal(a, b) for a, b in zip(w0, list(st.model.parameters())[:8]))
+
+
 def test_fast_bert_path_matches_huggingface_layers():
     """BERTLanguageEncoder's fused GPU path (packed QKV, fused attention / SDPA, fused residual+LN)
     against HuggingFace's own BertModel.forward on the same weights, bf16 autocast, dropout off:
