@@ -237,6 +237,26 @@ GPS_API int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, in
                                                void *dx, void *dh, float *dgamma_part, float *dbeta_part,
                                                gps_stream_t stream);
 
+/* ---- per-object input processing of the data loader ------------------------------------------------
+ * Replaces ScanBase._obj_processing_post (data/datasets/base.py:697-740: optional rotation, centre/size
+ * -> obj_locs, box, subsample n_points, centre on the sample mean, scale to the unit ball), the loader's
+ * colour scaling colors / 127.5 - 1 (base.py:74-76) and the padding to max_obj_len + obj_masks of
+ * data/datasets/dataset_wrapper.py:62-70, for all object slots of a batch in one launch.
+ *   xyz (N,3) f32, rgb (N,3) u8 (rgb_is_u8 != 0) or f32 in 0..255: the RAW scene points, every object's
+ *   points contiguous; obj_offsets (n_obj+1) int64 CSR into them.
+ *   row_obj (n_rows) int32: object id of output row r, or -1 = padding slot (features 1.0, locs 0, mask 0).
+ *   sample_idx (n_rows, n_points) int32 object-local indices (the loader's np.random.choice draw), or NULL:
+ *   drawn on the device from `seed` (with replacement iff the object has < n_points points, else a keyed
+ *   permutation prefix -- distinct indices).  rot (n_rot,3,3) f32 + row_rot (n_rows) int32 (-1 = none),
+ *   both NULL for no rotation.  Outputs: obj_fts (n_rows, n_points, 6) f32, obj_locs (n_rows, 6) f32,
+ *   obj_boxes (n_rows, 6) f32 or NULL, obj_masks (n_rows) u8 or NULL.  n_points <= 2048.
+ * Arithmetic in float64, rounded to f32 at the end, like the reference for uint8 colours. */
+GPS_API int gps_obj_processing_post(int n_rows, int n_points, const float *xyz, const void *rgb, int rgb_is_u8,
+                                    const int64_t *obj_offsets, const int32_t *row_obj,
+                                    const int32_t *sample_idx, uint64_t seed, const float *rot,
+                                    const int32_t *row_rot, float *obj_fts, float *obj_locs, float *obj_boxes,
+                                    uint8_t *obj_masks, gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,14 @@ def test_argument_validation_without_gpu():
     assert lib.gps_add_dropout_layernorm_forward(0, 768, 0, 1, None, None, None, None, 1e-5, 0.0, 0, None, None,
                                                  None, None, None, None) == 0
     assert lib.gps_ln_partial_rows(8320) == 1024 and lib.gps_ln_partial_rows(5) == 2
+    # gps_obj_processing_post(n_rows, n_points, xyz, rgb, rgb_is_u8, offsets, row_obj, sample_idx, seed, rot,
+    #                         row_rot, fts, locs, boxes, masks, stream)
+    assert lib.gps_obj_processing_post(0, 1024, None, None, 1, None, None, None, 0, None, None, None, None, None,
+                                       None, None) == 0
+    assert lib.gps_obj_processing_post(4, 0, 1, 1, 1, 1, 1, None, 0, None, None, 1, 1, None, None, None) == -1
+    assert lib.gps_obj_processing_post(4, 4096, 1, 1, 1, 1, 1, None, 0, None, None, 1, 1, None, None, None) == -2
+    assert lib.gps_obj_processing_post(4, 1024, 1, None, 1, 1, 1, None, 0, None, None, 1, 1, None, None, None) == -1
+    assert lib.gps_obj_processing_post(4, 1024, 1, 1, 1, 1, 1, None, 0, 1, None, 1, 1, None, None, None) == -1  # rot w/o row_rot
 
 
 def test_no_oracle_import_in_product_code():

@@ -124,6 +124,29 @@ def main():
            "frac_8TBps": round(total_bq_group_bytes / total_bq_group_us / 1e3 / 8000, 4)}
     print(agg)
     rows.append(agg)
+    # loader-side object processing (gps_obj_processing_post): 64 scenes x 80 slots x 1024 points from
+    # HBM-resident raw scans (ScanNet-like object sizes: log-uniform 50..20000 points)
+    import numpy as np
+    from sceneverse_amd.data import gpu_objects as G
+    rng = np.random.default_rng(0)
+    packed = G.PackedScans(dev)
+    for s in range(16):
+        n = int(rng.integers(20, 80))
+        ks = np.exp(rng.uniform(np.log(50), np.log(20000), size=n)).astype(np.int64)
+        pts = rng.normal(size=(int(ks.sum()), 3)).astype(np.float32)
+        col = rng.integers(0, 256, size=(int(ks.sum()), 3), dtype=np.uint8)
+        packed.add_scan(f"s{s}", pts, col, np.repeat(np.arange(n), ks), list(range(n)))
+    packed.finalize()
+    slots = G.batch_rows(packed, [f"s{i % 16}" for i in range(args.batch)], 80)
+    nbytes = G._algorithmic_bytes(packed, slots, slots.numel(), 1024)
+    slots_d = slots.to(dev)
+    us = timeit(lambda: G.obj_processing_post(packed, slots_d, 1024, seed=1))
+    row = {"op": f"obj_processing_post ({args.batch}x80 slots, 1024 pts, device sampler)", "us": round(us, 2),
+           "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1),
+           "frac_8TBps": round(nbytes / us / 1e3 / 8000, 4),
+           "raw_points_per_batch": int(packed.sizes_host[slots.reshape(-1).numpy()[slots.reshape(-1).numpy() >= 0]].sum())}
+    print(row, flush=True)
+    rows.append(row)
     if args.json:
         with open(args.json, "w") as f:
             json.dump({"batch": args.batch, "objects": b, "rows": rows}, f, indent=1)
