@@ -72,7 +72,14 @@ def test_kernel_matches_reference_loader_outputs(case):
     out = G.obj_processing_post(packed, rows, num_points, rot=[rot], sample_idx=sidx, need_boxes=True)
     fts, locs, boxes = (out[k][0].cpu().numpy() for k in ("obj_fts", "obj_locs", "obj_boxes"))
     tol = dict(rel=1.2e-7, ab=1e-7) if cdt == "uint8" else dict(rel=2e-6, ab=2e-6)
-    eq = close_f32(fts[:n_obj], GOLD[f"{name}/fts"], **tol)
+    ref_fts = GOLD[f"{name}/fts"].copy()
+    if cdt != "uint8":
+        # float32 colours make the reference run in float32, where the all-identical object's x - mean is
+        # rounding noise of ~1 ulp(|x|) that can exceed the 1e-6 threshold and then gets scaled to the unit
+        # ball; in float64 it is ~1e-16 and stays (correctly) ~0.  Not a parity target: compare to 0.
+        assert np.all(np.abs(fts[1, :, :3]) < 1e-6)
+        ref_fts[1, :, :3] = fts[1, :, :3]
+    eq = close_f32(fts[:n_obj], ref_fts, **tol)
     close_f32(locs[:n_obj], GOLD[f"{name}/locs"], **tol)
     close_f32(boxes[:n_obj], GOLD[f"{name}/boxes"], **tol)
     if cdt == "uint8":
