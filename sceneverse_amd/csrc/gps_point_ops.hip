@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
                                                              int32_t *__restrict__ idx) {
   extern __shared__ int32_t bq_rows[];  // kWavesPerBlock rows of nsample ints
   const int obj = blockIdx.x;
-  const int L = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());   // w provably wave-uniform
+  const int L = lane_id(), w = wave_id();
   const float *p = xyz + (size_t)obj * n * 3;
   const float *q = new_xyz + (size_t)obj * m * 3;
   int32_t *o = idx + (size_t)obj * m * nsample;
@@ -313,84 +313,49 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
   }
   const int nchunks = (n + kWave - 1) / kWave;
 
-  if (R > 0) {
-    // Register-resident cloud: a wave takes TWO centres per sweep, so that the distance arithmetic is
-    // packed fp32 (v_pk_add_f32 / v_pk_mul_f32: both halves individually IEEE-rounded, i.e. the same
-    // pinned ((dx*dx + dy*dy) + dz*dz) per centre) -- 8 packed + 2 compares per (2 centres, 64 points)
-    // instead of 2 x 9 scalar-lane instructions.  Each centre keeps its own hit count / early exit.
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    int32_t *row1 = row + kWavesPerBlock * nsample;
-    const unsigned long long tail =
-        (n % kWave) ? ((1ull << (n % kWave)) - 1ull) : ~0ull;         // valid lanes of the last chunk
-    for (int j = 2 * w; j < m; j += 2 * kWavesPerBlock) {
-      const bool two = j + 1 < m;                                     // wave-uniform
-      const int j1 = two ? j + 1 : j;
-      f2 cx, cy, cz;
-      cx.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 0])));
-      cy.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 1])));
-      cz.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 2])));
-      cx.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j1 * 3 + 0])));
-      cy.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j1 * 3 + 1])));
-      cz.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j1 * 3 + 2])));
-      int cnt0 = 0, first0 = 0, cnt1 = two ? 0 : nsample, first1 = 0;
-#pragma unroll
-      for (int i = 0; i < RR; ++i) {
-        if ((cnt0 < nsample || cnt1 < nsample) && i < nchunks) {      // wave-uniform
-          const int k = i * kWave + L;
-          const f2 bx = {px[i], px[i]}, by = {py[i], py[i]}, bz = {pz[i], pz[i]};
-          const f2 dx = cx - bx, dy = cy - by, dz = cz - bz;
-          const f2 d2 = (dx * dx + dy * dy) + dz * dz;
-          const unsigned long long valid = (i == nchunks - 1) ? tail : ~0ull;
-          const unsigned long long m0 = __ballot(d2.x < radius2) & valid;
-          const unsigned long long m1 = __ballot(d2.y < radius2) & valid;
-          if (cnt0 < nsample && m0) {
-            const int pos = cnt0 + (int)__builtin_amdgcn_mbcnt_hi(
-                                       (unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
-            if (((m0 >> L) & 1ull) && pos < nsample) row[pos] = k;
-            if (cnt0 == 0) first0 = i * kWave + (__ffsll((long long)m0) - 1);
-            cnt0 += __popcll(m0);
-          }
-          if (cnt1 < nsample && m1) {
-            const int pos = cnt1 + (int)__builtin_amdgcn_mbcnt_hi(
-                                       (unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-            if (((m1 >> L) & 1ull) && pos < nsample) row1[pos] = k;
-            if (cnt1 == 0) first1 = i * kWave + (__ffsll((long long)m1) - 1);
-            cnt1 += __popcll(m1);
-          }
-        }
-      }
-      if (cnt0 > nsample) cnt0 = nsample;
-      if (cnt1 > nsample) cnt1 = nsample;
-      // same-wave LDS write -> read: the compiler's lgkmcnt wait orders them, no barrier needed
-      for (int t = L; t < nsample; t += kWave) o[j * nsample + t] = t < cnt0 ? row[t] : first0;
-      if (two)
-        for (int t = L; t < nsample; t += kWave) o[j1 * nsample + t] = t < cnt1 ? row1[t] : first1;
-    }
-    return;
-  }
-
   for (int j = w; j < m; j += kWavesPerBlock) {
     float cx = q[j * 3 + 0], cy = q[j * 3 + 1], cz = q[j * 3 + 2];
     cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx)));
     cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
     cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cz)));
     int cnt = 0, first = 0;
-    for (int i = 0; i < nchunks && cnt < nsample; ++i) {
-      const int k = i * kWave + L;
-      const bool in = k < n;
-      const float x = in ? p[k * 3 + 0] : 0.f, y = in ? p[k * 3 + 1] : 0.f,
-                  z = in ? p[k * 3 + 2] : 0.f;
-      const float dx = cx - x, dy = cy - y, dz = cz - z;
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      const bool hit = in && (d2 < radius2);
-      const unsigned long long mask = __ballot(hit);
-      if (mask) {
-        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi(
-                                  (unsigned)(mask >> 32),
-                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (hit && pos < nsample) row[pos] = k;
-        if (cnt == 0) first = i * kWave + (__ffsll((long long)mask) - 1);
-        cnt += __popcll(mask);
+    if (R > 0) {
+#pragma unroll
+      for (int i = 0; i < RR; ++i) {
+        if (cnt < nsample && i < nchunks) {  // wave-uniform
+          const int k = i * kWave + L;
+          const float dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
+          const bool hit = (k < n) && (d2 < radius2);
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi(
+                                      (unsigned)(mask >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (hit && pos < nsample) row[pos] = k;
+            if (cnt == 0) first = i * kWave + (__ffsll((long long)mask) - 1);
+            cnt += __popcll(mask);
+          }
+        }
+      }
+    } else {
+      for (int i = 0; i < nchunks && cnt < nsample; ++i) {
+        const int k = i * kWave + L;
+        const bool in = k < n;
+        const float x = in ? p[k * 3 + 0] : 0.f, y = in ? p[k * 3 + 1] : 0.f,
+                    z = in ? p[k * 3 + 2] : 0.f;
+        const float dx = cx - x, dy = cy - y, dz = cz - z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        const bool hit = in && (d2 < radius2);
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+          const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi(
+                                    (unsigned)(mask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (hit && pos < nsample) row[pos] = k;
+          if (cnt == 0) first = i * kWave + (__ffsll((long long)mask) - 1);
+          cnt += __popcll(mask);
+        }
       }
     }
     if (cnt > nsample) cnt = nsample;
@@ -829,7 +794,7 @@ int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *
   if ((long long)b * m * nsample == 0) return GPS_OK;
   if (!new_xyz || !idx || (n > 0 && !xyz)) return GPS_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)2 * gps::kWavesPerBlock * nsample * sizeof(int32_t);   // two centres per wave
+  const size_t lds = (size_t)gps::kWavesPerBlock * nsample * sizeof(int32_t);
   if (lds > (size_t)kLdsBudget) return GPS_ERR_UNSUPPORTED;
   const dim3 grid(b), block(gps::kBlock);
   const int need = (n + gps::kWave - 1) / gps::kWave;
