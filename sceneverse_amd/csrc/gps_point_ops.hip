@@ -292,75 +292,92 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
                                                              int32_t *__restrict__ idx) {
   extern __shared__ int32_t bq_rows[];  // kWavesPerBlock rows of nsample ints
   const int obj = blockIdx.x;
-  const int L = lane_id(), w = wave_id();
+  const int L = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
   const float *p = xyz + (size_t)obj * n * 3;
   const float *q = new_xyz + (size_t)obj * m * 3;
   int32_t *o = idx + (size_t)obj * m * nsample;
   int32_t *row = bq_rows + w * nsample;
   const float radius2 = radius * radius;
-
-  constexpr int RR = R > 0 ? R : 1;
-  float px[RR], py[RR], pz[RR];
-  if (R > 0) {
-#pragma unroll
-    for (int i = 0; i < RR; ++i) {
-      const int k = i * kWave + L;
-      const bool in = k < n;
-      px[i] = in ? p[k * 3 + 0] : 0.f;
-      py[i] = in ? p[k * 3 + 1] : 0.f;
-      pz[i] = in ? p[k * 3 + 2] : 0.f;
-    }
-  }
   const int nchunks = (n + kWave - 1) / kWave;
 
+  // One compaction step: `mask` = lanes of chunk `chunk` inside the ball.  Hits are appended to the
+  // wave's LDS row in lane (= index) order; wave-uniform bookkeeping stays in SGPRs.
+  auto take = [&](unsigned long long mask, int chunk, bool lane_hit, int &cnt, int &first) {
+    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (lane_hit && pos < nsample) row[pos] = chunk * kWave + L;
+    if (cnt == 0) first = chunk * kWave + (__ffsll((long long)mask) - 1);
+    cnt += __popcll(mask);
+  };
+
+  if (R > 1) {
+    // Register-resident cloud held as PAIRS of consecutive chunks, so that the distance arithmetic of
+    // two chunks against one centre is packed fp32 (v_pk_add_f32 / v_pk_mul_f32: each half individually
+    // IEEE-rounded, i.e. the pinned ((dx*dx + dy*dy) + dz*dz) per point): 8 packed ops + 2 compares per
+    // 128 points.  The two chunk masks are consumed in index order, each with its own early exit.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int RP = R > 1 ? R / 2 : 1;
+    f2 px[RP], py[RP], pz[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const int k0 = (2 * i) * kWave + L, k1 = k0 + kWave;
+      const bool in0 = k0 < n, in1 = k1 < n;
+      // lanes past the end of the cloud sit at x = +inf: d2 = +inf is never inside the ball, so the
+      // ballots need no validity mask (finite centres; no inf - inf anywhere)
+      px[i].x = in0 ? p[k0 * 3 + 0] : INFINITY;  px[i].y = in1 ? p[k1 * 3 + 0] : INFINITY;
+      py[i].x = in0 ? p[k0 * 3 + 1] : 0.f;  py[i].y = in1 ? p[k1 * 3 + 1] : 0.f;
+      pz[i].x = in0 ? p[k0 * 3 + 2] : 0.f;  pz[i].y = in1 ? p[k1 * 3 + 2] : 0.f;
+    }
+    for (int j = w; j < m; j += kWavesPerBlock) {
+      const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 0])));
+      const float c1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 1])));
+      const float c2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 2])));
+      const f2 cx = {c0, c0}, cy = {c1, c1}, cz = {c2, c2};
+      int cnt = 0, first = 0;
+#pragma unroll
+      for (int i = 0; i < RP; ++i) {
+        if (cnt < nsample && 2 * i < nchunks) {                          // wave-uniform
+          const f2 dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
+          const f2 d2 = (dx * dx + dy * dy) + dz * dz;
+          const bool h0 = d2.x < radius2, h1 = d2.y < radius2;
+          const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+          if (m0) take(m0, 2 * i, h0, cnt, first);
+          if (m1 && cnt < nsample) take(m1, 2 * i + 1, h1, cnt, first);
+        }
+      }
+      if (cnt > nsample) cnt = nsample;
+      // same-wave LDS write -> read: the compiler's lgkmcnt wait orders them, no barrier needed
+      for (int t = L; t < nsample; t += kWave) o[j * nsample + t] = t < cnt ? row[t] : first;
+    }
+    return;
+  }
+
+  // R == 1: a single (possibly partial) chunk in registers; R == 0: streamed from L1/L2
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (R == 1 && L < n) { qx = p[L * 3 + 0]; qy = p[L * 3 + 1]; qz = p[L * 3 + 2]; }
   for (int j = w; j < m; j += kWavesPerBlock) {
     float cx = q[j * 3 + 0], cy = q[j * 3 + 1], cz = q[j * 3 + 2];
     cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx)));
     cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
     cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cz)));
     int cnt = 0, first = 0;
-    if (R > 0) {
-#pragma unroll
-      for (int i = 0; i < RR; ++i) {
-        if (cnt < nsample && i < nchunks) {  // wave-uniform
-          const int k = i * kWave + L;
-          const float dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
-          const float d2 = (dx * dx + dy * dy) + dz * dz;
-          const bool hit = (k < n) && (d2 < radius2);
-          const unsigned long long mask = __ballot(hit);
-          if (mask) {
-            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi(
-                                      (unsigned)(mask >> 32),
-                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            if (hit && pos < nsample) row[pos] = k;
-            if (cnt == 0) first = i * kWave + (__ffsll((long long)mask) - 1);
-            cnt += __popcll(mask);
-          }
-        }
+    for (int i = 0; i < nchunks && cnt < nsample; ++i) {
+      const int k = i * kWave + L;
+      const bool in = k < n;
+      float x = qx, y = qy, z = qz;
+      if (R == 0) {
+        x = in ? p[k * 3 + 0] : 0.f;
+        y = in ? p[k * 3 + 1] : 0.f;
+        z = in ? p[k * 3 + 2] : 0.f;
       }
-    } else {
-      for (int i = 0; i < nchunks && cnt < nsample; ++i) {
-        const int k = i * kWave + L;
-        const bool in = k < n;
-        const float x = in ? p[k * 3 + 0] : 0.f, y = in ? p[k * 3 + 1] : 0.f,
-                    z = in ? p[k * 3 + 2] : 0.f;
-        const float dx = cx - x, dy = cy - y, dz = cz - z;
-        const float d2 = (dx * dx + dy * dy) + dz * dz;
-        const bool hit = in && (d2 < radius2);
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-          const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi(
-                                    (unsigned)(mask >> 32),
-                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-          if (hit && pos < nsample) row[pos] = k;
-          if (cnt == 0) first = i * kWave + (__ffsll((long long)mask) - 1);
-          cnt += __popcll(mask);
-        }
-      }
+      const float dx = cx - x, dy = cy - y, dz = cz - z;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const bool hit = in && (d2 < radius2);
+      const unsigned long long mask = __ballot(hit);
+      if (mask) take(mask, i, hit, cnt, first);
     }
     if (cnt > nsample) cnt = nsample;
-    // same-wave LDS write -> read: the compiler's lgkmcnt wait orders them, no barrier needed
-    for (int s = L; s < nsample; s += kWave) o[j * nsample + s] = s < cnt ? row[s] : first;
+    for (int t = L; t < nsample; t += kWave) o[j * nsample + t] = t < cnt ? row[t] : first;
   }
 }
 
