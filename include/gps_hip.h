@@ -243,7 +243,9 @@ GPS_API int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, in
  * colour scaling colors / 127.5 - 1 (base.py:74-76) and the padding to max_obj_len + obj_masks of
  * data/datasets/dataset_wrapper.py:62-70, for all object slots of a batch in one launch.
  *   xyz (N,3) f32, rgb (N,3) u8 (rgb_is_u8 != 0) or f32 in 0..255: the RAW scene points, every object's
- *   points contiguous; obj_offsets (n_obj+1) int64 CSR into them.
+ *   points contiguous; obj_offsets (n_obj+1) int64 CSR into them.  rgb == NULL selects the packed layout:
+ *   xyz then points at N 16-byte records {f32 x, y, z; u8 r, g, b, pad} (16-byte aligned) -- one vector
+ *   load per point, colours gathered together with the coordinates.
  *   row_obj (n_rows) int32: object id of output row r, or -1 = padding slot (features 1.0, locs 0, mask 0).
  *   sample_idx (n_rows, n_points) int32 object-local indices (the loader's np.random.choice draw), or NULL:
  *   drawn on the device from `seed` (with replacement iff the object has < n_points points, else a keyed

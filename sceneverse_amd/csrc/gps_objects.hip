@@ -5,14 +5,15 @@
 // base.py:74-76 and the padding to max_obj_len + obj_masks of data/datasets/dataset_wrapper.py:62-70.
 // The reference does this per object in numpy on the data-loader workers and ships the result
 // (126 MB/step/GPU at B=64) over PCIe; here the scenes stay resident in HBM in their RAW form
-// (xyz f32 + rgb u8 = 15 B/point, objects contiguous, CSR offsets) and ONE launch produces the
+// (xyz f32 + rgb u8, as 16-byte records or as two arrays; objects contiguous, CSR offsets) and ONE launch produces the
 // batch-ready (rows, num_points, 6) f32 tensor + obj_locs + obj_boxes + obj_masks.
 //
 // One workgroup (256 threads) per output row (= object slot of a scene, or a padding slot).
 //   pass 1  all k points of the object: rotate, sum / min / max  -> centre, size, box
 //   pass 2  the num_points sampled points (indices given, or drawn on the device) kept in VGPRs:
 //           mean -> max norm -> (x - mean) / max_dist, colours, written as f32
-// HBM-bound byte work: k*15 B read once + num_points*(15 + 4) B gathered + num_points*24 B written.
+// HBM-bound byte work: k*16 B streamed once (the gathers of pass 2 then hit lines the stream left in
+// L2) + num_points*24 B written.
 // Arithmetic is float64 like the reference (numpy promotes [xyz f32 | rgb u8 / 127.5 - 1] to f64)
 // and rounded to f32 at the end like the loader's `.float()`; only the summation ORDER of the two
 // means differs from numpy's pairwise sum (<= 1 f32 ulp after rounding, tests/test_gpu_objects.py).
@@ -85,6 +86,10 @@ struct Rot {
   }
 };
 
+// REC16: `xyz` is an array of 16-byte records {f32 x, y, z; u8 r, g, b, pad} (one aligned 16-B load per
+// point in the stream, and the sampled points -- colours included -- are gathered from lines the stream
+// just pulled through L2); otherwise xyz (N,3) and the colours are separate arrays.
+template <bool REC16>
 __global__ __launch_bounds__(kBlock) void obj_processing_post_kernel(
     int n_points, const float *__restrict__ xyz, const uint8_t *__restrict__ rgb_u8,
     const float *__restrict__ rgb_f32, const int64_t *__restrict__ obj_offsets,
@@ -118,13 +123,20 @@ __global__ __launch_bounds__(kBlock) void obj_processing_post_kernel(
 #pragma unroll
     for (int i = 0; i < 9; ++i) R.m[i] = (double)r[i];
   }
-  const float *p = xyz + (size_t)begin * 3;
+  const float *p = xyz + (size_t)begin * (REC16 ? 4 : 3);
+  const float4 *p4 = reinterpret_cast<const float4 *>(xyz) + begin;
 
   // ---- pass 1: centre / size / box over ALL points of the (rotated) object --------------------
   double sx = 0, sy = 0, sz = 0;
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (uint32_t i = tid; i < k; i += kBlock) {
-    double x = p[(size_t)i * 3], y = p[(size_t)i * 3 + 1], z = p[(size_t)i * 3 + 2];
+    double x, y, z;
+    if (REC16) {
+      const float4 r = p4[i];
+      x = r.x; y = r.y; z = r.z;
+    } else {
+      x = p[(size_t)i * 3]; y = p[(size_t)i * 3 + 1]; z = p[(size_t)i * 3 + 2];
+    }
     R.apply(x, y, z);
     sx += x; sy += y; sz += z;
     lo[0] = fmin(lo[0], x); lo[1] = fmin(lo[1], y); lo[2] = fmin(lo[2], z);
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void obj_processing_post_kernel(
   const bool replace = k < (uint32_t)n_points;
   const uint64_t key = mix64(seed ^ mix64((uint64_t)row));   // per output row: a scene drawn twice differs
   double px[kMaxPer], py[kMaxPer], pz[kMaxPer];
-  uint32_t src[kMaxPer];
+  uint32_t src[kMaxPer];                         // sampled index, or (REC16) the record's colour word
   sx = sy = sz = 0;
 #pragma unroll
   for (int i = 0; i < kMaxPer; ++i) {
@@ -171,8 +183,15 @@ __global__ __launch_bounds__(kBlock) void obj_processing_post_kernel(
       uint32_t s = sample_idx ? (uint32_t)sample_idx[(size_t)row * n_points + j]
                               : sample_index(key, (uint32_t)j, k, replace);
       s = s < k ? s : k - 1;                     // a caller-supplied index is clamped, never trusted
-      src[i] = s;
-      double x = p[(size_t)s * 3], y = p[(size_t)s * 3 + 1], z = p[(size_t)s * 3 + 2];
+      double x, y, z;
+      if (REC16) {
+        const float4 r = p4[s];
+        x = r.x; y = r.y; z = r.z;
+        src[i] = __float_as_uint(r.w);
+      } else {
+        x = p[(size_t)s * 3]; y = p[(size_t)s * 3 + 1]; z = p[(size_t)s * 3 + 2];
+        src[i] = s;
+      }
       R.apply(x, y, z);
       px[i] = x; py[i] = y; pz[i] = z;
       sx += x; sy += y; sz += z;
@@ -216,7 +235,11 @@ __global__ __launch_bounds__(kBlock) void obj_processing_post_kernel(
       o[1] = (float)(py[i] / max_dist);
       o[2] = (float)(pz[i] / max_dist);
       const size_t c = ((size_t)begin + src[i]) * 3;
-      if (rgb_u8) {                              // colors / 127.5 - 1 in f64 (uint8 promotes), then .float()
+      if (REC16) {                               // colours came with the record (little-endian r, g, b)
+        o[3] = (float)((double)(src[i] & 255u) / 127.5 - 1.0);
+        o[4] = (float)((double)((src[i] >> 8) & 255u) / 127.5 - 1.0);
+        o[5] = (float)((double)((src[i] >> 16) & 255u) / 127.5 - 1.0);
+      } else if (rgb_u8) {                       // colors / 127.5 - 1 in f64 (uint8 promotes), then .float()
         o[3] = (float)((double)rgb_u8[c] / 127.5 - 1.0);
         o[4] = (float)((double)rgb_u8[c + 1] / 127.5 - 1.0);
         o[5] = (float)((double)rgb_u8[c + 2] / 127.5 - 1.0);
@@ -239,10 +262,18 @@ extern "C" int gps_obj_processing_post(int n_rows, int n_points, const float *xy
   if (n_rows < 0 || n_points <= 0) return GPS_ERR_INVALID_ARGUMENT;
   if (n_points > gps_obj::kBlock * gps_obj::kMaxPer) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
-  if (!xyz || !rgb || !obj_offsets || !row_obj || !obj_fts || !obj_locs) return GPS_ERR_INVALID_ARGUMENT;
+  if (!xyz || !obj_offsets || !row_obj || !obj_fts || !obj_locs) return GPS_ERR_INVALID_ARGUMENT;
   if ((rot == nullptr) != (row_rot == nullptr)) return GPS_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(gps_obj::obj_processing_post_kernel, dim3(n_rows), dim3(gps_obj::kBlock), 0, (hipStream_t)stream, n_points,
-                     xyz, rgb_is_u8 ? (const uint8_t *)rgb : nullptr, rgb_is_u8 ? nullptr : (const float *)rgb,
-                     obj_offsets, row_obj, sample_idx, seed, rot, row_rot, obj_fts, obj_locs, obj_boxes, obj_masks);
+  if (!rgb) {                                    // 16-byte records: colours travel in the 4th word
+    if (((uintptr_t)xyz & 15u) != 0) return GPS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(gps_obj::obj_processing_post_kernel<true>, dim3(n_rows), dim3(gps_obj::kBlock), 0,
+                       (hipStream_t)stream, n_points, xyz, nullptr, nullptr, obj_offsets, row_obj, sample_idx, seed,
+                       rot, row_rot, obj_fts, obj_locs, obj_boxes, obj_masks);
+  } else {
+    hipLaunchKernelGGL(gps_obj::obj_processing_post_kernel<false>, dim3(n_rows), dim3(gps_obj::kBlock), 0,
+                       (hipStream_t)stream, n_points, xyz, rgb_is_u8 ? (const uint8_t *)rgb : nullptr,
+                       rgb_is_u8 ? nullptr : (const float *)rgb, obj_offsets, row_obj, sample_idx, seed, rot,
+                       row_rot, obj_fts, obj_locs, obj_boxes, obj_masks);
+  }
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }

@@ -6,8 +6,8 @@ Reference (what this replaces on the data-loader workers):
     ScanBase._obj_processing_post  data/datasets/base.py:697-740  rotate, obj_locs, box, subsample, normalise
     dataset wrapper padding        data/datasets/dataset_wrapper.py:62-70  pad to max_obj_len, obj_masks
 
-MI355X form: every scan is uploaded ONCE in its raw on-disk layout (xyz f32 + rgb u8 = 15 B/point
-instead of the loader's 48 B/point float64 rows), points regrouped so that each kept instance is
+MI355X form: every scan is uploaded ONCE in its raw on-disk precision (xyz f32 + rgb u8, packed as
+16-byte records, instead of the loader's 48 B/point float64 rows), points regrouped so that each kept instance is
 contiguous (same within-instance order as `pcds[mask]`), with a CSR offset table.  A training batch
 is then described by a (B, max_obj_len) table of object ids; `obj_processing_post` turns it into the
 model's `obj_fts / obj_locs / obj_masks` (+ boxes) on the device -- no per-object host work, no
@@ -27,8 +27,12 @@ from .. import _native
 class PackedScans:
     """Raw scans resident on one device.  Build with add_scan(...) x n, then finalize()."""
 
-    def __init__(self, device: torch.device | str = "cuda"):
+    def __init__(self, device: torch.device | str = "cuda", records: bool = True):
+        """records=True (default, uint8 colours only): store points as 16-byte records {x, y, z f32; r, g, b
+        u8; pad} -- one aligned vector load per point, colours gathered with the coordinates.
+        records=False: xyz (N,3) and rgb (N,3) as two arrays (also the layout for float32 colours)."""
         self.device = torch.device(device)
+        self.records = records
         self._xyz: List[np.ndarray] = []
         self._rgb: List[np.ndarray] = []
         self._sizes: List[int] = []
@@ -66,10 +70,16 @@ class PackedScans:
         off = np.zeros(len(sizes) + 1, dtype=np.int64)
         np.cumsum(sizes, out=off[1:])
         self.sizes_host = sizes
-        self.xyz = torch.from_numpy(np.concatenate(self._xyz, 0) if self._xyz else np.zeros((0, 3), np.float32)
-                                    ).to(self.device)
-        self.rgb = torch.from_numpy(np.concatenate(self._rgb, 0) if self._rgb else np.zeros((0, 3), np.uint8)
-                                    ).to(self.device)
+        xyz = np.concatenate(self._xyz, 0) if self._xyz else np.zeros((0, 3), np.float32)
+        rgb = np.concatenate(self._rgb, 0) if self._rgb else np.zeros((0, 3), np.uint8)
+        if self.records and rgb.dtype == np.uint8:
+            rec = np.zeros((xyz.shape[0], 4), dtype=np.float32)
+            rec[:, :3] = xyz
+            rec.view(np.uint8).reshape(-1, 16)[:, 12:15] = rgb
+            self.xyz, self.rgb = torch.from_numpy(rec).to(self.device), None
+        else:
+            self.records = False
+            self.xyz, self.rgb = torch.from_numpy(xyz).to(self.device), torch.from_numpy(rgb).to(self.device)
         self.obj_offsets = torch.from_numpy(off).to(self.device)
         self._xyz, self._rgb = [], []
         return self
@@ -136,7 +146,8 @@ def obj_processing_post(packed: PackedScans, row_obj: torch.Tensor, num_points: 
     from ..pointnet2._ext import _timed
     with torch.cuda.device(dev), _timed(f"obj_processing_post(rows={n_rows},P={num_points})", nbytes):
         st = _native.load().gps_obj_processing_post(
-            n_rows, num_points, packed.xyz.data_ptr(), packed.rgb.data_ptr(), int(packed.rgb.dtype == torch.uint8),
+            n_rows, num_points, packed.xyz.data_ptr(), packed.rgb.data_ptr() if packed.rgb is not None else None,
+            int(packed.rgb is None or packed.rgb.dtype == torch.uint8),
             packed.obj_offsets.data_ptr(), row_obj.data_ptr(),
             sample_idx.data_ptr() if sample_idx is not None else None, int(seed) & ((1 << 64) - 1),
             rot_ptr, row_rot_ptr, fts.data_ptr(), locs.data_ptr(), boxes.data_ptr() if need_boxes else None,
@@ -166,10 +177,10 @@ def rot_rows(rot, B: int, O: int, dev):
 
 
 def _algorithmic_bytes(packed: PackedScans, row_obj_host, n_rows: int, num_points: int) -> int:
-    """Each object's raw points read once (15 or 24 B/point) + the sampled points gathered + the f32
-    feature rows written.  With the row table already on the device the object sizes of THIS batch are
-    not known on the host without a sync: the mean object size stands in for them."""
-    per_pt = 12 + 3 * packed.rgb.element_size()
+    """Each object's raw points read once (16-byte records; 15 or 24 B/point as two arrays) + the sampled
+    points gathered + the f32 feature rows written.  With the row table already on the device the object
+    sizes of THIS batch are not known on the host without a sync: the mean object size stands in."""
+    per_pt = 16 if packed.rgb is None else 12 + 3 * packed.rgb.element_size()
     if row_obj_host is not None:
         ids = row_obj_host.reshape(-1).numpy()
         k_total = int(packed.sizes_host[ids[ids >= 0]].sum())

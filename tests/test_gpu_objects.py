@@ -26,7 +26,7 @@ DEV = "cuda"
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "obj_processing_ref.npz"))
 
 
-def pack(objs, shuffle_seed=0, scan_id="s0", packed=None):
+def pack(objs, shuffle_seed=0, scan_id="s0", packed=None, records=True):
     """Objects -> one raw scan (points interleaved across instances, as on disk) -> PackedScans."""
     pts = np.concatenate([p for p, _ in objs], 0)
     col = np.concatenate([c for _, c in objs], 0)
@@ -38,7 +38,7 @@ def pack(objs, shuffle_seed=0, scan_id="s0", packed=None):
     for i in range(len(objs)):
         out_idx[np.flatnonzero(lab_p == 100 + i)] = np.flatnonzero(lab == 100 + i)
     own = packed is None
-    packed = packed or G.PackedScans(DEV)
+    packed = packed or G.PackedScans(DEV, records=records)
     packed.add_scan(scan_id, pts[out_idx], col[out_idx], lab[out_idx], [100 + i for i in range(len(objs))] + [999])
     return packed.finalize() if own else packed
 
@@ -58,11 +58,13 @@ def close_f32(got, ref64, rel=1.2e-7, ab=1e-7):
     return float(np.mean(got[big] == ref[big]))
 
 
+@pytest.mark.parametrize("records", [True, False], ids=["rec16", "two_arrays"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_kernel_matches_reference_loader_outputs(case):
+def test_kernel_matches_reference_loader_outputs(case, records):
     name, scene_seed, np_seed, n_obj, num_points, cdt, split, ks = case
     objs = case_objs(case)
-    packed = pack(objs, shuffle_seed=scene_seed)
+    packed = pack(objs, shuffle_seed=scene_seed, records=records)
+    assert packed.records == (records and cdt == "uint8")
     assert packed.n_objects == n_obj and list(packed.sizes_host) == [len(p) for p, _ in objs]
     np.random.seed(np_seed)
     rot, idxs = O.draw_like_reference(ks, num_points, split, True)
