@@ -169,6 +169,9 @@ def main() -> None:
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
     ap.add_argument("--graph-dp", action="store_true",
                     help="force the split-graph data-parallel form at world_size 1 (what N > 1 runs; for A/B)")
+    ap.add_argument("--no-splitk", action="store_true",
+                    help="weight gradients of the big-token Linears as single library GEMMs (A/B of "
+                         "sceneverse_amd/common/wgrad_splitk.py)")
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     args = ap.parse_args()
@@ -198,7 +201,7 @@ def main() -> None:
     # (--graph-dp: 3 graphs around eager RCCL collectives, all-reduce exposed) cannot.
     use_graph = (world == 1 and not args.no_graph) or args.graph_dp
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
-                        graph=("dp" if args.graph_dp else use_graph))
+                        graph=("dp" if args.graph_dp else use_graph), splitk_wgrad=not args.no_splitk)
     use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
 
@@ -224,7 +227,8 @@ def main() -> None:
             torch.cuda.empty_cache()
             use_graph = False
             cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
-            step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=False)
+            step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=False,
+                                splitk_wgrad=not args.no_splitk)
             graph_note = f"eager (graph capture failed: {type(e).__name__})"
     for _ in range(args.warmup):
         step.step(dict(batch))

@@ -51,9 +51,12 @@ from .optim.build import build_optim
 class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
-                 bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3):
+                 bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
+                 splitk_wgrad: bool = True):
         self.cfg = cfg
         self.device = torch.device(device)
+        # weight gradients of the big-token Linears as split-K bmm + fp32 sum (common/wgrad_splitk.py)
+        self.splitk_wgrad = bool(splitk_wgrad) and self.device.type == "cuda"
         torch.manual_seed(seed)
         self.model = build_model(cfg).to(self.device)
         world = dist_utils.get_world_size()
@@ -141,7 +144,7 @@ class GPSTrainStep:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._begin_step()
-                with self._autocast():
+                with self._autocast(), self._splitk():
                     out = self.net(data_dict)
                 self._gather_features(out)
                 with self._autocast():
@@ -177,7 +180,7 @@ class GPSTrainStep:
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._begin_step()
-                with self._autocast():
+                with self._autocast(), self._splitk():
                     out = self.net(static_dict)
             self._gather_features(out)
             torch.cuda.synchronize(self.device)
@@ -216,9 +219,13 @@ class GPSTrainStep:
             from .modules.layers import fused_attention
             fused_attention.begin_step(self.device)
 
+    def _splitk(self):
+        from .common.wgrad_splitk import splitk_wgrad
+        return splitk_wgrad(self.splitk_wgrad and self.amp_dtype == torch.bfloat16)
+
     def forward_loss(self, data_dict):
         self._begin_step()
-        with self._autocast():
+        with self._autocast(), self._splitk():
             out = self.net(data_dict)
             total, losses = self.loss(out)
         return out, total, losses
