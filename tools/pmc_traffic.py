@@ -51,8 +51,11 @@ def main(fetch_csv, write_csv, out):
     fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     cal = [k for k in fetch if "copy" in k.lower() and max(fetch[k]) > 0]
     cal_k = max(cal, key=lambda k: max(fetch[k]))
-    f_unit = CAL_BYTES / (sum(fetch[cal_k]) / len(fetch[cal_k]))
-    w_unit = CAL_BYTES / (sum(write[cal_k]) / len(write[cal_k]))
+    # only the 512 MiB calibration copies: other (tiny) launches of the same copy kernel are ignored
+    big_f = [v for v in fetch[cal_k] if v >= 0.5 * max(fetch[cal_k])]
+    big_w = [v for v in write[cal_k] if v >= 0.5 * max(write[cal_k])]
+    f_unit = CAL_BYTES / (sum(big_f) / len(big_f))
+    w_unit = CAL_BYTES / (sum(big_w) / len(big_w))
     res = {"calibration": {"kernel": cal_k[:80], "known_bytes_each_way": CAL_BYTES,
                            "bytes_per_FETCH_SIZE_unit": f_unit, "bytes_per_WRITE_SIZE_unit": w_unit},
            "per_launch_hbm_bytes": {}, "per_launch_detail": {}}
