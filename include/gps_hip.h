@@ -259,6 +259,16 @@ GPS_API int gps_obj_processing_post(int n_rows, int n_points, const float *xyz, 
                                     const int32_t *row_rot, float *obj_fts, float *obj_locs, float *obj_boxes,
                                     uint8_t *obj_masks, gps_stream_t stream);
 
+/* ---- bias gradients: column sums of a bf16 matrix ---------------------------------------------------
+ * Replaces the `dY.sum(0)` autograd derives for the bias of every nn.Linear in the transformer stacks
+ * (modules/layers/transformers.py:115-154, 285-316; HF BertLayer behind modules/language/bert.py:21-26).
+ * x (rows, ld >= cols) bf16, cols and ld multiples of 8, x 16-byte aligned (else GPS_ERR_UNSUPPORTED);
+ * partials: scratch of gps_colsum_parts(rows, cols) * cols floats; out (cols) fp32 = column sums with
+ * fp32 accumulation in a fixed (deterministic) order. */
+GPS_API int gps_colsum_parts(int rows, int cols);
+GPS_API int gps_colsum_bf16(int rows, int cols, const void *x, long long ld, float *partials, float *out,
+                            gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgps_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "gps_hip.h")
 
 GPS_OK = 0
+GPS_ERR_UNSUPPORTED = -2
 _lib = None
 
 _vp = ctypes.c_void_p
@@ -40,6 +41,8 @@ SIGNATURES = {
     "gps_sa_mlp_forward_bf16x3": [_i] * 8 + [_vp] * 7,
     "gps_obj_processing_post": [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp],
+    "gps_colsum_parts": [_i, _i],
+    "gps_colsum_bf16": [_i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_masked_ce_forward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_masked_ce_backward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp],

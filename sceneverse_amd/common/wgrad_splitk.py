@@ -9,10 +9,14 @@ and hands autograd an fp32 gradient directly (no bf16 -> fp32 cast launch); meas
 profiles/r1/splitk_probe.txt (10-35 % off the tuned single GEMM).  Same arithmetic class as autocast's
 own path: bf16 operands, fp32 accumulation -- the partial sums are simply kept in fp32 longer.
 
+The bias gradient of the same calls (db = column sums of dY, up to 19 200 x 3 072 bf16) goes to
+libgps_hip.so's gps_colsum_bf16 (two-stage, deterministic, HBM-bound) instead of torch's generic reduce.
+
 Mechanism: inside `with splitk_wgrad():` F.linear is routed, for eligible calls, through
-    y = F.linear(x16, W.detach(), b)          # forward, dX and db exactly as before
-    y = _AttachWGrad.apply(y, x16, W)         # identity in forward; backward adds dW = splitk(dY, x16)
-so nothing about the forward pass or the other gradients changes.  Outside the context (and for small
+    y = F.linear(x16, W.detach(), b.detach()) # forward and dX exactly as before
+    y = _AttachWGrad.apply(y, x16, W, b)      # identity in forward; backward adds dW = splitk(dY, x16)
+                                              # and db = colsum(dY)
+so nothing about the forward pass or the input gradient changes.  Outside the context (and for small
 or unsupported shapes) F.linear is untouched.
 """
 from __future__ import annotations
@@ -50,11 +54,30 @@ def splitk_wgrad_mm(dy2: torch.Tensor, x2: torch.Tensor, splits: int) -> torch.T
     return torch.bmm(a, b, out_dtype=torch.float32).sum(0)
 
 
+def colsum_bf16(dy2: torch.Tensor) -> torch.Tensor:
+    """(T, N) bf16 -> (N,) fp32 column sums on libgps_hip.so (gps_colsum_bf16)."""
+    from .. import _native
+    lib = _native.load()
+    T, N = dy2.shape
+    out = torch.empty(N, dtype=torch.float32, device=dy2.device)
+    parts = lib.gps_colsum_parts(T, N)
+    scratch = torch.empty((max(parts, 1), N), dtype=torch.float32, device=dy2.device)
+    from ..pointnet2._ext import _timed
+    with torch.cuda.device(dy2.device), _timed(f"colsum_bf16(rows={T},cols={N})", 2 * T * N + 4 * N):
+        st = lib.gps_colsum_bf16(T, N, dy2.data_ptr(), dy2.stride(0), scratch.data_ptr(), out.data_ptr(),
+                                 torch.cuda.current_stream(dy2.device).cuda_stream)
+    if st == _native.GPS_ERR_UNSUPPORTED:            # columns / pitch not a multiple of 8: not this kernel's shape
+        return dy2.sum(0, dtype=torch.float32)
+    _native.check(st, "colsum_bf16")
+    return out
+
+
 class _AttachWGrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, x16, w, splits):
+    def forward(ctx, y, x16, w, b, splits):
         ctx.save_for_backward(x16)
         ctx.splits = splits
+        ctx.has_bias = b is not None
         return y.view_as(y)
 
     @staticmethod
@@ -65,13 +88,14 @@ class _AttachWGrad(torch.autograd.Function):
             dy2 = dy2.to(torch.bfloat16)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dw = splitk_wgrad_mm(dy2, x16.reshape(-1, x16.shape[-1]), ctx.splits)
-        return dy, None, dw, None
+        dw = splitk_wgrad_mm(dy2, x16.reshape(-1, x16.shape[-1]), ctx.splits) if ctx.needs_input_grad[2] else None
+        db = colsum_bf16(dy2) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return dy, None, dw, db, None
 
 
 def _linear(x, w, b=None):
-    if (_ACTIVE and isinstance(w, torch.nn.Parameter) and w.requires_grad and w.is_cuda and w.dtype == torch.float32
-            and w.dim() == 2 and x.is_cuda and x.dim() >= 2 and x.dtype in (torch.bfloat16, torch.float32)
+    if (_ACTIVE and torch.is_tensor(w) and w.requires_grad and w.is_cuda and w.dtype == torch.float32
+            and w.dim() == 2 and (b is None or (b.dtype == torch.float32 and b.dim() == 1)) and x.is_cuda and x.dim() >= 2 and x.dtype in (torch.bfloat16, torch.float32)
             and torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")
             and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         tokens = x.numel() // x.shape[-1]
@@ -80,8 +104,8 @@ def _linear(x, w, b=None):
             x16 = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
             if not x16.is_contiguous():
                 x16 = x16.contiguous()
-            y = _ORIG_LINEAR(x16, w.detach(), b)
-            return _AttachWGrad.apply(y, x16, w, splits)
+            y = _ORIG_LINEAR(x16, w.detach(), b.detach() if b is not None else None)
+            return _AttachWGrad.apply(y, x16, w, b, splits)
     return _ORIG_LINEAR(x, w, b)
 
 

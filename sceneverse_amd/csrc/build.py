@@ -19,6 +19,7 @@ SOURCES = [
     ("gps_losses.hip", []),
     ("gps_layernorm.hip", []),
     ("gps_objects.hip", []),
+    ("gps_reduce.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-I" + os.path.join(ROOT, "include")]

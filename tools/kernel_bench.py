@@ -165,6 +165,18 @@ def main():
            "raw_points_per_batch": int(packed.sizes_host[slots.reshape(-1).numpy()[slots.reshape(-1).numpy() >= 0]].sum())}
     print(row, flush=True)
     rows.append(row)
+    # bias-gradient column sums (gps_colsum_bf16) next to torch's reduction of the same matrix
+    from sceneverse_amd.common import wgrad_splitk as WS
+    for T, N in ((19200, 3072), (19200, 768), (8320, 2048), (5120, 2376)):
+        dy = torch.randn(T, N, device=dev).to(torch.bfloat16)
+        us = timeit(lambda: WS.colsum_bf16(dy))
+        us_t = timeit(lambda: dy.sum(0))
+        nb = 2 * T * N + 4 * N
+        row = {"op": f"colsum_bf16 ({T}x{N})", "us": round(us, 2), "algorithmic_bytes": nb,
+               "GBps": round(nb / us / 1e3, 1), "frac_8TBps": round(nb / us / 1e3 / 8000, 4),
+               "torch_sum_us": round(us_t, 2)}
+        print(row, flush=True)
+        rows.append(row)
     if args.json:
         with open(args.json, "w") as f:
             json.dump({"batch": args.batch, "objects": b, "rows": rows}, f, indent=1)
