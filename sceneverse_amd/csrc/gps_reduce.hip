@@ -8,7 +8,7 @@
 // is 0.3-0.4 ms.  HBM-bound, algorithmic bytes = rows * cols * 2 read once.
 //
 // Stage 1: grid (cols / 256, P row chunks), 256 threads = 8 row lanes x 32 column groups of 8 bf16
-//          (one 16-byte load per thread and row, 512 contiguous bytes per row and wave half; four loads
+//          (one 16-byte load per thread and row, 512 contiguous bytes per row and wave half; eight loads
 //          in flight), fp32 accumulation, 8 -> 1 over the row lanes through LDS, partial row written.
 // Stage 2: the P partial rows summed in a fixed order (deterministic; no atomics).
 #include <hip/hip_runtime.h>
@@ -44,12 +44,12 @@ __global__ __launch_bounds__(kBlock) void colsum_stage1_kernel(int rows, int col
   if (col < cols) {
     const uint16_t *p = x + col;
     int r = r0 + rl;
-    for (; r + 3 * kRowLanes < r1; r += 4 * kRowLanes) {
-      const u32x4 a = *reinterpret_cast<const u32x4 *>(p + (size_t)r * ld);
-      const u32x4 b = *reinterpret_cast<const u32x4 *>(p + (size_t)(r + kRowLanes) * ld);
-      const u32x4 c = *reinterpret_cast<const u32x4 *>(p + (size_t)(r + 2 * kRowLanes) * ld);
-      const u32x4 d = *reinterpret_cast<const u32x4 *>(p + (size_t)(r + 3 * kRowLanes) * ld);
-      add8(acc, a); add8(acc, b); add8(acc, c); add8(acc, d);
+    for (; r + 7 * kRowLanes < r1; r += 8 * kRowLanes) {          // eight 16-byte loads in flight
+      u32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const u32x4 *>(p + (size_t)(r + k * kRowLanes) * ld);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) add8(acc, v[k]);
     }
     for (; r < r1; r += kRowLanes) add8(acc, *reinterpret_cast<const u32x4 *>(p + (size_t)r * ld));
   }
@@ -65,23 +65,40 @@ __global__ __launch_bounds__(kBlock) void colsum_stage1_kernel(int rows, int col
   }
 }
 
-// out[c] = sum_p partials[p][c]: 64 columns per workgroup, 4 waves split the partial rows
-__global__ __launch_bounds__(kBlock) void colsum_stage2_kernel(int parts, int cols, const float *__restrict__ partials,
-                                                               float *__restrict__ out) {
-  __shared__ float s[4][64];
+// out[c] = sum_p partials[p][c]: 64 columns per workgroup, 16 waves split the partial rows (four loads in
+// flight each); the 16 wave sums are added in a fixed order
+constexpr int kStage2Waves = 16;
+__global__ __launch_bounds__(kStage2Waves * 64) void colsum_stage2_kernel(int parts, int cols,
+                                                                          const float *__restrict__ partials,
+                                                                          float *__restrict__ out) {
+  __shared__ float s[kStage2Waves][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  float a = 0.f;
-  if (c < cols)
-    for (int p = w; p < parts; p += 4) a += partials[(size_t)p * cols + c];
-  s[w][lane] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    int p = w;
+    for (; p + 3 * kStage2Waves < parts; p += 4 * kStage2Waves) {
+      a0 += partials[(size_t)p * cols + c];
+      a1 += partials[(size_t)(p + kStage2Waves) * cols + c];
+      a2 += partials[(size_t)(p + 2 * kStage2Waves) * cols + c];
+      a3 += partials[(size_t)(p + 3 * kStage2Waves) * cols + c];
+    }
+    for (; p < parts; p += kStage2Waves) a0 += partials[(size_t)p * cols + c];
+  }
+  s[w][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (w == 0 && c < cols) out[c] = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+  if (w == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kStage2Waves; ++k) t += s[k][lane];
+    out[c] = t;
+  }
 }
 
 __host__ inline int parts_for(int rows, int cols) {
   const int col_blocks = (cols + kColsPerBlock - 1) / kColsPerBlock;
-  int parts = 1024 / (col_blocks > 0 ? col_blocks : 1);      // ~4 workgroups per CU
+  int parts = 768 / (col_blocks > 0 ? col_blocks : 1);       // ~3 workgroups per CU
+  if (parts > 256) parts = 256;
   const int max_parts = (rows + 63) / 64;                     // at least 64 rows per part
   if (parts > max_parts) parts = max_parts;
   return parts < 1 ? 1 : parts;
@@ -111,7 +128,7 @@ extern "C" int gps_colsum_bf16(int rows, int cols, const void *x, long long ld, 
   const dim3 grid1((cols + gps_red::kColsPerBlock - 1) / gps_red::kColsPerBlock, parts);
   hipLaunchKernelGGL(gps_red::colsum_stage1_kernel, grid1, dim3(gps_red::kBlock), 0, s, rows, cols,
                      (const uint16_t *)x, ld, rpp, partials);
-  hipLaunchKernelGGL(gps_red::colsum_stage2_kernel, dim3((cols + 63) / 64), dim3(gps_red::kBlock), 0, s, parts, cols,
-                     partials, out);
+  hipLaunchKernelGGL(gps_red::colsum_stage2_kernel, dim3((cols + 63) / 64), dim3(gps_red::kStage2Waves * 64), 0, s,
+                     parts, cols, partials, out);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }

@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu():
     assert lib.gps_colsum_bf16(4, 768, 1, 100, 1, 1, None) == -1                   # ld < cols
     assert lib.gps_colsum_bf16(4, 100, 16, 104, 1, 1, None) == -2                  # cols not a multiple of 8
     assert lib.gps_colsum_bf16(4, 0, None, 0, None, None, None) == 0
-    assert lib.gps_colsum_parts(19200, 768) == 300 and lib.gps_colsum_parts(0, 768) == 0
+    assert lib.gps_colsum_parts(19200, 768) == 240 and lib.gps_colsum_parts(0, 768) == 0
     # gps_obj_processing_post(n_rows, n_points, xyz, rgb, rgb_is_u8, offsets, row_obj, sample_idx, seed, rot,
     #                         row_rot, fts, locs, boxes, masks, stream)
     assert lib.gps_obj_processing_post(0, 1024, None, None, 1, None, None, None, 0, None, None, None, None, None,
