@@ -28,7 +28,8 @@ import torch.nn.functional as F
 
 _ORIG_LINEAR = F.linear
 _ACTIVE = False
-MIN_TOKENS = 5000
+MIN_TOKENS = 5000            # split the token reduction of dW from here on
+MIN_TOKENS_BIAS = 2048       # route the bias gradient through gps_colsum_bf16 from here on (dW unsplit)
 
 
 def pick_splits(tokens: int, n_out: int, n_in: int) -> int:
@@ -49,6 +50,8 @@ def splitk_wgrad_mm(dy2: torch.Tensor, x2: torch.Tensor, splits: int) -> torch.T
     """dy2 (T, N), x2 (T, K) bf16 -> dy2^T @ x2 as fp32 (N, K), the reduction split into `splits` chunks."""
     T, N = dy2.shape
     K = x2.shape[1]
+    if splits <= 1:                      # the library's (tuned) single GEMM, as autograd would run it
+        return torch.mm(dy2.t(), x2).float()
     a = dy2.view(splits, T // splits, N).transpose(1, 2)
     b = x2.view(splits, T // splits, K)
     return torch.bmm(a, b, out_dtype=torch.float32).sum(0)
@@ -100,7 +103,7 @@ def _linear(x, w, b=None):
             and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         tokens = x.numel() // x.shape[-1]
         splits = pick_splits(tokens, w.shape[0], w.shape[1])
-        if splits > 1:
+        if splits > 1 or (b is not None and tokens >= MIN_TOKENS_BIAS and w.shape[0] % 8 == 0):
             x16 = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
             if not x16.is_contiguous():
                 x16 = x16.contiguous()

@@ -16,7 +16,8 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("tokens,n_in,n_out,shape3d", [(8320, 768, 2048, True), (19200, 768, 768, True),
-                                                       (5120, 2048, 768, False), (6000, 512, 256, False)])
+                                                       (5120, 2048, 768, False), (6000, 512, 256, False),
+                                                       (3200, 768, 3072, True)])
 def test_splitk_path_matches_autocast_linear(tokens, n_in, n_out, shape3d):
     torch.manual_seed(0)
     lin = nn.Linear(n_in, n_out).to(DEV)
@@ -25,7 +26,7 @@ def test_splitk_path_matches_autocast_linear(tokens, n_in, n_out, shape3d):
         x = x.view(64, tokens // 64, n_in)
     g = torch.randn(*x.shape[:-1], n_out, device=DEV)
     splits = W.pick_splits(tokens, n_out, n_in)
-    assert splits > 1 and tokens % splits == 0
+    assert (splits > 1 and tokens % splits == 0) or tokens == 3200      # 3 200 tokens: bias path only
 
     def run(ctx):
         lin.zero_grad(set_to_none=True)
@@ -48,7 +49,8 @@ def test_splitk_path_matches_autocast_linear(tokens, n_in, n_out, shape3d):
     scale = ref.abs().max().item()
     e_split = (dw1 - ref).abs().max().item() / scale
     e_single = (dw0 - ref).abs().max().item() / scale
-    assert e_split <= 1e-4, e_split                  # fp32 partials: only accumulation-order noise
+    if splits > 1:
+        assert e_split <= 1e-4, e_split              # fp32 partials: only accumulation-order noise
     assert e_split <= e_single + 1e-6, (e_split, e_single)
     assert e_single < 1e-2
     # bias gradient: fp32 column sums of the bf16 dY (gps_colsum_bf16) vs autocast's bf16-rounded reduction
@@ -75,7 +77,7 @@ def test_colsum_kernel(rows, cols, ld):
 
 def test_small_or_odd_calls_are_left_alone():
     lin = nn.Linear(768, 768).to(DEV)
-    x = torch.randn(64, 50, 768, device=DEV, requires_grad=True)       # 3 200 tokens: below the threshold
+    x = torch.randn(16, 50, 768, device=DEV, requires_grad=True)       # 800 tokens: below both thresholds
     with torch.autocast("cuda", dtype=torch.bfloat16), W.splitk_wgrad():
         y = lin(x)
         assert type(y.grad_fn).__name__ != "_AttachWGradBackward"
