@@ -6,8 +6,8 @@ import sys
 
 
 def family(n: str) -> str:
-    if 'gps_sa::' in n or 'gps::' in n or 'gps_attn::' in n or 'gps_loss::' in n or 'gps_ln::' in n:
-        return 'libgps_hip ' + re.sub(r'.*?(?:gps_sa::x3|gps_sa|gps_attn|gps_loss|gps_ln|gps)::(\w+).*', r'\1', n)
+    if any(t in n for t in ('gps_sa::', 'gps::', 'gps_attn::', 'gps_loss::', 'gps_ln::', 'gps_red::', 'gps_obj::')):
+        return 'libgps_hip ' + re.sub(r'.*?(?:gps_sa::x3|gps_sa|gps_attn|gps_loss|gps_ln|gps_red|gps_obj|gps)::(\w+).*', r'\1', n)
     if 'BatchNorm' in n: return 'MIOpen BatchNorm'
     if 'max_pool' in n: return 'max_pool'
     if n.startswith('Cijk') and '_SB_' in n: return 'fp32 GEMM (rocBLAS/hipBLASLt)'
