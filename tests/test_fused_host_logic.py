@@ -105,3 +105,64 @@ def test_seed_stream_never_repeats_and_keeps_saved_views_stable():
     # consecutive words differ by the stream increment modulo 2^64
     a, b = st.next(), st.next()
     assert (int(b.item()) - int(a.item())) % (1 << 64) == FA._SEED_INC
+
+
+def test_splitk_chunk_choice_and_routing_rules_on_cpu():
+    """Host logic of common/wgrad_splitk.py: chunk counts divide the token count, leave >= 512 tokens per
+    chunk, never exceed 16, small problems are left alone; on CPU tensors F.linear is never rerouted."""
+    import torch
+    import torch.nn.functional as F
+    from sceneverse_amd.common import wgrad_splitk as W
+    for tokens in (5120, 8320, 19200, 20000, 12345):
+        for n_out, n_in in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (2376, 768), (30522, 768)):
+            s = W.pick_splits(tokens, n_out, n_in)
+            assert 1 <= s <= 16 and tokens % s == 0 and (s == 1 or tokens // s >= 512)
+    assert W.pick_splits(19200, 768, 768) == 16 and W.pick_splits(19200, 3072, 768) == 4
+    assert W.pick_splits(4999, 768, 768) == 1 and W.pick_splits(19200, 768, 6) == 1
+    lin = torch.nn.Linear(16, 16)
+    x = torch.randn(6000, 16, requires_grad=True)
+    with W.splitk_wgrad():
+        assert F.linear is W._linear
+        y = lin(x)
+        assert type(y.grad_fn).__name__ != "_AttachWGradBackward"
+    assert F.linear is W._ORIG_LINEAR
+    with W.splitk_wgrad(False):
+        assert F.linear is W._ORIG_LINEAR
+
+
+def test_packed_scans_host_side_on_cpu():
+    """PackedScans / batch_rows (sceneverse_amd/data/gpu_objects.py) without a GPU: instances regrouped in
+    the loader's order with their own point order kept, empty instances skipped like `np.sum(mask) == 0`,
+    16-byte records carry the colours, the row table pads with -1 and honours obj_select."""
+    import numpy as np
+    import pytest
+    import torch
+    from sceneverse_amd.data import gpu_objects as G
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(50, 3)).astype(np.float32)
+    col = rng.integers(0, 256, size=(50, 3), dtype=np.uint8)
+    lab = rng.integers(0, 4, size=50)
+    for records in (True, False):
+        p = G.PackedScans("cpu", records=records)
+        p.add_scan("a", pts, col, lab, [2, 0, 7, 3])            # instance 7 has no points
+        p.add_scan("b", pts[:10], col[:10], lab[:10] * 0 + 5, [5])
+        p.finalize()
+        assert p.scan_inst_ids("a") == [2, 0, 3] and list(p.scan_objects("a")) == [0, 1, 2]
+        assert list(p.scan_objects("b")) == [3] and p.n_objects == 4
+        off = p.obj_offsets.numpy()
+        for o, inst in enumerate([2, 0, 3]):
+            sel = np.flatnonzero(lab == inst)
+            got = p.xyz.numpy()[off[o]:off[o + 1]]
+            assert np.array_equal(got[:, :3], pts[sel])
+            if records:
+                assert p.rgb is None and got.shape[1] == 4
+                assert np.array_equal(np.ascontiguousarray(got).view(np.uint8).reshape(-1, 16)[:, 12:15], col[sel])
+            else:
+                assert np.array_equal(p.rgb.numpy()[off[o]:off[o + 1]], col[sel])
+        rows = G.batch_rows(p, ["b", "a"], 4)
+        assert rows.dtype == torch.int32 and rows.tolist() == [[3, -1, -1, -1], [0, 1, 2, -1]]
+        assert G.batch_rows(p, ["a"], 2, obj_select=[[2, 0]]).tolist() == [[2, 0]]
+        with pytest.raises(ValueError):
+            G.batch_rows(p, ["a"], 2)
+        with pytest.raises(RuntimeError):                       # product path is GPU-only: no CPU fallback
+            G.obj_processing_post(p, rows, 64)

@@ -28,6 +28,8 @@ NAMES = [
     (r"add_dropout_ln_fwd_kernel", "add_dropout_layernorm_forward"),
     (r"attn_bwd_kernel", "attn_backward"),
     (r"attn_fwd_kernel", "attn_forward"),
+    (r"colsum_stage1_kernel", "colsum_bf16_stage1"),
+    (r"obj_processing_post_kernel", "obj_processing_post"),
     (r"group_points_kernel", "group_points"),
     (r"gather_points_kernel", "gather_points"),
 ]
@@ -41,7 +43,7 @@ def per_kernel(path, counter):
             if r.get("Counter_Name") != counter:
                 continue
             k = r["Kernel_Name"]
-            if "add_dropout_ln_" in k or "gps_attn::" in k:
+            if "add_dropout_ln_" in k or "gps_attn::" in k or "gps_red::" in k:
                 k = f"{k} grid={r.get('Grid_Size', '?')}"
             acc[k].append(float(r["Counter_Value"]))
     return acc

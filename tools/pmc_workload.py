@@ -72,6 +72,26 @@ def main():
         mask = torch.zeros(64, L, dtype=torch.bool, device=dev)
         for _ in range(3):
             _FusedSelfAttention.apply(packed, pl, mask, 12, 0.0, 0, None).float().sum().backward()
+    # bias-gradient column sums and the loader-side object kernel
+    import numpy as np
+    from sceneverse_amd.common import wgrad_splitk as WS
+    from sceneverse_amd.data import gpu_objects as G
+    for T, N in ((19200, 3072), (19200, 768), (8320, 2048)):
+        dy = torch.randn(T, N, device=dev).to(torch.bfloat16)
+        for _ in range(3):
+            WS.colsum_bf16(dy)
+    rng = np.random.default_rng(0)
+    scans = G.PackedScans(dev)
+    for s in range(16):
+        n = int(rng.integers(20, 80))
+        ks = np.exp(rng.uniform(np.log(50), np.log(20000), size=n)).astype(np.int64)
+        scans.add_scan(f"s{s}", rng.normal(size=(int(ks.sum()), 3)).astype(np.float32),
+                       rng.integers(0, 256, size=(int(ks.sum()), 3), dtype=np.uint8), np.repeat(np.arange(n), ks),
+                       list(range(n)))
+    scans.finalize()
+    slots = G.batch_rows(scans, [f"s{i % 16}" for i in range(64)], 80).to(dev)
+    for _ in range(3):
+        G.obj_processing_post(scans, slots, 1024, seed=1)
     torch.cuda.synchronize()
 
 
