@@ -172,6 +172,9 @@ def main() -> None:
     ap.add_argument("--no-splitk", action="store_true",
                     help="weight gradients of the big-token Linears as single library GEMMs (A/B of "
                          "sceneverse_amd/common/wgrad_splitk.py)")
+    ap.add_argument("--no-fused-emb", action="store_true",
+                    help="BERT word-table gradient through torch's sort-based embedding backward (A/B of "
+                         "modules/language/fused_embedding.py)")
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     args = ap.parse_args()
@@ -183,6 +186,9 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the GPS hot path has no CPU fallback")
+    if args.no_fused_emb:
+        from sceneverse_amd.modules.language import bert as _bert
+        _bert.set_fused_embedding(False)
     # GPS_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 and the collectives go over gloo, so
     # the N > 1 code path can be exercised end to end on a one-GPU box (RCCL refuses two ranks on one GPU)
     share = os.environ.get("GPS_BENCH_SHARE_GPU") == "1"

@@ -269,6 +269,16 @@ GPS_API int gps_colsum_parts(int rows, int cols);
 GPS_API int gps_colsum_bf16(int rows, int cols, const void *x, long long ld, float *partials, float *out,
                             gps_stream_t stream);
 
+/* ---- dense gradient of an embedding table -----------------------------------------------------------
+ * Replaces the backward of the word-embedding lookup of the language encoder (HF BertEmbeddings behind
+ * modules/language/bert.py:21-26; torch: sort + segment reduction + scatter).  ids (n) int64, dy (n, ld >= d)
+ * fp32, out (num_rows, d) fp32 = for every table row the sum of dy[t] over the tokens t with ids[t] == row
+ * (zero for rows never referenced and for row padding_idx; pass -1 for "no padding row"; ids outside
+ * [0, num_rows) are ignored).  Duplicates are added in ascending token order: the result is deterministic.
+ * scratch: 2 * num_rows int32.  d and ld multiples of 4, d <= 2048, dy / out 16-byte aligned. */
+GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, const float *dy, long long ld,
+                               long long padding_idx, int32_t *scratch, float *out, gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

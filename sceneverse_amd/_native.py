@@ -41,6 +41,7 @@ SIGNATURES = {
     "gps_sa_mlp_forward_bf16x3": [_i] * 8 + [_vp] * 7,
     "gps_obj_processing_post": [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp],
+    "gps_embedding_grad": [_i, _i, _i, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_colsum_parts": [_i, _i],
     "gps_colsum_bf16": [_i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_masked_ce_forward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],

@@ -20,6 +20,7 @@ SOURCES = [
     ("gps_layernorm.hip", []),
     ("gps_objects.hip", []),
     ("gps_reduce.hip", []),
+    ("gps_embedding.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-I" + os.path.join(ROOT, "include")]

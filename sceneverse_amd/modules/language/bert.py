@@ -17,11 +17,18 @@ from ..build import LANGUAGE_REGISTRY
 # Same mathematics as transformers.models.bert.modeling_bert.BertLayer (post-norm, exact GELU,
 # key-padding mask from the attention mask, dropout on probabilities and on both branches).
 _FAST = True
+_FAST_EMB = True
 
 
 def set_fast_bert(flag: bool) -> None:
     global _FAST
     _FAST = bool(flag)
+
+
+def set_fused_embedding(flag: bool) -> None:
+    """Word-table gradient through libgps_hip.so (fused_embedding.py) inside the fast path; off = HF module."""
+    global _FAST_EMB
+    _FAST_EMB = bool(flag)
 
 
 @LANGUAGE_REGISTRY.register()
@@ -52,8 +59,12 @@ class BERTLanguageEncoder(nn.Module):
     def _fast_forward(self, txt_ids, txt_masks):
         from ..layers.fused_attention import fused_self_attention, supported as attn_supported
         from ..layers.fused_norm import add_dropout_layer_norm
+        from . import fused_embedding
         m, H = self.model, self.bert_config.num_attention_heads
-        x = m.embeddings(input_ids=txt_ids)                     # (B, L, D) fp32 under autocast
+        if _FAST_EMB and fused_embedding.supported(m.embeddings, txt_ids):
+            x = fused_embedding.bert_embeddings(m.embeddings, txt_ids)      # same values, sort-free backward
+        else:
+            x = m.embeddings(input_ids=txt_ids)                 # (B, L, D) fp32 under autocast
         x16 = x                                                 # bf16 copy of x once a fused LN made one
         B, L, D = x.shape
         pad = txt_masks == 0

@@ -51,6 +51,12 @@ def test_argument_validation_without_gpu():
     assert lib.gps_add_dropout_layernorm_forward(0, 768, 0, 1, None, None, None, None, 1e-5, 0.0, 0, None, None,
                                                  None, None, None, None) == 0
     assert lib.gps_ln_partial_rows(8320) == 1024 and lib.gps_ln_partial_rows(5) == 2
+    # gps_embedding_grad(n, d, num_rows, ids, dy, ld, padding_idx, scratch, out, stream)
+    assert lib.gps_embedding_grad(4, 768, 0, None, None, 768, -1, None, None, None) == 0
+    assert lib.gps_embedding_grad(4, 770, 10, 1, 16, 772, -1, 1, 16, None) == -2    # d not a multiple of 4
+    assert lib.gps_embedding_grad(4, 4096, 10, 1, 16, 4096, -1, 1, 16, None) == -2  # d > 2048
+    assert lib.gps_embedding_grad(4, 768, 10, 1, 16, 100, -1, 1, 16, None) == -1    # ld < d
+    assert lib.gps_embedding_grad(-1, 768, 10, 1, 16, 768, -1, 1, 16, None) == -1
     assert lib.gps_colsum_bf16(4, 768, 1, 100, 1, 1, None) == -1                   # ld < cols
     assert lib.gps_colsum_bf16(4, 100, 16, 104, 1, 1, None) == -2                  # cols not a multiple of 8
     assert lib.gps_colsum_bf16(4, 0, None, 0, None, None, None) == 0
