@@ -52,22 +52,33 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(int n, int d, int num_rows,
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   int found = 1;
-  for (int base = t + 1; base < n && found < want; base += 64) {
-    const int tt = base + lane;
-    const bool match = tt < n && ids[tt] == id;
-    unsigned long long mask = __ballot(match);
-    while (mask) {                                                        // ascending token order
-      const int row = base + (__ffsll((long long)mask) - 1);
-      mask &= mask - 1ull;
+  // ids are scanned kAhead x 64 at a time: the loads of one trip are independent, so an id that occurs
+  // across the whole batch ([CLS], [SEP]) costs n / (64 * kAhead) memory round trips, not n / 64
+  constexpr int kAhead = 8;
+  for (int base = t + 1; base < n && found < want; base += 64 * kAhead) {
+    unsigned long long masks[kAhead];
 #pragma unroll
-      for (int c = 0; c < kMaxChunks; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (c < chunks && col < d) {
-          const float4 v = *reinterpret_cast<const float4 *>(dy + (size_t)row * ld + col);
-          acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+    for (int u = 0; u < kAhead; ++u) {
+      const int tt = base + u * 64 + lane;
+      const bool match = tt < n && ids[tt] == id;
+      masks[u] = __ballot(match);
+    }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      unsigned long long mask = masks[u];
+      while (mask) {                                                      // ascending token order
+        const int row = base + u * 64 + (__ffsll((long long)mask) - 1);
+        mask &= mask - 1ull;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (c < chunks && col < d) {
+            const float4 v = *reinterpret_cast<const float4 *>(dy + (size_t)row * ld + col);
+            acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+          }
         }
+        ++found;
       }
-      ++found;
     }
   }
 #pragma unroll
