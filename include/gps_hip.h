@@ -279,6 +279,65 @@ GPS_API int gps_colsum_bf16(int rows, int cols, const void *x, long long ld, flo
 GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, const float *dy, long long ld,
                                long long padding_idx, int32_t *scratch, float *out, gps_stream_t stream);
 
+/* ---- bf16 MFMA GEMMs of the transformer projections / FFNs -------------------------------------------
+ * Replaces the nn.Linear contractions of the GPS transformer layers -- w_qs / w_ks / w_vs / fc / lang_cond_fc
+ * (modules/layers/transformers.py:173-186, 193-197), nn.MultiheadAttention's in/out projections (:120-121, 141)
+ * and the FFNs (:123-125, 148-152, 301-316) -- forward, input gradient and weight gradient, with the bias,
+ * activation, dropout and activation-derivative steps the reference runs as separate elementwise kernels
+ * applied in the epilogue.  bf16 operands, fp32 accumulation (v_mfma_f32_16x16x32_bf16).
+ *
+ *   form GPS_GEMM_NT  C (M,N) = A (M,K) . B (N,K)^T      A, B K-major (lda, ldb = row pitches in elements)
+ *   form GPS_GEMM_NN  C (M,N) = A (M,K) . B (K,N)        B reduction-major
+ *   form GPS_GEMM_TN  C (M,N) = A (K,M)^T . B (K,N)      both reduction-major; C fp32; K may be split
+ *
+ * epilogue (C is bf16 unless stated):
+ *   GPS_GEMM_EPI_BIAS       C = acc + bias                                   (bias (N) fp32, may be NULL)
+ *   GPS_GEMM_EPI_BIAS_GELU  pre = bf16(acc + bias) -> aux_out (if not NULL); C = dropout(gelu(pre))   (erf GELU)
+ *   GPS_GEMM_EPI_BIAS_RELU  C = dropout(relu(acc + bias))
+ *   GPS_GEMM_EPI_DGELU      C = acc * gelu'(aux) * dropout-mask              (aux (M,N) bf16 = saved pre)
+ *   GPS_GEMM_EPI_DRELU      C = acc * (aux != 0 ? 1/(1-p) : 0)               (aux (M,N) bf16 = saved dropout(relu()))
+ *   GPS_GEMM_EPI_F32        C fp32 = acc; form TN only.  With colsum != NULL also colsum (M) fp32 = column sums of
+ *                           A over K (the bias gradient when A = dY).
+ * dropout: keep an element iff rng(seed + *seed_dev, m * N + n) >= p * 2^32, scale kept ones by 1/(1-p); the mask
+ *   of GPS_GEMM_EPI_DGELU is recomputed from the same (seed, index), nothing is stored.  p_drop = 0: none.
+ * splits (TN only): K is cut into `splits` ranges whose fp32 partial tiles go to `workspace`
+ *   (gps_gemm_workspace_floats() floats) and are summed in split order by a second launch (deterministic);
+ *   gps_gemm_pick_splits() gives the default.  variant: tile configuration 0..3, or -1 = chosen from the shape.
+ * Requirements (else GPS_ERR_UNSUPPORTED): lda, ldb, K multiples of 8; N, ldc, ldaux multiples of 4; for
+ *   reduction-major operands their column count (N, and M in form TN) a multiple of 8; A, B, C, bias 16-byte aligned. */
+#define GPS_GEMM_NT 0
+#define GPS_GEMM_NN 1
+#define GPS_GEMM_TN 2
+#define GPS_GEMM_EPI_BIAS 0
+#define GPS_GEMM_EPI_BIAS_GELU 1
+#define GPS_GEMM_EPI_BIAS_RELU 2
+#define GPS_GEMM_EPI_DGELU 3
+#define GPS_GEMM_EPI_DRELU 4
+#define GPS_GEMM_EPI_F32 5
+typedef struct gps_gemm_args {
+  int form, epilogue, M, N, K, splits, variant, reserved;
+  const void *A;
+  long long lda;
+  const void *B;
+  long long ldb;
+  void *C;
+  long long ldc;
+  const float *bias;
+  const void *aux;
+  long long ldaux;
+  void *aux_out;
+  long long ldaux_out;
+  float *workspace;
+  float *colsum;
+  const void *seed_dev; /* optional device uint64 added to `seed` (HIP-graph replays advance it on the device) */
+  unsigned long long seed;
+  float p_drop;
+  int reserved2;
+} gps_gemm_args;
+GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
+GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
+GPS_API int gps_gemm_bf16(const gps_gemm_args *args, gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

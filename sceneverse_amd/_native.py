@@ -23,8 +23,26 @@ _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 
+
+
+class GemmArgs(ctypes.Structure):
+    """struct gps_gemm_args of include/gps_hip.h, field for field."""
+    _fields_ = [("form", _i), ("epilogue", _i), ("M", _i), ("N", _i), ("K", _i), ("splits", _i), ("variant", _i),
+                ("reserved", _i),
+                ("A", _vp), ("lda", ctypes.c_longlong), ("B", _vp), ("ldb", ctypes.c_longlong),
+                ("C", _vp), ("ldc", ctypes.c_longlong), ("bias", _vp),
+                ("aux", _vp), ("ldaux", ctypes.c_longlong), ("aux_out", _vp), ("ldaux_out", ctypes.c_longlong),
+                ("workspace", _vp), ("colsum", _vp), ("seed_dev", _vp), ("seed", ctypes.c_ulonglong),
+                ("p_drop", _f), ("reserved2", _i)]
+
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32 = 0, 1, 2, 3, 4, 5
+
 # name -> argtypes, mirroring include/gps_hip.h one to one
 SIGNATURES = {
+    "gps_gemm_pick_splits": [_i, _i, _i, _i],
+    "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -90,6 +108,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_sa_mlp_layer_floats.argtypes = [_i, _i]
     lib.gps_sa_mlp_layer_floats_bf16x3.restype = ctypes.c_longlong
     lib.gps_sa_mlp_layer_floats_bf16x3.argtypes = [_i, _i]
+    lib.gps_gemm_workspace_floats.restype = ctypes.c_longlong
+    lib.gps_gemm_workspace_floats.argtypes = [_i, _i, _i, _i]
     lib.gps_ln_partial_rows.restype = _i
     lib.gps_ln_partial_rows.argtypes = [_i]
     for name, argtypes in SIGNATURES.items():

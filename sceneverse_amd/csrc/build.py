@@ -21,6 +21,7 @@ SOURCES = [
     ("gps_objects.hip", []),
     ("gps_reduce.hip", []),
     ("gps_embedding.hip", []),
+    ("gps_gemm.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-I" + os.path.join(ROOT, "include")]
@@ -44,24 +45,43 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile + link under an exclusive file lock and publish the library with an atomic rename: when the N
+    ranks of a torchrun job reach their first native call together, one of them builds, the others wait on the
+    lock and then find an up-to-date library (never a half-written one)."""
     if not force and not needs_build():
         return LIB
-    cc = hipcc()
-    objs = []
-    for src, extra in SOURCES:
-        path = os.path.join(HERE, src)
-        if not os.path.exists(path):
-            continue
-        obj = os.path.join(HERE, src.rsplit(".", 1)[0] + ".o")
-        cmd = [cc, *COMMON, *extra, "-c", path, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    import fcntl
+    from concurrent.futures import ThreadPoolExecutor
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():        # another process built it while we waited
+                return LIB
+            cc = hipcc()
+            jobs = []
+            for src, extra in SOURCES:
+                path = os.path.join(HERE, src)
+                if not os.path.exists(path):
+                    continue
+                obj = os.path.join(HERE, src.rsplit(".", 1)[0] + ".o")
+                jobs.append(([cc, *COMMON, *extra, "-c", path, "-o", obj], obj))
+
+            def run(job):
+                if verbose:
+                    print(" ".join(job[0]))
+                subprocess.check_call(job[0])
+                return job[1]
+
+            with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(run, jobs))
+            tmp = f"{LIB}.tmp.{os.getpid()}"
+            cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -1,0 +1,535 @@
+// gps_gemm.hip -- hand-written bf16 MFMA GEMMs for the projection / FFN layers of the GPS transformers on
+// MI355X (gfx950): every contraction of
+//     MultiHeadAttentionSpatial  w_qs / w_ks / w_vs / lang_cond_fc / fc   modules/layers/transformers.py:173-186,193-197
+//     nn.MultiheadAttention      in_proj / out_proj                        modules/layers/transformers.py:120-121,141
+//     FFN linear1 / linear2 (+ GELU / ReLU, dropout)                       modules/layers/transformers.py:123-125,148-152,301-316
+// in the three operand orders a training step needs, as ONE kernel template:
+//
+//     form NT   Y  (M x N) = X (M x K) . W (N x K)^T   forward            both operands K-major
+//     form NN   dX (M x N) = dY (M x K) . W (K x N)    input gradient     B reduction-major  (ds_read_b64_tr_b16)
+//     form TN   dW (M x N) = dY (K x M)^T . X (K x N)  weight gradient    both reduction-major, split over K
+//                                                                          (K = tokens), fp32 out, bias gradient
+//                                                                          (column sums of dY) from the same tiles
+//
+// bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16.  Structure of a workgroup (4 or 8 waves):
+//   * BM x BN output tile, BK = 64 per stage, every operand stage copied global -> LDS by global_load_lds_dwordx4
+//     (no VGPR round trip), two or three stage buffers, ONE workgroup barrier per stage;
+//   * the LDS images are swizzled through the per-lane SOURCE address (gps_gemm_layout.h): K-major fragments are
+//     conflict-free ds_read_b128, reduction-major ones conflict-free hardware-transposed reads, so
+//     no operand is ever transposed by stores and the weight never needs a transposed copy in HBM;
+//   * the MFMA is issued with the operands swapped (D = B-frag x A-frag), so a lane ends up with FOUR CONSECUTIVE
+//     output columns of one row: 8-byte bf16 / 16-byte fp32 stores, bias / activation / dropout applied in registers;
+//   * out-of-range rows, columns and the K tail read a 64-byte block of zeros instead of being predicated;
+//   * block id -> tile map keeps the tiles of one XCD (block id mod 8) contiguous in (split, tile_m, tile_n).
+// Epilogues: bias | bias + GELU (+ dropout, also stores the pre-activation) | bias + ReLU (+ dropout) |
+//            x GELU'(pre) x dropout-mask | x ReLU'(h) | fp32 (partial) sums + column sums.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gps_gemm_layout.h"
+#include "gps_hip.h"
+
+namespace gps_gemm {
+
+using namespace gps_gemm_layout;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __attribute__((aligned(64))) const unsigned int g_zero_block[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+enum Epi : int {
+  EPI_BIAS = 0,        // C bf16 = acc + bias
+  EPI_BIAS_GELU = 1,   // aux_out bf16 = pre = acc + bias; C bf16 = dropout(gelu(bf16(pre)))
+  EPI_BIAS_RELU = 2,   // C bf16 = dropout(relu(acc + bias))
+  EPI_DGELU = 3,       // C bf16 = acc * gelu'(aux) * dropout-mask(idx)          (aux = saved pre-activation)
+  EPI_DRELU = 4,       // C bf16 = acc * (aux != 0 ? keep_scale : 0)              (aux = saved FFN hidden)
+  EPI_F32 = 5,         // C fp32 = acc (splits == 1) or partial[split] = acc; optional column sums of A
+};
+
+struct Params {
+  int M, N, K;
+  const uint16_t *A;
+  long long lda;
+  const uint16_t *B;
+  long long ldb;
+  void *C;
+  long long ldc;
+  const float *bias;
+  const uint16_t *aux;
+  long long ldaux;
+  uint16_t *aux_out;
+  long long ldaux_out;
+  float *partial;          // EPI_F32, splits > 1: (splits, M, N)
+  float *colsum;           // EPI_F32: (splits, M) partial column sums of A over k (or (M) when splits == 1), or null
+  int splits, kt_per_split, nkt;
+  int ntm, ntn;
+  float keep_scale;
+  unsigned int drop_thr;
+  unsigned long long seed;
+  const unsigned long long *seed_dev;
+};
+
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even (finite inputs)
+  unsigned int u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((unsigned int)h << 16); }
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+// counter-based dropout RNG shared with gps_layernorm.hip / gps_attention.hip (splitmix64 finaliser)
+__device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned int)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ void glds16(const void *src, void *lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-operand staging state: one 64-bit source pointer per piece this wave copies, a validity bit per piece
+// (rows / columns outside the matrix read the zero block and never advance)
+// ---------------------------------------------------------------------------------------------------------
+template <int ROWS, bool RM, int NW>
+struct Stager {
+  static constexpr int NPIECE = ROWS / 8 / NW;      // pieces per wave and stage (tile = ROWS x 64 bf16 = ROWS / 8 KiB)
+  static_assert(ROWS % (8 * NW) == 0, "tile rows must split evenly over the waves");
+  unsigned long long ptr[NPIECE];                   // source address of this lane's 16 bytes (zero block if outside)
+  unsigned int valid;                               // bit j: piece j of this lane lies inside the matrix
+  unsigned int kidx[NPIECE];                        // RM: k row inside the stage; KM: first k of the chunk
+  unsigned int step;                                // bytes one stage advances the source
+
+  // mat: K-major  -> element (r, k) at mat[r * ld + k], r in [0, rows): tile rows r0 .. r0 + ROWS - 1
+  //      red-major -> element (k, c) at mat[k * ld + c], c in [0, rows): tile columns r0 .. r0 + ROWS - 1
+  __device__ __forceinline__ void init(const uint16_t *mat, long long ld, int rows, int r0, int k_begin, int wave,
+                                       int lane) {
+    const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_block;
+    valid = 0u;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int q = j * NW + wave;
+      bool ok;
+      const uint16_t *src;
+      if (!RM) {
+        int row, chunk;
+        km_stage_src(q, lane, row, chunk);
+        ok = r0 + row < rows;
+        kidx[j] = 8u * chunk;
+        src = mat + (size_t)(ok ? r0 + row : 0) * ld + k_begin + 8 * chunk;
+      } else {
+        int k, chunk;
+        rm_stage_src<ROWS>(q, lane, k, chunk);
+        ok = r0 + 8 * chunk < rows;
+        kidx[j] = (unsigned int)k;
+        src = mat + (size_t)(k_begin + k) * ld + (ok ? r0 + 8 * chunk : 0);
+      }
+      const unsigned long long full = ok ? ~0ull : 0ull;
+      ptr[j] = zero + (((unsigned long long)(uintptr_t)src - zero) & full);
+      valid |= ok ? (1u << j) : 0u;
+    }
+    step = RM ? (unsigned int)(BK * ld * 2) : (unsigned int)(BK * 2);
+  }
+  // copy one stage into `tile` (LDS, ROWS * 128 bytes); k_left = reduction indices still inside the matrix
+  // (>= 64 for every stage but a ragged last one).  Branch-free: invalid lanes point at the zero block and stay.
+  template <bool TAIL>
+  __device__ __forceinline__ void issue(unsigned char *tile, int k_left, int wave) {
+    const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_block;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      unsigned long long p = ptr[j];
+      if (TAIL) {
+        const unsigned long long full = ((int)kidx[j] < k_left) ? ~0ull : 0ull;
+        p = zero + ((p - zero) & full);
+      }
+      glds16(reinterpret_cast<const void *>((uintptr_t)p), tile + (j * NW + wave) * PIECE);
+      ptr[j] += (unsigned long long)((0u - ((valid >> j) & 1u)) & step);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// fragment reads (lane (i, g): element order of gps_gemm_layout.h)
+// ---------------------------------------------------------------------------------------------------------
+template <int ROWS, bool RM>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char *tile, int r0, int ks, int lane) {
+  if (RM) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(tile + rm_frag<ROWS>(r0, ks, lane, 0)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(tile + rm_frag<ROWS>(r0, ks, lane, 1)));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + km_frag(r0 + (lane & 15), ks, lane >> 4));
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF>
+__global__ __launch_bounds__(WGM *WGN * 64, (WGM * WGN == 4 && NBUF != 2) ? 1 : 2) void gemm_kernel(const Params P) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF * STAGE
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+
+  // block -> (split, tile_m, tile_n); tile_n fastest so that the tiles of one XCD share A row panels
+  const int ntiles = P.ntm * P.ntn;
+  const int vid = xcd_virtual_id(blockIdx.x, ntiles * P.splits);
+  const int split = vid / ntiles, tile = vid - split * ntiles;
+  const int tile_m = tile / P.ntn, tile_n = tile - tile_m * P.ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt0 = split * P.kt_per_split;
+  const int kt1 = min(P.nkt, kt0 + P.kt_per_split);
+
+  Stager<BM, ATR, NW> sa;
+  Stager<BN, BTR, NW> sb;
+  sa.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
+  sb.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient of the TN form: column sums of A over k via an all-ones operand (wave column 0 of tile_n 0)
+  const bool do_colsum = (EPI == EPI_F32) && P.colsum != nullptr && tile_n == 0 && wn0 == 0;
+  f32x4 csum[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) csum[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // 8 x bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+  auto issue_stage = [&](int buf, int kt) {
+    unsigned char *base = smem + buf * STAGE;
+    const int k_left = P.K - kt * BK;
+    if (k_left >= BK) {
+      sa.template issue<false>(base, k_left, wave);
+      sb.template issue<false>(base + A_BYTES, k_left, wave);
+    } else {
+      sa.template issue<true>(base, k_left, wave);
+      sb.template issue<true>(base + A_BYTES, k_left, wave);
+    }
+  };
+  auto compute_stage = [&](int buf) {
+    const unsigned char *As = smem + buf * STAGE;
+    const unsigned char *Bs = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = read_frag<BM, ATR>(As, wm0 + 16 * a, ks, lane);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = read_frag<BN, BTR>(Bs, wn0 + 16 * b, ks, lane);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[a], acc[a][b], 0, 0, 0);
+      if (EPI == EPI_F32) {
+        if (do_colsum) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) csum[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], csum[a], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  if (kt0 < kt1) {
+    if (NBUF == 2) {
+      issue_stage(0, kt0);
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // stage kt visible to all waves; everyone is done with stage kt - 1
+        if (kt + 1 < kt1) issue_stage(cur ^ 1, kt + 1);
+        compute_stage(cur);
+      }
+    } else {
+      // three buffers: the copy of stage kt + 2 is issued while kt is computed, stage kt + 1 stays in flight
+      // across the barrier (counted vmcnt + raw s_barrier: __syncthreads() would drain it, guide section 5)
+      constexpr int NP = Stager<BM, ATR, NW>::NPIECE + Stager<BN, BTR, NW>::NPIECE;
+      static_assert(NP == 4 || NP == 6 || NP == 8, "extend the vmcnt table");
+      issue_stage(0, kt0);
+      if (kt0 + 1 < kt1) issue_stage(1, kt0 + 1);
+      int cur = 0;
+      for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) {
+          if (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          if (NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          if (NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < kt1) issue_stage(cur == 0 ? 2 : cur - 1, kt + 2);     // the buffer stage kt - 1 occupied
+        compute_stage(cur);
+        cur = (cur == 2) ? 0 : cur + 1;
+      }
+    }
+  }
+
+  // ---- epilogue: lane (i, g) holds C[m0 + wm0 + 16 a + i][n0 + wn0 + 16 b + 4 g + 0..3] ---------------------------
+  const int i = lane & 15, g = lane >> 4;
+  if (EPI == EPI_F32) {
+    float *out = (P.splits > 1) ? P.partial + (size_t)split * P.M * P.N : reinterpret_cast<float *>(P.C);
+    const long long ldo = (P.splits > 1) ? (long long)P.N : P.ldc;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int m = m0 + wm0 + 16 * a + i;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn0 + 16 * b + 4 * g;
+        if (m < P.M && n < P.N) *reinterpret_cast<f32x4 *>(out + (size_t)m * ldo + n) = acc[a][b];
+      }
+      if (do_colsum && g == 0 && m < P.M) P.colsum[(size_t)split * P.M + m] = csum[a][0];
+    }
+    return;
+  }
+  const bool dropout = P.drop_thr != 0u;
+  const unsigned long long seed = dropout ? P.seed + (P.seed_dev ? *P.seed_dev : 0ull) : 0ull;
+  uint16_t *C = reinterpret_cast<uint16_t *>(P.C);
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + wn0 + 16 * b + 4 * g;
+    if (n >= P.N) continue;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) && P.bias)
+      bias = *reinterpret_cast<const f32x4 *>(P.bias + n);
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int m = m0 + wm0 + 16 * a + i;
+      if (m >= P.M) continue;
+      f32x4 v = acc[a][b] + bias;
+      const unsigned long long idx = (unsigned long long)m * (unsigned long long)P.N + (unsigned long long)n;
+      if (EPI == EPI_BIAS_GELU) {
+        const u32x2 pre = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+        if (P.aux_out) *reinterpret_cast<u32x2 *>(P.aux_out + (size_t)m * P.ldaux_out + n) = pre;
+        v[0] = gelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
+        v[1] = gelu_f(bf2f((uint16_t)(pre[0] >> 16)));
+        v[2] = gelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
+        v[3] = gelu_f(bf2f((uint16_t)(pre[1] >> 16)));
+      } else if (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (EPI == EPI_DGELU) {
+        const u32x2 pre = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
+        v[0] *= dgelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
+        v[1] *= dgelu_f(bf2f((uint16_t)(pre[0] >> 16)));
+        v[2] *= dgelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
+        v[3] *= dgelu_f(bf2f((uint16_t)(pre[1] >> 16)));
+      } else if (EPI == EPI_DRELU) {
+        const u32x2 h = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
+        v[0] = (h[0] & 0x7FFFu) ? v[0] * P.keep_scale : 0.f;
+        v[1] = (h[0] & 0x7FFF0000u) ? v[1] * P.keep_scale : 0.f;
+        v[2] = (h[1] & 0x7FFFu) ? v[2] * P.keep_scale : 0.f;
+        v[3] = (h[1] & 0x7FFF0000u) ? v[3] * P.keep_scale : 0.f;
+      }
+      if (dropout && (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_DGELU)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rng_u32(seed, idx + r) >= P.drop_thr ? v[r] * P.keep_scale : 0.f;
+      }
+      const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+      *reinterpret_cast<u32x2 *>(C + (size_t)m * P.ldc + n) = o;
+    }
+  }
+}
+
+// out[e] = sum over splits of partial[s][e] in split order (deterministic); the same for the column sums
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long long elems, const float *__restrict__ partial,
+                                                           float *__restrict__ out, long long ldo, int ncols,
+                                                           int m_rows, const float *__restrict__ colsum_partial,
+                                                           float *__restrict__ colsum_out, int main_blocks) {
+  if ((int)blockIdx.x < main_blocks) {
+    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= elems) return;
+    f32x4 s = *reinterpret_cast<const f32x4 *>(partial + e);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(partial + (size_t)k * elems + e);
+    const long long r = e / ncols, c = e - r * ncols;
+    *reinterpret_cast<f32x4 *>(out + r * ldo + c) = s;
+  } else {
+    const int m = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (m >= m_rows) return;
+    float s = colsum_partial[m];
+    for (int k = 1; k < splits; ++k) s += colsum_partial[(size_t)k * m_rows + m];
+    colsum_out[m] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF>
+int launch_cfg(Params &P, hipStream_t s) {
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int LDS = NBUF * STAGE;
+  static_assert(LDS <= 160 * 1024, "stage buffers exceed the LDS of a CU");
+  static_assert(!ATR || BM >= 64, "reduction-major A needs a tile of at least 64 columns");
+  P.ntm = (P.M + BM - 1) / BM;
+  P.ntn = (P.N + BN - 1) / BN;
+  auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF>;
+  static bool attr_done = false;
+  if (LDS > 64 * 1024 && !attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return GPS_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const long long blocks = (long long)P.ntm * P.ntn * P.splits;
+  if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WGM * WGN * 64), LDS, s, P);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+// tile configurations ("variants"): 0 = 128x128 / 4 waves / 2 buffers (2 workgroups per CU),
+// 1 = 256x128 / 8 waves / 2 buffers, 2 = 128x128 / 4 waves / 3 buffers (counted vmcnt), 3 = 128x64 / 4 waves / 2 buffers
+constexpr int kVariants = 4;
+template <bool ATR, bool BTR, int EPI>
+int launch_variant(Params &P, int variant, hipStream_t s) {
+  switch (variant) {
+    case 0: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);
+    case 1: return launch_cfg<256, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+    case 2: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 3>(P, s);
+    case 3: return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 2>(P, s);
+    default: return GPS_ERR_INVALID_ARGUMENT;
+  }
+}
+
+inline int tile_m_of(int variant) { return variant == 1 ? 256 : 128; }
+inline int tile_n_of(int variant) { return variant == 3 ? 64 : 128; }
+
+// default variant: the largest tile that still gives every CU about two workgroups' worth of tiles
+inline int pick_variant(int M, int N, int splits) {
+  auto tiles = [&](int v) {
+    return (long long)((M + tile_m_of(v) - 1) / tile_m_of(v)) * ((N + tile_n_of(v) - 1) / tile_n_of(v)) * splits;
+  };
+  if (tiles(1) >= 2 * 256) return 1;
+  if (tiles(0) >= 256) return 0;
+  return 3;
+}
+
+}  // namespace gps_gemm
+
+extern "C" {
+
+int gps_gemm_pick_splits(int form, int M, int N, int K) {
+  if (form != GPS_GEMM_TN) return 1;
+  // weight gradient: M x N is small (a few dozen 128 x 128 tiles), K = tokens is long.  Split K so that the grid
+  // is about two workgroups per CU, every split keeps >= 8 stages, at most 32 splits.
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const int nkt = (K + 63) / 64;
+  int s = (int)((512 + tiles - 1) / tiles);
+  if (s > 32) s = 32;
+  if (s > nkt / 8) s = nkt / 8;
+  return s < 1 ? 1 : s;
+}
+
+long long gps_gemm_workspace_floats(int form, int M, int N, int splits) {
+  if (form != GPS_GEMM_TN || splits <= 1) return 0;
+  return (long long)splits * ((long long)M * N + M);
+}
+
+int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
+  using namespace gps_gemm;
+  if (!a || a->M < 0 || a->N < 0 || a->K < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->form < 0 || a->form > 2 || a->epilogue < 0 || a->epilogue > 5) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->M == 0 || a->N == 0) return GPS_OK;
+  if (!a->A || !a->B || !a->C) return GPS_ERR_INVALID_ARGUMENT;
+  // 16-byte global chunks and 8 / 16-byte stores: leading dimensions in multiples of 8 elements, N of 4, K of 8
+  if ((a->lda & 7) || (a->ldb & 7) || (a->K & 7) || (a->N & 3)) return GPS_ERR_UNSUPPORTED;
+  if (((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15)) return GPS_ERR_UNSUPPORTED;
+  const bool f32out = a->epilogue == GPS_GEMM_EPI_F32;
+  if (f32out != (a->form == GPS_GEMM_TN)) return GPS_ERR_UNSUPPORTED;       // fp32 sums <=> weight-gradient form
+  if (a->ldc & 3) return GPS_ERR_UNSUPPORTED;
+  if (a->form == GPS_GEMM_TN && (a->M & 7)) return GPS_ERR_UNSUPPORTED;     // A is M-contiguous there
+  if (a->form != GPS_GEMM_NT && (a->N & 7)) return GPS_ERR_UNSUPPORTED;     // B is N-contiguous there
+  if ((a->epilogue == GPS_GEMM_EPI_DGELU || a->epilogue == GPS_GEMM_EPI_DRELU) && (!a->aux || (a->ldaux & 3)))
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (a->aux_out && (a->ldaux_out & 3)) return GPS_ERR_UNSUPPORTED;
+  if (a->p_drop < 0.f || a->p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->bias && ((uintptr_t)a->bias & 15)) return GPS_ERR_UNSUPPORTED;
+
+  Params P = {};
+  P.M = a->M; P.N = a->N; P.K = a->K;
+  P.A = (const uint16_t *)a->A; P.lda = a->lda;
+  P.B = (const uint16_t *)a->B; P.ldb = a->ldb;
+  P.C = a->C; P.ldc = a->ldc;
+  P.bias = a->bias;
+  P.aux = (const uint16_t *)a->aux; P.ldaux = a->ldaux;
+  P.aux_out = (uint16_t *)a->aux_out; P.ldaux_out = a->ldaux_out;
+  P.nkt = (a->K + BK - 1) / BK;
+  P.splits = 1;
+  if (a->form == GPS_GEMM_TN && a->splits > 1) P.splits = a->splits < P.nkt ? a->splits : (P.nkt > 0 ? P.nkt : 1);
+  P.kt_per_split = (P.nkt + P.splits - 1) / P.splits;
+  P.splits = P.kt_per_split > 0 ? (P.nkt + P.kt_per_split - 1) / P.kt_per_split : 1;   // no empty split
+  if (P.splits < 1) P.splits = 1;
+  P.keep_scale = a->p_drop > 0.f ? 1.f / (1.f - a->p_drop) : 1.f;
+  P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
+  P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->K == 0) P.nkt = 0;
+
+  int variant = a->variant;
+  if (variant < 0) variant = pick_variant(a->M, a->N, P.splits);
+  if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->form == GPS_GEMM_TN && variant == 3) variant = 0;      // reduction-major tiles are at least 128 wide
+
+  int st;
+  if (a->form == GPS_GEMM_NT) {
+    switch (a->epilogue) {
+      case GPS_GEMM_EPI_BIAS: st = launch_variant<false, false, EPI_BIAS>(P, variant, s); break;
+      case GPS_GEMM_EPI_BIAS_GELU: st = launch_variant<false, false, EPI_BIAS_GELU>(P, variant, s); break;
+      case GPS_GEMM_EPI_BIAS_RELU: st = launch_variant<false, false, EPI_BIAS_RELU>(P, variant, s); break;
+      default: return GPS_ERR_UNSUPPORTED;
+    }
+  } else if (a->form == GPS_GEMM_NN) {
+    switch (a->epilogue) {
+      case GPS_GEMM_EPI_BIAS: st = launch_variant<false, true, EPI_BIAS>(P, variant, s); break;
+      case GPS_GEMM_EPI_DGELU: st = launch_variant<false, true, EPI_DGELU>(P, variant, s); break;
+      case GPS_GEMM_EPI_DRELU: st = launch_variant<false, true, EPI_DRELU>(P, variant, s); break;
+      default: return GPS_ERR_UNSUPPORTED;
+    }
+  } else {
+    if (P.splits > 1) {
+      if (!a->workspace) return GPS_ERR_INVALID_ARGUMENT;
+      P.partial = a->workspace;
+      P.colsum = a->colsum ? a->workspace + (size_t)P.splits * a->M * a->N : nullptr;
+    } else {
+      P.colsum = a->colsum;
+    }
+    st = launch_variant<true, true, EPI_F32>(P, variant, s);
+    if (st == GPS_OK && P.splits > 1) {
+      const long long elems = (long long)a->M * a->N;
+      const int main_blocks = (int)((elems / 4 + 255) / 256);
+      const int cs_blocks = a->colsum ? (a->M + 255) / 256 : 0;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(main_blocks + cs_blocks), dim3(256), 0, s, P.splits, elems, P.partial,
+                         reinterpret_cast<float *>(a->C), a->ldc, a->N, a->M, P.colsum, a->colsum, main_blocks);
+      st = hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+    }
+  }
+  return st;
+}
+
+}  // extern "C"

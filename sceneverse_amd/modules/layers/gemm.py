@@ -1,0 +1,323 @@
+"""Host side of libgps_hip.so's bf16 MFMA GEMMs (include/gps_hip.h gps_gemm_bf16): the nn.Linear
+contractions of the reference's transformer layers
+
+    w_qs / w_ks / w_vs / lang_cond_fc / fc      modules/layers/transformers.py:173-186, 193-197
+    nn.MultiheadAttention in_proj / out_proj    modules/layers/transformers.py:120-121, 141
+    linear1 -> activation -> dropout -> linear2 modules/layers/transformers.py:123-125, 148-152, 301-316
+
+as explicit autograd functions (no global F.linear patching):
+
+    linear(x, weight, bias)                       y = x W^T + b
+    packed_linear(x, [(W_i, b_i), ...])           y = x [W_0; W_1; ...]^T + [b_0; b_1; ...]   (one GEMM)
+    ffn(x, W1, b1, W2, b2, act, p_drop, training) y = dropout(act(x W1^T + b1)) W2^T + b2
+
+Parameters stay fp32 masters (checkpoint- and optimizer-compatible with the reference); the GEMMs read a
+persistent bf16 SHADOW of every weight that is refreshed only when the master changed (`_version`) -- or
+written by the optimizer kernel itself (optim/fused_adamw.py) -- instead of autocast's per-call casts.
+Forward / input-gradient / weight-gradient all run on the hand-written kernels; bias, GELU / ReLU, FFN
+dropout and their derivatives live in the GEMM epilogues, weight and bias gradients come back in fp32.
+GPU only: callers keep the torch formulation for CPU tensors (tests, gloo runs).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from ... import _native
+from ..._native import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32, GEMM_NN, GEMM_NT,
+                        GEMM_TN, GemmArgs)
+
+_ENABLED = True
+_VARIANT = {GEMM_NT: -1, GEMM_NN: -1, GEMM_TN: -1}       # -1 = the library's shape heuristic
+
+
+def set_gemm_backend(enabled: bool) -> None:
+    """False: layers fall back to F.linear (hipBLASLt) -- for A/B runs only."""
+    global _ENABLED
+    _ENABLED = bool(enabled)
+
+
+def set_gemm_variant(form: int, variant: int) -> None:
+    _VARIANT[form] = int(variant)
+
+
+def enabled() -> bool:
+    return _ENABLED
+
+
+def usable(x: torch.Tensor, in_features: int, out_features: int) -> bool:
+    """The kernels serve GPU tensors under bf16 execution with 8-multiple feature counts."""
+    if not (_ENABLED and x.is_cuda and in_features % 8 == 0 and out_features % 8 == 0):
+        return False
+    if x.dtype == torch.bfloat16:
+        return True
+    return x.dtype == torch.float32 and torch.is_autocast_enabled("cuda") and \
+        torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return t.data_ptr() if t is not None else None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_FORM_NAME = {GEMM_NT: "nt", GEMM_NN: "nn", GEMM_TN: "tn"}
+
+
+def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int,
+         C: torch.Tensor, ldc: int, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
+         ldaux: int = 0, aux_out: Optional[torch.Tensor] = None, ldaux_out: int = 0,
+         workspace: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, p_drop: float = 0.0,
+         seed_dev: Optional[torch.Tensor] = None, splits: int = 1, variant: Optional[int] = None) -> None:
+    """Thin checked call of gps_gemm_bf16 on the current stream (shapes in the header's convention)."""
+    a = GemmArgs()
+    a.form, a.epilogue, a.M, a.N, a.K = form, epilogue, M, N, K
+    a.splits = splits
+    a.variant = _VARIANT[form] if variant is None else variant
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc
+    a.bias = _ptr(bias)
+    a.aux, a.ldaux, a.aux_out, a.ldaux_out = _ptr(aux), ldaux, _ptr(aux_out), ldaux_out
+    a.workspace, a.colsum, a.seed_dev = _ptr(workspace), _ptr(colsum), _ptr(seed_dev)
+    a.seed, a.p_drop = 0, float(p_drop)
+    from ...pointnet2._ext import _timed
+    nbytes = 2 * (M * K + N * K) + (4 if epilogue == EPI_F32 else 2) * M * N
+    with torch.cuda.device(A.device), _timed(f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K},epi={epilogue})", nbytes,
+                                             2 * M * N * K, "bf16"):
+        st = _native.load().gps_gemm_bf16(ctypes.byref(a), _stream())
+    _native.check(st, f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K})")
+
+
+# ---- the three contractions of a Linear -------------------------------------------------------------------
+def linear_forward(x16: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str] = None,
+                   p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None, want_pre: bool = False):
+    """x16 (T, K) bf16, w16 (N, K) bf16, bias (N) fp32 -> y (T, N) bf16 [, pre-activation (T, N) bf16]."""
+    T, K = x16.shape
+    N = w16.shape[0]
+    y = torch.empty((T, N), dtype=torch.bfloat16, device=x16.device)
+    pre = torch.empty_like(y) if (want_pre and act == "gelu") else None
+    epi = {None: EPI_BIAS, "gelu": EPI_BIAS_GELU, "relu": EPI_BIAS_RELU}[act]
+    gemm(GEMM_NT, epi, T, N, K, x16, x16.stride(0), w16, w16.stride(0), y, N, bias=bias, aux_out=pre, ldaux_out=N,
+         p_drop=p_drop if act else 0.0, seed_dev=seed_dev)
+    return (y, pre) if want_pre else y
+
+
+def linear_dgrad(dy16: torch.Tensor, w16: torch.Tensor, act: Optional[str] = None, aux: Optional[torch.Tensor] = None,
+                 p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy16 (T, N) bf16, w16 (N, K) bf16 -> dx (T, K) bf16 = dy W, optionally times the derivative of the
+    activation that PRODUCED this layer's input (aux = its saved pre-activation (gelu) / output (relu))."""
+    T, N = dy16.shape
+    K = w16.shape[1]
+    dx = torch.empty((T, K), dtype=torch.bfloat16, device=dy16.device)
+    epi = {None: EPI_BIAS, "gelu": EPI_DGELU, "relu": EPI_DRELU}[act]
+    gemm(GEMM_NN, epi, T, K, N, dy16, dy16.stride(0), w16, w16.stride(0), dx, K, aux=aux,
+         ldaux=aux.stride(0) if aux is not None else 0, p_drop=p_drop if act else 0.0, seed_dev=seed_dev)
+    return dx
+
+
+_WS = {}
+
+
+def _workspace(device, floats: int) -> torch.Tensor:
+    """Split-K scratch, one growing buffer per device and stream (safe: launches on a stream are ordered)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = _WS[key] = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+    return buf
+
+
+def linear_wgrad(dy16: torch.Tensor, x16: torch.Tensor, want_bias: bool = True):
+    """dy16 (T, N) bf16, x16 (T, K) bf16 -> dW (N, K) fp32 = dy^T x, db (N) fp32 = column sums of dy."""
+    T, N = dy16.shape
+    K = x16.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy16.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy16.device) if want_bias else None
+    lib = _native.load()
+    splits = int(lib.gps_gemm_pick_splits(GEMM_TN, N, K, T))
+    ws = None
+    if splits > 1:
+        ws = _workspace(dy16.device, int(lib.gps_gemm_workspace_floats(GEMM_TN, N, K, splits)))
+    gemm(GEMM_TN, EPI_F32, N, K, T, dy16, dy16.stride(0), x16, x16.stride(0), dw, K, workspace=ws, colsum=db,
+         splits=splits)
+    return dw, db
+
+
+# ---- bf16 shadows of the fp32 master weights ---------------------------------------------------------------
+class _Shadow:
+    __slots__ = ("w16", "b32", "versions")
+
+    def __init__(self):
+        self.w16 = None
+        self.b32 = None
+        self.versions = None
+
+
+_SHADOWS = {}
+
+
+def _versions(params) -> tuple:
+    return tuple(p._version for p in params if p is not None)
+
+
+def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+    """(w16, b32): bf16 copy of the row-wise concatenation of `weights` and fp32 concatenation of `biases`,
+    rebuilt only when one of the masters changed since the last call.  A single weight returns its own bias
+    tensor (no copy).  The optimizer kernel may write these buffers itself and call `mark_fresh`."""
+    key = tuple(id(w) for w in weights)
+    sh = _SHADOWS.get(key)
+    if sh is None:
+        sh = _SHADOWS[key] = _Shadow()
+    ver = _versions(list(weights) + list(biases))
+    dev = weights[0].device
+    if sh.w16 is None or sh.w16.device != dev:
+        rows = sum(w.shape[0] for w in weights)
+        sh.w16 = torch.empty((rows, weights[0].shape[1]), dtype=torch.bfloat16, device=dev)
+        sh.b32 = None
+        sh.versions = None
+    if sh.versions != ver:
+        with torch.no_grad():
+            r = 0
+            for w in weights:
+                sh.w16[r:r + w.shape[0]].copy_(w)
+                r += w.shape[0]
+            if all(b is not None for b in biases):
+                if len(biases) == 1:
+                    sh.b32 = biases[0].detach()
+                else:
+                    if sh.b32 is None or sh.b32.data_ptr() in [b.data_ptr() for b in biases]:
+                        sh.b32 = torch.empty(sh.w16.shape[0], dtype=torch.float32, device=dev)
+                    r = 0
+                    for b in biases:
+                        sh.b32[r:r + b.shape[0]].copy_(b)
+                        r += b.shape[0]
+            else:
+                sh.b32 = None
+        sh.versions = ver
+    return sh.w16, sh.b32
+
+
+def shadow_entry(weights: Sequence[torch.Tensor]):
+    """The shadow record of a weight group (None before its first use): the optimizer writes through it."""
+    return _SHADOWS.get(tuple(id(w) for w in weights))
+
+
+def mark_fresh(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]) -> None:
+    sh = shadow_entry(weights)
+    if sh is not None:
+        sh.versions = _versions(list(weights) + list(biases))
+
+
+def clear_shadows() -> None:
+    _SHADOWS.clear()
+
+
+def _as_rows16(x: torch.Tensor) -> torch.Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype != torch.bfloat16:
+        x2 = x2.to(torch.bfloat16)
+    if x2.stride(-1) != 1 or (x2.stride(0) % 8) or (x2.data_ptr() % 16):
+        x2 = x2.contiguous()
+    return x2
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b over the concatenation of n weight blocks (n = 1: a plain Linear)."""
+
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        weights, biases = wb[:n], wb[n:]
+        w16, b32 = shadow_of(weights, biases)
+        x16 = _as_rows16(x)
+        y = linear_forward(x16, w16, b32)
+        ctx.save_for_backward(x16, w16)
+        ctx.meta = (x.shape, x.dtype, n, [w.shape[0] for w in weights], [b is not None for b in biases])
+        return y.view(*x.shape[:-1], w16.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w16 = ctx.saved_tensors
+        x_shape, x_dtype, n, rows, has_b = ctx.meta
+        dy16 = _as_rows16(dy)
+        need_w = any(ctx.needs_input_grad[2:2 + n])
+        need_b = any(ctx.needs_input_grad[2 + n:])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dy16, w16).view(x_shape)
+            if dx.dtype != x_dtype:
+                dx = dx.to(x_dtype)
+        dws, dbs = [None] * n, [None] * n
+        if need_w or need_b:
+            dw, db = linear_wgrad(dy16, x16, want_bias=need_b)
+            r = 0
+            for i in range(n):
+                if ctx.needs_input_grad[2 + i]:
+                    dws[i] = dw[r:r + rows[i]]
+                if has_b[i] and ctx.needs_input_grad[2 + n + i]:
+                    dbs[i] = db[r:r + rows[i]]
+                r += rows[i]
+        return (dx, None, *dws, *dbs)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return _LinearFn.apply(x, 1, weight, bias)
+
+
+def packed_linear(x: torch.Tensor, layers: Sequence[torch.nn.Linear]) -> torch.Tensor:
+    """One GEMM for several Linears that read the same input; output columns in the order given."""
+    return _LinearFn.apply(x, len(layers), *[m.weight for m in layers], *[m.bias for m in layers])
+
+
+class _FFNFn(torch.autograd.Function):
+    """y = dropout(act(x W1^T + b1)) W2^T + b2 : two forward GEMMs, four backward GEMMs, no elementwise launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, p_drop, seed_dev):
+        w1_16, b1_32 = shadow_of((w1,), (b1,))
+        w2_16, b2_32 = shadow_of((w2,), (b2,))
+        x16 = _as_rows16(x)
+        h, pre = linear_forward(x16, w1_16, b1_32, act=act, p_drop=p_drop, seed_dev=seed_dev, want_pre=True)
+        y = linear_forward(h, w2_16, b2_32)
+        ctx.save_for_backward(x16, w1_16, w2_16, h, pre, seed_dev)
+        ctx.meta = (x.shape, x.dtype, act, float(p_drop), b1 is not None, b2 is not None)
+        return y.view(*x.shape[:-1], w2_16.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w1_16, w2_16, h, pre, seed_dev = ctx.saved_tensors
+        x_shape, x_dtype, act, p_drop, has_b1, has_b2 = ctx.meta
+        dy16 = _as_rows16(dy)
+        dw2, db2 = linear_wgrad(dy16, h, want_bias=has_b2)
+        dpre = linear_dgrad(dy16, w2_16, act=act, aux=pre if act == "gelu" else h, p_drop=p_drop, seed_dev=seed_dev)
+        dw1, db1 = linear_wgrad(dpre, x16, want_bias=has_b1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dpre, w1_16).view(x_shape)
+            if dx.dtype != x_dtype:
+                dx = dx.to(x_dtype)
+        return dx, dw1, db1, dw2, db2, None, None, None
+
+
+def ffn(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear, act: str, p_drop: float,
+        training: bool) -> torch.Tensor:
+    """act in {"gelu", "relu"}; dropout between activation and linear2 as the reference's layers apply it."""
+    p = float(p_drop) if training else 0.0
+    seed_dev = None
+    if p > 0.0:
+        from .fused_attention import _next_device_seed
+        seed_dev = _next_device_seed(x.device)
+    return _FFNFn.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, act, p, seed_dev)
+
+
+def activation_name(fn) -> Optional[str]:
+    """Maps the layer's activation callable (modules/utils.get_activation_fn) to an epilogue name."""
+    import torch.nn.functional as F
+    if fn is F.gelu:
+        return "gelu"
+    if fn is F.relu:
+        return "relu"
+    name = getattr(fn, "__name__", "")
+    return name if name in ("gelu", "relu") else None

@@ -85,7 +85,7 @@ def gather_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     b, c, n = points.shape
     m = idx.shape[1]
     out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device), _timed("gather_points", 4 * (b * c * n + b * m + b * c * m)):
+    with torch.cuda.device(points.device), _timed("gather_points", 4 * (b * m + 2 * b * c * m)):   # idx + gathered elements read, output written
         st = _native.load().gps_gather_points(b, c, n, m, points.data_ptr(), idx.data_ptr(),
                                               out.data_ptr(), _stream())
     _native.check(st, "gather_points")

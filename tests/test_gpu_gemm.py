@@ -1,0 +1,223 @@
+"""bf16 MFMA GEMMs of libgps_hip.so (gps_gemm_bf16) against fp32 torch.mm on the SAME bf16-rounded operands:
+forward (NT), input gradient (NN), weight gradient (TN, split-K, bias gradient), every tile variant, ragged
+edges and K tails, the fused epilogues, and the autograd functions the layers call (modules/layers/gemm.py).
+Tolerance: the product of bf16 operands is exact in fp32, so the only errors are fp32 accumulation order
+(~1e-6 relative) and the final bf16 rounding of the output (2^-9 relative): the bar is 2^-7 * max|ref| per
+element for bf16 outputs and 1e-4 relative for fp32 outputs."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sceneverse_amd import _native  # noqa: E402
+from sceneverse_amd.modules.layers import gemm as G  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL16 = 2.0 ** -7
+
+
+def _rand16(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (scale * torch.randn(*shape, generator=g)).to(torch.bfloat16).to(DEV)
+
+
+def _close16(got, ref, what):
+    ref = ref.float()
+    err = (got.float() - ref).abs().max().item()
+    bound = TOL16 * ref.abs().max().item() + 1e-6
+    assert err <= bound, f"{what}: max err {err:.3e} > {bound:.3e}"
+
+
+# (M, N, K): transformer shapes of the GPS step + ragged / tiny / tail cases
+NT_SHAPES = [(5120, 768, 768), (8320, 2304, 768), (5120, 2376, 768), (5120, 2048, 768), (8320, 768, 2048),
+             (3200, 3072, 768), (300, 72, 40), (129, 8, 8), (1, 768, 768), (257, 132, 200), (640, 640, 2376)]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_forward_nt(M, N, K, variant):
+    x, w = _rand16(M, K, seed=1), _rand16(N, K, scale=0.05, seed=2)
+    b = torch.randn(N, device=DEV)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    G.gemm(_native.GEMM_NT, _native.EPI_BIAS, M, N, K, x, K, w, K, y, N, bias=b, variant=variant)
+    _close16(y, x.float() @ w.float().t() + b, f"NT {M}x{N}x{K} v{variant}")
+
+
+def test_forward_nt_strided_operands_and_output():
+    """Row pitches larger than the logical width (views into packed buffers)."""
+    M, N, K = 520, 264, 136
+    xb, wb = _rand16(M, K + 24, seed=3), _rand16(N, K + 8, scale=0.1, seed=4)
+    x, w = xb[:, :K], wb[:, :K]
+    yb = torch.full((M, N + 12), 7.0, dtype=torch.bfloat16, device=DEV)
+    G.gemm(_native.GEMM_NT, _native.EPI_BIAS, M, N, K, x, xb.stride(0), w, wb.stride(0), yb, yb.stride(0))
+    _close16(yb[:, :N], x.float() @ w.float().t(), "NT strided")
+    assert torch.all(yb[:, N:] == 7.0)                       # nothing written past N
+
+
+NN_SHAPES = [(5120, 768, 768), (8320, 768, 2304), (5120, 768, 2376), (8320, 2048, 768), (5120, 768, 2048),
+             (300, 40, 72), (129, 8, 8), (257, 200, 136), (640, 2376, 640)]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", NN_SHAPES)
+def test_dgrad_nn(M, N, K, variant):
+    dy, w = _rand16(M, K, seed=5), _rand16(K, N, scale=0.05, seed=6)      # w is (out = K, in = N)
+    dx = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    G.gemm(_native.GEMM_NN, _native.EPI_BIAS, M, N, K, dy, K, w, N, dx, N, variant=variant)
+    _close16(dx, dy.float() @ w.float(), f"NN {M}x{N}x{K} v{variant}")
+
+
+# (tokens, out, in)
+TN_SHAPES = [(5120, 768, 768), (8320, 2304, 768), (5120, 2376, 768), (8320, 2048, 768), (8320, 768, 2048),
+             (19200, 768, 768), (3200, 3072, 768), (300, 72, 40), (129, 8, 8), (1000, 136, 264), (77, 768, 768)]
+
+
+@pytest.mark.parametrize("splits", [1, -1, 7])
+@pytest.mark.parametrize("T,N,K", TN_SHAPES)
+def test_wgrad_tn(T, N, K, splits):
+    dy, x = _rand16(T, N, seed=7), _rand16(T, K, seed=8)
+    lib = _native.load()
+    s = int(lib.gps_gemm_pick_splits(_native.GEMM_TN, N, K, T)) if splits < 0 else splits
+    dw = torch.empty(N, K, device=DEV)
+    db = torch.empty(N, device=DEV)
+    ws = torch.empty(max(1, int(lib.gps_gemm_workspace_floats(_native.GEMM_TN, N, K, s))), device=DEV)
+    for variant in (0, 1, 2):
+        dw.fill_(float("nan"))
+        db.fill_(float("nan"))
+        G.gemm(_native.GEMM_TN, _native.EPI_F32, N, K, T, dy, N, x, K, dw, K, workspace=ws, colsum=db, splits=s,
+               variant=variant)
+        ref = dy.float().t() @ x.float()
+        scale = ref.abs().max().item()
+        assert (dw - ref).abs().max().item() <= 1e-4 * scale + 1e-5, f"TN {T}x{N}x{K} s{s} v{variant}"
+        refb = dy.float().sum(0)
+        assert (db - refb).abs().max().item() <= 1e-4 * refb.abs().max().item() + 1e-4
+
+
+def test_wgrad_is_deterministic():
+    dy, x = _rand16(8320, 768, seed=9), _rand16(8320, 2048, seed=10)
+    a, _ = G.linear_wgrad(dy, x)
+    b, _ = G.linear_wgrad(dy, x)
+    assert torch.equal(a, b)
+
+
+def _gelu_ref(pre16):
+    return F.gelu(pre16.float())
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_activation_epilogues_forward_and_backward(act, p):
+    T, Kin, Hid = 1300, 136, 264
+    x, w1 = _rand16(T, Kin, seed=11), _rand16(Hid, Kin, scale=0.2, seed=12)
+    b1 = torch.randn(Hid, device=DEV)
+    seed_dev = torch.tensor([123456789], dtype=torch.int64, device=DEV)
+    h, pre = G.linear_forward(x, w1, b1, act=act, p_drop=p, seed_dev=seed_dev, want_pre=True)
+    pre_ref = (x.float() @ w1.float().t() + b1)
+    if act == "gelu":
+        _close16(pre, pre_ref, "pre-activation")
+        full = _gelu_ref(pre)                       # the kernel applies GELU to the bf16-rounded pre-activation
+    else:
+        full = torch.relu(pre_ref)
+    keep = torch.ones_like(full, dtype=torch.bool)
+    if p > 0:
+        keep = (h != 0) | (full.abs() < 1e-3)       # the mask is whatever the kernel drew
+        frac = 1.0 - ((h == 0) & (full.abs() > 1e-3)).float().mean().item() / max((full.abs() > 1e-3).float().mean().item(), 1e-9)
+        assert abs(frac - (1 - p)) < 0.02, frac
+    ref_h = torch.where(keep, full / (1 - p), torch.zeros_like(full))
+    _close16(h, ref_h, f"{act} hidden p={p}")
+    # backward epilogue: dpre = (dy W2) * act'(pre) * mask / (1 - p), the mask recomputed from (seed, index)
+    Out = 72
+    dy, w2 = _rand16(T, Out, seed=13), _rand16(Out, Hid, scale=0.2, seed=14)
+    dpre = G.linear_dgrad(dy, w2, act=act, aux=pre if act == "gelu" else h, p_drop=p, seed_dev=seed_dev)
+    dh = dy.float() @ w2.float()
+    if act == "gelu":
+        z = pre.float().requires_grad_(True)
+        F.gelu(z).sum().backward()
+        dact = z.grad
+    else:
+        dact = (h != 0).float()
+    mask = (h != 0) if p > 0 else torch.ones_like(keep)
+    ref = dh * dact * (mask.float() / (1 - p))
+    if p > 0 and act == "gelu":                     # elements with gelu(pre) == 0 exactly cannot reveal their mask
+        sel = full.abs() > 1e-3
+        _close16(torch.where(sel, dpre.float(), torch.zeros_like(ref)), torch.where(sel, ref, torch.zeros_like(ref)),
+                 "dgelu x mask")
+    else:
+        _close16(dpre, ref, f"d{act} p={p}")
+
+
+def _rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+def test_linear_and_packed_linear_autograd():
+    torch.manual_seed(0)
+    lins = [torch.nn.Linear(768, n).to(DEV) for n in (768, 768, 768, 72)]
+    x = torch.randn(64, 80, 768, device=DEV, requires_grad=True)
+    g = torch.randn(64, 80, 768 * 3 + 72, device=DEV)
+    y = G.packed_linear(x, lins)
+    (y.float() * g).sum().backward()
+    got = [x.grad.clone()] + [m.weight.grad.clone() for m in lins] + [m.bias.grad.clone() for m in lins]
+    x.grad = None
+    for m in lins:
+        m.zero_grad(set_to_none=True)
+    x16 = x.detach().to(torch.bfloat16).float().requires_grad_(True)
+    W = torch.cat([m.weight for m in lins], 0).to(torch.bfloat16).float()
+    b = torch.cat([m.bias for m in lins], 0)
+    Wl = W.detach().requires_grad_(True)
+    bl = b.detach().requires_grad_(True)
+    yr = x16 @ Wl.t() + bl
+    _close16(y, yr.detach(), "packed forward")
+    (yr * g.to(torch.bfloat16).float()).sum().backward()
+    assert _rel_l2(got[0], x16.grad) < 1e-2
+    r = 0
+    for i, m in enumerate(lins):
+        n = m.weight.shape[0]
+        assert _rel_l2(got[1 + i], Wl.grad[r:r + n]) < 1e-2
+        assert _rel_l2(got[5 + i], bl.grad[r:r + n]) < 1e-2
+        r += n
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_ffn_autograd_matches_torch(act):
+    torch.manual_seed(1)
+    l1, l2 = torch.nn.Linear(768, 2048).to(DEV), torch.nn.Linear(2048, 768).to(DEV)
+    x = torch.randn(40, 130, 768, device=DEV, requires_grad=True)
+    g = torch.randn(40, 130, 768, device=DEV)
+    y = G.ffn(x, l1, l2, act, 0.1, training=False)
+    (y.float() * g).sum().backward()
+    got = [x.grad.clone(), l1.weight.grad.clone(), l1.bias.grad.clone(), l2.weight.grad.clone(), l2.bias.grad.clone()]
+    x.grad = None
+    l1.zero_grad(set_to_none=True)
+    l2.zero_grad(set_to_none=True)
+    fn = F.gelu if act == "gelu" else F.relu
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yr = l2(fn(l1(x)))
+    (yr.float() * g).sum().backward()
+    ref = [x.grad, l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad]
+    _close16(y, yr.detach(), "ffn forward")
+    for a, b, name in zip(got, ref, ["dx", "dW1", "db1", "dW2", "db2"]):
+        assert _rel_l2(a, b) < 2e-2, (name, _rel_l2(a, b))
+
+
+def test_shadow_refresh_follows_the_master():
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    x = torch.randn(8, 64, device=DEV)
+    y0 = G.linear(x, lin.weight, lin.bias).float()
+    with torch.no_grad():
+        lin.weight.mul_(2.0)
+    y1 = G.linear(x, lin.weight, lin.bias).float()
+    ref = x.to(torch.bfloat16).float() @ lin.weight.to(torch.bfloat16).float().t() + lin.bias
+    _close16(y1, ref, "after in-place update")
+    assert not torch.allclose(y0, y1)
+
+
+def test_unsupported_shapes_are_refused():
+    x, w = _rand16(16, 12), _rand16(8, 12)
+    y = torch.empty(16, 8, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_native.GpsNativeError):
+        G.gemm(_native.GEMM_NT, _native.EPI_BIAS, 16, 8, 12, x, 12, w, 12, y, 8)      # K not a multiple of 8

@@ -1,0 +1,103 @@
+"""Per-shape timing of the hand-written bf16 GEMMs (all tile variants) against the library GEMM torch calls for
+the same contraction (hipBLASLt / rocBLAS, with the tuned solutions of profiles/tunableop_gfx950*.csv when
+PYTORCH_TUNABLEOP_* is set by the caller).  Interleaved rounds inside one process (guide rule 24).
+
+    python tools/gemm_bench.py --json gpurun_out/gemm_bench.json
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+_TUNED = os.path.join(ROOT, "profiles", "tunableop_gfx950.csv")
+if os.path.exists(_TUNED.replace(".csv", "0.csv")) and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
+    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+    os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
+    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = _TUNED
+import torch  # noqa: E402
+
+from sceneverse_amd import _native  # noqa: E402
+from sceneverse_amd.modules.layers import gemm as G  # noqa: E402
+
+# (tokens, in, out) of the Linears in one GPS pre-train step at B = 64
+LAYERS = [(5120, 768, 2376), (5120, 768, 768), (5120, 768, 2048), (5120, 2048, 768),
+          (8320, 768, 2304), (8320, 768, 768), (8320, 768, 2048), (8320, 2048, 768),
+          (19200, 768, 2304), (19200, 768, 768), (19200, 768, 3072), (19200, 3072, 768),
+          (3200, 768, 2304), (3200, 768, 768), (3200, 768, 3072), (3200, 3072, 768)]
+
+
+def timeit(fns, rounds=20, inner=5):
+    """fns: {name: callable}; interleaved; -> {name: median us}"""
+    for f in fns.values():
+        f()
+    torch.cuda.synchronize()
+    res = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, f in fns.items():
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(inner):
+                f()
+            e.record()
+            e.synchronize()
+            res[k].append(1e3 * s.elapsed_time(e) / inner)
+    return {k: sorted(v)[len(v) // 2] for k, v in res.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--rounds", type=int, default=15)
+    args = ap.parse_args()
+    dev = "cuda"
+    lib = _native.load()
+    out = []
+    for T, K, N in LAYERS:
+        x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+        w = (0.02 * torch.randn(N, K, device=dev)).to(torch.bfloat16)
+        b = torch.randn(N, device=dev)
+        b16 = b.to(torch.bfloat16)
+        dy = torch.randn(T, N, device=dev).to(torch.bfloat16)
+        y = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty(T, K, dtype=torch.bfloat16, device=dev)
+        dw = torch.empty(N, K, device=dev)
+        db = torch.empty(N, device=dev)
+        flops = 2.0 * T * K * N
+        row = {"tokens": T, "in": K, "out": N}
+        # forward
+        fns = {"lib": lambda: torch.nn.functional.linear(x, w, b16)}
+        for v in range(4):
+            fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NT, _native.EPI_BIAS, T, N, K, x, K, w, K, y, N, bias=b, variant=v))
+        t = timeit(fns, args.rounds)
+        row["fwd_us"] = {k: round(v, 2) for k, v in t.items()}
+        # dgrad
+        fns = {"lib": lambda: torch.mm(dy, w)}
+        for v in range(4):
+            fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NN, _native.EPI_BIAS, T, K, N, dy, N, w, K, dx, K, variant=v))
+        t = timeit(fns, args.rounds)
+        row["dgrad_us"] = {k: round(v, 2) for k, v in t.items()}
+        # wgrad (+ bias gradient): library = mm + fp32 cast + column sum, as autograd runs it under autocast
+        fns = {"lib": lambda: (torch.mm(dy.t(), x).float(), dy.sum(0, dtype=torch.float32))}
+        for s in sorted({1, int(lib.gps_gemm_pick_splits(_native.GEMM_TN, N, K, T)), 8, 16}):
+            ws = torch.empty(max(1, int(lib.gps_gemm_workspace_floats(_native.GEMM_TN, N, K, s))), device=dev)
+            for v in (0, 1, 2):
+                fns[f"v{v}s{s}"] = (lambda v=v, s=s, ws=ws: G.gemm(_native.GEMM_TN, _native.EPI_F32, N, K, T, dy, N, x, K, dw, K,
+                                                                  workspace=ws, colsum=db, splits=s, variant=v))
+        t = timeit(fns, args.rounds)
+        row["wgrad_us"] = {k: round(v, 2) for k, v in t.items()}
+        row["default_splits"] = int(lib.gps_gemm_pick_splits(_native.GEMM_TN, N, K, T))
+        best = {k: min((v for n, v in row[k].items() if n != "lib")) for k in ("fwd_us", "dgrad_us", "wgrad_us")}
+        row["best_TFLOPs"] = {k: round(flops / best[k] / 1e6, 1) for k in best}
+        row["lib_TFLOPs"] = {k: round(flops / row[k]["lib"] / 1e6, 1) for k in best}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+    if args.json:
+        os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
+        with open(args.json, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

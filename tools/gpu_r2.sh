@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-2 gpurun driver: stages selected by name; outputs under gpurun_out/<tag>/.
+set -u
+TAG=${1:-r2a}
+WHAT=${2:-gemm}
+REPO=$PWD
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ts() { echo "[$(date +%H:%M:%S)] $*"; }
+{ echo "nproc $(nproc)"; free -g | head -2; } > $OUT/host.txt 2>&1
+if [[ $WHAT == *trprobe* ]]; then
+  ts trprobe; timeout 120 python tools/probes/run_tr_b16_probe.py > $OUT/tr_probe.txt 2>&1; echo "tr probe exit $?"; head -20 $OUT/tr_probe.txt
+fi
+if [[ $WHAT == *gemmtest* ]]; then
+  ts gemmtest; timeout 900 python -m pytest tests/test_gpu_gemm.py -m gpu -q -x > $OUT/pytest_gemm.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gemm.log
+  tail -25 $OUT/pytest_gemm.log
+fi
+if [[ $WHAT == *gemmbench* ]]; then
+  ts gemmbench; timeout 600 python tools/gemm_bench.py --json $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "gemm bench exit $?"; tail -20 $OUT/gemm_bench.log
+fi
+if [[ $WHAT == *alltests* ]]; then
+  ts pytest; timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  grep -E "^(FAILED|ERROR)|passed|failed|exit" $OUT/pytest_gpu.log | head -40
+fi
+if [[ $WHAT == *bench* && $WHAT != *gemmbench* || $WHAT == *stepbench* ]]; then
+  ts bench; timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
+  tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err
+fi
+if [[ $WHAT == *kbench* ]]; then
+  ts kernel_bench; timeout 300 python tools/kernel_bench.py --json $OUT/kernel_bench.json > $OUT/kernel_bench.log 2>&1; tail -5 $OUT/kernel_bench.log
+fi
+if [[ $WHAT == *prof* ]]; then
+  ts rocprof
+  rm -rf /tmp/prof && mkdir -p /tmp/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench --output-format csv -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.log 2>&1; echo "rocprof exit $?")
+  mkdir -p $OUT/prof
+  find /tmp/prof -name '*stats*.csv' -exec cp {} $OUT/prof/ \;
+  f=$(ls $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -40 "$f" | cut -c1-200
+  tail -3 $OUT/prof_bench.log
+fi
+ts done; du -sh $REPO/gpurun_out
