@@ -404,8 +404,10 @@ int launch_cfg(Params &P, hipStream_t s) {
 }
 
 // tile configurations ("variants"): 0 = 128x128 / 4 waves / 2 buffers (2 workgroups per CU),
-// 1 = 256x128 / 8 waves / 2 buffers, 2 = 128x128 / 4 waves / 3 buffers (counted vmcnt), 3 = 128x64 / 4 waves / 2 buffers
-constexpr int kVariants = 4;
+// 1 = 256x128 / 8 waves / 2 buffers, 2 = 128x128 / 4 waves / 3 buffers (counted vmcnt), 3 = 128x64 / 4 waves / 2 buffers,
+// 4 = 256x256 / 8 waves (128x64 per wave) / 2 buffers: half the L2 -> LDS bytes per flop of variant 0, for the
+// shapes with enough 256x256 tiles to fill the chip
+constexpr int kVariants = 5;
 template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
@@ -413,12 +415,15 @@ int launch_variant(Params &P, int variant, hipStream_t s) {
     case 1: return launch_cfg<256, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
     case 2: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 3>(P, s);
     case 3: return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 2>(P, s);
+    case 4:
+      if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);   // 256 x 256 with two transposed
+      else return launch_cfg<256, 256, 2, 4, ATR, BTR, EPI, 2>(P, s);                 // operands exceeds 256 VGPRs
     default: return GPS_ERR_INVALID_ARGUMENT;
   }
 }
 
-inline int tile_m_of(int variant) { return variant == 1 ? 256 : 128; }
-inline int tile_n_of(int variant) { return variant == 3 ? 64 : 128; }
+inline int tile_m_of(int variant) { return (variant == 1 || variant == 4) ? 256 : 128; }
+inline int tile_n_of(int variant) { return variant == 3 ? 64 : (variant == 4 ? 256 : 128); }
 
 // default variant: the largest tile that still gives every CU about two workgroups' worth of tiles
 inline int pick_variant(int M, int N, int splits) {
@@ -458,7 +463,8 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   if (a->M == 0 || a->N == 0) return GPS_OK;
   if (!a->A || !a->B || !a->C) return GPS_ERR_INVALID_ARGUMENT;
   // 16-byte global chunks and 8 / 16-byte stores: leading dimensions in multiples of 8 elements, N of 4, K of 8
-  if ((a->lda & 7) || (a->ldb & 7) || (a->K & 7) || (a->N & 3)) return GPS_ERR_UNSUPPORTED;
+  if ((a->lda & 7) || (a->ldb & 7) || (a->N & 3)) return GPS_ERR_UNSUPPORTED;
+  if (a->form != GPS_GEMM_TN && (a->K & 7)) return GPS_ERR_UNSUPPORTED;     // K-major operands: whole 16-byte chunks
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15)) return GPS_ERR_UNSUPPORTED;
   const bool f32out = a->epilogue == GPS_GEMM_EPI_F32;
   if (f32out != (a->form == GPS_GEMM_TN)) return GPS_ERR_UNSUPPORTED;       // fp32 sums <=> weight-gradient form
@@ -494,7 +500,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   int variant = a->variant;
   if (variant < 0) variant = pick_variant(a->M, a->N, P.splits);
   if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
-  if (a->form == GPS_GEMM_TN && variant == 3) variant = 0;      // reduction-major tiles are at least 128 wide
+  if (a->form == GPS_GEMM_TN && variant >= 3) variant = 0;      // reduction-major A: 128 x 128 or 256 x 128 tiles
 
   int st;
   if (a->form == GPS_GEMM_NT) {

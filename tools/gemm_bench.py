@@ -28,18 +28,26 @@ LAYERS = [(5120, 768, 2376), (5120, 768, 768), (5120, 768, 2048), (5120, 2048, 7
           (3200, 768, 2304), (3200, 768, 768), (3200, 768, 3072), (3200, 3072, 768)]
 
 
-def timeit(fns, rounds=20, inner=5):
-    """fns: {name: callable}; interleaved; -> {name: median us}"""
-    for f in fns.values():
+def timeit(fns, rounds=12, inner=10):
+    """fns: {name: callable}; every candidate is captured `inner` times into ONE HIP graph and the replays are
+    timed interleaved (GPU time, not the host's launch rate); -> {name: median us per call}"""
+    graphs = {}
+    for k, f in fns.items():
         f()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(inner):
+                f()
+        g.replay()
+        graphs[k] = g
     torch.cuda.synchronize()
     res = {k: [] for k in fns}
     for _ in range(rounds):
-        for k, f in fns.items():
+        for k, g in graphs.items():
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            for _ in range(inner):
-                f()
+            g.replay()
             e.record()
             e.synchronize()
             res[k].append(1e3 * s.elapsed_time(e) / inner)
@@ -49,12 +57,38 @@ def timeit(fns, rounds=20, inner=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
-    ap.add_argument("--rounds", type=int, default=15)
+    ap.add_argument("--rounds", type=int, default=12)
+    ap.add_argument("--only", type=int, default=-1, help="index into LAYERS: time just that layer")
+    ap.add_argument("--pmc-loop", default=None,
+                    help="form:variant -- run ONE kernel configuration of layer --only 30 times (for rocprofv3 --pmc)")
     args = ap.parse_args()
     dev = "cuda"
     lib = _native.load()
     out = []
-    for T, K, N in LAYERS:
+    layers = LAYERS if args.only < 0 else [LAYERS[args.only]]
+    if args.pmc_loop:
+        form, variant = args.pmc_loop.split(":")
+        T, K, N = layers[0]
+        x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+        w = (0.02 * torch.randn(N, K, device=dev)).to(torch.bfloat16)
+        dy = torch.randn(T, N, device=dev).to(torch.bfloat16)
+        y = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty(T, K, dtype=torch.bfloat16, device=dev)
+        dw = torch.empty(N, K, device=dev)
+        s = int(lib.gps_gemm_pick_splits(_native.GEMM_TN, N, K, T))
+        ws = torch.empty(max(1, int(lib.gps_gemm_workspace_floats(_native.GEMM_TN, N, K, s))), device=dev)
+        for _ in range(30):
+            if form == "nt":
+                G.gemm(_native.GEMM_NT, _native.EPI_BIAS, T, N, K, x, K, w, K, y, N, variant=int(variant))
+            elif form == "nn":
+                G.gemm(_native.GEMM_NN, _native.EPI_BIAS, T, K, N, dy, N, w, K, dx, K, variant=int(variant))
+            elif form == "lib":
+                torch.nn.functional.linear(x, w)
+            else:
+                G.gemm(_native.GEMM_TN, _native.EPI_F32, N, K, T, dy, N, x, K, dw, K, workspace=ws, splits=s, variant=int(variant))
+        torch.cuda.synchronize()
+        return
+    for T, K, N in layers:
         x = torch.randn(T, K, device=dev).to(torch.bfloat16)
         w = (0.02 * torch.randn(N, K, device=dev)).to(torch.bfloat16)
         b = torch.randn(N, device=dev)
@@ -68,13 +102,13 @@ def main():
         row = {"tokens": T, "in": K, "out": N}
         # forward
         fns = {"lib": lambda: torch.nn.functional.linear(x, w, b16)}
-        for v in range(4):
+        for v in range(5):
             fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NT, _native.EPI_BIAS, T, N, K, x, K, w, K, y, N, bias=b, variant=v))
         t = timeit(fns, args.rounds)
         row["fwd_us"] = {k: round(v, 2) for k, v in t.items()}
         # dgrad
         fns = {"lib": lambda: torch.mm(dy, w)}
-        for v in range(4):
+        for v in range(5):
             fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NN, _native.EPI_BIAS, T, K, N, dy, N, w, K, dx, K, variant=v))
         t = timeit(fns, args.rounds)
         row["dgrad_us"] = {k: round(v, 2) for k, v in t.items()}
