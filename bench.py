@@ -11,10 +11,18 @@ scenes per GPU, 80 objects x 1024 points x 6 ch, 50-token sentence + 300-token s
 (BASELINE.json configs[1]; SURVEY.md section 8(d) "config 2").  Synthetic inputs, random-init
 weights; inputs are resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed.
 
+`--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N
+ranks (reference behaviour: common/launch_utils.py:26-42); a WORLD_SIZE that disagrees with --gpus is an error.
+
 The single JSON line also carries
-  roofline      the dominant native kernel by time, its ALGORITHMIC bytes / measured duration
-                (HIP events on the launch stream, recorded inside the timed steps) vs 8 TB/s
-  kernels       the same for every libgps_hip.so launch shape seen in a step
+  roofline      the kernel with the largest time per step among ALL kernels of the step (native launches by
+                HIP events, everything else by a torch.profiler pass): ALGORITHMIC flops (or bytes) / measured
+                duration vs the dense MFMA peak of its dtype (or 8 TB/s); executed-MFMA utilisation of the
+                split-bf16 point kernels is reported separately as `mfma_utilisation`
+  headline      the north-star fractions: unfused ball_query+group vs the HBM roof (the six launches of the
+                reference API timed here), in-scope transformer FLOPs vs the bf16 MFMA peak, attention core
+  kernels       per launch shape of libgps_hip.so: time, algorithmic work, roof fraction
+  step_kernels  top kernels of the whole step by time (torch.profiler), native or not
   cpu_baseline  the oracle port (oracle/gps_torch_reference.py + C point ops + HF BERT, fp32, all
                 host cores) timed on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -103,7 +111,7 @@ def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("GPS_CPU_BASELINE_THREADS", "64"))))
+    cores = max(1, min(cores, int(os.environ.get("GPS_CPU_BASELINE_THREADS", str(cores)))))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     # parameter container with the reference's names, built from shapes only (no product forward)
@@ -142,10 +150,10 @@ def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
     one_step()  # warm-up
     t0 = time.perf_counter()
     done = 0
-    for _ in range(steps):     # bounded sample: stop early once ~30 s of CPU work are spent
+    for _ in range(steps):     # bounded sample: at least 3 steps, then stop once ~30 s of CPU work are spent
         one_step()
         done += 1
-        if time.perf_counter() - t0 > 30.0:
+        if done >= 3 and time.perf_counter() - t0 > 30.0:
             break
     steps = done
     dt = time.perf_counter() - t0
@@ -164,14 +172,14 @@ def main() -> None:
     ap.add_argument("--n-obj", type=int, default=80)
     ap.add_argument("--n-pts", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
     ap.add_argument("--graph-dp", action="store_true",
                     help="force the split-graph data-parallel form at world_size 1 (what N > 1 runs; for A/B)")
-    ap.add_argument("--no-splitk", action="store_true",
-                    help="weight gradients of the big-token Linears as single library GEMMs (A/B of "
-                         "sceneverse_amd/common/wgrad_splitk.py)")
+    ap.add_argument("--no-native-gemm", action="store_true",
+                    help="projections / FFNs through F.linear -> hipBLASLt instead of libgps_hip.so's MFMA GEMMs "
+                         "(A/B of sceneverse_amd/modules/layers/gemm.py)")
     ap.add_argument("--no-fused-emb", action="store_true",
                     help="BERT word-table gradient through torch's sort-based embedding backward (A/B of "
                          "modules/language/fused_embedding.py)")
@@ -207,7 +215,7 @@ def main() -> None:
     # (--graph-dp: 3 graphs around eager RCCL collectives, all-reduce exposed) cannot.
     use_graph = (world == 1 and not args.no_graph) or args.graph_dp
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
-                        graph=("dp" if args.graph_dp else use_graph), splitk_wgrad=not args.no_splitk)
+                        graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm)
     use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
 
@@ -234,7 +242,7 @@ def main() -> None:
             use_graph = False
             cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
             step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=False,
-                                splitk_wgrad=not args.no_splitk)
+                                native_gemm=not args.no_native_gemm)
             graph_note = f"eager (graph capture failed: {type(e).__name__})"
     for _ in range(args.warmup):
         step.step(dict(batch))

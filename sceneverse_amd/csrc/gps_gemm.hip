@@ -82,6 +82,11 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((unsi
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
   return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
 }
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+__device__ __forceinline__ u32x2 pack4(const f32x4 &v) {     // v_cvt_pk_bf16_f32: round to nearest even
+  const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  return __builtin_bit_cast(u32x2, h);
+}
 // counter-based dropout RNG shared with gps_layernorm.hip / gps_attention.hip (splitmix64 finaliser)
 __device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
   unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
@@ -100,63 +105,67 @@ __device__ __forceinline__ void glds16(const void *src, void *lds_dst) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// per-operand staging state: one 64-bit source pointer per piece this wave copies, a validity bit per piece
-// (rows / columns outside the matrix read the zero block and never advance)
+// per-operand staging state.  A stage is copied with buffer_load_dwordx4 ... lds: the per-lane byte offset of its
+// 16 bytes (voff, one VGPR per piece, fixed for the whole kernel) + a wave-uniform SGPR offset that advances by
+// one stage per iteration -- no per-stage vector arithmetic at all.  Rows / columns outside the matrix are
+// CLAMPED to the last valid one (finite duplicates that only feed output rows / columns which are never stored);
+// only a ragged K tail needs zeros, and only its stage takes the slower path that points invalid lanes at a
+// zero block.
 // ---------------------------------------------------------------------------------------------------------
 template <int ROWS, bool RM, int NW>
 struct Stager {
   static constexpr int NPIECE = ROWS / 8 / NW;      // pieces per wave and stage (tile = ROWS x 64 bf16 = ROWS / 8 KiB)
   static_assert(ROWS % (8 * NW) == 0, "tile rows must split evenly over the waves");
-  unsigned long long ptr[NPIECE];                   // source address of this lane's 16 bytes (zero block if outside)
-  unsigned int valid;                               // bit j: piece j of this lane lies inside the matrix
-  unsigned int kidx[NPIECE];                        // RM: k row inside the stage; KM: first k of the chunk
-  unsigned int step;                                // bytes one stage advances the source
+  unsigned int voff[NPIECE];
+  unsigned int kidx[NPIECE];                        // RM: k row inside the stage; KM: first k of the chunk (tail only)
+  __amdgpu_buffer_rsrc_t rsrc;
+  const unsigned char *base;
+  unsigned int soff, step;
 
   // mat: K-major  -> element (r, k) at mat[r * ld + k], r in [0, rows): tile rows r0 .. r0 + ROWS - 1
   //      red-major -> element (k, c) at mat[k * ld + c], c in [0, rows): tile columns r0 .. r0 + ROWS - 1
   __device__ __forceinline__ void init(const uint16_t *mat, long long ld, int rows, int r0, int k_begin, int wave,
                                        int lane) {
-    const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_block;
-    valid = 0u;
+    base = reinterpret_cast<const unsigned char *>(mat);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(mat), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int q = j * NW + wave;
-      bool ok;
-      const uint16_t *src;
       if (!RM) {
         int row, chunk;
         km_stage_src(q, lane, row, chunk);
-        ok = r0 + row < rows;
+        const int r = min(r0 + row, rows - 1);
         kidx[j] = 8u * chunk;
-        src = mat + (size_t)(ok ? r0 + row : 0) * ld + k_begin + 8 * chunk;
+        voff[j] = (unsigned int)(((long long)r * ld + 8 * chunk) * 2);
       } else {
         int k, chunk;
         rm_stage_src<ROWS>(q, lane, k, chunk);
-        ok = r0 + 8 * chunk < rows;
+        const int c = min(r0 + 8 * chunk, rows - 8);
         kidx[j] = (unsigned int)k;
-        src = mat + (size_t)(k_begin + k) * ld + (ok ? r0 + 8 * chunk : 0);
+        voff[j] = (unsigned int)(((long long)k * ld + c) * 2);
       }
-      const unsigned long long full = ok ? ~0ull : 0ull;
-      ptr[j] = zero + (((unsigned long long)(uintptr_t)src - zero) & full);
-      valid |= ok ? (1u << j) : 0u;
     }
     step = RM ? (unsigned int)(BK * ld * 2) : (unsigned int)(BK * 2);
+    soff = (unsigned int)k_begin / BK * step;
   }
-  // copy one stage into `tile` (LDS, ROWS * 128 bytes); k_left = reduction indices still inside the matrix
-  // (>= 64 for every stage but a ragged last one).  Branch-free: invalid lanes point at the zero block and stay.
-  template <bool TAIL>
-  __device__ __forceinline__ void issue(unsigned char *tile, int k_left, int wave) {
+  // copy one full stage into `tile` (LDS, ROWS * 128 bytes)
+  __device__ __forceinline__ void issue_full(unsigned char *tile, int wave) {
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(tile + (j * NW + wave) * PIECE),
+                                               16, voff[j], soff, 0, 0);
+    soff += step;
+  }
+  // the ragged last stage: only k_left (< 64) reduction indices are inside the matrix, the rest reads zeros
+  __device__ __forceinline__ void issue_tail(unsigned char *tile, int k_left, int wave) {
     const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_block;
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
-      unsigned long long p = ptr[j];
-      if (TAIL) {
-        const unsigned long long full = ((int)kidx[j] < k_left) ? ~0ull : 0ull;
-        p = zero + ((p - zero) & full);
-      }
-      glds16(reinterpret_cast<const void *>((uintptr_t)p), tile + (j * NW + wave) * PIECE);
-      ptr[j] += (unsigned long long)((0u - ((valid >> j) & 1u)) & step);
+      const unsigned long long p = (unsigned long long)(uintptr_t)base + voff[j] + soff;
+      const unsigned long long full = ((int)kidx[j] < k_left) ? ~0ull : 0ull;
+      glds16(reinterpret_cast<const void *>((uintptr_t)(zero + ((p - zero) & full))), tile + (j * NW + wave) * PIECE);
     }
+    soff += step;
   }
 };
 
@@ -182,8 +191,31 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char *tile, int r0, i
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `stages` * NP of this wave's copies are outstanding (stages <= MAXS, wave-uniform)
+template <int NP, int MAXS>
+__device__ __forceinline__ void wait_stages(int stages) {
+  if constexpr (MAXS == 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (stages >= MAXS) wait_vmcnt<NP * MAXS>();
+    else wait_stages<NP, MAXS - 1>(stages);
+  }
+}
+
+constexpr int lds_bytes(int BM, int BN, int NBUF) { return NBUF * (BM + BN) * BK * 2; }
+constexpr int waves_per_simd(int BM, int BN, int NW, int NBUF) {
+  const int blocks = (160 * 1024) / lds_bytes(BM, BN, NBUF);
+  const int w = (blocks < 1 ? 1 : blocks) * NW / 4;
+  return w < 1 ? 1 : (w > 2 ? 2 : w);     // the accumulators never leave room for more than 2
+}
+
 template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF>
-__global__ __launch_bounds__(WGM *WGN * 64, (WGM * WGN == 4 && NBUF != 2) ? 1 : 2) void gemm_kernel(const Params P) {
+__global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBUF)) void gemm_kernel(const Params P) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
@@ -194,19 +226,25 @@ __global__ __launch_bounds__(WGM *WGN * 64, (WGM * WGN == 4 && NBUF != 2) ? 1 : 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
 
-  // block -> (split, tile_m, tile_n); tile_n fastest so that the tiles of one XCD share A row panels
+  // block -> (split, tile_m, tile_n).  The blocks of one XCD (block id mod 8) take a contiguous range of virtual
+  // ids; inside a split the tiles are walked in groups of GM tile rows, tile_m fastest, so that the workgroups
+  // resident on an XCD at any time share a few A row panels and a few B panels (both stay in its 4 MiB L2).
+  constexpr int GM = 8;
   const int ntiles = P.ntm * P.ntn;
   const int vid = xcd_virtual_id(blockIdx.x, ntiles * P.splits);
   const int split = vid / ntiles, tile = vid - split * ntiles;
-  const int tile_m = tile / P.ntn, tile_n = tile - tile_m * P.ntn;
+  const int group = tile / (GM * P.ntn), in_group = tile - group * (GM * P.ntn);
+  const int gm = min(GM, P.ntm - group * GM);
+  const int tile_n = in_group / gm, tile_m = group * GM + (in_group - tile_n * gm);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kt0 = split * P.kt_per_split;
-  const int kt1 = min(P.nkt, kt0 + P.kt_per_split);
+  const int nst = min(P.nkt, kt0 + P.kt_per_split) - kt0;
 
   Stager<BM, ATR, NW> sa;
   Stager<BN, BTR, NW> sb;
   sa.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
   sb.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
+  constexpr int NP = Stager<BM, ATR, NW>::NPIECE + Stager<BN, BTR, NW>::NPIECE;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -221,16 +259,17 @@ __global__ __launch_bounds__(WGM *WGN * 64, (WGM * WGN == 4 && NBUF != 2) ? 1 : 
   const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // 8 x bf16 1.0
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-  auto issue_stage = [&](int buf, int kt) {
+  int k_left = P.K - kt0 * BK;                       // reduction indices from the next stage to issue onwards
+  auto issue_stage = [&](int buf) {
     unsigned char *base = smem + buf * STAGE;
-    const int k_left = P.K - kt * BK;
     if (k_left >= BK) {
-      sa.template issue<false>(base, k_left, wave);
-      sb.template issue<false>(base + A_BYTES, k_left, wave);
+      sa.issue_full(base, wave);
+      sb.issue_full(base + A_BYTES, wave);
     } else {
-      sa.template issue<true>(base, k_left, wave);
-      sb.template issue<true>(base + A_BYTES, k_left, wave);
+      sa.issue_tail(base, k_left, wave);
+      sb.issue_tail(base + A_BYTES, k_left, wave);
     }
+    k_left -= BK;
   };
   auto compute_stage = [&](int buf) {
     const unsigned char *As = smem + buf * STAGE;
@@ -256,39 +295,20 @@ __global__ __launch_bounds__(WGM *WGN * 64, (WGM * WGN == 4 && NBUF != 2) ? 1 : 
     }
   };
 
-  if (kt0 < kt1) {
-    if (NBUF == 2) {
-      issue_stage(0, kt0);
-      for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // stage kt visible to all waves; everyone is done with stage kt - 1
-        if (kt + 1 < kt1) issue_stage(cur ^ 1, kt + 1);
-        compute_stage(cur);
-      }
-    } else {
-      // three buffers: the copy of stage kt + 2 is issued while kt is computed, stage kt + 1 stays in flight
-      // across the barrier (counted vmcnt + raw s_barrier: __syncthreads() would drain it, guide section 5)
-      constexpr int NP = Stager<BM, ATR, NW>::NPIECE + Stager<BN, BTR, NW>::NPIECE;
-      static_assert(NP == 4 || NP == 6 || NP == 8, "extend the vmcnt table");
-      issue_stage(0, kt0);
-      if (kt0 + 1 < kt1) issue_stage(1, kt0 + 1);
-      int cur = 0;
-      for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) {
-          if (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          if (NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          if (NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < kt1) issue_stage(cur == 0 ? 2 : cur - 1, kt + 2);     // the buffer stage kt - 1 occupied
-        compute_stage(cur);
-        cur = (cur == 2) ? 0 : cur + 1;
-      }
-    }
+  // ring of NBUF stage buffers: NBUF - 1 stages are in flight ahead of the one being computed; each wave waits for
+  // ITS OWN copies of the stage with a counted vmcnt, the (raw) barrier then makes every wave's copies visible and
+  // guarantees that the buffer about to be refilled (the one computed in the previous iteration) is no longer read
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s)
+    if (s < nst) issue_stage(s);
+  int cur = 0, fill = NBUF - 1;
+  for (int it = 0; it < nst; ++it) {
+    wait_stages<NP, NBUF - 2>(min(nst - 1 - it, NBUF - 2));
+    __builtin_amdgcn_s_barrier();
+    if (it + NBUF - 1 < nst) issue_stage(fill);
+    compute_stage(cur);
+    cur = (cur == NBUF - 1) ? 0 : cur + 1;
+    fill = (fill == NBUF - 1) ? 0 : fill + 1;
   }
 
   // ---- epilogue: lane (i, g) holds C[m0 + wm0 + 16 a + i][n0 + wn0 + 16 b + 4 g + 0..3] ---------------------------
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(WGM *WGN * 64, (WGM * WGN == 4 && NBUF != 2) ? 1 : 
       f32x4 v = acc[a][b] + bias;
       const unsigned long long idx = (unsigned long long)m * (unsigned long long)P.N + (unsigned long long)n;
       if (EPI == EPI_BIAS_GELU) {
-        const u32x2 pre = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+        const u32x2 pre = pack4(v);
         if (P.aux_out) *reinterpret_cast<u32x2 *>(P.aux_out + (size_t)m * P.ldaux_out + n) = pre;
         v[0] = gelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
         v[1] = gelu_f(bf2f((uint16_t)(pre[0] >> 16)));
@@ -351,8 +371,7 @@ __global__ __launch_bounds__(WGM *WGN * 64, (WGM * WGN == 4 && NBUF != 2) ? 1 : 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rng_u32(seed, idx + r) >= P.drop_thr ? v[r] * P.keep_scale : 0.f;
       }
-      const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-      *reinterpret_cast<u32x2 *>(C + (size_t)m * P.ldc + n) = o;
+      *reinterpret_cast<u32x2 *>(C + (size_t)m * P.ldc + n) = pack4(v);
     }
   }
 }
@@ -383,10 +402,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long lon
 // ---------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF>
 int launch_cfg(Params &P, hipStream_t s) {
-  constexpr int STAGE = (BM + BN) * BK * 2;
-  constexpr int LDS = NBUF * STAGE;
+  constexpr int LDS = lds_bytes(BM, BN, NBUF);
   static_assert(LDS <= 160 * 1024, "stage buffers exceed the LDS of a CU");
-  static_assert(!ATR || BM >= 64, "reduction-major A needs a tile of at least 64 columns");
   P.ntm = (P.M + BM - 1) / BM;
   P.ntn = (P.N + BN - 1) / BN;
   auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF>;
@@ -403,34 +420,39 @@ int launch_cfg(Params &P, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
-// tile configurations ("variants"): 0 = 128x128 / 4 waves / 2 buffers (2 workgroups per CU),
-// 1 = 256x128 / 8 waves / 2 buffers, 2 = 128x128 / 4 waves / 3 buffers (counted vmcnt), 3 = 128x64 / 4 waves / 2 buffers,
-// 4 = 256x256 / 8 waves (128x64 per wave) / 2 buffers: half the L2 -> LDS bytes per flop of variant 0, for the
-// shapes with enough 256x256 tiles to fill the chip
-constexpr int kVariants = 5;
+// tile configurations ("variants"): tile (BM x BN), wave grid, stage buffers (LDS) -> resident workgroups per CU
+//   0  128x128  2x2  2 bufs ( 64 KB)  2/CU      1  128x128  2x2  4 bufs (128 KB)  1/CU     2  128x128  4x2  4 bufs  1/CU
+//   3  128x64   2x2  3 bufs ( 72 KB)  2/CU      4  256x256  2x4  2 bufs (128 KB)  1/CU     5  256x128  4x2  3 bufs (144 KB)
+//   6  128x64   2x2  6 bufs (144 KB)  1/CU      7  128x128  4x2  2 bufs ( 64 KB)  2/CU
+constexpr int kVariants = 8;
+struct VariantShape { int bm, bn; };
+constexpr VariantShape kShapes[kVariants] = {{128, 128}, {128, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128}};
 template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
     case 0: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);
-    case 1: return launch_cfg<256, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
-    case 2: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 3>(P, s);
-    case 3: return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 2>(P, s);
+    case 1: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 4>(P, s);
+    case 2: return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 4>(P, s);
+    case 3:
+      if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);   // reduction-major A tiles are >= 128 wide
+      else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 3>(P, s);
     case 4:
       if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);   // 256 x 256 with two transposed
       else return launch_cfg<256, 256, 2, 4, ATR, BTR, EPI, 2>(P, s);                 // operands exceeds 256 VGPRs
+    case 5: return launch_cfg<256, 128, 4, 2, ATR, BTR, EPI, 3>(P, s);
+    case 6:
+      if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 4>(P, s);
+      else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 6>(P, s);
+    case 7: return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
     default: return GPS_ERR_INVALID_ARGUMENT;
   }
 }
 
-inline int tile_m_of(int variant) { return (variant == 1 || variant == 4) ? 256 : 128; }
-inline int tile_n_of(int variant) { return variant == 3 ? 64 : (variant == 4 ? 256 : 128); }
-
 // default variant: the largest tile that still gives every CU about two workgroups' worth of tiles
 inline int pick_variant(int M, int N, int splits) {
   auto tiles = [&](int v) {
-    return (long long)((M + tile_m_of(v) - 1) / tile_m_of(v)) * ((N + tile_n_of(v) - 1) / tile_n_of(v)) * splits;
+    return (long long)((M + kShapes[v].bm - 1) / kShapes[v].bm) * ((N + kShapes[v].bn - 1) / kShapes[v].bn) * splits;
   };
-  if (tiles(1) >= 2 * 256) return 1;
   if (tiles(0) >= 256) return 0;
   return 3;
 }
@@ -466,6 +488,11 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   if ((a->lda & 7) || (a->ldb & 7) || (a->N & 3)) return GPS_ERR_UNSUPPORTED;
   if (a->form != GPS_GEMM_TN && (a->K & 7)) return GPS_ERR_UNSUPPORTED;     // K-major operands: whole 16-byte chunks
   if (((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15)) return GPS_ERR_UNSUPPORTED;
+  // 32-bit byte offsets into A and B (buffer addressing)
+  {
+    const long long ra = a->form == GPS_GEMM_TN ? a->K : a->M, rb = a->form == GPS_GEMM_NT ? a->N : a->K;
+    if (ra * a->lda * 2 >= 0x7FFFFFFFLL || rb * a->ldb * 2 >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+  }
   const bool f32out = a->epilogue == GPS_GEMM_EPI_F32;
   if (f32out != (a->form == GPS_GEMM_TN)) return GPS_ERR_UNSUPPORTED;       // fp32 sums <=> weight-gradient form
   if (a->ldc & 3) return GPS_ERR_UNSUPPORTED;
@@ -500,7 +527,6 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   int variant = a->variant;
   if (variant < 0) variant = pick_variant(a->M, a->N, P.splits);
   if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
-  if (a->form == GPS_GEMM_TN && variant >= 3) variant = 0;      // reduction-major A: 128 x 128 or 256 x 128 tiles
 
   int st;
   if (a->form == GPS_GEMM_NT) {

@@ -52,11 +52,13 @@ class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
-                 splitk_wgrad: bool = True):
+                 native_gemm: bool = True):
         self.cfg = cfg
         self.device = torch.device(device)
-        # weight gradients of the big-token Linears as split-K bmm + fp32 sum (common/wgrad_splitk.py)
-        self.splitk_wgrad = bool(splitk_wgrad) and self.device.type == "cuda"
+        # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
+        # False = hipBLASLt through F.linear, kept for A/B runs
+        from .modules.layers import gemm as _gemm
+        _gemm.set_gemm_backend(bool(native_gemm))
         torch.manual_seed(seed)
         self.model = build_model(cfg).to(self.device)
         world = dist_utils.get_world_size()
@@ -144,7 +146,7 @@ class GPSTrainStep:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._begin_step()
-                with self._autocast(), self._splitk():
+                with self._autocast():
                     out = self.net(data_dict)
                 self._gather_features(out)
                 with self._autocast():
@@ -180,7 +182,7 @@ class GPSTrainStep:
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._begin_step()
-                with self._autocast(), self._splitk():
+                with self._autocast():
                     out = self.net(static_dict)
             self._gather_features(out)
             torch.cuda.synchronize(self.device)
@@ -219,13 +221,9 @@ class GPSTrainStep:
             from .modules.layers import fused_attention
             fused_attention.begin_step(self.device)
 
-    def _splitk(self):
-        from .common.wgrad_splitk import splitk_wgrad
-        return splitk_wgrad(self.splitk_wgrad and self.amp_dtype == torch.bfloat16)
-
     def forward_loss(self, data_dict):
         self._begin_step()
-        with self._autocast(), self._splitk():
+        with self._autocast():
             out = self.net(data_dict)
             total, losses = self.loss(out)
         return out, total, losses
@@ -281,6 +279,11 @@ class GPSTrainStep:
             return total, losses
         data_dict['cur_step'] = self.global_step
         data_dict['total_steps'] = 1 << 30
+        if self._graph is not None:
+            # an eager step after graph replays (bench's timing pass): replays update the masters without
+            # touching their Python-side version counters, so the bf16 shadows must be rebuilt from them
+            from .modules.layers import gemm as _gemm
+            _gemm.invalidate_shadows()
         out, total, losses = self.forward_loss(data_dict)
         self.optimizer.zero_grad(set_to_none=True)
         total.backward()

@@ -57,6 +57,7 @@ class BERTLanguageEncoder(nn.Module):
                 and getattr(cfg, "position_embedding_type", "absolute") == "absolute")
 
     def _fast_forward(self, txt_ids, txt_masks):
+        from ..layers import gemm
         from ..layers.fused_attention import fused_self_attention, supported as attn_supported
         from ..layers.fused_norm import add_dropout_layer_norm
         from . import fused_embedding
@@ -71,10 +72,14 @@ class BERTLanguageEncoder(nn.Module):
         training = self.training
         for layer in m.encoder.layer:
             sa, so = layer.attention.self, layer.attention.output
-            w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0)
-            b = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0)
+            native = gemm.usable(x16, D, D) and layer.intermediate.dense.out_features % 8 == 0
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-                packed = F.linear(x16, w, b)
+                if native:
+                    packed = gemm.packed_linear(x16, [sa.query, sa.key, sa.value])
+                else:
+                    w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0)
+                    b = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0)
+                    packed = F.linear(x16, w, b)
                 if attn_supported(D, H, L):
                     ctx = fused_self_attention(packed, H, None, pad, dropout_p=sa.dropout.p, training=training)
                 else:   # long captions: torch SDPA (flash) on views of the packed projection
@@ -83,10 +88,14 @@ class BERTLanguageEncoder(nn.Module):
                         q, k, v, attn_mask=pad.logical_not()[:, None, None, :],
                         dropout_p=sa.dropout.p if training else 0.0)
                     ctx = ctx.transpose(1, 2).reshape(B, L, D)
-                x, x16 = add_dropout_layer_norm(x, so.dense(ctx), so.LayerNorm, so.dropout.p, training,
-                                                want_bf16=True)
-                inter = layer.intermediate.intermediate_act_fn(layer.intermediate.dense(x16))
-                x, x16 = add_dropout_layer_norm(x, layer.output.dense(inter), layer.output.LayerNorm,
+                attn_out = gemm.linear(ctx, so.dense.weight, so.dense.bias) if native else so.dense(ctx)
+                x, x16 = add_dropout_layer_norm(x, attn_out, so.LayerNorm, so.dropout.p, training, want_bf16=True)
+                if native:      # dense + GELU + dense as two GEMMs with fused epilogues (HF: no dropout in between)
+                    ffn_out = gemm.ffn(x16, layer.intermediate.dense, layer.output.dense, "gelu", 0.0, training)
+                else:
+                    inter = layer.intermediate.intermediate_act_fn(layer.intermediate.dense(x16))
+                    ffn_out = layer.output.dense(inter)
+                x, x16 = add_dropout_layer_norm(x, ffn_out, layer.output.LayerNorm,
                                                 layer.output.dropout.p, training, want_bf16=True)
         return x
 

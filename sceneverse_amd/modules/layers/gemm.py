@@ -173,8 +173,8 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
         sh = _SHADOWS[key] = _Shadow()
     ver = _versions(list(weights) + list(biases))
     dev = weights[0].device
-    if sh.w16 is None or sh.w16.device != dev:
-        rows = sum(w.shape[0] for w in weights)
+    rows = sum(w.shape[0] for w in weights)
+    if sh.w16 is None or sh.w16.device != dev or tuple(sh.w16.shape) != (rows, weights[0].shape[1]):
         sh.w16 = torch.empty((rows, weights[0].shape[1]), dtype=torch.bfloat16, device=dev)
         sh.b32 = None
         sh.versions = None
@@ -209,6 +209,12 @@ def mark_fresh(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.
     sh = shadow_entry(weights)
     if sh is not None:
         sh.versions = _versions(list(weights) + list(biases))
+
+
+def invalidate_shadows() -> None:
+    """Force a rebuild of every shadow at its next use (masters changed behind Python's back: graph replays)."""
+    for sh in _SHADOWS.values():
+        sh.versions = None
 
 
 def clear_shadows() -> None:

@@ -167,8 +167,14 @@ class MultiHeadAttentionSpatial(nn.Module):
 
     def _forward_fused(self, x, pairwise_locs, key_padding_mask):
         """fusion 'cond', self-attention, bf16 on the GPU: ONE projection GEMM producing
-        [q | k | v | per-head (bias, w_1..w_5)] and one fused attention launch."""
+        [q | k | v | per-head (bias, w_1..w_5)] (libgps_hip.so's MFMA GEMM on a persistent packed bf16
+        copy of the four weights) and one fused attention launch."""
+        from . import gemm
         from .fused_attention import fused_self_attention
+        if gemm.usable(x, self.d_model, self.d_model):
+            packed = gemm.packed_linear(x, [self.w_qs, self.w_ks, self.w_vs, self.lang_cond_fc])
+            out = fused_self_attention(packed, self.n_head, pairwise_locs, key_padding_mask)
+            return gemm.linear(out, self.fc.weight, self.fc.bias), None
         w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.lang_cond_fc.weight], 0)
         bias = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias, self.lang_cond_fc.bias], 0)
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
@@ -247,11 +253,18 @@ class MultiheadSelfAttention(nn.Module):
         want = self.need_weights if need_weights is None else need_weights
         if (self._same and key is query and value is query and attn_mask is None and not want
                 and _use_hip(query, self.embed_dim, self.num_heads)):
+            from . import gemm
             from .fused_attention import fused_self_attention
-            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-                packed = F.linear(query, self.in_proj_weight, self.in_proj_bias)
+            native = gemm.usable(query, self.embed_dim, self.embed_dim)
+            if native:
+                packed = gemm.linear(query, self.in_proj_weight, self.in_proj_bias)
+            else:
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    packed = F.linear(query, self.in_proj_weight, self.in_proj_bias)
             out = fused_self_attention(packed, self.num_heads, None, key_padding_mask,
                                        dropout_p=self.dropout, training=self.training)
+            if native:
+                return gemm.linear(out, self.out_proj.weight, self.out_proj.bias), None
             return self.out_proj(out), None
         E = self.embed_dim
         bq, bk, bv = self.in_proj_bias[:E], self.in_proj_bias[E:2 * E], self.in_proj_bias[2 * E:]
@@ -283,6 +296,14 @@ class MultiheadSelfAttention(nn.Module):
 
 
 def _ffn(layer, x):
+    """linear2(dropout(activation(linear1(x)))) -- on the GPU in bf16: two MFMA GEMMs with the bias, activation
+    and dropout in their epilogues (libgps_hip.so), backward likewise (modules/layers/gemm.py)."""
+    from . import gemm
+    if x.is_cuda:
+        act = gemm.activation_name(layer.activation)
+        if act is not None and gemm.usable(x, layer.linear1.in_features, layer.linear1.out_features) \
+                and layer.linear2.out_features % 8 == 0:
+            return gemm.ffn(x, layer.linear1, layer.linear2, act, layer.dropout.p, layer.training)
     return layer.linear2(layer.dropout(layer.activation(layer.linear1(x))))
 
 

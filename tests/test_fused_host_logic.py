@@ -107,27 +107,41 @@ def test_seed_stream_never_repeats_and_keeps_saved_views_stable():
     assert (int(b.item()) - int(a.item())) % (1 << 64) == FA._SEED_INC
 
 
-def test_splitk_chunk_choice_and_routing_rules_on_cpu():
-    """Host logic of common/wgrad_splitk.py: chunk counts divide the token count, leave >= 512 tokens per
-    chunk, never exceed 16, small problems are left alone; on CPU tensors F.linear is never rerouted."""
+def test_gemm_host_logic_on_cpu():
+    """Host logic of modules/layers/gemm.py without a GPU: the native GEMMs are never chosen for CPU tensors
+    (layers keep the torch formulation), the bf16 shadow of a weight group is rebuilt exactly when a master
+    changed, packed groups concatenate rows and biases in order, split counts are sane."""
     import torch
+    from sceneverse_amd import _native
+    from sceneverse_amd.modules.layers import gemm as G
+    x = torch.randn(4, 16)
+    assert not G.usable(x, 16, 16) and not G.usable(x.to(torch.bfloat16), 16, 16)
+    lins = [torch.nn.Linear(16, n) for n in (16, 8, 24)]
+    w16, b32 = G.shadow_of([m.weight for m in lins], [m.bias for m in lins])
+    assert w16.shape == (48, 16) and w16.dtype == torch.bfloat16 and b32.shape == (48,)
+    assert torch.equal(w16, torch.cat([m.weight for m in lins]).to(torch.bfloat16))
+    assert torch.equal(b32, torch.cat([m.bias for m in lins]))
+    again, _ = G.shadow_of([m.weight for m in lins], [m.bias for m in lins])
+    assert again.data_ptr() == w16.data_ptr() and again._version == w16._version       # no rebuild
+    with torch.no_grad():
+        lins[1].weight.add_(1.0)
+    w16b, _ = G.shadow_of([m.weight for m in lins], [m.bias for m in lins])
+    assert w16b.data_ptr() == w16.data_ptr()                                            # refreshed in place
+    assert torch.equal(w16b[16:24], lins[1].weight.to(torch.bfloat16))
+    G.invalidate_shadows()
+    assert G.shadow_entry([m.weight for m in lins]).versions is None
+    single_w, single_b = G.shadow_of([lins[0].weight], [lins[0].bias])
+    assert single_b.data_ptr() == lins[0].bias.data_ptr()                              # one bias: no copy
+    G.clear_shadows()
+    lib = _native.load()
+    for tokens in (77, 3200, 5120, 8320, 19200):
+        for n_out, n_in in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (2376, 768)):
+            s = lib.gps_gemm_pick_splits(_native.GEMM_TN, n_out, n_in, tokens)
+            assert 1 <= s <= 32 and (s == 1 or (tokens + 63) // 64 // s >= 8)
+            assert lib.gps_gemm_workspace_floats(_native.GEMM_TN, n_out, n_in, s) == (0 if s == 1 else s * (n_out * n_in + n_out))
+    assert lib.gps_gemm_pick_splits(_native.GEMM_NT, 5120, 768, 768) == 1
     import torch.nn.functional as F
-    from sceneverse_amd.common import wgrad_splitk as W
-    for tokens in (5120, 8320, 19200, 20000, 12345):
-        for n_out, n_in in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (2376, 768), (30522, 768)):
-            s = W.pick_splits(tokens, n_out, n_in)
-            assert 1 <= s <= 16 and tokens % s == 0 and (s == 1 or tokens // s >= 512)
-    assert W.pick_splits(19200, 768, 768) == 16 and W.pick_splits(19200, 3072, 768) == 4
-    assert W.pick_splits(4999, 768, 768) == 1 and W.pick_splits(19200, 768, 6) == 1
-    lin = torch.nn.Linear(16, 16)
-    x = torch.randn(6000, 16, requires_grad=True)
-    with W.splitk_wgrad():
-        assert F.linear is W._linear
-        y = lin(x)
-        assert type(y.grad_fn).__name__ != "_AttachWGradBackward"
-    assert F.linear is W._ORIG_LINEAR
-    with W.splitk_wgrad(False):
-        assert F.linear is W._ORIG_LINEAR
+    assert G.activation_name(F.gelu) == "gelu" and G.activation_name(F.relu) == "relu" and G.activation_name(F.glu) is None
 
 
 def test_packed_scans_host_side_on_cpu():

@@ -37,7 +37,7 @@ NT_SHAPES = [(5120, 768, 768), (8320, 2304, 768), (5120, 2376, 768), (5120, 2048
              (3200, 3072, 768), (300, 72, 40), (129, 8, 8), (1, 768, 768), (257, 132, 200), (640, 640, 2376)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_forward_nt(M, N, K, variant):
     x, w = _rand16(M, K, seed=1), _rand16(N, K, scale=0.05, seed=2)
@@ -62,7 +62,7 @@ NN_SHAPES = [(5120, 768, 768), (8320, 768, 2304), (5120, 768, 2376), (8320, 2048
              (300, 40, 72), (129, 8, 8), (257, 200, 136), (640, 2376, 640)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", NN_SHAPES)
 def test_dgrad_nn(M, N, K, variant):
     dy, w = _rand16(M, K, seed=5), _rand16(K, N, scale=0.05, seed=6)      # w is (out = K, in = N)
@@ -85,7 +85,7 @@ def test_wgrad_tn(T, N, K, splits):
     dw = torch.empty(N, K, device=DEV)
     db = torch.empty(N, device=DEV)
     ws = torch.empty(max(1, int(lib.gps_gemm_workspace_floats(_native.GEMM_TN, N, K, s))), device=DEV)
-    for variant in (0, 1, 2, 4):
+    for variant in (0, 1, 2, 5, 7):
         dw.fill_(float("nan"))
         db.fill_(float("nan"))
         G.gemm(_native.GEMM_TN, _native.EPI_F32, N, K, T, dy, N, x, K, dw, K, workspace=ws, colsum=db, splits=s,

@@ -22,7 +22,7 @@ fi
 if [[ $WHAT == *gemmpmc* ]]; then
   ts gemmpmc
   rocprofv3 -L > $OUT/pmc_list.txt 2>&1
-  for cfg in nt:0 nt:4 lib:0 nn:0 tn:0; do
+  for cfg in nt:0 nt:1 nt:2 nt:5; do
     for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
       tag=$(echo ${cfg}_${grp%% *} | tr ':' '_')
       rm -rf /tmp/pmc_$tag

@@ -166,7 +166,7 @@ def main():
     print(row, flush=True)
     rows.append(row)
     # bias-gradient column sums (gps_colsum_bf16) next to torch's reduction of the same matrix
-    from sceneverse_amd.common import wgrad_splitk as WS
+    from sceneverse_amd.common import colsum as WS
     for T, N in ((19200, 3072), (19200, 768), (8320, 2048), (5120, 2376)):
         dy = torch.randn(T, N, device=dev).to(torch.bfloat16)
         us = timeit(lambda: WS.colsum_bf16(dy))

@@ -74,7 +74,7 @@ def main():
             _FusedSelfAttention.apply(packed, pl, mask, 12, 0.0, 0, None).float().sum().backward()
     # bias-gradient column sums and the loader-side object kernel
     import numpy as np
-    from sceneverse_amd.common import wgrad_splitk as WS
+    from sceneverse_amd.common import colsum as WS
     from sceneverse_amd.data import gpu_objects as G
     for T, N in ((19200, 3072), (19200, 768), (8320, 2048)):
         dy = torch.randn(T, N, device=dev).to(torch.bfloat16)
