@@ -163,6 +163,112 @@ def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
                       f"on {cores} host threads, after 1 warm-up step; {dt:.1f} s"}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_command(argv: list, gpus: int, port: int) -> list:
+    """The torchrun command this script re-executes itself under when asked for N > 1 GPUs without a launcher
+    environment (one rank per GPU; the reference's launcher does the same job: common/launch_utils.py:26-42)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def resolve_world(gpus: int, env=os.environ):
+    """-> ("spawn", None) | ("run", world).  Raises SystemExit when --gpus and the launcher disagree."""
+    if gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    has_launcher = "RANK" in env and "WORLD_SIZE" in env
+    if not has_launcher:
+        return ("spawn", None) if gpus > 1 else ("run", 1)
+    world = int(env["WORLD_SIZE"])
+    if world != gpus:
+        raise SystemExit(f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks")
+    return ("run", world)
+
+
+def bq_group_unfused(batch) -> dict:
+    """The north star's `ball_query + group` figure: the six launches of the reference API at this workload
+    (SA1: ball_query, group xyz, group rgb; SA2: ball_query, group xyz, group feats), each timed as a HIP-graph
+    replay of 10 calls, algorithmic bytes of SURVEY.md 8(d) (365 888 B per object) over the summed time."""
+    from sceneverse_amd.pointnet2 import _ext as hip
+    pcs = batch["obj_fts"].reshape(-1, batch["obj_fts"].shape[-2], 6)
+    xyz = pcs[..., :3].contiguous()
+    rgb = pcs[..., 3:].transpose(1, 2).contiguous()
+    b, n = xyz.shape[0], xyz.shape[1]
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    fps = hip.furthest_point_sampling(xyz, 32)
+    new_xyz = hip.gather_points(xyz_t, fps).transpose(1, 2).contiguous()
+    idx = hip.ball_query(new_xyz, xyz, 0.2, 32)
+    fps2 = hip.furthest_point_sampling(new_xyz, 16)
+    nx_t = new_xyz.transpose(1, 2).contiguous()
+    nx2 = hip.gather_points(nx_t, fps2).transpose(1, 2).contiguous()
+    idx2 = hip.ball_query(nx2, new_xyz, 0.4, 32)
+    feats = torch.randn(b, 128, 32, device=xyz.device)
+    ops = [("ball_query SA1", lambda: hip.ball_query(new_xyz, xyz, 0.2, 32), b * ((n + 32) * 12 + 32 * 32 * 4)),
+           ("ball_query SA2", lambda: hip.ball_query(nx2, new_xyz, 0.4, 32), b * ((32 + 16) * 12 + 16 * 32 * 4)),
+           ("group SA1 xyz", lambda: hip.group_points(xyz_t, idx), b * (3 * n * 4 + 1024 * 4 + 3 * 1024 * 4)),
+           ("group SA1 rgb", lambda: hip.group_points(rgb, idx), b * (3 * n * 4 + 1024 * 4 + 3 * 1024 * 4)),
+           ("group SA2 xyz", lambda: hip.group_points(nx_t, idx2), b * (3 * 32 * 4 + 512 * 4 + 3 * 512 * 4)),
+           ("group SA2 feats", lambda: hip.group_points(feats, idx2), b * (128 * 32 * 4 + 512 * 4 + 128 * 512 * 4))]
+    rows, tot_us, tot_b = [], 0.0, 0
+    for name, fn, nbytes in ops:
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(10):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) * 1e3 / 10
+        rows.append({"op": name, "us": round(us, 2), "algorithmic_bytes": nbytes,
+                     "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)})
+        tot_us += us
+        tot_b += nbytes
+    return {"launches": rows, "us": round(tot_us, 2), "algorithmic_bytes": tot_b,
+            "achieved_GBps": round(tot_b / tot_us / 1e3, 1), "frac_hbm": round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 4)}
+
+
+def profile_step_kernels(step, batch, n_steps: int = 2) -> list:
+    """All kernels of the step by total time (torch.profiler over eager steps): [{name, ms_per_step, launches}]."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        step.step(dict(batch))
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(n_steps):
+                step.step(dict(batch))
+            torch.cuda.synchronize()
+        rows = []
+        for ev in prof.key_averages():
+            t = getattr(ev, "device_time_total", None)
+            if t is None:
+                t = getattr(ev, "cuda_time_total", 0.0)
+            if t and ev.count:
+                rows.append({"name": ev.key[:120], "ms_per_step": round(t / 1e3 / n_steps, 4),
+                             "launches_per_step": round(ev.count / n_steps, 1)})
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        return rows
+    except Exception as e:  # noqa: BLE001 -- the profiler pass is reporting only
+        print(f"[bench] torch.profiler pass failed ({type(e).__name__}: {e})", file=sys.stderr)
+        return []
+
+
+# in-scope transformer work per pair, fwd + bwd (SURVEY.md 8(d), probe-measured on the reference code):
+# 4 spatial layers at T = 80 (3.643 GFLOP fwd) + 4 joint layers at T = 130 (5.936 GFLOP fwd), x 3
+IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR = 28.73
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +291,14 @@ def main() -> None:
                          "modules/language/fused_embedding.py)")
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the reporting-only passes after the timed region (profiler, unfused point-op timing)")
     args = ap.parse_args()
+
+    mode, world_expected = resolve_world(args.gpus)
+    if mode == "spawn":
+        import subprocess
+        raise SystemExit(subprocess.call(spawn_command(sys.argv[1:], args.gpus, _free_port())))
 
     from sceneverse_amd.common import dist_utils
     from sceneverse_amd.data.synthetic import synth_batch
@@ -201,8 +314,8 @@ def main() -> None:
     # the N > 1 code path can be exercised end to end on a one-GPU box (RCCL refuses two ranks on one GPU)
     share = os.environ.get("GPS_BENCH_SHARE_GPU") == "1"
     rank, world, local = dist_utils.init_from_env("gloo" if share else "nccl")
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != world_expected:
+        raise SystemExit(f"--gpus {args.gpus} but {world} rank(s) were initialised")
     if share:
         local = 0
     dev = torch.device("cuda", local)
@@ -226,24 +339,14 @@ def main() -> None:
 
     graph_note = None
     if use_graph:
-        # engine preparation (untimed, before the W warm-up steps): eager steps + one capture
-        try:
-            for _ in range(step.graph_warmup + 1):
-                step.step(dict(batch))
-            torch.cuda.synchronize()
-            graph_note = ("whole step replayed as one HIP graph" if step.graph else
-                          "3 HIP graphs per step (forward | losses+backward | clip+AdamW) around eager RCCL "
-                          "all-gather / all-reduce")
-        except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a requirement
-            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-            del step
-            torch.cuda.empty_cache()
-            use_graph = False
-            cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
-            step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=False,
-                                native_gemm=not args.no_native_gemm)
-            graph_note = f"eager (graph capture failed: {type(e).__name__})"
+        # engine preparation (untimed, before the W warm-up steps): eager steps + one capture.  A failed capture
+        # is an error, not a silent eager run: `value` would be ~25 % lower without anyone noticing.
+        for _ in range(step.graph_warmup + 1):
+            step.step(dict(batch))
+        torch.cuda.synchronize()
+        graph_note = ("whole step replayed as one HIP graph" if step.graph else
+                      "3 HIP graphs per step (forward | losses+backward | clip+AdamW) around eager RCCL "
+                      "all-gather / all-reduce")
     for _ in range(args.warmup):
         step.step(dict(batch))
     barrier()
@@ -266,43 +369,102 @@ def main() -> None:
         kern = hip_ext.profile_stop()
         for k in kern.values():
             k["launches"] = k["launches"] * args.steps / 3.0
-        step.graph, step.graph_dp = saved
     else:
         kern = hip_ext.profile_stop()
+        saved = None
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
     final_loss = float(loss)
+    step_kernels, bqg = [], None
+    if rank == 0 and not args.no_extras:
+        if world == 1:
+            step_kernels = profile_step_kernels(step, batch)        # eager steps (graph flags are off here)
+        bqg = bq_group_unfused(batch)
+    if saved is not None:
+        step.graph, step.graph_dp = saved
 
     if rank == 0:
+        pairs_per_s = args.batch * world * args.steps / dt
         kernels = []
         for name, k in sorted(kern.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]):
             sec = k["avg_us"] * 1e-6
             gbs = k["bytes_per_launch"] / sec / 1e9
             row = {"kernel": name, "launches_per_step": k["launches"] / args.steps,
-                   "avg_us": round(k["avg_us"], 2), "algorithmic_bytes": int(k["bytes_per_launch"]),
+                   "avg_us": round(k["avg_us"], 2), "ms_per_step": round(k["avg_us"] * k["launches"] / args.steps / 1e3, 4),
+                   "algorithmic_bytes": int(k["bytes_per_launch"]),
                    "achieved_GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
-            # which roof bounds the kernel: the one its algorithmic work would take longer on
+            # which roof bounds the kernel: the one its algorithmic work would take longer on.  The point
+            # kernels compute fp32 products as 3 bf16 MFMAs: their ALGORITHMIC flops are priced against the
+            # bf16 peak they run on (frac), the executed-MFMA rate is reported as mfma_utilisation.
             t_hbm = k["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
-            peak_tf = MFMA_PEAK_TFLOPS.get(k.get("mfma_dtype") or "", 0.0)
-            t_mfma = k["flops_per_launch"] / (peak_tf * 1e12) if peak_tf else 0.0
+            mfma_dtype = k.get("mfma_dtype") or ""
+            split3 = "bf16x3" in name
+            peak_tf = MFMA_PEAK_TFLOPS.get("bf16" if split3 else mfma_dtype, 0.0)
+            algo_flops = k["flops_per_launch"] / 3.0 if split3 else k["flops_per_launch"]
+            t_mfma = algo_flops / (peak_tf * 1e12) if peak_tf else 0.0
             if t_mfma > t_hbm:
-                tf = k["flops_per_launch"] / sec / 1e12
-                row.update({"bound": "mfma", "algorithmic_flops": int(k["flops_per_launch"]),
-                            "mfma_dtype": k["mfma_dtype"], "achieved_TFLOPs": round(tf, 1),
-                            "frac": round(tf / peak_tf, 4)})
+                tf = algo_flops / sec / 1e12
+                row.update({"bound": "mfma", "algorithmic_flops": int(algo_flops), "mfma_dtype": "bf16" if split3 else mfma_dtype,
+                            "achieved_TFLOPs": round(tf, 1), "frac": round(tf / peak_tf, 4)})
+                if split3:
+                    row["mfma_utilisation"] = round(3.0 * tf / peak_tf, 4)
             else:
                 row.update({"bound": "hbm", "frac": row["frac_hbm"]})
             kernels.append(row)
+        # dominant kernel over ALL kernels of the step: native launch shapes (above) vs every other kernel name
+        # the profiler saw (library GEMMs, torch elementwise / optimizer kernels)
+        native_names = ("gps_",)
+        others = [r for r in step_kernels if not any(tag in r["name"] for tag in native_names)]
         dom = kernels[0] if kernels else None
+        dom_other = others[0] if others else None
         traffic = None
         if dom is not None and os.path.exists(PMC_TRAFFIC):
             with open(PMC_TRAFFIC) as f:
                 traffic = json.load(f).get("per_launch_hbm_bytes", {}).get(dom["kernel"])
+        if dom is None:
+            roofline = None
+        elif dom_other is not None and dom_other["ms_per_step"] > dom["ms_per_step"]:
+            roofline = {"bound": None, "kernel": dom_other["name"], "achieved": None, "peak": None, "unit": None,
+                        "frac": None, "traffic": None, "ms_per_step": dom_other["ms_per_step"],
+                        "note": "the kernel with the largest time per step is not a libgps_hip.so launch; its "
+                                "algorithmic work is not known to this script",
+                        "largest_native": {"kernel": dom["kernel"], "bound": dom["bound"], "frac": dom["frac"],
+                                           "ms_per_step": dom["ms_per_step"]}}
+        elif dom["bound"] == "mfma":
+            roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],
+                        "peak": MFMA_PEAK_TFLOPS[dom["mfma_dtype"]], "unit": "TFLOP/s", "frac": dom["frac"],
+                        "dtype": dom["mfma_dtype"], "traffic": traffic, "ms_per_step": dom["ms_per_step"],
+                        **({"mfma_utilisation": dom["mfma_utilisation"]} if "mfma_utilisation" in dom else {})}
+        else:
+            roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
+                        "ms_per_step": dom["ms_per_step"]}
+        attn = [r for r in kernels if r["kernel"].startswith("attn_")]
+        attn_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in attn)
+        attn_sec = sum(r["avg_us"] * 1e-6 * r["launches_per_step"] for r in attn)
+        gemm_rows = [r for r in kernels if r["kernel"].startswith("gemm_")]
+        gemm_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in gemm_rows)
+        gemm_sec = sum(r["avg_us"] * 1e-6 * r["launches_per_step"] for r in gemm_rows)
+        headline = {
+            "ball_query_group_unfused": bqg,
+            "transformer_in_scope": {
+                "gflop_per_pair": IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR,
+                "achieved_TFLOPs": round(IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR * pairs_per_s / 1e3, 1),
+                "frac_of_bf16_mfma_peak": round(IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR * pairs_per_s / 1e3 / MFMA_PEAK_TFLOPS["bf16"], 4),
+                "note": "in-scope transformer FLOPs per pair x whole-step pairs/s: the whole step (BERT, point "
+                        "encoder, heads, optimizer) is in the denominator's time"},
+            "native_gemms": None if not gemm_sec else {
+                "achieved_TFLOPs": round(gemm_flops / gemm_sec / 1e12, 1), "ms_per_step": round(gemm_sec * 1e3, 3),
+                "frac_of_bf16_mfma_peak": round(gemm_flops / gemm_sec / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4)},
+            "attention_core": None if not attn_sec else {
+                "achieved_TFLOPs": round(attn_flops / attn_sec / 1e12, 1), "ms_per_step": round(attn_sec * 1e3, 3),
+                "frac_of_bf16_mfma_peak": round(attn_flops / attn_sec / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4)},
+        }
         result = {
             "metric": "GPS pre-train pairs/sec (fwd+bwd)",
-            "value": round(args.batch * world * args.steps / dt, 2),
+            "value": round(pairs_per_s, 2),
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -319,25 +481,16 @@ def main() -> None:
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
                        "point_ops": "fp32-accurate split-bf16 MFMA (libgps_hip.so)",
+                       "gemms": "hipBLASLt (A/B run)" if args.no_native_gemm else "libgps_hip.so bf16 MFMA (gps_gemm_bf16)",
                        "launch": graph_note or "eager",
                        "kernel_timing": ("HIP events around each native launch, eager steps right after the "
                                          "timed graph replays" if use_graph else
                                          "HIP events around each native launch inside the timed steps"),
                        "final_loss": round(final_loss, 4)},
-            "roofline": None if dom is None else (
-                {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],
-                 "peak": MFMA_PEAK_TFLOPS[dom["mfma_dtype"]], "unit": "TFLOP/s", "frac": dom["frac"],
-                 "dtype": dom["mfma_dtype"], "traffic": traffic,
-                 **({"flops_counted": "split-bf16: every fp32-accurate product is 3 bf16 MFMAs (hi*hi + hi*lo + "
-                                      "lo*hi), the cheapest MFMA form that meets the 1e-4 parity bar of the "
-                                      "fp32 reference path; achieved/frac count those 3",
-                     "achieved_fp32_equivalent": round(dom["achieved_TFLOPs"] / 3.0, 1),
-                     "frac_of_fp32_mfma_peak": round(dom["achieved_TFLOPs"] / 3.0 / MFMA_PEAK_TFLOPS["fp32"], 3)}
-                    if "bf16x3" in dom["kernel"] else {})}
-                if dom["bound"] == "mfma" else
-                {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],
-                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic}),
+            "roofline": roofline,
+            "headline": headline,
             "kernels": kernels,
+            "step_kernels": step_kernels[:25],
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.n_obj, args.n_pts)

@@ -118,7 +118,6 @@ struct Stager {
   static_assert(ROWS % (8 * NW) == 0, "tile rows must split evenly over the waves");
   unsigned int voff[NPIECE];
   unsigned int kidx[NPIECE];                        // RM: k row inside the stage; KM: first k of the chunk (tail only)
-  __amdgpu_buffer_rsrc_t rsrc;
   const unsigned char *base;
   unsigned int soff, step;
 
@@ -127,7 +126,6 @@ struct Stager {
   __device__ __forceinline__ void init(const uint16_t *mat, long long ld, int rows, int r0, int k_begin, int wave,
                                        int lane) {
     base = reinterpret_cast<const unsigned char *>(mat);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(mat), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int q = j * NW + wave;
@@ -150,10 +148,14 @@ struct Stager {
   }
   // copy one full stage into `tile` (LDS, ROWS * 128 bytes)
   __device__ __forceinline__ void issue_full(unsigned char *tile, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in hipcc's HOST pass over this file
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(tile + (j * NW + wave) * PIECE),
                                                16, voff[j], soff, 0, 0);
+#endif
     soff += step;
   }
   // the ragged last stage: only k_left (< 64) reduction indices are inside the matrix, the rest reads zeros
@@ -191,6 +193,48 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char *tile, int r0, i
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
+// one stage of both operands into the stage buffer at `base` (A tile, then B tile)
+template <int BM, int BN, bool ATR, bool BTR, int NW>
+__device__ __forceinline__ void issue_stage(Stager<BM, ATR, NW> &sa, Stager<BN, BTR, NW> &sb, unsigned char *base,
+                                            int &k_left, int wave) {
+  if (k_left >= BK) {
+    sa.issue_full(base, wave);
+    sb.issue_full(base + BM * BK * 2, wave);
+  } else {
+    sa.issue_tail(base, k_left, wave);
+    sb.issue_tail(base + BM * BK * 2, k_left, wave);
+  }
+  k_left -= BK;
+}
+
+// the MFMAs of one stage: acc[a][b] += B-fragment b x A-fragment a (operands swapped: a lane ends up with four
+// consecutive output columns of one row); optional column sums of A through an all-ones operand
+template <int BM, int BN, int TM, int TN, bool ATR, bool BTR, bool COLSUM>
+__device__ __forceinline__ void compute_stage(const unsigned char *As, int wm0, int wn0, int lane, f32x4 (&acc)[TM][TN],
+                                              f32x4 (&csum)[TM], bool do_colsum) {
+  const unsigned char *Bs = As + BM * BK * 2;
+  const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // 8 x bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+#pragma unroll
+  for (int ks = 0; ks < BK / 32; ++ks) {
+    bf16x8 af[TM], bf[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) af[a] = read_frag<BM, ATR>(As, wm0 + 16 * a, ks, lane);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[b] = read_frag<BN, BTR>(Bs, wn0 + 16 * b, ks, lane);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[a], acc[a][b], 0, 0, 0);
+    if (COLSUM) {
+      if (do_colsum) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) csum[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], csum[a], 0, 0, 0);
+      }
+    }
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
@@ -256,57 +300,20 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   f32x4 csum[TM];
 #pragma unroll
   for (int a = 0; a < TM; ++a) csum[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // 8 x bf16 1.0
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
   int k_left = P.K - kt0 * BK;                       // reduction indices from the next stage to issue onwards
-  auto issue_stage = [&](int buf) {
-    unsigned char *base = smem + buf * STAGE;
-    if (k_left >= BK) {
-      sa.issue_full(base, wave);
-      sb.issue_full(base + A_BYTES, wave);
-    } else {
-      sa.issue_tail(base, k_left, wave);
-      sb.issue_tail(base + A_BYTES, k_left, wave);
-    }
-    k_left -= BK;
-  };
-  auto compute_stage = [&](int buf) {
-    const unsigned char *As = smem + buf * STAGE;
-    const unsigned char *Bs = As + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 af[TM], bf[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = read_frag<BM, ATR>(As, wm0 + 16 * a, ks, lane);
-#pragma unroll
-      for (int b = 0; b < TN; ++b) bf[b] = read_frag<BN, BTR>(Bs, wn0 + 16 * b, ks, lane);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[a], acc[a][b], 0, 0, 0);
-      if (EPI == EPI_F32) {
-        if (do_colsum) {
-#pragma unroll
-          for (int a = 0; a < TM; ++a) csum[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], csum[a], 0, 0, 0);
-        }
-      }
-    }
-  };
-
   // ring of NBUF stage buffers: NBUF - 1 stages are in flight ahead of the one being computed; each wave waits for
   // ITS OWN copies of the stage with a counted vmcnt, the (raw) barrier then makes every wave's copies visible and
   // guarantees that the buffer about to be refilled (the one computed in the previous iteration) is no longer read
 #pragma unroll
   for (int s = 0; s < NBUF - 1; ++s)
-    if (s < nst) issue_stage(s);
+    if (s < nst) issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + s * STAGE, k_left, wave);
   int cur = 0, fill = NBUF - 1;
   for (int it = 0; it < nst; ++it) {
     wait_stages<NP, NBUF - 2>(min(nst - 1 - it, NBUF - 2));
     __builtin_amdgcn_s_barrier();
-    if (it + NBUF - 1 < nst) issue_stage(fill);
-    compute_stage(cur);
+    if (it + NBUF - 1 < nst) issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + fill * STAGE, k_left, wave);
+    compute_stage<BM, BN, TM, TN, ATR, BTR, EPI == EPI_F32>(smem + cur * STAGE, wm0, wn0, lane, acc, csum, do_colsum);
     cur = (cur == NBUF - 1) ? 0 : cur + 1;
     fill = (fill == NBUF - 1) ? 0 : fill + 1;
   }

@@ -180,3 +180,24 @@ def test_packed_scans_host_side_on_cpu():
             G.batch_rows(p, ["a"], 2)
         with pytest.raises(RuntimeError):                       # product path is GPU-only: no CPU fallback
             G.obj_processing_post(p, rows, 64)
+
+
+def test_bench_rank_resolution_rules():
+    """bench.py --gpus N: no launcher environment -> self-spawn for N > 1; a launcher whose WORLD_SIZE disagrees
+    with --gpus is an error (never a silent one-GPU run)."""
+    import sys
+    import pytest
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    assert bench.resolve_world(1, {}) == ("run", 1)
+    assert bench.resolve_world(8, {}) == ("spawn", None)
+    assert bench.resolve_world(8, {"RANK": "3", "WORLD_SIZE": "8"}) == ("run", 8)
+    for gpus, world in ((8, 2), (1, 2), (2, 1)):
+        with pytest.raises(SystemExit):
+            bench.resolve_world(gpus, {"RANK": "0", "WORLD_SIZE": str(world)})
+    cmd = bench.spawn_command(["--gpus", "4", "--steps", "3"], 4, 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]

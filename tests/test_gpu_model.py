@@ -309,3 +309,23 @@ def test_bench_n2_code_path_on_one_gpu():
     assert out["value"] > 0 and abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) < 0.02 * out["value"]
     assert "cpu_baseline" not in out and out["roofline"] is not None
     assert out["config"]["final_loss"] == out["config"]["final_loss"]
+
+
+def test_bench_self_spawns_its_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment: the script re-executes itself under
+    torch.distributed.run with two ranks (sharing cuda:0 over gloo here) and reports n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GPS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-extras"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16
