@@ -209,12 +209,40 @@ __device__ __forceinline__ void issue_stage(Stager<BM, ATR, NW> &sa, Stager<BN, 
 
 // the MFMAs of one stage: acc[a][b] += B-fragment b x A-fragment a (operands swapped: a lane ends up with four
 // consecutive output columns of one row); optional column sums of A through an all-ones operand
-template <int BM, int BN, int TM, int TN, bool ATR, bool BTR, bool COLSUM>
+template <int BM, int BN, int TM, int TN, bool ATR, bool BTR, bool COLSUM, bool PF>
 __device__ __forceinline__ void compute_stage(const unsigned char *As, int wm0, int wn0, int lane, f32x4 (&acc)[TM][TN],
                                               f32x4 (&csum)[TM], bool do_colsum) {
   const unsigned char *Bs = As + BM * BK * 2;
   const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // 8 x bf16 1.0
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+  if (PF) {
+    // all fragment reads of the stage are issued before its first MFMA: one exposed LDS latency per stage, the
+    // MFMAs of the first K step then cover the reads of the second
+    bf16x8 af[BK / 32][TM], bf[BK / 32][TN];
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[ks][a] = read_frag<BM, ATR>(As, wm0 + 16 * a, ks, lane);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[ks][b] = read_frag<BN, BTR>(Bs, wn0 + 16 * b, ks, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][b], af[ks][a], acc[a][b], 0, 0, 0);
+      if (COLSUM) {
+        if (do_colsum) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) csum[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][a], csum[a], 0, 0, 0);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ks = 0; ks < BK / 32; ++ks) {
     bf16x8 af[TM], bf[TN];
@@ -258,7 +286,7 @@ constexpr int waves_per_simd(int BM, int BN, int NW, int NBUF) {
   return w < 1 ? 1 : (w > 2 ? 2 : w);     // the accumulators never leave room for more than 2
 }
 
-template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF>
+template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF, bool PF>
 __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBUF)) void gemm_kernel(const Params P) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -313,7 +341,7 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
     wait_stages<NP, NBUF - 2>(min(nst - 1 - it, NBUF - 2));
     __builtin_amdgcn_s_barrier();
     if (it + NBUF - 1 < nst) issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + fill * STAGE, k_left, wave);
-    compute_stage<BM, BN, TM, TN, ATR, BTR, EPI == EPI_F32>(smem + cur * STAGE, wm0, wn0, lane, acc, csum, do_colsum);
+    compute_stage<BM, BN, TM, TN, ATR, BTR, EPI == EPI_F32, PF>(smem + cur * STAGE, wm0, wn0, lane, acc, csum, do_colsum);
     cur = (cur == NBUF - 1) ? 0 : cur + 1;
     fill = (fill == NBUF - 1) ? 0 : fill + 1;
   }
@@ -407,13 +435,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long lon
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF>
+template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF, bool PF = false>
 int launch_cfg(Params &P, hipStream_t s) {
   constexpr int LDS = lds_bytes(BM, BN, NBUF);
   static_assert(LDS <= 160 * 1024, "stage buffers exceed the LDS of a CU");
   P.ntm = (P.M + BM - 1) / BM;
   P.ntn = (P.N + BN - 1) / BN;
-  auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF>;
+  auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF, PF>;
   static bool attr_done = false;
   if (LDS > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
@@ -427,10 +455,11 @@ int launch_cfg(Params &P, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
-// tile configurations ("variants"): tile (BM x BN), wave grid, stage buffers (LDS) -> resident workgroups per CU
-//   0  128x128  2x2  2 bufs ( 64 KB)  2/CU      1  128x128  2x2  4 bufs (128 KB)  1/CU     2  128x128  4x2  4 bufs  1/CU
-//   3  128x64   2x2  3 bufs ( 72 KB)  2/CU      4  256x256  2x4  2 bufs (128 KB)  1/CU     5  256x128  4x2  3 bufs (144 KB)
-//   6  128x64   2x2  6 bufs (144 KB)  1/CU      7  128x128  4x2  2 bufs ( 64 KB)  2/CU
+// tile configurations ("variants"): tile (BM x BN), wave grid, stage buffers (LDS) -> resident workgroups per CU,
+// PF = all fragment reads of a stage issued before its first MFMA
+//   0  128x128  2x2  2 bufs ( 64 KB)  2/CU      1  128x128  2x2  2 bufs  PF            2  128x128  4x2  2 bufs  PF
+//   3  128x64   2x2  3 bufs ( 72 KB)  2/CU      4  256x256  2x4  2 bufs (128 KB)  1/CU  5  256x128  4x2  2 bufs ( 96 KB) 1/CU
+//   6  128x64   2x2  2 bufs ( 48 KB)  3/CU      7  128x128  4x2  2 bufs ( 64 KB)  2/CU
 constexpr int kVariants = 8;
 struct VariantShape { int bm, bn; };
 constexpr VariantShape kShapes[kVariants] = {{128, 128}, {128, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128}};
@@ -438,18 +467,18 @@ template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
     case 0: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);
-    case 1: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 4>(P, s);
-    case 2: return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 4>(P, s);
+    case 1: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2, true>(P, s);
+    case 2: return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2, true>(P, s);
     case 3:
       if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);   // reduction-major A tiles are >= 128 wide
       else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 3>(P, s);
     case 4:
       if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);   // 256 x 256 with two transposed
       else return launch_cfg<256, 256, 2, 4, ATR, BTR, EPI, 2>(P, s);                 // operands exceeds 256 VGPRs
-    case 5: return launch_cfg<256, 128, 4, 2, ATR, BTR, EPI, 3>(P, s);
+    case 5: return launch_cfg<256, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
     case 6:
-      if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 4>(P, s);
-      else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 6>(P, s);
+      if constexpr (ATR) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 2>(P, s);
     case 7: return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
     default: return GPS_ERR_INVALID_ARGUMENT;
   }

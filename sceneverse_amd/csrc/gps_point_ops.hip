@@ -314,7 +314,15 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
     // Register-resident cloud held as PAIRS of consecutive chunks, so that the distance arithmetic of
     // two chunks against one centre is packed fp32 (v_pk_add_f32 / v_pk_mul_f32: each half individually
     // IEEE-rounded, i.e. the pinned ((dx*dx + dy*dy) + dz*dz) per point): 8 packed ops + 2 compares per
-    // 128 points.  The two chunk masks are consumed in index order, each with its own early exit.
+    // 128 points.
+    //
+    // Compaction without a per-chunk scalar chain (round 1 spent its time there: ballot -> branch -> mbcnt ->
+    // LDS write -> popcount, ~12 scalar instructions per hit chunk on the CU's one scalar unit).  Now every
+    // chunk of a pair does, unconditionally: compare -> mask in an SGPR pair; slot = hits so far + mbcnt(mask)
+    // (2 VALU); one LDS store whose ADDRESS is selected by the mask (hit lanes -> row[slot], the others ->
+    // a private dummy word: no exec masking, no branch); hits so far += s_bcnt1(mask) (2 scalar ops).  One
+    // scalar compare per PAIR of chunks ends the scan once nsample hits exist.  Slots are the ascending point
+    // index order, so the first nsample of them are exactly the reference's serial scan.
     typedef float f2 __attribute__((ext_vector_type(2)));
     constexpr int RP = R > 1 ? R / 2 : 1;
     f2 px[RP], py[RP], pz[RP];
@@ -328,26 +336,35 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
       py[i].x = in0 ? p[k0 * 3 + 1] : 0.f;  py[i].y = in1 ? p[k1 * 3 + 1] : 0.f;
       pz[i].x = in0 ? p[k0 * 3 + 2] : 0.f;  pz[i].y = in1 ? p[k1 * 3 + 2] : 0.f;
     }
+    // per-wave LDS: row of nsample + 128 slots (a pair of chunks may overshoot nsample by < 128) + 64 dummy words
+    const int row_len = nsample + 2 * kWave;
+    int32_t *wrow = bq_rows + w * (row_len + kWave);
+    int32_t *dummy = wrow + row_len + L;
     for (int j = w; j < m; j += kWavesPerBlock) {
       const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 0])));
       const float c1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 1])));
       const float c2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 2])));
       const f2 cx = {c0, c0}, cy = {c1, c1}, cz = {c2, c2};
-      int cnt = 0, first = 0;
+      int cnt = 0;                                                          // wave-uniform (SGPR)
 #pragma unroll
       for (int i = 0; i < RP; ++i) {
-        if (cnt < nsample && 2 * i < nchunks) {                          // wave-uniform
+        if (cnt < nsample && 2 * i < nchunks) {                            // one scalar test per pair
           const f2 dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
           const f2 d2 = (dx * dx + dy * dy) + dz * dz;
           const bool h0 = d2.x < radius2, h1 = d2.y < radius2;
           const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-          if (m0) take(m0, 2 * i, h0, cnt, first);
-          if (m1 && cnt < nsample) take(m1, 2 * i + 1, h1, cnt, first);
+          const int s0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, (unsigned)cnt));
+          *(h0 ? wrow + s0 : dummy) = (2 * i) * kWave + L;
+          cnt += __popcll(m0);
+          const int s1 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, (unsigned)cnt));
+          *(h1 ? wrow + s1 : dummy) = (2 * i + 1) * kWave + L;
+          cnt += __popcll(m1);
         }
       }
       if (cnt > nsample) cnt = nsample;
       // same-wave LDS write -> read: the compiler's lgkmcnt wait orders them, no barrier needed
-      for (int t = L; t < nsample; t += kWave) o[j * nsample + t] = t < cnt ? row[t] : first;
+      const int first = cnt > 0 ? wrow[0] : 0;
+      for (int t = L; t < nsample; t += kWave) o[j * nsample + t] = t < cnt ? wrow[t] : first;
     }
     return;
   }
@@ -811,7 +828,8 @@ int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *
   if ((long long)b * m * nsample == 0) return GPS_OK;
   if (!new_xyz || !idx || (n > 0 && !xyz)) return GPS_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)gps::kWavesPerBlock * nsample * sizeof(int32_t);
+  // per wave: a row of nsample slots (+ 128 overshoot slots + 64 dummy words of the register-resident form)
+  const size_t lds = (size_t)gps::kWavesPerBlock * (nsample + 3 * gps::kWave) * sizeof(int32_t);
   if (lds > (size_t)kLdsBudget) return GPS_ERR_UNSUPPORTED;
   const dim3 grid(b), block(gps::kBlock);
   const int need = (n + gps::kWave - 1) / gps::kWave;

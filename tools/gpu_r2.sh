@@ -19,6 +19,10 @@ fi
 if [[ $WHAT == *gemmbench* ]]; then
   ts gemmbench; timeout 600 python tools/gemm_bench.py --json $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "gemm bench exit $?"; tail -20 $OUT/gemm_bench.log
 fi
+if [[ $WHAT == *pointtest* ]]; then
+  ts pointtest; timeout 900 python -m pytest tests/test_gpu_point_ops.py tests/test_gpu_vs_reference_ext.py tests/test_gpu_sa_fused.py -m gpu -q > $OUT/pytest_point.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_point.log
+  tail -8 $OUT/pytest_point.log
+fi
 if [[ $WHAT == *gemmpmc* ]]; then
   ts gemmpmc
   rocprofv3 -L > $OUT/pmc_list.txt 2>&1
