@@ -484,13 +484,13 @@ int launch_variant(Params &P, int variant, hipStream_t s) {
   }
 }
 
-// default variant: the largest tile that still gives every CU about two workgroups' worth of tiles
-inline int pick_variant(int M, int N, int splits) {
-  auto tiles = [&](int v) {
-    return (long long)((M + kShapes[v].bm - 1) / kShapes[v].bm) * ((N + kShapes[v].bn - 1) / kShapes[v].bn) * splits;
-  };
-  if (tiles(0) >= 256) return 0;
-  return 3;
+// default variant from the per-shape timings of profiles/r2/gemm_bench_*.json: the 8-wave 128 x 128 tile (two
+// workgroups = 16 waves per CU) once there are enough tiles to fill the chip more than once, else 128 x 64 tiles at
+// three workgroups per CU; weight gradients: 8 waves with the fragment reads of a stage issued up front
+inline int pick_variant(int form, int M, int N, int splits) {
+  if (form == GPS_GEMM_TN) return 2;
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * splits;
+  return tiles >= 384 ? 7 : 6;
 }
 
 }  // namespace gps_gemm
@@ -499,12 +499,11 @@ extern "C" {
 
 int gps_gemm_pick_splits(int form, int M, int N, int K) {
   if (form != GPS_GEMM_TN) return 1;
-  // weight gradient: M x N is small (a few dozen 128 x 128 tiles), K = tokens is long.  Split K so that the grid
-  // is about two workgroups per CU, every split keeps >= 8 stages, at most 32 splits.
+  // weight gradient: M x N is small (a few dozen 128 x 128 tiles), K = tokens is long.  Eight splits measured
+  // best from 36 to 432 tiles (profiles/r2/gemm_bench_*.json), sixteen below that; every split keeps >= 8 stages.
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
   const int nkt = (K + 63) / 64;
-  int s = (int)((512 + tiles - 1) / tiles);
-  if (s > 32) s = 32;
+  int s = tiles < 24 ? 16 : 8;
   if (s > nkt / 8) s = nkt / 8;
   return s < 1 ? 1 : s;
 }
@@ -561,7 +560,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   if (a->K == 0) P.nkt = 0;
 
   int variant = a->variant;
-  if (variant < 0) variant = pick_variant(a->M, a->N, P.splits);
+  if (variant < 0) variant = pick_variant(a->form, a->M, a->N, P.splits);
   if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
 
   int st;

@@ -45,6 +45,20 @@ if [[ $WHAT == *bench* && $WHAT != *gemmbench* || $WHAT == *stepbench* ]]; then
   ts bench; timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
   tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err
 fi
+if [[ $WHAT == *benchab* ]]; then
+  ts bench-ab
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_native.json 2> $OUT/bench_native.err; echo "bench native exit $?"
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-native-gemm --no-extras > $OUT/bench_lib.json 2> $OUT/bench_lib.err; echo "bench lib exit $?"
+  python - <<PYEOF
+import json
+for n in ("native","lib"):
+    try:
+        d=json.loads(open("$OUT/bench_%s.json"%n).read().strip().splitlines()[-1])
+        print(n, d["value"], d["ms_per_step"], d["roofline"] and (d["roofline"]["kernel"], d["roofline"]["frac"]))
+    except Exception as e:
+        print(n, "failed", e); print(open("$OUT/bench_%s.err"%n).read()[-1500:])
+PYEOF
+fi
 if [[ $WHAT == *kbench* ]]; then
   ts kernel_bench; timeout 300 python tools/kernel_bench.py --json $OUT/kernel_bench.json > $OUT/kernel_bench.log 2>&1; tail -5 $OUT/kernel_bench.log
 fi
