@@ -52,7 +52,7 @@ class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
-                 native_gemm: bool = True):
+                 native_gemm: bool = True, grad_compress: Optional[str] = "auto"):
         self.cfg = cfg
         self.device = torch.device(device)
         # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
@@ -91,22 +91,74 @@ class GPSTrainStep:
         self.grad_norm = cfg.solver.get("grad_norm", None)
         self.amp_dtype = amp_dtype if self.device.type == "cuda" else None
         self.net: nn.Module = self.model
-        if use_ddp:
-            from torch.nn.parallel import DistributedDataParallel as DDP
-            # find_unused_parameters like the reference: 13 trainable tensors never receive a gradient
-            # (SURVEY.md 2b C1).  DDP's static_graph=True would avoid the per-iteration traversal but
-            # let the replicas drift apart after the first step in tests/test_dist_gloo.py -- not used.
-            kw = dict(find_unused_parameters=True, gradient_as_bucket_view=True,
-                      bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
-            if self.device.type == "cuda":
-                self.net = DDP(self.model, device_ids=[self.device.index], **kw)
-            else:
-                self.net = DDP(self.model, **kw)
+        # DDP is built lazily at the first step: that step first runs ONE local forward + backward to find the
+        # trainable tensors that never receive a gradient in this configuration (13 in the pre-train config: BERT
+        # pooler, sem_cls_embed_layer, sem_mask_embeddings, obj_pred_head -- SURVEY.md 2b C1), freezes them, and
+        # only then wraps the model: the reducer needs no per-iteration unused-parameter search
+        # (find_unused_parameters=False; the reference pays for the search every step, trainer/build.py:66) and the
+        # buckets hold exactly the tensors that are reduced.
+        self._want_ddp = bool(use_ddp)
+        self._ddp_kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
+        # gradient compression: bf16 on the wire (246 MB instead of 491 MB per step), fp32 accumulation of the
+        # decompressed buckets; "auto" = on for RCCL, off for gloo (CPU tests compare against exact means)
+        self.grad_compress = grad_compress
+        self.frozen_unused: list = []
         self.global_step = 0
         if self.graph_dp and dist_utils.is_dist():
             with torch.no_grad():                      # what DDP does at construction
                 for t in list(self.model.parameters()) + list(self.model.buffers()):
                     torch.distributed.broadcast(t, src=0)
+
+    # ---- torch DDP, built at the first step ----------------------------------------------------------
+    def _needs_buffer_broadcast(self) -> bool:
+        """Buffers that change during training (BatchNorm running statistics of an unfrozen encoder) must stay
+        identical across ranks, as under the reference's Accelerate/DDP default; with every BN layer frozen
+        (GPS pre-train / fine-tune configs) there is nothing to broadcast."""
+        for m in self.model.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats:
+                return True
+        return False
+
+    def prepare(self, data_dict) -> None:
+        """Build the DDP wrapper now (it is otherwise built by the first `step`)."""
+        if self._want_ddp:
+            self._build_ddp(data_dict)
+
+    def _build_ddp(self, data_dict) -> None:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        self.model.train()
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = None
+        rng_cpu = torch.get_rng_state()
+        rng_dev = torch.cuda.get_rng_state(self.device) if self.device.type == "cuda" else None
+        with self._autocast():
+            out = self.model(dict(data_dict))
+            total, _ = self.loss(out)
+        total.backward()
+        named = dict(self.model.named_parameters())
+        self.frozen_unused = sorted(n for n, p in named.items() if p.requires_grad and p.grad is None)
+        for n in self.frozen_unused:
+            named[n].requires_grad_(False)
+        for p in params:
+            p.grad = None
+        torch.set_rng_state(rng_cpu)                       # the probe must not shift the training RNG streams
+        if rng_dev is not None:
+            torch.cuda.set_rng_state(rng_dev, self.device)
+        kw = dict(self._ddp_kw, find_unused_parameters=False, broadcast_buffers=self._needs_buffer_broadcast())
+        if self.device.type == "cuda":
+            self.net = DDP(self.model, device_ids=[self.device.index], **kw)
+        else:
+            self.net = DDP(self.model, **kw)
+        compress = self.grad_compress
+        if compress == "auto":
+            compress = "bf16" if torch.distributed.get_backend() == "nccl" else None
+        if compress == "bf16":
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            self.net.register_comm_hook(state=None, hook=default_hooks.bf16_compress_hook)
+        elif compress is not None:
+            raise ValueError(f"grad_compress={compress!r}")
+        self._want_ddp = False
 
     # ---- split-graph data parallelism ------------------------------------------------------------
     def _dist_losses(self):
@@ -279,6 +331,8 @@ class GPSTrainStep:
             return total, losses
         data_dict['cur_step'] = self.global_step
         data_dict['total_steps'] = 1 << 30
+        if self._want_ddp:
+            self._build_ddp(data_dict)
         if self._graph is not None:
             # an eager step after graph replays (bench's timing pass): replays update the masters without
             # touching their Python-side version counters, so the bf16 shadows must be rebuilt from them

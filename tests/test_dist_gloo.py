@@ -7,7 +7,8 @@ layers/objects so two replicas fit the CPU suite's time budget):
   * `TextSceneBetweenBatch` sees world_size x B rows when cfg.num_gpu > 1;
   * after DDP steps on DIFFERENT per-rank shards the replicas hold identical parameters, and the
     gradient DDP leaves on each rank is the mean of the two single-process gradients;
-  * the 13 never-used trainable tensors do not deadlock the reducer (find_unused_parameters).
+  * the 13 never-used trainable tensors are found by the probe step and frozen, so the reducer runs with
+    find_unused_parameters=False; bf16-compressed gradient buckets keep the replicas identical.
 
 Point ops are routed to the CPU oracle (tests only): libgps_hip.so has no CPU path by design.
 """
@@ -84,6 +85,8 @@ def _worker(rank, world, port, tmp):
                           if p.grad is not None})
 
         ddp = GPSTrainStep(_small_cfg(lp, world, between_batch=False), device="cpu", ddp=True, seed=5)
+        ddp.prepare(dict(shards[rank], cur_step=0, total_steps=10))      # probe step: finds + freezes unused tensors
+        result["wrapped"] = type(ddp.net).__name__
         ddp.net.eval()
         ddp.model.zero_grad(set_to_none=True)
         out, total, losses = ddp.forward_loss(dict(shards[rank], cur_step=0, total_steps=10))
@@ -97,6 +100,7 @@ def _worker(rank, world, port, tmp):
             worst = max(worst, (p.grad - want).abs().max().item() / denom)
         result["grad_mean_rel_err"] = worst
         result["n_unused"] = sum(1 for p in ddp.model.parameters() if p.requires_grad and p.grad is None)
+        result["n_frozen_unused"] = len(ddp.frozen_unused)
 
         # -- the between-batch contrastive loss sees world x B rows (features of the other rank
         #    arrive through all_gather, without gradient)
@@ -131,8 +135,9 @@ def _worker(rank, world, port, tmp):
         eng._allreduce_grads()
         result["graph_dp_allreduce_ok"] = bool(torch.allclose(eng._flat_grad, torch.full((10,), (world - 1) / 2.0)))
 
-        # -- two optimisation steps (full loss list) on different shards keep the replicas identical
-        ddp = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=True, seed=5)
+        # -- two optimisation steps (full loss list) on different shards keep the replicas identical; gradients
+        #    travel as bf16 (the compression hook of the RCCL path), accumulate in fp32
+        ddp = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=True, seed=5, grad_compress="bf16")
         for i in range(2):
             ddp.step(dict(synth_batch(2, n_obj=6, n_pts=1024, scene_txt_len=40,
                                       seed=200 + 10 * i + rank, min_real=3)))
@@ -158,5 +163,6 @@ def test_ddp_world_size_2_gloo():
         assert r["loss_finite"], r
         assert r["grad_mean_rel_err"] < 1e-4, r
         assert r["between_batch_err"] < 1e-6, r
-        assert r["n_unused"] >= 13, r
+        assert r["wrapped"] == "DistributedDataParallel", r
+        assert r["n_frozen_unused"] >= 13 and r["n_unused"] == 0, r     # found by the probe step, frozen before the wrap
         assert r["graph_dp_gather_ok"] and r["graph_dp_allreduce_ok"], r
