@@ -179,7 +179,8 @@ GPS_API int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int
  * device pointer to one uint64 that is added to `seed` when the kernel runs (lets a captured HIP
  * graph draw a fresh mask on every replay), NULL to use `seed` alone.
  * out (B, L, ld_o) bf16; lse (B,H,L) fp32 log-sum-exp of the logits (saved for backward).
- * bf16 MFMA with fp32 accumulation; softmax in fp32.  head_dim must be 64, L <= 256. */
+ * bf16 MFMA with fp32 accumulation; softmax in fp32.  head_dim must be 64; L <= 304 (forward and backward),
+ * forward alone up to L = 512. */
 GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                              int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
                              float p_drop, unsigned long long seed, const void *seed_dev, void *out,
@@ -315,7 +316,7 @@ GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, c
 #define GPS_GEMM_EPI_DRELU 4
 #define GPS_GEMM_EPI_F32 5
 typedef struct gps_gemm_args {
-  int form, epilogue, M, N, K, splits, variant, reserved;
+  int form, epilogue, M, N, K, splits, variant, reserved; /* reserved: 0 (timing experiments: bit 0 skips the stage copies, bit 1 the MFMAs) */
   const void *A;
   long long lda;
   const void *B;
@@ -337,6 +338,44 @@ typedef struct gps_gemm_args {
 GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
 GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
 GPS_API int gps_gemm_bf16(const gps_gemm_args *args, gps_stream_t stream);
+
+/* ---- optimizer step: gradient clipping + AdamW over all parameter tensors ------------------------------
+ * Replaces `accelerator.clip_grad_norm_` + `optimizer.step()` of the reference's training step
+ * (trainer/default_trainer.py:18-24; torch.nn.utils.clip_grad_norm_ with the L2 norm, torch.optim.AdamW built by
+ * optim/optimizer/optim.py:9-14) with three launches over device-resident tables:
+ *   tensors  one record per parameter with a gradient: fp32 master / gradient / both moments (numel each), and
+ *            optionally a bf16 shadow and / or an fp32 mirror of the parameter that are rewritten with the new
+ *            values (what gps_gemm_bf16 and packed bias vectors read), and the index of its hyper-parameter group;
+ *   groups   lr (read from *lr_dev when lr_dev is not NULL: HIP-graph replays see the scheduler's in-place
+ *            updates), betas, eps, decoupled weight decay;
+ *   chunks   (tensor index, chunk index) pairs, gps_adamw_chunk_elems() elements per chunk, one workgroup each.
+ * max_grad_norm > 0: every gradient is scaled by min(1, max_grad_norm / (||g||_2 + 1e-6)) inside the update
+ * (gradients themselves are not modified); <= 0: no clipping.  scalars (3 floats, persistent): [0] clip
+ * coefficient, [1] total gradient norm of this step, [2] step count -- incremented by the call, used for the
+ * bias corrections 1 - beta^step; zero it before the first step.  partial: scratch of n_chunks floats.
+ * Update rule per element, exactly torch.optim.AdamW (amsgrad = False, maximize = False):
+ *   p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+ *   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps). */
+typedef struct gps_adamw_tensor {
+  void *param;
+  const void *grad;
+  void *exp_avg;
+  void *exp_avg_sq;
+  void *shadow_bf16; /* may be NULL */
+  void *mirror_f32;  /* may be NULL */
+  long long numel;
+  int group;
+  int reserved;
+} gps_adamw_tensor;
+typedef struct gps_adamw_group {
+  const void *lr_dev; /* device float or NULL */
+  float lr, beta1, beta2, eps, weight_decay;
+  int reserved;
+} gps_adamw_group;
+GPS_API int gps_adamw_chunk_elems(void);
+GPS_API int gps_adamw_step(int n_chunks, const gps_adamw_tensor *tensors, const gps_adamw_group *groups,
+                           const int32_t *chunks, float max_grad_norm, float *partial, float *scalars,
+                           gps_stream_t stream);
 
 #ifdef __cplusplus
 }

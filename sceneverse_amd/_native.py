@@ -41,6 +41,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32 = 0, 1, 2,
 
 # name -> argtypes, mirroring include/gps_hip.h one to one
 SIGNATURES = {
+    "gps_adamw_step": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp],
     "gps_gemm_pick_splits": [_i, _i, _i, _i],
     "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
@@ -110,6 +111,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_sa_mlp_layer_floats_bf16x3.argtypes = [_i, _i]
     lib.gps_gemm_workspace_floats.restype = ctypes.c_longlong
     lib.gps_gemm_workspace_floats.argtypes = [_i, _i, _i, _i]
+    lib.gps_adamw_chunk_elems.restype = _i
+    lib.gps_adamw_chunk_elems.argtypes = []
     lib.gps_ln_partial_rows.restype = _i
     lib.gps_ln_partial_rows.argtypes = [_i]
     for name, argtypes in SIGNATURES.items():

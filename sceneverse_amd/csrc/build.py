@@ -22,6 +22,7 @@ SOURCES = [
     ("gps_reduce.hip", []),
     ("gps_embedding.hip", []),
     ("gps_gemm.hip", []),
+    ("gps_optim.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-I" + os.path.join(ROOT, "include")]

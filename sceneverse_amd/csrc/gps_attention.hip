@@ -818,7 +818,9 @@ int dispatch(Params &P, bool backward, hipStream_t s) {
   if (P.nt <= 5) return launch<5>(P, backward, s);
   if (P.nt <= 9) return launch<9>(P, backward, s);
   if (P.nt <= 16) return launch<16>(P, backward, s);
-  return GPS_ERR_UNSUPPORTED;
+  if (P.nt <= 19) return launch<19>(P, backward, s);       // 300-token scene captions (all_pretrain.yaml:35-36,46)
+  if (P.nt <= 32 && !backward) return launch<32>(P, backward, s);   // T = 512 (BASELINE configs[4]), forward only:
+  return GPS_ERR_UNSUPPORTED;                              // the key/value + transposed tiles of a backward pass exceed 160 KB
 }
 
 }  // namespace gps_attn

@@ -52,7 +52,7 @@ class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
-                 native_gemm: bool = True, grad_compress: Optional[str] = "auto"):
+                 native_gemm: bool = True, grad_compress: Optional[str] = "auto", native_optimizer: bool = True):
         self.cfg = cfg
         self.device = torch.device(device)
         # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
@@ -78,6 +78,8 @@ class GPSTrainStep:
         self._graph = None
         self._static = None
         param_groups = self.model.get_opt_params()
+        if not native_optimizer:                       # A/B: torch's AdamW + clip_grad_norm_ instead of gps_adamw_step
+            cfg.solver.optim.args["native_optimizer"] = False
         if self.graph or self.graph_dp:
             # capturable optimizer state: step counters and learning rates live on the device
             cfg.solver.optim.args["capturable"] = True
@@ -185,6 +187,10 @@ class GPSTrainStep:
             self._flat_grad.mul_(1.0 / self.world)
 
     def _clip_and_step(self):
+        from .optim.fused_adamw import GpsAdamW
+        if isinstance(self.optimizer, GpsAdamW):       # clipping happens inside the optimizer pass
+            self.optimizer.step(max_grad_norm=self.grad_norm)
+            return
         if self.grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.optimizer.step()
@@ -284,9 +290,7 @@ class GPSTrainStep:
         out, total, losses = self.forward_loss(data_dict)
         self.optimizer.zero_grad(set_to_none=True)
         total.backward()
-        if self.grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
-        self.optimizer.step()
+        self._clip_and_step()
         return total, losses
 
     def _graph_step(self, data_dict):
@@ -341,9 +345,7 @@ class GPSTrainStep:
         out, total, losses = self.forward_loss(data_dict)
         self.optimizer.zero_grad(set_to_none=True)
         total.backward()
-        if self.grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
-        self.optimizer.step()
+        self._clip_and_step()
         self.scheduler.step()
         self.global_step += 1
         return total.detach(), {k: v.detach() for k, v in losses.items()}

@@ -21,6 +21,7 @@ GPU only: callers keep the torch formulation for CPU tensors (tests, gloo runs).
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -72,12 +73,14 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
          C: torch.Tensor, ldc: int, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
          ldaux: int = 0, aux_out: Optional[torch.Tensor] = None, ldaux_out: int = 0,
          workspace: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, p_drop: float = 0.0,
-         seed_dev: Optional[torch.Tensor] = None, splits: int = 1, variant: Optional[int] = None) -> None:
+         seed_dev: Optional[torch.Tensor] = None, splits: int = 1, variant: Optional[int] = None,
+         ablate: int = 0) -> None:
     """Thin checked call of gps_gemm_bf16 on the current stream (shapes in the header's convention)."""
     a = GemmArgs()
     a.form, a.epilogue, a.M, a.N, a.K = form, epilogue, M, N, K
     a.splits = splits
     a.variant = _VARIANT[form] if variant is None else variant
+    a.reserved = ablate
     a.A, a.lda, a.B, a.ldb, a.C, a.ldc = A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc
     a.bias = _ptr(bias)
     a.aux, a.ldaux, a.aux_out, a.ldaux_out = _ptr(aux), ldaux, _ptr(aux_out), ldaux_out
@@ -148,15 +151,38 @@ def linear_wgrad(dy16: torch.Tensor, x16: torch.Tensor, want_bias: bool = True):
 
 # ---- bf16 shadows of the fp32 master weights ---------------------------------------------------------------
 class _Shadow:
-    __slots__ = ("w16", "b32", "versions")
+    __slots__ = ("w16", "b32", "versions", "weight_ids", "bias_ids", "row_offsets", "owners")
 
     def __init__(self):
         self.w16 = None
         self.b32 = None
         self.versions = None
+        self.owners = None          # weak references to the masters: an id() can be recycled after a module dies
+        self.weight_ids = ()
+        self.bias_ids = ()
+        self.row_offsets = ()
 
 
 _SHADOWS = {}
+_REGISTRY_VERSION = 0          # bumped whenever a shadow buffer is (re)allocated: the optimizer re-reads the map
+
+
+def registry_version() -> int:
+    return _REGISTRY_VERSION
+
+
+def shadow_targets() -> dict:
+    """id(parameter) -> (bf16 shadow view or None, fp32 mirror view or None): where the optimizer kernel writes
+    the updated value of a parameter besides its fp32 master."""
+    out = {}
+    for sh in _SHADOWS.values():
+        if sh.w16 is None:
+            continue
+        for wid, bid, off, nxt in zip(sh.weight_ids, sh.bias_ids, sh.row_offsets, sh.row_offsets[1:] + (sh.w16.shape[0],)):
+            out[wid] = (sh.w16[off:nxt], None)
+            if bid is not None and sh.b32 is not None and len(sh.weight_ids) > 1:
+                out[bid] = (None, sh.b32[off:nxt])
+    return out
 
 
 def _versions(params) -> tuple:
@@ -173,11 +199,24 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
         sh = _SHADOWS[key] = _Shadow()
     ver = _versions(list(weights) + list(biases))
     dev = weights[0].device
+    masters = [t for t in list(weights) + list(biases) if t is not None]
+    if sh.owners is None or len(sh.owners) != len(masters) or any(r() is not t for r, t in zip(sh.owners, masters)):
+        sh.owners = tuple(weakref.ref(t) for t in masters)      # first use, or the ids now name other tensors
+        sh.versions = None
     rows = sum(w.shape[0] for w in weights)
     if sh.w16 is None or sh.w16.device != dev or tuple(sh.w16.shape) != (rows, weights[0].shape[1]):
+        global _REGISTRY_VERSION
+        _REGISTRY_VERSION += 1
         sh.w16 = torch.empty((rows, weights[0].shape[1]), dtype=torch.bfloat16, device=dev)
         sh.b32 = None
         sh.versions = None
+        sh.weight_ids = tuple(id(w) for w in weights)
+        sh.bias_ids = tuple(id(b) if b is not None else None for b in biases)
+        offs, r = [], 0
+        for w in weights:
+            offs.append(r)
+            r += w.shape[0]
+        sh.row_offsets = tuple(offs)
     if sh.versions != ver:
         with torch.no_grad():
             r = 0
@@ -190,6 +229,7 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
                 else:
                     if sh.b32 is None or sh.b32.data_ptr() in [b.data_ptr() for b in biases]:
                         sh.b32 = torch.empty(sh.w16.shape[0], dtype=torch.float32, device=dev)
+                        _REGISTRY_VERSION += 1
                     r = 0
                     for b in biases:
                         sh.b32[r:r + b.shape[0]].copy_(b)
@@ -218,7 +258,9 @@ def invalidate_shadows() -> None:
 
 
 def clear_shadows() -> None:
+    global _REGISTRY_VERSION
     _SHADOWS.clear()
+    _REGISTRY_VERSION += 1
 
 
 def _as_rows16(x: torch.Tensor) -> torch.Tensor:

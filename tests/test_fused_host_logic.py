@@ -133,6 +133,15 @@ def test_gemm_host_logic_on_cpu():
     single_w, single_b = G.shadow_of([lins[0].weight], [lins[0].bias])
     assert single_b.data_ptr() == lins[0].bias.data_ptr()                              # one bias: no copy
     G.clear_shadows()
+    # a dead module's id() may be recycled by the next one: the cache must notice (weak references to the masters)
+    import gc
+    for _ in range(30):
+        lin = torch.nn.Linear(16, 16)
+        w16, _b = G.shadow_of([lin.weight], [lin.bias])
+        assert torch.equal(w16, lin.weight.to(torch.bfloat16))
+        del lin, w16, _b
+        gc.collect()
+    G.clear_shadows()
     lib = _native.load()
     for tokens in (77, 3200, 5120, 8320, 19200):
         for n_out, n_in in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (2376, 768)):

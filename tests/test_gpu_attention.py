@@ -62,7 +62,7 @@ def _close(a, b, tol, what):
 
 
 CASES = [(3, 80, True), (8, 80, True), (2, 130, False), (8, 130, False), (2, 37, True), (1, 200, True),
-         (2, 16, False), (2, 256, False)]
+         (2, 16, False), (2, 256, False), (2, 300, False), (1, 300, True), (8, 300, False)]
 
 
 @pytest.mark.parametrize("B,L,spatial", CASES)
@@ -86,6 +86,19 @@ def test_forward_backward_match_fp32_formulation(B, L, spatial):
     # padded keys receive no gradient through k and v
     if mask is not None:
         assert g[..., D:3 * D][mask].abs().max().item() == 0.0
+
+
+def test_forward_up_to_512_tokens():
+    """T = 512 (BASELINE configs[4]): forward only (the backward tiles of a 512-token head exceed the LDS)."""
+    from sceneverse_amd import _native
+    packed, pl, mask = _inputs(2, 512, False, seed=77)
+    ref = ref_attention(packed.float(), pl, mask)
+    out = _FusedSelfAttention.apply(packed.to(DEV), None, mask.to(DEV), H, 0.0, 0, None)
+    _close(out, ref, 2e-2, "out L=512")
+    x = packed.to(DEV).requires_grad_(True)
+    out = _FusedSelfAttention.apply(x, None, mask.to(DEV), H, 0.0, 0, None)
+    with pytest.raises(_native.GpsNativeError):
+        out.float().sum().backward()
 
 
 def test_dropout_is_reproducible_linear_and_adjoint():

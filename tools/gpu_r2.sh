@@ -19,9 +19,28 @@ fi
 if [[ $WHAT == *gemmbench* ]]; then
   ts gemmbench; timeout 600 python tools/gemm_bench.py --json $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "gemm bench exit $?"; tail -20 $OUT/gemm_bench.log
 fi
+if [[ $WHAT == *newtests* ]]; then
+  ts newtests; timeout 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_optim.py tests/test_a16_vs_golden.py tests/test_gpu_attention.py tests/test_gpu_model.py -m gpu -q -x > $OUT/pytest_new.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_new.log
+  tail -15 $OUT/pytest_new.log | cut -c1-300
+fi
+if [[ $WHAT == *benchnative* ]]; then
+  ts bench-native
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_native.json 2> $OUT/bench_native.err; echo "bench native exit $?"
+  tail -c 600 $OUT/bench_native.err
+  python - <<PYEOF
+import json
+d=json.loads(open("$OUT/bench_native.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"])
+for k in d["kernels"][:14]: print(k["kernel"][:60], k["launches_per_step"], k["avg_us"], k["ms_per_step"], k["frac"])
+for k in d["step_kernels"][:16]: print(k["name"][:90], k["ms_per_step"], k["launches_per_step"])
+PYEOF
+fi
 if [[ $WHAT == *pointtest* ]]; then
   ts pointtest; timeout 900 python -m pytest tests/test_gpu_point_ops.py tests/test_gpu_vs_reference_ext.py tests/test_gpu_sa_fused.py -m gpu -q > $OUT/pytest_point.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_point.log
   tail -8 $OUT/pytest_point.log
+fi
+if [[ $WHAT == *ablate* ]]; then
+  ts ablate; timeout 300 python tools/gemm_bench.py --ablate > $OUT/gemm_ablate.log 2>&1; tail -4 $OUT/gemm_ablate.log
 fi
 if [[ $WHAT == *gemmpmc* ]]; then
   ts gemmpmc
@@ -41,7 +60,7 @@ if [[ $WHAT == *alltests* ]]; then
   ts pytest; timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
   grep -E "^(FAILED|ERROR)|passed|failed|exit" $OUT/pytest_gpu.log | head -40
 fi
-if [[ $WHAT == *bench* && $WHAT != *gemmbench* || $WHAT == *stepbench* ]]; then
+if [[ $WHAT == *stepbench* ]]; then
   ts bench; timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
   tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err
 fi
