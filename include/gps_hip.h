@@ -350,9 +350,11 @@ GPS_API int gps_gemm_bf16(const gps_gemm_args *args, gps_stream_t stream);
  *            updates), betas, eps, decoupled weight decay;
  *   chunks   (tensor index, chunk index) pairs, gps_adamw_chunk_elems() elements per chunk, one workgroup each.
  * max_grad_norm > 0: every gradient is scaled by min(1, max_grad_norm / (||g||_2 + 1e-6)) inside the update
- * (gradients themselves are not modified); <= 0: no clipping.  scalars (3 floats, persistent): [0] clip
- * coefficient, [1] total gradient norm of this step, [2] step count -- incremented by the call, used for the
- * bias corrections 1 - beta^step; zero it before the first step.  partial: scratch of n_chunks floats.
+ * (gradients themselves are not modified); <= 0: no clipping.  scalars (2 floats): [0] clip coefficient,
+ * [1] total gradient norm of this step.  steps: persistent per-parameter step counts (float), indexed by each
+ * record's step_slot; the call adds 1 to the slot of every tensor in the table and uses the result for the bias
+ * corrections 1 - beta^step (torch counts steps per parameter); zero them before the first step.
+ * partial: scratch of n_chunks floats.
  * Update rule per element, exactly torch.optim.AdamW (amsgrad = False, maximize = False):
  *   p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
  *   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps). */
@@ -365,7 +367,7 @@ typedef struct gps_adamw_tensor {
   void *mirror_f32;  /* may be NULL */
   long long numel;
   int group;
-  int reserved;
+  int step_slot;
 } gps_adamw_tensor;
 typedef struct gps_adamw_group {
   const void *lr_dev; /* device float or NULL */
@@ -373,8 +375,8 @@ typedef struct gps_adamw_group {
   int reserved;
 } gps_adamw_group;
 GPS_API int gps_adamw_chunk_elems(void);
-GPS_API int gps_adamw_step(int n_chunks, const gps_adamw_tensor *tensors, const gps_adamw_group *groups,
-                           const int32_t *chunks, float max_grad_norm, float *partial, float *scalars,
+GPS_API int gps_adamw_step(int n_tensors, int n_chunks, const gps_adamw_tensor *tensors, const gps_adamw_group *groups,
+                           const int32_t *chunks, float max_grad_norm, float *partial, float *scalars, float *steps,
                            gps_stream_t stream);
 
 #ifdef __cplusplus

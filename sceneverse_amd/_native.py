@@ -41,7 +41,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32 = 0, 1, 2,
 
 # name -> argtypes, mirroring include/gps_hip.h one to one
 SIGNATURES = {
-    "gps_adamw_step": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp],
+    "gps_adamw_step": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "gps_gemm_pick_splits": [_i, _i, _i, _i],
     "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],

@@ -58,9 +58,12 @@ __global__ __launch_bounds__(kThreads) void sumsq_kernel(const gps_adamw_tensor 
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-// scal[0] = clip coefficient, scal[1] = total gradient norm, scal[2] = step count (float, after the increment)
+// scal[0] = clip coefficient, scal[1] = total gradient norm; steps[slot] += 1 for every tensor updated by this call
+// (torch.optim.AdamW counts steps PER PARAMETER: one that had no gradient in some iterations lags behind)
 __global__ __launch_bounds__(kThreads) void finish_norm_kernel(int n_partial, const float *__restrict__ partial, float max_norm,
-                                                                float *__restrict__ scal) {
+                                                                float *__restrict__ scal, int n_tensors,
+                                                                const gps_adamw_tensor *__restrict__ tensors,
+                                                                float *__restrict__ steps) {
   __shared__ double red[kThreads];
   double s = 0.0;
   for (int i = threadIdx.x; i < n_partial; i += kThreads) s += (double)partial[i];
@@ -76,8 +79,8 @@ __global__ __launch_bounds__(kThreads) void finish_norm_kernel(int n_partial, co
     if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
     scal[0] = coef;
     scal[1] = norm;
-    scal[2] = scal[2] + 1.f;
   }
+  for (int i = threadIdx.x; i < n_tensors; i += kThreads) steps[tensors[i].step_slot] += 1.f;
 }
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float coef, float lr, float b1, float b2, float eps,
@@ -92,11 +95,12 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 
 __global__ __launch_bounds__(kThreads) void adamw_kernel(const gps_adamw_tensor *__restrict__ tensors,
                                                           const gps_adamw_group *__restrict__ groups,
-                                                          const int2 *__restrict__ chunks, const float *__restrict__ scal) {
+                                                          const int2 *__restrict__ chunks, const float *__restrict__ scal,
+                                                          const float *__restrict__ steps) {
   const int2 c = chunks[blockIdx.x];
   const gps_adamw_tensor t = tensors[c.x];
   const gps_adamw_group G = groups[t.group];
-  const float coef = scal[0], step = scal[2];
+  const float coef = scal[0], step = steps[t.step_slot];
   const float lr = G.lr_dev ? *reinterpret_cast<const float *>(G.lr_dev) : G.lr;
   const float bc1 = 1.f - powf(G.beta1, step), bc2 = 1.f - powf(G.beta2, step);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
@@ -142,18 +146,19 @@ extern "C" {
 
 int gps_adamw_chunk_elems(void) { return gps_optim::kChunk; }
 
-int gps_adamw_step(int n_chunks, const gps_adamw_tensor *tensors, const gps_adamw_group *groups, const int32_t *chunks,
-                   float max_grad_norm, float *partial, float *scalars, gps_stream_t stream) {
+int gps_adamw_step(int n_tensors, int n_chunks, const gps_adamw_tensor *tensors, const gps_adamw_group *groups,
+                   const int32_t *chunks, float max_grad_norm, float *partial, float *scalars, float *steps,
+                   gps_stream_t stream) {
   using namespace gps_optim;
-  if (n_chunks < 0) return GPS_ERR_INVALID_ARGUMENT;
-  if (n_chunks == 0) return GPS_OK;
-  if (!tensors || !groups || !chunks || !partial || !scalars) return GPS_ERR_INVALID_ARGUMENT;
+  if (n_chunks < 0 || n_tensors < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (n_chunks == 0 || n_tensors == 0) return GPS_OK;
+  if (!tensors || !groups || !chunks || !partial || !scalars || !steps) return GPS_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   const int2 *ch = reinterpret_cast<const int2 *>(chunks);
   if (max_grad_norm > 0.f) hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(kThreads), 0, s, tensors, ch, partial);
   hipLaunchKernelGGL(finish_norm_kernel, dim3(1), dim3(kThreads), 0, s, max_grad_norm > 0.f ? n_chunks : 0, partial, max_grad_norm,
-                     scalars);
-  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(kThreads), 0, s, tensors, groups, ch, scalars);
+                     scalars, n_tensors, tensors, steps);
+  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(kThreads), 0, s, tensors, groups, ch, scalars, steps);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

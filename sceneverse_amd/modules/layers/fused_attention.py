@@ -24,7 +24,7 @@ from ... import _native
 
 HEAD_DIM = 64
 SPATIAL_VEC = 6
-MAX_LEN = 304          # training (forward + backward); forward-only calls go to 512 (gps_hip.h)
+MAX_LEN = 256          # layers route longer sequences elsewhere: the kernels serve L <= 304 (forward 512) but spill there
 
 
 def supported(d_model: int, n_head: int, length: int) -> bool:

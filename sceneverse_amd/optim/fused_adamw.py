@@ -24,7 +24,7 @@ from .. import _native
 class _TensorRec(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
                 ("exp_avg_sq", ctypes.c_void_p), ("shadow_bf16", ctypes.c_void_p), ("mirror_f32", ctypes.c_void_p),
-                ("numel", ctypes.c_longlong), ("group", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("numel", ctypes.c_longlong), ("group", ctypes.c_int), ("step_slot", ctypes.c_int)]
 
 
 class _GroupRec(ctypes.Structure):
@@ -57,7 +57,13 @@ class GpsAdamW(torch.optim.Optimizer):
                 # float `initial_lr` keeps LambdaLR's arithmetic on the host; the live value is a device word
                 g.setdefault("initial_lr", float(g["lr"]))
                 g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
-        self._scalars = torch.zeros(3, dtype=torch.float32, device=dev)   # clip coefficient, grad norm, step
+        self._scalars = torch.zeros(2, dtype=torch.float32, device=dev)   # clip coefficient, grad norm
+        # per-parameter step counts (torch.optim.AdamW semantics), one persistent slot per parameter
+        self._slot = {}
+        for g in self.param_groups:
+            for p in g["params"]:
+                self._slot.setdefault(id(p), len(self._slot))
+        self._steps = torch.zeros(max(len(self._slot), 1), dtype=torch.float32, device=dev)
         self._sig = None
         self._tables = None
         self._keep = []          # device tables referenced by a captured graph must outlive it
@@ -66,11 +72,11 @@ class GpsAdamW(torch.optim.Optimizer):
         self._pinned = torch.empty(8 << 20, dtype=torch.uint8).pin_memory()
         self._pinned_off = 0
 
-    # torch.optim.AdamW-compatible state ('step' is one shared device counter)
+    # torch.optim.AdamW-compatible state ('step' is a 0-dim view of this parameter's slot in one device array)
     def _init_state(self, p):
         st = self.state[p]
         if "exp_avg" not in st:
-            st["step"] = self._scalars[2:3].view(())
+            st["step"] = self._steps[self._slot[id(p)]]
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
@@ -82,11 +88,10 @@ class GpsAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
-        if steps:
-            self._scalars[2] = max(steps)
-        for st in self.state.values():
-            st["step"] = self._scalars[2:3].view(())
+        for p, st in self.state.items():
+            if "step" in st:
+                self._steps[self._slot[id(p)]] = float(st["step"])
+                st["step"] = self._steps[self._slot[id(p)]]
         for g in self.param_groups:
             if not torch.is_tensor(g["lr"]):
                 g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self._device)
@@ -105,7 +110,7 @@ class GpsAdamW(torch.optim.Optimizer):
             r.exp_avg, r.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             r.shadow_bf16 = sh.data_ptr() if sh is not None else None
             r.mirror_f32 = mir.data_ptr() if mir is not None else None
-            r.numel, r.group = p.numel(), gi
+            r.numel, r.group, r.step_slot = p.numel(), gi, self._slot[id(p)]
             chunks.extend((i, c) for c in range((p.numel() + chunk - 1) // chunk))
         grec = (_GroupRec * len(self.param_groups))()
         for gi, g in enumerate(self.param_groups):
@@ -132,7 +137,7 @@ class GpsAdamW(torch.optim.Optimizer):
                 d = t.to(self._device)
             dev_tabs.append(d)
         partial = torch.empty(max(len(chunks), 1), dtype=torch.float32, device=self._device)
-        tabs = (dev_tabs[0], dev_tabs[1], dev_tabs[2], partial, len(chunks))
+        tabs = (dev_tabs[0], dev_tabs[1], dev_tabs[2], partial, len(chunks), len(entries))
         if capturing:
             self._keep.append(tabs)
         return tabs
@@ -161,14 +166,14 @@ class GpsAdamW(torch.optim.Optimizer):
         if sig != self._sig:
             self._tables = self._build_tables(entries, gemm.shadow_targets())
             self._sig = sig
-        tens, groups, chunks, partial, n_chunks = self._tables
+        tens, groups, chunks, partial, n_chunks, n_tensors = self._tables
         with torch.cuda.device(self._device):
             from ..pointnet2._ext import _timed
             n = sum(p.numel() for p, _ in entries)
             with _timed(f"adamw_step(params={n})", 28 * n + (4 * n if max_grad_norm else 0)):
-                st = _native.load().gps_adamw_step(n_chunks, tens.data_ptr(), groups.data_ptr(), chunks.data_ptr(),
+                st = _native.load().gps_adamw_step(n_tensors, n_chunks, tens.data_ptr(), groups.data_ptr(), chunks.data_ptr(),
                                                    float(max_grad_norm) if max_grad_norm else 0.0, partial.data_ptr(),
-                                                   self._scalars.data_ptr(),
+                                                   self._scalars.data_ptr(), self._steps.data_ptr(),
                                                    torch.cuda.current_stream(self._device).cuda_stream)
         _native.check(st, "adamw_step")
         return loss

@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu():
                                 None, None) == 0
     assert lib.gps_attn_forward(2, 12, 80, 32, 1, 1, 1, 2304, None, None, None, 0.0, 0, None, 1, 768, 1, None) == -2
     assert lib.gps_attn_forward(2, 12, 80, 64, 1, 1, 1, 2304, 1, None, None, 0.0, 0, None, 1, 768, 1, None) == -1
-    assert lib.gps_attn_forward(2, 12, 300, 64, 1, 1, 1, 2304, None, None, None, 0.0, 0, None, 1, 768, 1, None) == -2
+    assert lib.gps_attn_forward(2, 12, 600, 64, 1, 1, 1, 2304, None, None, None, 0.0, 0, None, 1, 768, 1, None) == -2
     assert lib.gps_masked_ce_forward(0, 30522, 1, None, 30522, None, -1, None, None, None) == 0
     assert lib.gps_masked_ce_forward(4, 30522, 1, 1, 100, 1, -1, 1, 1, None) == -1                   # ld < vocab
     assert lib.gps_add_dropout_layernorm_forward(4, 100, 0, 1, 1, 1, 1, 1, 1e-5, 0.0, 0, None, 1, None, 1, 1,
