@@ -386,47 +386,97 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   const bool dropout = P.drop_thr != 0u;
   const unsigned long long seed = dropout ? P.seed + (P.seed_dev ? *P.seed_dev : 0ull) : 0ull;
   uint16_t *C = reinterpret_cast<uint16_t *>(P.C);
+  // bias / activation / dropout of one 4-column group of row m -> the packed bf16 result (and the packed
+  // pre-activation through `pre` for the GELU form)
+  auto finish = [&](f32x4 v, int m, int n, const f32x4 &bias, u32x2 &pre) -> u32x2 {
+    v = v + bias;
+    const unsigned long long idx = (unsigned long long)m * (unsigned long long)P.N + (unsigned long long)n;
+    if (EPI == EPI_BIAS_GELU) {
+      pre = pack4(v);
+      v[0] = gelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
+      v[1] = gelu_f(bf2f((uint16_t)(pre[0] >> 16)));
+      v[2] = gelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
+      v[3] = gelu_f(bf2f((uint16_t)(pre[1] >> 16)));
+    } else if (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (EPI == EPI_DGELU) {
+      const u32x2 a = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
+      v[0] *= dgelu_f(bf2f((uint16_t)(a[0] & 0xFFFFu)));
+      v[1] *= dgelu_f(bf2f((uint16_t)(a[0] >> 16)));
+      v[2] *= dgelu_f(bf2f((uint16_t)(a[1] & 0xFFFFu)));
+      v[3] *= dgelu_f(bf2f((uint16_t)(a[1] >> 16)));
+    } else if (EPI == EPI_DRELU) {
+      const u32x2 h = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
+      v[0] = (h[0] & 0x7FFFu) ? v[0] * P.keep_scale : 0.f;
+      v[1] = (h[0] & 0x7FFF0000u) ? v[1] * P.keep_scale : 0.f;
+      v[2] = (h[1] & 0x7FFFu) ? v[2] * P.keep_scale : 0.f;
+      v[3] = (h[1] & 0x7FFF0000u) ? v[3] * P.keep_scale : 0.f;
+    }
+    if (dropout && (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_DGELU)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rng_u32(seed, idx + r) >= P.drop_thr ? v[r] * P.keep_scale : 0.f;
+    }
+    return pack4(v);
+  };
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU;
+  // Pairs of adjacent 16-column fragments leave as 16-byte stores: inside a pair, the even lane groups (g = 0, 2)
+  // send their 4 columns of fragment b + 1 to the odd group next to them and receive that group's 4 columns of
+  // fragment b, so every lane ends up with 8 consecutive columns of one row -- half the store instructions of the
+  // natural 8-byte form (the epilogue is store-ISSUE bound, guide T21).  Needs whole 8-column groups (N % 8 == 0)
+  // and 16-byte aligned rows; otherwise the 8-byte form below.
+  const bool wide = (TN % 2 == 0) && (P.N % 8 == 0) && (P.ldc % 8 == 0) &&
+                    (EPI != EPI_BIAS_GELU || P.aux_out == nullptr || P.ldaux_out % 8 == 0);
+  if (wide) {
+    const bool odd = g & 1;
+#pragma unroll
+    for (int b = 0; b < TN; b += 2) {
+      const int nb0 = n0 + wn0 + 16 * b + 4 * g, nb1 = nb0 + 16;       // this lane's 4 columns in fragments b, b + 1
+      f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+      if (HAS_BIAS && P.bias) {
+        if (nb0 < P.N) bias0 = *reinterpret_cast<const f32x4 *>(P.bias + nb0);
+        if (nb1 < P.N) bias1 = *reinterpret_cast<const f32x4 *>(P.bias + nb1);
+      }
+      const int n_out = n0 + wn0 + 16 * (b + (odd ? 1 : 0)) + 8 * (g >> 1);     // first of the 8 columns stored
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int m = m0 + wm0 + 16 * a + i;
+        const bool row_ok = m < P.M;
+        u32x2 pre0 = {0u, 0u}, pre1 = {0u, 0u}, o0 = {0u, 0u}, o1 = {0u, 0u};
+        if (row_ok && nb0 < P.N) o0 = finish(acc[a][b], m, nb0, bias0, pre0);
+        if (row_ok && nb1 < P.N) o1 = finish(acc[a][b + 1], m, nb1, bias1, pre1);
+        const u32x2 send = odd ? o0 : o1;
+        const u32x2 recv = {(unsigned int)__shfl_xor((int)send[0], 16, 64), (unsigned int)__shfl_xor((int)send[1], 16, 64)};
+        const u32x4 out = odd ? u32x4{recv[0], recv[1], o1[0], o1[1]} : u32x4{o0[0], o0[1], recv[0], recv[1]};
+        if (row_ok && n_out < P.N) *reinterpret_cast<u32x4 *>(C + (size_t)m * P.ldc + n_out) = out;
+        if (EPI == EPI_BIAS_GELU) {
+          if (P.aux_out) {
+            const u32x2 sp = odd ? pre0 : pre1;
+            const u32x2 rp = {(unsigned int)__shfl_xor((int)sp[0], 16, 64), (unsigned int)__shfl_xor((int)sp[1], 16, 64)};
+            const u32x4 po = odd ? u32x4{rp[0], rp[1], pre1[0], pre1[1]} : u32x4{pre0[0], pre0[1], rp[0], rp[1]};
+            if (row_ok && n_out < P.N) *reinterpret_cast<u32x4 *>(P.aux_out + (size_t)m * P.ldaux_out + n_out) = po;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int n = n0 + wn0 + 16 * b + 4 * g;
     if (n >= P.N) continue;
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) && P.bias)
-      bias = *reinterpret_cast<const f32x4 *>(P.bias + n);
+    if (HAS_BIAS && P.bias) bias = *reinterpret_cast<const f32x4 *>(P.bias + n);
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int m = m0 + wm0 + 16 * a + i;
       if (m >= P.M) continue;
-      f32x4 v = acc[a][b] + bias;
-      const unsigned long long idx = (unsigned long long)m * (unsigned long long)P.N + (unsigned long long)n;
+      u32x2 pre = {0u, 0u};
+      const u32x2 o = finish(acc[a][b], m, n, bias, pre);
       if (EPI == EPI_BIAS_GELU) {
-        const u32x2 pre = pack4(v);
         if (P.aux_out) *reinterpret_cast<u32x2 *>(P.aux_out + (size_t)m * P.ldaux_out + n) = pre;
-        v[0] = gelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
-        v[1] = gelu_f(bf2f((uint16_t)(pre[0] >> 16)));
-        v[2] = gelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
-        v[3] = gelu_f(bf2f((uint16_t)(pre[1] >> 16)));
-      } else if (EPI == EPI_BIAS_RELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (EPI == EPI_DGELU) {
-        const u32x2 pre = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
-        v[0] *= dgelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
-        v[1] *= dgelu_f(bf2f((uint16_t)(pre[0] >> 16)));
-        v[2] *= dgelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
-        v[3] *= dgelu_f(bf2f((uint16_t)(pre[1] >> 16)));
-      } else if (EPI == EPI_DRELU) {
-        const u32x2 h = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
-        v[0] = (h[0] & 0x7FFFu) ? v[0] * P.keep_scale : 0.f;
-        v[1] = (h[0] & 0x7FFF0000u) ? v[1] * P.keep_scale : 0.f;
-        v[2] = (h[1] & 0x7FFFu) ? v[2] * P.keep_scale : 0.f;
-        v[3] = (h[1] & 0x7FFF0000u) ? v[3] * P.keep_scale : 0.f;
       }
-      if (dropout && (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_DGELU)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rng_u32(seed, idx + r) >= P.drop_thr ? v[r] * P.keep_scale : 0.f;
-      }
-      *reinterpret_cast<u32x2 *>(C + (size_t)m * P.ldc + n) = pack4(v);
+      *reinterpret_cast<u32x2 *>(C + (size_t)m * P.ldc + n) = o;
     }
   }
 }

@@ -184,3 +184,68 @@ def test_full_bench_shapes_against_reference_on_sampled_scenes():
         sub = _FusedSelfAttention.apply(x[8:16].contiguous(), plg[8:16].contiguous() if plg is not None else None,
                                         mg[8:16].contiguous(), H, 0.0, 0, None)
         assert torch.equal(sub, out[8:16])
+
+
+def _rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("L,spatial", [(80, True), (130, False), (37, True)])
+def test_fused_core_against_the_pinned_oracle_formulation(L, spatial):
+    """gps_attn_forward / gps_attn_backward against oracle/gps_torch_reference.py (the restatement that
+    tests/test_oracle_vs_golden.py pins to the reference's own outputs), not against a test-local formula.
+    The q / k / v / output projections are identities, so the oracle's fp32 module and the product's bf16 module
+    see the same bf16-exact q = k = v = x and every difference comes from the attention core (+ the bf16
+    rounding of the conditioning vector).  Bounds: relative L2 <= 1e-2 per tensor AND max-norm 4e-2."""
+    from oracle import gps_torch_reference as R
+    B = 3
+    g = torch.Generator().manual_seed(1000 + L)
+    x = torch.randn(B, L, D, generator=g).to(torch.bfloat16).float()
+    n_real = torch.randint(max(2, L // 3), L + 1, (B,), generator=g)
+    pad = torch.arange(L)[None, :] >= n_real[:, None]
+    go = torch.randn(B, L, D, generator=g).to(torch.bfloat16).float()
+    eye = torch.eye(D)
+    if spatial:
+        mod = T.MultiHeadAttentionSpatial(D, H, spatial_multihead=True, spatial_dim=5, spatial_attn_fusion='cond')
+        with torch.no_grad():
+            for lin in (mod.w_qs, mod.w_ks, mod.w_vs, mod.fc):
+                lin.weight.copy_(eye)
+                lin.bias.zero_()
+            mod.lang_cond_fc.weight.copy_((0.05 * torch.randn(H * 6, D, generator=g)).to(torch.bfloat16).float())
+            mod.lang_cond_fc.bias.copy_(0.1 * torch.randn(H * 6, generator=g))
+        pl = torch.rand(B, L, L, 5, generator=g) * 2 - 1
+        sd = {f"a.{k}": v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+        xr = x.clone().requires_grad_(True)
+        ref, _ = R.spatial_attention(sd, "a", xr, pl, pad, H)
+    else:
+        mod = T.MultiheadSelfAttention(D, H, dropout=0.0)
+        with torch.no_grad():
+            mod.in_proj_weight.copy_(torch.cat([eye, eye, eye], 0))
+            mod.in_proj_bias.zero_()
+            mod.out_proj.weight.copy_(eye)
+            mod.out_proj.bias.zero_()
+        pl = None
+        sd = {f"a.{k}": v.detach().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+        xr = x.clone().requires_grad_(True)
+        ref, _ = R.mha_self_attention(sd, "a", xr, pad, H)
+    ref.backward(go)
+
+    mod = mod.to(DEV).eval()
+    xg = x.to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        if spatial:
+            out, _ = mod(xg, xg, xg, pl.to(DEV), key_padding_mask=pad.to(DEV))
+        else:
+            out, _ = mod(xg, xg, xg, key_padding_mask=pad.to(DEV))
+    assert out.dtype == torch.bfloat16                      # went through the fused bf16 path
+    out.backward(go.to(DEV).to(out.dtype))
+    checks = [("out", out, ref), ("dx", xg.grad, xr.grad)]
+    params = dict(mod.named_parameters())
+    names = ["lang_cond_fc.weight", "lang_cond_fc.bias", "w_qs.weight", "w_ks.weight", "w_vs.weight", "fc.weight"] \
+        if spatial else ["in_proj_weight", "in_proj_bias", "out_proj.weight"]
+    for n in names:
+        checks.append((f"d {n}", params[n].grad, sd[f"a.{n}"].grad))
+    for what, a, b in checks:
+        assert _rel_l2(a, b) <= 1e-2, (what, _rel_l2(a, b))
+        _close(a, b, 4e-2, what)

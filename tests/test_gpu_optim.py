@@ -45,7 +45,7 @@ def test_matches_torch_adamw_and_clip(max_norm):
             scale = pa.abs().max().item() + 1e-6
             assert (pa - pb).abs().max().item() <= 2e-6 * scale
     sa, sb = ref.state[a[0]], opt.state[b[0]]
-    assert float(sb["step"]) == 5.0 and float(opt.state[b[3]]["step"]) == float(ref.state[a[3]]["step"]) == 3.0 and (sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max().item() < 1e-6
+    assert float(sb["step"]) == 5.0 and float(opt.state[b[3]]["step"]) == float(ref.state[a[3]]["step"]) == 3.0 and (sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max().item() < 1e-5 * sa["exp_avg_sq"].abs().max().item()
 
 
 def test_scheduler_drives_the_device_learning_rate():
