@@ -58,13 +58,35 @@ PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")   # rocpr
 N_CLS = 607
 
 
-def gps_pretrain_cfg(lang_path: str, num_gpu: int = 1):
-    """Model/solver section of configs/final/all_pretrain.yaml:172-258 (reference)."""
+# workload presets: BASELINE.json configs[1] (default), configs[3] and configs[4]
+WORKLOADS = {
+    # GPS pre-train step of all_pretrain.yaml: B = 64 (:167), 80 objects x 1024 points, 50 + 300 tokens
+    "pretrain": dict(batch=64, n_obj=80, n_pts=1024, txt_len=50, heads="pretrain", scene_cap=True,
+                     losses=["lm_cls_loss", "TextObjWithinBatch", "TextSceneBetweenBatch"]),
+    # ScanRefer grounding fine-tune (finetune/scanrefer_finetune.yaml:164,245-251): B = 256, GroundHeadV1, og3d_loss
+    "finetune": dict(batch=256, n_obj=80, n_pts=1024, txt_len=50, heads="ground", scene_cap=False, losses=["og3d_loss"]),
+    # stress: 256 objects x 2048 points, 256-token text (T = 512 joint tokens), pre-train losses without the caption
+    "stress": dict(batch=8, n_obj=256, n_pts=2048, txt_len=256, heads="pretrain", scene_cap=False,
+                   losses=["lm_cls_loss", "TextObjWithinBatch"]),
+}
+
+
+def gps_pretrain_cfg(lang_path: str, num_gpu: int = 1, workload: str = "pretrain"):
+    """Model/solver section of configs/final/all_pretrain.yaml:172-258 (reference); `workload` swaps the head and
+    loss list for the fine-tune preset (finetune/scanrefer_finetune.yaml:245-258)."""
     from sceneverse_amd.common.config import ConfigNode
-    losses = ["lm_cls_loss", "TextObjWithinBatch", "TextSceneBetweenBatch"]
+    w = WORKLOADS[workload]
+    losses = list(w["losses"])
+    heads = {"pretrain": {"head_list": ["pretrain_head"],
+                          "pretrain_head": {"name": "OVPretrainHead",
+                                            "args": {"hidden_size": 768, "vocab_size": 30522}}},
+             "ground": {"head_list": ["ground_head"],
+                        "ground_head": {"name": "GroundHeadV1",
+                                        "args": {"hidden_size": 384, "input_size": 768, "sem_cls_size": 607,
+                                                 "dropout": 0.3, "detach_all_aux_loss": True}}}}[w["heads"]]
     return ConfigNode({
         "num_gpu": num_gpu, "task": "Pretrain",
-        "data": {"args": {"use_scene_cap": True}},
+        "data": {"args": {"use_scene_cap": bool(w["scene_cap"])}},
         "solver": {"lr": 5e-4, "grad_norm": 5.0,
                    "optim": {"name": "AdamW", "args": {"betas": [0.9, 0.98]}},
                    "sched": {"name": "warmup_cosine", "args": {"warmup_steps": 500, "minimum_ratio": 0.1}}},
@@ -84,9 +106,7 @@ def gps_pretrain_cfg(lang_path: str, num_gpu: int = 1):
                           "args": {"hidden_size": 768, "num_attention_heads": 12, "num_layers": 4,
                                    "dim_feedforward": 2048, "dim_loc": 6}, "lr": 1e-4},
             "inter": "before",
-            "heads": {"head_list": ["pretrain_head"],
-                      "pretrain_head": {"name": "OVPretrainHead",
-                                        "args": {"hidden_size": 768, "vocab_size": 30522}}},
+            "heads": heads,
             "loss_list": losses, "vis_loss_list": losses,
         },
     })
@@ -304,9 +324,13 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="scenes per GPU (all_pretrain.yaml:167)")
-    ap.add_argument("--n-obj", type=int, default=80)
-    ap.add_argument("--n-pts", type=int, default=1024)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="pretrain",
+                    help="workload preset: pretrain = BASELINE configs[1] (the headline metric), finetune = configs[3] "
+                         "(B = 256, GroundHeadV1, og3d_loss + one eval pass), stress = configs[4] (256 obj x 2048 pts, "
+                         "256 tokens)")
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the preset's)")
+    ap.add_argument("--n-obj", type=int, default=None)
+    ap.add_argument("--n-pts", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -330,6 +354,10 @@ def main() -> None:
         b, st, no, npts, th = json.loads(args.cpu_baseline_worker)
         print(json.dumps(_cpu_baseline_inproc(b, st, no, npts, th)), flush=True)
         return
+    preset = WORKLOADS[args.config]
+    args.batch = preset["batch"] if args.batch is None else args.batch
+    args.n_obj = preset["n_obj"] if args.n_obj is None else args.n_obj
+    args.n_pts = preset["n_pts"] if args.n_pts is None else args.n_pts
     mode, world_expected = resolve_world(args.gpus)
     if mode == "spawn":
         import subprocess
@@ -356,7 +384,7 @@ def main() -> None:
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world)
+    cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world, workload=args.config)
     # One GPU: the whole step as one HIP graph.  N > 1: torch DDP in eager mode -- since the BERT stack
     # moved onto the fused kernels the eager step is GPU-bound too (28.6 ms eager vs 28.0 ms graph on one
     # GPU), and DDP overlaps the 491 MB gradient all-reduce with backward, which the split-graph form
@@ -365,7 +393,10 @@ def main() -> None:
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
                         graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm)
     use_graph = step.graph or step.graph_dp
-    batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, seed=42 + rank, device=dev)
+    batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank,
+                        device=dev)
+    if not preset["scene_cap"]:
+        batch.pop("scene_txt_ids"), batch.pop("scene_txt_masks")
 
     def barrier():
         if world > 1:
@@ -412,11 +443,20 @@ def main() -> None:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
     final_loss = float(loss)
-    step_kernels, bqg = [], None
+    step_kernels, bqg, eval_metrics = [], None, None
+    if args.config == "finetune":
+        # one evaluation pass through the grounding metrics (evaluator/scanrefer_eval.py:14-87); synthetic boxes:
+        # the annotated target is the only object above both IoU thresholds
+        from sceneverse_amd.engine import scanrefer_accuracy
+        out, _, _ = step.evaluate(dict(batch))
+        onehot = torch.zeros_like(out["og3d_logits"], dtype=torch.long)
+        onehot.scatter_(1, batch["tgt_object_id"], 1)
+        eval_metrics = scanrefer_accuracy(out["og3d_logits"].float(), onehot, onehot)
     if rank == 0 and not args.no_extras:
         if world == 1:
             step_kernels = profile_step_kernels(step, batch)        # eager steps (graph flags are off here)
-        bqg = bq_group_unfused(batch)
+        if args.config == "pretrain":
+            bqg = bq_group_unfused(batch)
     if saved is not None:
         step.graph, step.graph_dp = saved
 
@@ -499,7 +539,8 @@ def main() -> None:
                 "frac_of_bf16_mfma_peak": round(attn_flops / attn_sec / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4)},
         }
         result = {
-            "metric": "GPS pre-train pairs/sec (fwd+bwd)",
+            "metric": "GPS pre-train pairs/sec (fwd+bwd)" if args.config == "pretrain" else
+                      f"GPS {args.config} pairs/sec (fwd+bwd)",
             "value": round(pairs_per_s, 2),
             "unit": "pairs/s",
             "n_gpus": world,
@@ -511,9 +552,14 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "fp32" if args.fp32 else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"GPS pre-train step (all_pretrain.yaml model, ScanNet-shaped synthetic "
-                                   f"scenes): {args.n_obj} obj x {args.n_pts} pts x 6 ch, 50-token sentence "
-                                   f"+ 300-token scene caption, fwd+loss+bwd+clip+AdamW",
+            "config": {"workload": (f"GPS pre-train step (all_pretrain.yaml model, ScanNet-shaped synthetic "
+                                    f"scenes): {args.n_obj} obj x {args.n_pts} pts x 6 ch, 50-token sentence "
+                                    f"+ 300-token scene caption, fwd+loss+bwd+clip+AdamW") if args.config == "pretrain" else
+                                   (f"GPS {args.config} step ({'finetune/scanrefer_finetune.yaml head + og3d_loss' if args.config == 'finetune' else 'BASELINE configs[4]'}): "
+                                    f"{args.n_obj} obj x {args.n_pts} pts x 6 ch, {preset['txt_len']}-token text, "
+                                    f"fwd+loss+bwd+clip+AdamW"),
+                       "preset": args.config,
+                       **({"eval": eval_metrics} if eval_metrics is not None else {}),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
                        "point_ops": "fp32-accurate split-bf16 MFMA (libgps_hip.so)",
@@ -528,7 +574,7 @@ def main() -> None:
             "kernels": kernels,
             "step_kernels": step_kernels[:25],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "pretrain":
             result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.n_obj, args.n_pts)
         print(json.dumps(result), flush=True)
     if world > 1:

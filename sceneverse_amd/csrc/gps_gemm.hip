@@ -66,7 +66,7 @@ struct Params {
   float *partial;          // EPI_F32, splits > 1: (splits, M, N)
   float *colsum;           // EPI_F32: (splits, M) partial column sums of A over k (or (M) when splits == 1), or null
   int splits, kt_per_split, nkt;
-  int ntm, ntn;
+  int ntm, ntn, gm;        // gm: tile rows walked together (L2 working set of the workgroups resident on an XCD)
   float keep_scale;
   unsigned int drop_thr;
   unsigned long long seed;
@@ -303,6 +303,7 @@ constexpr int lds_bytes(int BM, int BN, int NBUF) { return NBUF * (BM + BN) * BK
 constexpr int waves_per_simd(int BM, int BN, int NW, int NBUF) {
   const int blocks = (160 * 1024) / lds_bytes(BM, BN, NBUF);
   const int w = (blocks < 1 ? 1 : blocks) * NW / 4;
+  if (NW >= 16) return 4;                 // one 1024-thread workgroup: 4 waves per SIMD, 128 VGPRs each
   return w < 1 ? 1 : (w > 2 ? 2 : w);     // the accumulators never leave room for more than 2
 }
 
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   // block -> (split, tile_m, tile_n).  The blocks of one XCD (block id mod 8) take a contiguous range of virtual
   // ids; inside a split the tiles are walked in groups of GM tile rows, tile_m fastest, so that the workgroups
   // resident on an XCD at any time share a few A row panels and a few B panels (both stay in its 4 MiB L2).
-  constexpr int GM = 8;
+  const int GM = P.gm;
   const int ntiles = P.ntm * P.ntn;
   const int vid = xcd_virtual_id(blockIdx.x, ntiles * P.splits);
   const int split = vid / ntiles, tile = vid - split * ntiles;
@@ -511,6 +512,7 @@ int launch_cfg(Params &P, hipStream_t s) {
   static_assert(LDS <= 160 * 1024, "stage buffers exceed the LDS of a CU");
   P.ntm = (P.M + BM - 1) / BM;
   P.ntn = (P.N + BN - 1) / BN;
+  P.gm = BM >= 256 ? 4 : 8;           // ~16 (128-row) panels of K = 768 bf16 stay under the 4 MiB L2 of an XCD
   auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF, PF>;
   static bool attr_done = false;
   if (LDS > 64 * 1024 && !attr_done) {
@@ -527,17 +529,17 @@ int launch_cfg(Params &P, hipStream_t s) {
 
 // tile configurations ("variants"): tile (BM x BN), wave grid, stage buffers (LDS) -> resident workgroups per CU,
 // PF = all fragment reads of a stage issued before its first MFMA
-//   0  128x128  2x2  2 bufs ( 64 KB)  2/CU      1  128x128  2x2  2 bufs  PF            2  128x128  4x2  2 bufs  PF
+//   0  128x128  2x2  2 bufs ( 64 KB)  2/CU      1  256x128  8x2  3 bufs (144 KB) 16 waves  2  128x128  4x2  2 bufs  PF
 //   3  128x64   2x2  3 bufs ( 72 KB)  2/CU      4  256x256  2x4  2 bufs (128 KB)  1/CU  5  256x128  4x2  2 bufs ( 96 KB) 1/CU
 //   6  128x64   2x2  2 bufs ( 48 KB)  3/CU      7  128x128  4x2  2 bufs ( 64 KB)  2/CU
 constexpr int kVariants = 8;
 struct VariantShape { int bm, bn; };
-constexpr VariantShape kShapes[kVariants] = {{128, 128}, {128, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128}};
+constexpr VariantShape kShapes[kVariants] = {{128, 128}, {256, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128}};
 template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
     case 0: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);
-    case 1: return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2, true>(P, s);
+    case 1: return launch_cfg<256, 128, 8, 2, ATR, BTR, EPI, 3>(P, s);
     case 2: return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2, true>(P, s);
     case 3:
       if constexpr (ATR) return launch_cfg<128, 128, 2, 2, ATR, BTR, EPI, 2>(P, s);   // reduction-major A tiles are >= 128 wide

@@ -162,7 +162,11 @@ class GpsAdamW(torch.optim.Optimizer):
                 entries.append((p, gi))
         if not entries:
             return loss
-        sig = (gemm.registry_version(), tuple((p.data_ptr(), p.grad.data_ptr()) for p, _ in entries))
+        for g in self.param_groups:                 # a plain float assigned from outside (g["lr"] = 1e-4) moves onto
+            if not torch.is_tensor(g["lr"]):        # the device again: the kernel reads learning rates from device words
+                g["lr"] = torch.full((), float(g["lr"]), dtype=torch.float32, device=self._device)
+        sig = (gemm.registry_version(), tuple(g["lr"].data_ptr() for g in self.param_groups),
+               tuple((p.data_ptr(), p.grad.data_ptr()) for p, _ in entries))
         if sig != self._sig:
             self._tables = self._build_tables(entries, gemm.shadow_targets())
             self._sig = sig

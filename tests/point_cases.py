@@ -38,3 +38,10 @@ BQ_SHAPES = [(1024, 32, 0.2, 32), (32, 16, 0.4, 32), (1, 1, 0.5, 3), (100, 7, 0.
 # (c, n, npoint, nsample)
 GROUP_SHAPES = [(3, 1024, 32, 32), (3, 32, 16, 32), (128, 32, 16, 32), (1, 7, 3, 5), (5, 100, 7, 9),
                 (131, 33, 4, 6), (2, 20000, 5, 8), (64, 16, 1, 1)]
+
+# BASELINE configs[4] ("stress"): 2048 points per object.  Kept apart from the lists above, whose entries key the
+# committed reference-kernel fixture (tests/golden/point_ops_ref_gpu.pt); these run against the oracle and, on the
+# GPU box, against the reference's own kernels (oracle/_ref).
+STRESS_FPS_SHAPES = [(2048, 32)]
+STRESS_BQ_SHAPES = [(2048, 32, 0.2, 32)]
+STRESS_GROUP_SHAPES = [(3, 2048, 32, 32)]

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle.pointnet2_oracle import OracleExt
-from point_cases import BQ_SHAPES, FPS_SHAPES, GROUP_SHAPES, generic_cloud, sa1_cloud
+from point_cases import (BQ_SHAPES, FPS_SHAPES, GROUP_SHAPES, STRESS_BQ_SHAPES, STRESS_FPS_SHAPES,
+                         STRESS_GROUP_SHAPES, generic_cloud, sa1_cloud)
 from sceneverse_amd.pointnet2 import _ext as hip
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +30,7 @@ def test_fps_sa1_adversarial_and_synthetic():
     assert torch.equal(got, ref), _mismatch(got, ref)
 
 
-@pytest.mark.parametrize("n,m", FPS_SHAPES)
+@pytest.mark.parametrize("n,m", FPS_SHAPES + STRESS_FPS_SHAPES)
 def test_fps_shapes(n, m):
     x = generic_cloud(5, n, seed=n * 7 + m)
     ref = OracleExt.furthest_point_sampling(x, m)
@@ -52,7 +53,7 @@ def test_ball_query_sa1_sa2_chain():
     assert torch.equal(hip.furthest_point_sampling(new_xyz.to(DEV), 16).cpu(), fps2)
 
 
-@pytest.mark.parametrize("n,m,radius,nsample", BQ_SHAPES)
+@pytest.mark.parametrize("n,m,radius,nsample", BQ_SHAPES + STRESS_BQ_SHAPES)
 def test_ball_query_shapes(n, m, radius, nsample):
     x = generic_cloud(4, n, seed=n + m)
     centres = x[:, torch.randperm(n, generator=torch.Generator().manual_seed(1))[:m]].contiguous()
@@ -74,7 +75,7 @@ def test_ball_query_points_exactly_on_the_radius():
     assert torch.equal(got, ref), _mismatch(got, ref)
 
 
-@pytest.mark.parametrize("c,n,npoint,nsample", GROUP_SHAPES)
+@pytest.mark.parametrize("c,n,npoint,nsample", GROUP_SHAPES + STRESS_GROUP_SHAPES)
 def test_group_points_and_grad(c, n, npoint, nsample):
     g = torch.Generator().manual_seed(c * 1000 + n)
     b = 3

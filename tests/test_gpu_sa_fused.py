@@ -31,7 +31,10 @@ def _encoder(seed=0):
     return net.to(DEV).eval()
 
 
-def _clouds():
+def _clouds(n_pts=1024):
+    if n_pts != 1024:            # BASELINE configs[4]: 2048 points per object
+        d = synth_batch(2, n_obj=6, n_pts=n_pts, seed=13, min_real=4)
+        return d["obj_fts"].reshape(-1, n_pts, 6)
     adv = adversarial_objects(1024)
     rgb = torch.rand(adv.shape[0], 1024, 3) * 2 - 1
     d = synth_batch(2, n_obj=12, seed=11, min_real=6)
@@ -51,8 +54,9 @@ def precision(request):
     M.set_sa_precision("bf16x3")
 
 
-def test_fused_levels_match_unfused_ops():
-    net, pcs = _encoder(), _clouds().to(DEV)
+@pytest.mark.parametrize("n_pts", [1024, 2048])
+def test_fused_levels_match_unfused_ops(n_pts):
+    net, pcs = _encoder(), _clouds(n_pts).to(DEV)
     xyz = pcs[..., :3].contiguous()
     feats = pcs[..., 3:].transpose(1, 2).contiguous()
     with torch.no_grad():

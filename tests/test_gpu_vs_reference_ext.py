@@ -6,7 +6,7 @@ import torch
 
 from oracle import build_ref
 from oracle.pointnet2_oracle import OracleExt
-from point_cases import BQ_SHAPES, FPS_SHAPES, generic_cloud, sa1_cloud
+from point_cases import BQ_SHAPES, FPS_SHAPES, STRESS_BQ_SHAPES, STRESS_FPS_SHAPES, generic_cloud, sa1_cloud
 from sceneverse_amd.pointnet2 import _ext as hip
 from util import fps_divergence_is_rounding_tie
 
@@ -39,13 +39,13 @@ def test_sa_chain_three_way(ref):
     assert torch.equal(g_ref, hip.group_points(xd.transpose(1, 2).contiguous(), i_hip))
 
 
-@pytest.mark.parametrize("n,m", FPS_SHAPES)
+@pytest.mark.parametrize("n,m", FPS_SHAPES + STRESS_FPS_SHAPES)
 def test_fps_shapes_vs_reference_kernels(ref, n, m):
     x = generic_cloud(5, n, seed=n * 7 + m).to(DEV)
     assert torch.equal(ref.furthest_point_sampling(x, m), hip.furthest_point_sampling(x, m))
 
 
-@pytest.mark.parametrize("n,m,radius,nsample", BQ_SHAPES)
+@pytest.mark.parametrize("n,m,radius,nsample", BQ_SHAPES + STRESS_BQ_SHAPES)
 def test_ball_query_shapes_vs_reference_kernels(ref, n, m, radius, nsample):
     x = generic_cloud(4, n, seed=n + m).to(DEV)
     q = generic_cloud(4, m, seed=99).to(DEV)
