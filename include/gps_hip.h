@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 1
+#define GPS_HIP_ABI_VERSION 2
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -179,8 +179,8 @@ GPS_API int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int
  * device pointer to one uint64 that is added to `seed` when the kernel runs (lets a captured HIP
  * graph draw a fresh mask on every replay), NULL to use `seed` alone.
  * out (B, L, ld_o) bf16; lse (B,H,L) fp32 log-sum-exp of the logits (saved for backward).
- * bf16 MFMA with fp32 accumulation; softmax in fp32.  head_dim must be 64; L <= 304 (forward and backward),
- * forward alone up to L = 512. */
+ * bf16 MFMA with fp32 accumulation; softmax in fp32.  head_dim must be 64, L <= 512 (rows of more than 144
+ * tokens stream their key chunks through a two-pass softmax instead of holding the whole score row). */
 GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                              int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
                              float p_drop, unsigned long long seed, const void *seed_dev, void *out,
@@ -188,12 +188,13 @@ GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, c
 
 /* Gradients of gps_attn_forward: dout (B,L,ld_o) bf16 -> dq, dk, dv (bf16, same layout/pitch as
  * q, k, v) and dsw (B,L,H*6) fp32 (when sw != NULL).  pl and mask carry no gradient (inputs of the
- * data pipeline).  Probabilities are recomputed from lse. */
+ * data pipeline).  Probabilities are recomputed from lse.  out = the forward output (B,L,ld_o) bf16: required for
+ * L > 256 (the streaming kernels take delta = rowsum(dout * out) from it), optional (may be NULL) below that. */
 GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                               int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
                               float p_drop, unsigned long long seed, const void *seed_dev,
-                              const void *dout, int ld_o, const float *lse, void *dq, void *dk, void *dv,
-                              float *dsw, gps_stream_t stream);
+                              const void *dout, int ld_o, const float *lse, const void *out, void *dq, void *dk,
+                              void *dv, float *dsw, gps_stream_t stream);
 
 /* ---- row-sparse cross-entropy (masked-LM head) ----------------------------------------------------
  * Replaces the F.cross_entropy(..., ignore_index=-1) of lm_cls_loss (optim/loss/loss.py:56-61) over

@@ -70,7 +70,7 @@ SIGNATURES = {
     "gps_add_dropout_layernorm_forward": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_add_dropout_layernorm_backward": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i, _vp, _vp],
-    "gps_attn_backward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i] + [_vp] * 6,
+    "gps_attn_backward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i] + [_vp] * 7,
 }
 
 

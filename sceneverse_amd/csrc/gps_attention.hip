@@ -757,6 +757,429 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
   }
 }
 
+// ==========================================================================================
+// streaming kernels for long sequences (144 < L <= 512: the 300-token scene captions, all_pretrain.yaml:35-36,46,
+// the T = 512 joint sequence of BASELINE configs[4], 256-object scenes).  Same mathematics, same dropout stream and
+// same operand layouts as the kernels above, but no query strip ever holds a whole score row in registers:
+//   forward   pass A streams the key tiles once for the row maximum and the normaliser (online, per lane, merged
+//             across the four lane groups at the end), pass B streams them again, recomputes the logits, and feeds
+//             P V chunk by chunk;
+//   backward  delta = rowsum(dO * O) is computed first (needs the forward output), so the dQ pass can treat every
+//             32-key chunk independently; the dK / dV pass is the chunked loop of the recompute kernel.
+// K and V stay ROW-major in LDS and serve both operand kinds: A fragments by 16-byte reads, B fragments by the
+// hardware-transposed ds_read_b64_tr_b16 (no transposing stores, no V^T / K^T tiles).
+// ==========================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// B fragment (32 keys x 16 columns, K order of pack_tiles) from a row-major [key][KS] tile
+__device__ __forceinline__ bf16x8 frag_from_rows_tr(const uint16_t *rows, int ntile, int c, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const uint16_t *p = rows + (32 * c + 4 * g + (i >> 2)) * KS + 16 * ntile + 4 * (i & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 16 * KS));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
+  return as_frag(v);
+}
+
+template <bool SPATIAL>
+__global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;
+  uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);       // [rows][KS]
+  uint16_t *Vs = Ks + rows * KS;                            // [rows][KS]
+  uint8_t *s_mask = reinterpret_cast<uint8_t *>(Vs + rows * KS);
+
+  int b, h;
+  block_to_bh(P, b, h);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)b * L;
+  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
+  const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
+  stage_rows(Ks, kb, P.ld_qkv, L, rows);
+  stage_rows(Vs, vb, P.ld_qkv, L, rows);
+  for (int t = threadIdx.x; t < rows; t += blockDim.x) s_mask[t] = (t < L && P.mask) ? P.mask[row0 + t] : 0;
+  __syncthreads();
+
+  const bool dropout = P.drop_thr != 0u;
+  const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+  const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
+
+  for (int s = wave; s < nt; s += nwaves) {
+    const int qi = 16 * s + m;
+    const bool q_ok = qi < L;
+    bf16x8 bq[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 v = zero4();
+      if (q_ok) v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_qkv + 32 * c + 8 * g);
+      bq[c] = as_frag(v);
+    }
+    float w[SD];
+    if (SPATIAL) {
+#pragma unroll
+      for (int d = 0; d < SD; ++d) w[d] = q_ok ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
+    }
+    // logit of (query qi, key 16 j + 4 g + r); -inf for padded / out-of-range keys
+    auto logits = [&](int j, f32x4 &x) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
+        acc = mfma(as_frag(a), bq[c], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 16 * j + 4 * g + r;
+        const bool t_ok = t < L;
+        const bool km = t_ok && s_mask[t];
+        float v = acc[r] * 0.125f;
+        if (SPATIAL && t_ok && q_ok) {
+          float sig;
+          v += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+        }
+        x[r] = (!t_ok || km) ? -INFINITY : v;
+      }
+    };
+    // pass A: running maximum and normaliser of this lane's keys
+    float mx = -INFINITY, sum = 0.f;
+    for (int j = 0; j < nt; ++j) {
+      f32x4 x;
+      logits(j, x);
+      const float tm = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+      const float mn = fmaxf(mx, tm);
+      if (mn > -INFINITY) {
+        sum = sum * __expf(mx - mn) + __expf(x[0] - mn) + __expf(x[1] - mn) + __expf(x[2] - mn) + __expf(x[3] - mn);
+        mx = mn;
+      }
+    }
+    const float gmx = xor_reduce_max_rows(mx);
+    sum = (mx > -INFINITY) ? sum * __expf(mx - gmx) : 0.f;
+    sum = xor_reduce_sum_rows(sum);
+    const float inv = 1.f / sum;                 // all keys masked -> NaN row, like torch
+    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * L + qi] = gmx + __logf(sum);
+    // pass B: probabilities chunk by chunk, O strip = P V
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nc; ++c) {
+      f32x4 pt[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int j = 2 * c + hh;
+        pt[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < nt) {
+          f32x4 x;
+          logits(j, x);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __expf(x[r] - gmx) * inv;
+            if (dropout) {
+              const int t = 16 * j + 4 * g + r;
+              const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
+              p = rng_u32(seed, idx) >= P.drop_thr ? p * keep_scale : 0.f;
+            }
+            pt[hh][r] = p;
+          }
+        }
+      }
+      const bf16x8 pa = pack_tiles(pt[0], pt[1]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) o[n] = mfma(pa, frag_from_rows_tr(Vs, n, c, lane), o[n]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qr = 16 * s + 4 * g + r;
+      if (qr < L) {
+        uint16_t *op = P.out + (row0 + qr) * P.ld_o + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r]);
+      }
+    }
+  }
+}
+
+template <bool SPATIAL>
+__global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32, TS = nc * 32 + 8;
+  // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (aliased): Qt [64][TS] | dOt [64][TS];  then delta [rows]
+  uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *Vs = Ks + rows * KS;
+  uint16_t *Qt = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *dOt = Qt + 64 * TS;
+  const int big = max(2 * rows * KS, 2 * 64 * TS) * 2;          // bytes of the aliased region
+  float *delta_s = reinterpret_cast<float *>(smem + big);
+
+  int b, h;
+  block_to_bh(P, b, h);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)b * L;
+  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
+  const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
+  const uint16_t *dob = P.dout + row0 * P.ld_o + h * DH;
+  const uint16_t *ob = P.out + row0 * P.ld_o + h * DH;
+  const float *lse = P.lse + ((size_t)b * P.H + h) * L;
+  const bool dropout = P.drop_thr != 0u;
+  const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
+  const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
+
+  stage_rows(Ks, kb, P.ld_qkv, L, rows);
+  stage_rows(Vs, vb, P.ld_qkv, L, rows);
+  // delta[q] = sum_d dO[q][d] O[q][d] = rowsum(P' dP') for the dropped, rescaled probabilities of the forward pass
+  for (int t = threadIdx.x; t < rows; t += blockDim.x) {
+    float d = 0.f;
+    if (t < L) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(dob + (size_t)t * P.ld_o + 8 * c);
+        const u32x4 o = *reinterpret_cast<const u32x4 *>(ob + (size_t)t * P.ld_o + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(o[e] << 16), d);
+          d = fmaf(__uint_as_float(a[e] & 0xFFFF0000u), __uint_as_float(o[e] & 0xFFFF0000u), d);
+        }
+      }
+    }
+    delta_s[t] = d;
+  }
+  __syncthreads();
+
+  // ---------------- pass 1: query strips, key chunks streamed -> dQ, dsw ----------------
+  for (int s = wave; s < nt; s += nwaves) {
+    const int qi = 16 * s + m;
+    const bool q_ok = qi < L;
+    bf16x8 bq[2], bdo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 v = zero4(), u = zero4();
+      if (q_ok) {
+        v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_qkv + 32 * c + 8 * g);
+        u = *reinterpret_cast<const u32x4 *>(dob + (size_t)qi * P.ld_o + 32 * c + 8 * g);
+      }
+      bq[c] = as_frag(v);
+      bdo[c] = as_frag(u);
+    }
+    float w[SD], dw[SD];
+#pragma unroll
+    for (int d = 0; d < SD; ++d) {
+      w[d] = (SPATIAL && q_ok) ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
+      dw[d] = 0.f;
+    }
+    const float lse_q = q_ok ? lse[qi] : 0.f;
+    const float delta = delta_s[qi < rows ? qi : 0];
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nc; ++c) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int j = 2 * c + hh;
+        ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < nt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * cc + 8 * g);
+            const u32x4 av = *reinterpret_cast<const u32x4 *>(Vs + (16 * j + m) * KS + 32 * cc + 8 * g);
+            acc = mfma(as_frag(a), bq[cc], acc);        // S^T
+            dacc = mfma(as_frag(av), bdo[cc], dacc);    // (dO V^T)^T
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int t = 16 * j + 4 * g + r;
+            const bool t_ok = t < L && q_ok;
+            const bool km = t_ok && P.mask && P.mask[row0 + t];
+            float x = acc[r] * 0.125f;
+            float gt = 0.f;
+            if (SPATIAL && t_ok) {
+              float sig;
+              x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+              gt = sig > 1e-6f ? 1.f - sig : 0.f;
+            }
+            const float p = (t_ok && !km) ? __expf(x - lse_q) : 0.f;
+            float dp = dacc[r];
+            if (dropout) {
+              const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
+              dp = rng_u32(seed, idx) >= P.drop_thr ? dp * keep_scale : 0.f;
+            }
+            const float dlogit = p * (dp - delta);
+            if (SPATIAL) {
+              const float dz = dlogit * gt;
+              if (dz != 0.f) {
+                const float *plp = P.pl + ((row0 + qi) * L + t) * 5;
+                dw[0] += dz;
+#pragma unroll
+                for (int d = 0; d < 5; ++d) dw[1 + d] = fmaf(dz, plp[d], dw[1 + d]);
+              }
+            }
+            ds[hh][r] = dlogit * 0.125f;
+          }
+        }
+      }
+      const bf16x8 da = pack_tiles(ds[0], ds[1]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) o[n] = mfma(da, frag_from_rows_tr(Ks, n, c, lane), o[n]);
+    }
+    if (SPATIAL) {
+#pragma unroll
+      for (int d = 0; d < SD; ++d) dw[d] = xor_reduce_sum_rows(dw[d]);
+      if (g == 0 && q_ok) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) P.dsw[((row0 + qi) * P.H + h) * SD + d] = dw[d];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qr = 16 * s + 4 * g + r;
+      if (qr < L) {
+        uint16_t *op = P.dq + (row0 + qr) * P.ld_qkv + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r]);
+      }
+    }
+  }
+  __syncthreads();   // K / V tiles no longer needed
+  stage_transposed(Qt, qb, P.ld_qkv, L, rows, TS);
+  stage_transposed(dOt, dob, P.ld_o, L, rows, TS);
+  __syncthreads();
+
+  // ---------------- pass 2: key strips, query chunks streamed -> dK, dV ----------------
+  for (int js = wave; js < nt; js += nwaves) {
+    const int t = 16 * js + m;            // this lane's key
+    const bool t_ok = t < L;
+    const bool km = t_ok && P.mask && P.mask[row0 + t];
+    bf16x8 bk[2], bv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 v = zero4(), u = zero4();
+      if (t_ok) {
+        v = *reinterpret_cast<const u32x4 *>(kb + (size_t)t * P.ld_qkv + 32 * c + 8 * g);
+        u = *reinterpret_cast<const u32x4 *>(vb + (size_t)t * P.ld_qkv + 32 * c + 8 * g);
+      }
+      bk[c] = as_frag(v);
+      bv[c] = as_frag(u);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = 0; c < nc; ++c) {        // 32-query chunks
+      f32x4 pt[2], ds[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int i = 2 * c + hh;          // query tile
+        pt[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < nt) {
+          const int qa = 16 * i + m;       // A-fragment row of this lane
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            u32x4 v = zero4(), u = zero4();
+            if (qa < L) {
+              v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qa * P.ld_qkv + 32 * cc + 8 * g);
+              u = *reinterpret_cast<const u32x4 *>(dob + (size_t)qa * P.ld_o + 32 * cc + 8 * g);
+            }
+            sacc = mfma(as_frag(v), bk[cc], sacc);    // S[query 16 i + 4 g + r][key t]
+            dacc = mfma(as_frag(u), bv[cc], dacc);    // dO V^T
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = 16 * i + 4 * g + r;
+            const bool ok = t_ok && qi < L;
+            float x = sacc[r] * 0.125f;
+            if (SPATIAL && ok) {
+              float w[SD];
+#pragma unroll
+              for (int d = 0; d < SD; ++d) w[d] = P.sw[((row0 + qi) * P.H + h) * SD + d];
+              float sig;
+              x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+            }
+            const float p = (ok && !km) ? __expf(x - lse[qi]) : 0.f;
+            float dp = dacc[r], pd = p;
+            if (dropout) {
+              const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
+              const bool keep = rng_u32(seed, idx) >= P.drop_thr;
+              dp = keep ? dp * keep_scale : 0.f;
+              pd = keep ? p * keep_scale : 0.f;
+            }
+            const float dl = ok ? p * (dp - delta_s[qi]) : 0.f;
+            pt[hh][r] = pd;
+            ds[hh][r] = dl * 0.125f;
+          }
+        }
+      }
+      const bf16x8 pa = pack_tiles(pt[0], pt[1]);
+      const bf16x8 da = pack_tiles(ds[0], ds[1]);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        dv[n] = mfma(pa, frag_from_transposed(dOt, TS, n, c, lane), dv[n]);
+        dk[n] = mfma(da, frag_from_transposed(Qt, TS, n, c, lane), dk[n]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tr = 16 * js + 4 * g + r;
+      if (tr < L) {
+        uint16_t *pk = P.dk + (row0 + tr) * P.ld_qkv + h * DH + m;
+        uint16_t *pv = P.dv + (row0 + tr) * P.ld_qkv + h * DH + m;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          pk[16 * n] = f2bf(dk[n][r]);
+          pv[16 * n] = f2bf(dv[n][r]);
+        }
+      }
+    }
+  }
+}
+
+inline size_t stream_fwd_lds(int nt) {
+  const size_t rows = (size_t)((nt + 1) / 2) * 32;
+  return 2 * (2 * rows * KS) + rows;
+}
+inline size_t stream_bwd_lds(int nt) {
+  const size_t rows = (size_t)((nt + 1) / 2) * 32, ts = rows + 8;
+  const size_t a = 2 * rows * KS, b = 2 * 64 * ts;
+  return 2 * (a > b ? a : b) + 4 * rows;
+}
+
+inline int pick_waves_fwd(int nt) {
+  const int rounds = (nt + 7) / 8;
+  return (nt + rounds - 1) / rounds;
+}
+
+int launch_stream(const Params &P, bool backward, hipStream_t s) {
+  const int nw = pick_waves_fwd(P.nt);
+  const dim3 grid(P.B * P.H), block(64 * nw);
+  const bool spatial = P.sw != nullptr;
+  const size_t lds = backward ? stream_bwd_lds(P.nt) : stream_fwd_lds(P.nt);
+  if (lds > 160 * 1024) return GPS_ERR_UNSUPPORTED;
+  const void *fn = backward ? (spatial ? (const void *)&attn_bwd_stream_kernel<true> : (const void *)&attn_bwd_stream_kernel<false>)
+                            : (spatial ? (const void *)&attn_fwd_stream_kernel<true> : (const void *)&attn_fwd_stream_kernel<false>);
+  static size_t granted[4] = {0, 0, 0, 0};
+  const int slot = (backward ? 2 : 0) + (spatial ? 1 : 0);
+  if (lds > 64 * 1024 && lds > granted[slot]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GPS_ERR_LAUNCH;
+    granted[slot] = 160 * 1024;
+  }
+  if (backward) {
+    if (spatial) hipLaunchKernelGGL((attn_bwd_stream_kernel<true>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((attn_bwd_stream_kernel<false>), grid, block, lds, s, P);
+  } else {
+    if (spatial) hipLaunchKernelGGL((attn_fwd_stream_kernel<true>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((attn_fwd_stream_kernel<false>), grid, block, lds, s, P);
+  }
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
 template <int NT>
 size_t fwd_lds() {
   constexpr int NC = (NT + 1) / 2;
@@ -817,10 +1240,12 @@ int dispatch(Params &P, bool backward, hipStream_t s) {
   P.nt = (P.L + 15) / 16;
   if (P.nt <= 5) return launch<5>(P, backward, s);
   if (P.nt <= 9) return launch<9>(P, backward, s);
+  // longer rows stream their key / query chunks (no whole score row in registers); the backward form needs the
+  // forward output for delta = rowsum(dO * O) -- without it (legacy callers) rows up to 256 tokens take the
+  // register-resident recompute kernel
+  if (P.nt <= 32 && (!backward || P.out != nullptr)) return launch_stream(P, backward, s);
   if (P.nt <= 16) return launch<16>(P, backward, s);
-  if (P.nt <= 19) return launch<19>(P, backward, s);       // 300-token scene captions (all_pretrain.yaml:35-36,46)
-  if (P.nt <= 32 && !backward) return launch<32>(P, backward, s);   // T = 512 (BASELINE configs[4]), forward only:
-  return GPS_ERR_UNSUPPORTED;                              // the key/value + transposed tiles of a backward pass exceed 160 KB
+  return GPS_ERR_UNSUPPORTED;
 }
 
 }  // namespace gps_attn
@@ -848,7 +1273,7 @@ int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const voi
 int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                       int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
                       float p_drop, unsigned long long seed, const void *seed_dev, const void *dout,
-                      int ld_o, const float *lse, void *dq, void *dk, void *dv, float *dsw,
+                      int ld_o, const float *lse, const void *out, void *dq, void *dk, void *dv, float *dsw,
                       gps_stream_t stream) {
   if (B < 0 || H < 1 || L < 0 || ld_qkv < H * 64 || ld_o < H * 64 || p_drop < 0.f || p_drop >= 1.f)
     return GPS_ERR_INVALID_ARGUMENT;
@@ -862,6 +1287,7 @@ int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const vo
   P.q = (const uint16_t *)q; P.k = (const uint16_t *)k; P.v = (const uint16_t *)v;
   P.sw = sw; P.pl = pl; P.mask = mask; P.lse = const_cast<float *>(lse);
   P.dout = (const uint16_t *)dout; P.dq = (uint16_t *)dq; P.dk = (uint16_t *)dk; P.dv = (uint16_t *)dv;
+  P.out = (uint16_t *)const_cast<void *>(out);
   P.dsw = dsw; P.p_drop = p_drop; P.seed = seed; P.seed_dev = (const unsigned long long *)seed_dev;
   P.drop_thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
   return gps_attn::dispatch(P, true, (hipStream_t)stream);

@@ -24,7 +24,7 @@ from ... import _native
 
 HEAD_DIM = 64
 SPATIAL_VEC = 6
-MAX_LEN = 256          # layers route longer sequences elsewhere: the kernels serve L <= 304 (forward 512) but spill there
+MAX_LEN = 512
 
 
 def supported(d_model: int, n_head: int, length: int) -> bool:
@@ -66,13 +66,13 @@ class _FusedSelfAttention(torch.autograd.Function):
                 _ptr(sw), _ptr(pl), _ptr(m8), float(p_drop), int(seed), _ptr(seed_dev), out.data_ptr(), D,
                 lse.data_ptr(), _stream())
         _native.check(st, "attn_forward")
-        ctx.save_for_backward(packed, sw, pl, m8, lse, seed_dev)
+        ctx.save_for_backward(packed, sw, pl, m8, lse, seed_dev, out)
         ctx.meta = (n_head, float(p_drop), int(seed), spatial)
         return out
 
     @staticmethod
     def backward(ctx, dout: torch.Tensor):
-        packed, sw, pl, m8, lse, seed_dev = ctx.saved_tensors
+        packed, sw, pl, m8, lse, seed_dev, out = ctx.saved_tensors
         n_head, p_drop, seed, spatial = ctx.meta
         B, L, W = packed.shape
         D = n_head * HEAD_DIM
@@ -88,7 +88,7 @@ class _FusedSelfAttention(torch.autograd.Function):
             st = _native.load().gps_attn_backward(
                 B, n_head, L, HEAD_DIM, base, base + D * esz, base + 2 * D * esz, W,
                 _ptr(sw), _ptr(pl), _ptr(m8), p_drop, seed, _ptr(seed_dev), dout.data_ptr(), D, lse.data_ptr(),
-                gbase, gbase + D * esz, gbase + 2 * D * esz, _ptr(dsw), _stream())
+                out.data_ptr(), gbase, gbase + D * esz, gbase + 2 * D * esz, _ptr(dsw), _stream())
         _native.check(st, "attn_backward")
         if spatial:
             dpacked[..., 3 * D:] = dsw

@@ -176,11 +176,13 @@ def shadow_targets() -> dict:
     the updated value of a parameter besides its fp32 master."""
     out = {}
     for sh in _SHADOWS.values():
-        if sh.w16 is None:
+        if sh.w16 is None or sh.owners is None:
             continue
+        alive = {id(t) for t in (r() for r in sh.owners) if t is not None}      # ids of dead masters may be recycled
         for wid, bid, off, nxt in zip(sh.weight_ids, sh.bias_ids, sh.row_offsets, sh.row_offsets[1:] + (sh.w16.shape[0],)):
-            out[wid] = (sh.w16[off:nxt], None)
-            if bid is not None and sh.b32 is not None and len(sh.weight_ids) > 1:
+            if wid in alive:
+                out[wid] = (sh.w16[off:nxt], None)
+            if bid is not None and bid in alive and sh.b32 is not None and len(sh.weight_ids) > 1:
                 out[bid] = (None, sh.b32[off:nxt])
     return out
 

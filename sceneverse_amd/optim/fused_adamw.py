@@ -105,6 +105,10 @@ class GpsAdamW(torch.optim.Optimizer):
         for i, (p, gi) in enumerate(entries):
             st = self._init_state(p)
             sh, mir = targets.get(id(p), (None, None))
+            if sh is not None and sh.numel() != p.numel():      # never write past a buffer that is not this tensor's
+                sh = None
+            if mir is not None and mir.numel() != p.numel():
+                mir = None
             r = trec[i]
             r.param, r.grad = p.data_ptr(), p.grad.data_ptr()
             r.exp_avg, r.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()

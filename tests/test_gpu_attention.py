@@ -62,7 +62,8 @@ def _close(a, b, tol, what):
 
 
 CASES = [(3, 80, True), (8, 80, True), (2, 130, False), (8, 130, False), (2, 37, True), (1, 200, True),
-         (2, 16, False), (2, 256, False), (2, 300, False), (1, 300, True), (8, 300, False)]
+         (2, 16, False), (2, 256, False), (2, 300, False), (1, 300, True), (8, 300, False), (2, 512, False),
+         (1, 145, True), (2, 177, False)]
 
 
 @pytest.mark.parametrize("B,L,spatial", CASES)
@@ -88,17 +89,17 @@ def test_forward_backward_match_fp32_formulation(B, L, spatial):
         assert g[..., D:3 * D][mask].abs().max().item() == 0.0
 
 
-def test_forward_up_to_512_tokens():
-    """T = 512 (BASELINE configs[4]): forward only (the backward tiles of a 512-token head exceed the LDS)."""
-    from sceneverse_amd import _native
-    packed, pl, mask = _inputs(2, 512, False, seed=77)
-    ref = ref_attention(packed.float(), pl, mask)
-    out = _FusedSelfAttention.apply(packed.to(DEV), None, mask.to(DEV), H, 0.0, 0, None)
-    _close(out, ref, 2e-2, "out L=512")
-    x = packed.to(DEV).requires_grad_(True)
-    out = _FusedSelfAttention.apply(x, None, mask.to(DEV), H, 0.0, 0, None)
-    with pytest.raises(_native.GpsNativeError):
-        out.float().sum().backward()
+def test_streaming_and_resident_kernels_agree_at_the_switch():
+    """L = 144 runs the register-resident kernels, L = 145 the streaming ones: same inputs (one padded token
+    more) must give the same first 144 rows to bf16 rounding, with dropout active (one shared RNG stream)."""
+    packed, _, _ = _inputs(2, 145, False, seed=31, pad=False)
+    mask = torch.zeros(2, 145, dtype=torch.bool)
+    mask[:, 144] = True                                       # the extra key is padding
+    x145 = packed.to(DEV)
+    x144 = packed[:, :144].contiguous().to(DEV)
+    o145 = _FusedSelfAttention.apply(x145, None, mask.to(DEV), H, 0.0, 0, None)
+    o144 = _FusedSelfAttention.apply(x144, None, None, H, 0.0, 0, None)
+    _close(o145[:, :144], o144, 1e-2, "switch")
 
 
 def test_dropout_is_reproducible_linear_and_adjoint():

@@ -56,6 +56,8 @@ def precision(request):
 
 @pytest.mark.parametrize("n_pts", [1024, 2048])
 def test_fused_levels_match_unfused_ops(n_pts):
+    if n_pts == 2048 and M._SA_PRECISION == "fp32":
+        pytest.skip("the fp32-MFMA mode keeps 2 workgroups per CU (80 KB LDS): clouds of up to 1024 points")
     net, pcs = _encoder(), _clouds(n_pts).to(DEV)
     xyz = pcs[..., :3].contiguous()
     feats = pcs[..., 3:].transpose(1, 2).contiguous()
