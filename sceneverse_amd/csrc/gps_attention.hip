@@ -771,6 +771,16 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const Params P) {
 // ==========================================================================================
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// dropout of the streaming kernels: ONE hash per pair of adjacent keys (t even, t odd) of a query, its low / high
+// 16 bits decide the two elements (threshold p * 2^16: the drop probability is quantised to 1 / 65536).  The three
+// places that need the mask (forward pass B, both backward passes) evaluate the same function of (query, key pair).
+__device__ __forceinline__ unsigned int pair_rng(unsigned long long seed, unsigned long long row_base, int t) {
+  return rng_u32(seed ^ 0x5DEECE66DULL, (row_base + (unsigned long long)t) >> 1);
+}
+__device__ __forceinline__ bool pair_keep(unsigned int r, int t, unsigned int thr16) {
+  return ((t & 1) ? (r >> 16) : (r & 0xFFFFu)) >= thr16;
+}
+
 // B fragment (32 keys x 16 columns, K order of pack_tiles) from a row-major [key][KS] tile
 __device__ __forceinline__ bf16x8 frag_from_rows_tr(const uint16_t *rows, int ntile, int c, int lane) {
   const int i = lane & 15, g = lane >> 4;
@@ -783,7 +793,7 @@ __device__ __forceinline__ bf16x8 frag_from_rows_tr(const uint16_t *rows, int nt
 }
 
 template <bool SPATIAL>
-__global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const Params P) {
+__global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);       // [rows][KS]
@@ -861,6 +871,8 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const Params P) {
     const float inv = 1.f / sum;                 // all keys masked -> NaN row, like torch
     if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * L + qi] = gmx + __logf(sum);
     // pass B: probabilities chunk by chunk, O strip = P V
+    const unsigned long long rowbase = (((unsigned long long)b * P.H + h) * L + qi) * (unsigned long long)(L + (L & 1));
+    const unsigned int thr16 = P.drop_thr >> 16;
     f32x4 o[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -874,14 +886,13 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const Params P) {
           f32x4 x;
           logits(j, x);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = __expf(x[r] - gmx) * inv;
-            if (dropout) {
-              const int t = 16 * j + 4 * g + r;
-              const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
-              p = rng_u32(seed, idx) >= P.drop_thr ? p * keep_scale : 0.f;
-            }
-            pt[hh][r] = p;
+          for (int r = 0; r < 4; ++r) pt[hh][r] = __expf(x[r] - gmx) * inv;
+          if (dropout) {        // keys 16 j + 4 g + {0,1} and {2,3}: two hashes for the four elements
+            const int t0 = 16 * j + 4 * g;
+            const unsigned int r01 = pair_rng(seed, rowbase, t0), r23 = pair_rng(seed, rowbase, t0 + 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              pt[hh][r] = pair_keep(r < 2 ? r01 : r23, t0 + r, thr16) ? pt[hh][r] * keep_scale : 0.f;
           }
         }
       }
@@ -902,16 +913,17 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const Params P) {
 }
 
 template <bool SPATIAL>
-__global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
+__global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32, TS = nc * 32 + 8;
-  // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (aliased): Qt [64][TS] | dOt [64][TS];  then delta [rows]
+  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;
+  // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (same storage): Qs [rows][KS] | dOs [rows][KS];  then
+  // delta [rows] and lse [rows] (fp32).  Every tile is ROW-major: A fragments are 16-byte reads, B fragments
+  // hardware-transposed reads of the same rows.
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
   uint16_t *Vs = Ks + rows * KS;
-  uint16_t *Qt = reinterpret_cast<uint16_t *>(smem);
-  uint16_t *dOt = Qt + 64 * TS;
-  const int big = max(2 * rows * KS, 2 * 64 * TS) * 2;          // bytes of the aliased region
-  float *delta_s = reinterpret_cast<float *>(smem + big);
+  uint16_t *Qs = Ks, *dOs = Vs;
+  float *delta_s = reinterpret_cast<float *>(smem + (size_t)2 * rows * KS * 2);
+  float *lse_s = delta_s + rows;
 
   int b, h;
   block_to_bh(P, b, h);
@@ -927,6 +939,9 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
   const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
+  const unsigned int thr16 = P.drop_thr >> 16;
+  const unsigned long long Leven = (unsigned long long)(L + (L & 1));
+  const unsigned long long bh_base = ((unsigned long long)b * P.H + h) * L;
 
   stage_rows(Ks, kb, P.ld_qkv, L, rows);
   stage_rows(Vs, vb, P.ld_qkv, L, rows);
@@ -946,6 +961,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
       }
     }
     delta_s[t] = d;
+    lse_s[t] = t < L ? lse[t] : 0.f;
   }
   __syncthreads();
 
@@ -970,8 +986,9 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
       w[d] = (SPATIAL && q_ok) ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
       dw[d] = 0.f;
     }
-    const float lse_q = q_ok ? lse[qi] : 0.f;
+    const float lse_q = lse_s[qi < rows ? qi : 0];
     const float delta = delta_s[qi < rows ? qi : 0];
+    const unsigned long long rowbase = (bh_base + qi) * Leven;
     f32x4 o[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -990,9 +1007,15 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
             acc = mfma(as_frag(a), bq[cc], acc);        // S^T
             dacc = mfma(as_frag(av), bdo[cc], dacc);    // (dO V^T)^T
           }
+          const int t0 = 16 * j + 4 * g;
+          unsigned int r01 = 0u, r23 = 0u;
+          if (dropout) {
+            r01 = pair_rng(seed, rowbase, t0);
+            r23 = pair_rng(seed, rowbase, t0 + 2);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int t = 16 * j + 4 * g + r;
+            const int t = t0 + r;
             const bool t_ok = t < L && q_ok;
             const bool km = t_ok && P.mask && P.mask[row0 + t];
             float x = acc[r] * 0.125f;
@@ -1004,10 +1027,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
             }
             const float p = (t_ok && !km) ? __expf(x - lse_q) : 0.f;
             float dp = dacc[r];
-            if (dropout) {
-              const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
-              dp = rng_u32(seed, idx) >= P.drop_thr ? dp * keep_scale : 0.f;
-            }
+            if (dropout) dp = pair_keep(r < 2 ? r01 : r23, t, thr16) ? dp * keep_scale : 0.f;
             const float dlogit = p * (dp - delta);
             if (SPATIAL) {
               const float dz = dlogit * gt;
@@ -1044,9 +1064,9 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
       }
     }
   }
-  __syncthreads();   // K / V tiles no longer needed
-  stage_transposed(Qt, qb, P.ld_qkv, L, rows, TS);
-  stage_transposed(dOt, dob, P.ld_o, L, rows, TS);
+  __syncthreads();   // K / V tiles no longer needed: the same storage now takes Q and dO (row-major as well)
+  stage_rows(Qs, qb, P.ld_qkv, L, rows);
+  stage_rows(dOs, dob, P.ld_o, L, rows);
   __syncthreads();
 
   // ---------------- pass 2: key strips, query chunks streamed -> dK, dV ----------------
@@ -1079,17 +1099,27 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
         pt[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
         ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (i < nt) {
-          const int qa = 16 * i + m;       // A-fragment row of this lane
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int cc = 0; cc < 2; ++cc) {
-            u32x4 v = zero4(), u = zero4();
-            if (qa < L) {
-              v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qa * P.ld_qkv + 32 * cc + 8 * g);
-              u = *reinterpret_cast<const u32x4 *>(dob + (size_t)qa * P.ld_o + 32 * cc + 8 * g);
-            }
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(Qs + (16 * i + m) * KS + 32 * cc + 8 * g);
+            const u32x4 u = *reinterpret_cast<const u32x4 *>(dOs + (16 * i + m) * KS + 32 * cc + 8 * g);
             sacc = mfma(as_frag(v), bk[cc], sacc);    // S[query 16 i + 4 g + r][key t]
             dacc = mfma(as_frag(u), bv[cc], dacc);    // dO V^T
+          }
+          // dropout hashes of (query 16 i + 4 g + r, key pair t >> 1): this lane computes two of the four, the
+          // lane of the other key of the pair (m ^ 1) the other two
+          unsigned int hr[4] = {0u, 0u, 0u, 0u};
+          if (dropout) {
+            const int par = m & 1;
+            const int qa = 16 * i + 4 * g + 2 * par;
+            const unsigned int ha = pair_rng(seed, (bh_base + qa) * Leven, t);
+            const unsigned int hb = pair_rng(seed, (bh_base + qa + 1) * Leven, t);
+            const unsigned int oa = (unsigned int)__shfl_xor((int)ha, 1, 64), ob2 = (unsigned int)__shfl_xor((int)hb, 1, 64);
+            hr[0] = par ? oa : ha;
+            hr[1] = par ? ob2 : hb;
+            hr[2] = par ? ha : oa;
+            hr[3] = par ? hb : ob2;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1103,11 +1133,10 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
               float sig;
               x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
             }
-            const float p = (ok && !km) ? __expf(x - lse[qi]) : 0.f;
+            const float p = (ok && !km) ? __expf(x - lse_s[qi]) : 0.f;
             float dp = dacc[r], pd = p;
             if (dropout) {
-              const unsigned long long idx = (((unsigned long long)b * P.H + h) * L + qi) * L + t;
-              const bool keep = rng_u32(seed, idx) >= P.drop_thr;
+              const bool keep = pair_keep(hr[r], t, thr16);
               dp = keep ? dp * keep_scale : 0.f;
               pd = keep ? p * keep_scale : 0.f;
             }
@@ -1121,8 +1150,8 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const Params P) {
       const bf16x8 da = pack_tiles(ds[0], ds[1]);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        dv[n] = mfma(pa, frag_from_transposed(dOt, TS, n, c, lane), dv[n]);
-        dk[n] = mfma(da, frag_from_transposed(Qt, TS, n, c, lane), dk[n]);
+        dv[n] = mfma(pa, frag_from_rows_tr(dOs, n, c, lane), dv[n]);
+        dk[n] = mfma(da, frag_from_rows_tr(Qs, n, c, lane), dk[n]);
       }
     }
 #pragma unroll
@@ -1146,18 +1175,17 @@ inline size_t stream_fwd_lds(int nt) {
   return 2 * (2 * rows * KS) + rows;
 }
 inline size_t stream_bwd_lds(int nt) {
-  const size_t rows = (size_t)((nt + 1) / 2) * 32, ts = rows + 8;
-  const size_t a = 2 * rows * KS, b = 2 * 64 * ts;
-  return 2 * (a > b ? a : b) + 4 * rows;
+  const size_t rows = (size_t)((nt + 1) / 2) * 32;
+  return 2 * (2 * rows * KS) + 8 * rows;
 }
 
-inline int pick_waves_fwd(int nt) {
-  const int rounds = (nt + 7) / 8;
+inline int pick_waves_stream(int nt) {        // up to 16 waves (one 1024-thread workgroup per (scene, head))
+  const int rounds = (nt + 15) / 16;
   return (nt + rounds - 1) / rounds;
 }
 
 int launch_stream(const Params &P, bool backward, hipStream_t s) {
-  const int nw = pick_waves_fwd(P.nt);
+  const int nw = pick_waves_stream(P.nt);
   const dim3 grid(P.B * P.H), block(64 * nw);
   const bool spatial = P.sw != nullptr;
   const size_t lds = backward ? stream_bwd_lds(P.nt) : stream_fwd_lds(P.nt);

@@ -85,7 +85,7 @@ def test_forward_backward_match_fp32_formulation(B, L, spatial):
     if spatial:
         _close(g[..., 3 * D:], gr[..., 3 * D:], 4e-2, "dsw")
     # padded keys receive no gradient through k and v
-    if mask is not None:
+    if mask is not None and mask.any():
         assert g[..., D:3 * D][mask].abs().max().item() == 0.0
 
 
@@ -102,8 +102,9 @@ def test_streaming_and_resident_kernels_agree_at_the_switch():
     _close(o145[:, :144], o144, 1e-2, "switch")
 
 
-def test_dropout_is_reproducible_linear_and_adjoint():
-    B, L = 2, 80
+@pytest.mark.parametrize("L", [80, 200, 300])
+def test_dropout_is_reproducible_linear_and_adjoint(L):
+    B = 2
     packed, pl, mask = _inputs(B, L, True, seed=9)
     pl, mask = pl.to(DEV), mask.to(DEV)
     p, seed = 0.3, 1234567
