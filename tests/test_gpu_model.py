@@ -273,9 +273,10 @@ def test_pairwise_locs_kernel_matches_the_torch_formulation(golden_cpu):
 
 def test_ddp_wrapper_runs_on_the_fused_path_with_rccl():
     """torch DDP (backend nccl = RCCL) around the GPS model on the GPU, world_size 1: exercises what
-    bench.py runs at N > 1 -- bucket views, find_unused_parameters against the fused autograd
-    functions (packed projections, fused attention / LN / CE), the RCCL all-gather of the
-    between-batch loss -- minus the second rank.  Loss must stay finite and go down."""
+    bench.py runs at N > 1 -- the probe step that freezes the never-used tensors, bucket views, bf16
+    gradient compression over RCCL, the fused autograd functions (MFMA GEMMs, fused attention / LN / CE,
+    the fused AdamW pass reading bucket views), the RCCL all-gather of the between-batch loss -- minus
+    the second rank.  Loss must stay finite and go down."""
     import socket
     import torch.distributed as dist
     from bench import gps_pretrain_cfg, _lang_dir
@@ -294,12 +295,12 @@ def test_ddp_wrapper_runs_on_the_fused_path_with_rccl():
         cfg.solver.sched.args.warmup_steps = 1
         st = GPSTrainStep(cfg, device=DEV, ddp=True, graph=False)
         from torch.nn.parallel import DistributedDataParallel as DDP
-        assert isinstance(st.net, DDP)
         batch = synth_batch(4, n_obj=16, seed=3, min_real=5, device=DEV)
         losses = [st.step(dict(batch))[0].item() for _ in range(6)]
+        assert isinstance(st.net, DDP)                           # built by the first step, after the probe
         assert all(l == l for l in losses) and losses[-1] < losses[0], losses
-        n_none = sum(1 for p in st.model.parameters() if p.requires_grad and p.grad is None)
-        assert n_none >= 13
+        assert len(st.frozen_unused) >= 13                       # found by the probe, frozen before the wrap
+        assert sum(1 for p in st.model.parameters() if p.requires_grad and p.grad is None) == 0
     finally:
         dist.destroy_process_group()
 
