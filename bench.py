@@ -54,7 +54,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, same guide
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")   # rocprofv3 --pmc, see tools/pmc_traffic.py
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")   # rocprofv3 --pmc, see tools/pmc_traffic.py
 N_CLS = 607
 
 

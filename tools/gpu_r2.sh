@@ -81,6 +81,20 @@ fi
 if [[ $WHAT == *kbench* ]]; then
   ts kernel_bench; timeout 300 python tools/kernel_bench.py --json $OUT/kernel_bench.json > $OUT/kernel_bench.log 2>&1; tail -5 $OUT/kernel_bench.log
 fi
+if [[ $WHAT == *pmctraffic* ]]; then
+  ts pmc
+  rm -rf /tmp/pmc && mkdir -p /tmp/pmc
+  (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc -o fetch --output-format csv -- python $REPO/tools/pmc_workload.py > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?")
+  (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc -o write --output-format csv -- python $REPO/tools/pmc_workload.py > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?")
+  mkdir -p $OUT/pmc
+  f=$(find /tmp/pmc -name 'fetch_counter_collection.csv' | head -1); w=$(find /tmp/pmc -name 'write_counter_collection.csv' | head -1)
+  python tools/pmc_traffic.py $f $w $OUT/pmc/pmc_traffic.json | tail -40
+fi
+if [[ $WHAT == *fullbench* ]]; then
+  ts fullbench; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err
+  timeout 600 python bench.py --config finetune --steps 5 --warmup 2 > $OUT/bench_finetune.json 2> $OUT/bench_finetune.err; echo "finetune exit $?"; tail -c 800 $OUT/bench_finetune.json | head -c 600; tail -3 $OUT/bench_finetune.err
+  timeout 600 python bench.py --config stress --steps 5 --warmup 2 > $OUT/bench_stress.json 2> $OUT/bench_stress.err; echo "stress exit $?"; tail -c 800 $OUT/bench_stress.json | head -c 600; tail -3 $OUT/bench_stress.err
+fi
 if [[ $WHAT == *prof* ]]; then
   ts rocprof
   rm -rf /tmp/prof && mkdir -p /tmp/prof

@@ -26,6 +26,12 @@ NAMES = [
     (r"ball_query_kernel<1>", "ball_query(n=32,m=16,ns=32)"),
     (r"add_dropout_ln_bwd_kernel", "add_dropout_layernorm_backward"),
     (r"add_dropout_ln_fwd_kernel", "add_dropout_layernorm_forward"),
+    (r"attn_bwd_stream_kernel", "attn_backward(L=300,spatial=0)"),
+    (r"attn_fwd_stream_kernel", "attn_forward(L=300,spatial=0)"),
+    (r"gemm_kernel<128, 128, 4, 2, false, false, 1,", "gemm_nt(M=19200,N=3072,K=768,epi=1)"),
+    (r"gemm_kernel<128, 128, 4, 2, false, true, 0,", "gemm_nn(M=19200,N=768,K=3072,epi=0)"),
+    (r"gemm_kernel<128, 128, 4, 2, true, true, 5,", "gemm_tn(M=3072,N=768,K=19200,epi=5)"),
+    (r"adamw_kernel", "adamw_step(pmc workload: 25 165 824 parameters)"),
     (r"attn_bwd_kernel", "attn_backward"),
     (r"attn_fwd_kernel", "attn_forward"),
     (r"colsum_stage1_kernel", "colsum_bf16_stage1"),
@@ -66,7 +72,7 @@ def main(fetch_csv, write_csv, out):
             if re.search(re.escape(pat), k):
                 fb = f_unit * sum(fetch[k]) / len(fetch[k])
                 wb = w_unit * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
-                if name in ("group_points", "gather_points") or " grid=" in k:
+                if name in ("group_points", "gather_points") or (" grid=" in k and "stream" not in k):
                     name = f"{name}#{len(res['per_launch_detail'])}" + (k[k.rfind(" grid="):] if " grid=" in k else "")
                 res["per_launch_hbm_bytes"][name] = int(fb + wb)
                 res["per_launch_detail"][name] = {"symbol": k[:100], "read_bytes": int(fb), "write_bytes": int(wb),

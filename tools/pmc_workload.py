@@ -65,13 +65,33 @@ def main():
         h = torch.randn(rows, 768, device=dev).to(torch.bfloat16).requires_grad_(True)
         for _ in range(3):
             add_dropout_layer_norm(x, h, norm, 0.1, True).sum().backward()
-    for L, spatial in ((80, True), (130, False)):
+    for L, spatial in ((80, True), (130, False), (300, False)):
         W = 3 * 768 + (72 if spatial else 0)
         packed = torch.randn(64, L, W, device=dev).to(torch.bfloat16).requires_grad_(True)
         pl = torch.rand(64, L, L, 5, device=dev) if spatial else None
         mask = torch.zeros(64, L, dtype=torch.bool, device=dev)
         for _ in range(3):
             _FusedSelfAttention.apply(packed, pl, mask, 12, 0.0, 0, None).float().sum().backward()
+    # the MFMA GEMMs of the largest Linears of the step (forward GELU, input gradient x GELU', weight gradient) and
+    # the optimizer pass; tools/pmc_traffic.py tells the launches of one kernel symbol apart by their grid size
+    from sceneverse_amd import _native
+    from sceneverse_amd.modules.layers import gemm as GM
+    T, K, N = 19200, 768, 3072
+    x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+    w = (0.02 * torch.randn(N, K, device=dev)).to(torch.bfloat16)
+    b = torch.randn(N, device=dev)
+    dyb = torch.randn(T, N, device=dev).to(torch.bfloat16)
+    for _ in range(3):
+        h, pre = GM.linear_forward(x, w, b, act="gelu", want_pre=True)
+        GM.linear_dgrad(dyb, w, None)
+        GM.linear_wgrad(dyb, x)
+    ps = [torch.nn.Parameter(torch.randn(4096, 768, device=dev)) for _ in range(8)]
+    from sceneverse_amd.optim.fused_adamw import GpsAdamW
+    opt = GpsAdamW(ps, lr=1e-3)
+    for p_ in ps:
+        p_.grad = torch.randn_like(p_)
+    for _ in range(3):
+        opt.step(max_grad_norm=1.0)
     # bias-gradient column sums and the loader-side object kernel
     import numpy as np
     from sceneverse_amd.common import colsum as WS
