@@ -27,6 +27,7 @@
 // dK and dV.  Probabilities are recomputed from the saved log-sum-exp, never stored.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gps_hip.h"
 
@@ -1266,6 +1267,14 @@ int launch(const Params &P, bool backward, hipStream_t s) {
 
 int dispatch(Params &P, bool backward, hipStream_t s) {
   P.nt = (P.L + 15) / 16;
+  // rows of up to 144 tokens: register-resident kernels (one launch holds a whole score row per query strip);
+  // GPS_ATTN_STREAM_MIN_NT (16-token tiles, default 10) moves the switch to the streaming kernels for experiments
+  static const int stream_min_nt = [] {
+    const char *e = getenv("GPS_ATTN_STREAM_MIN_NT");
+    const int v = e ? atoi(e) : 10;
+    return v < 1 ? 1 : v;
+  }();
+  if (P.nt >= stream_min_nt && P.nt <= 32 && (!backward || P.out != nullptr)) return launch_stream(P, backward, s);
   if (P.nt <= 5) return launch<5>(P, backward, s);
   if (P.nt <= 9) return launch<9>(P, backward, s);
   // longer rows stream their key / query chunks (no whole score row in registers); the backward form needs the
