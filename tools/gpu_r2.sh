@@ -60,6 +60,9 @@ if [[ $WHAT == *alltests* ]]; then
   ts pytest; timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
   grep -E "^(FAILED|ERROR)|passed|failed|exit" $OUT/pytest_gpu.log | head -40
 fi
+if [[ $WHAT == *attrib* ]]; then
+  ts attrib; timeout 600 python tools/step_attrib.py --out $OUT/step_attrib.txt > $OUT/step_attrib.log 2>&1; echo "attrib exit $?"; tail -5 $OUT/step_attrib.log
+fi
 if [[ $WHAT == *stepbench* ]]; then
   ts bench; timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
   tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err
