@@ -227,8 +227,13 @@ GPS_API int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int
                                               gps_stream_t stream);
 /* rows of the partial dgamma/dbeta buffers the backward call fills (one per workgroup). */
 GPS_API int gps_ln_partial_rows(int n_rows);
-/* out[2][d] = column sums of part[2][parts][d] ([dgamma | dbeta] partial rows -> their totals). */
-GPS_API int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, gps_stream_t stream);
+/* out[2][d] = column sums of part[2][parts][d] ([dgamma | dbeta] partial rows -> their totals), in a fixed
+ * summation order.  scratch (optional): gps_ln_reduce_scratch_bytes(d) bytes of device memory, ZERO before its
+ * first use and left zero by every call (second-level partial rows + arrival counters of the row slices; one
+ * stream at a time); NULL = one workgroup per 64 columns walks all rows (slow above a few dozen rows). */
+GPS_API long long gps_ln_reduce_scratch_bytes(int d);
+GPS_API int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, void *scratch,
+                                   gps_stream_t stream);
 /* dy (x's dtype) [+ dy_bf16: gradient that arrived through the bf16 copy, may be NULL] -> dx (x's
  * dtype), dh (h's dtype), dgamma_part / dbeta_part (gps_ln_partial_rows(n_rows), d) fp32: the caller
  * sums them over the first axis. */

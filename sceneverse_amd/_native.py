@@ -66,7 +66,7 @@ SIGNATURES = {
     "gps_masked_ce_forward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_masked_ce_backward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp],
-    "gps_ln_reduce_partials": [_i, _i, _vp, _vp, _vp],
+    "gps_ln_reduce_partials": [_i, _i, _vp, _vp, _vp, _vp],
     "gps_add_dropout_layernorm_forward": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_add_dropout_layernorm_backward": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i, _vp, _vp],
@@ -115,6 +115,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_adamw_chunk_elems.argtypes = []
     lib.gps_ln_partial_rows.restype = _i
     lib.gps_ln_partial_rows.argtypes = [_i]
+    lib.gps_ln_reduce_scratch_bytes.restype = ctypes.c_longlong
+    lib.gps_ln_reduce_scratch_bytes.argtypes = [_i]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -209,27 +209,59 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
 }
 
 // out[c] = sum_r part[r][c] for the 2*d columns of the [dgamma | dbeta] partial rows
-// (part is [2][parts][d]; out is [2][d]).  A workgroup owns 64 columns: its 4 waves split the rows
-// (each wave reads 256 contiguous bytes per row, 8 rows in flight per thread), then combine in LDS.
+// (part is [2][parts][d]; out is [2][d]).  Workgroup (cg, rg) owns 64 columns x one slice of the rows: its 4 waves
+// split the slice (256 contiguous bytes per row and wave, 8 rows in flight per thread), combine in LDS and write
+// one row of second-level partials; the LAST workgroup of a column group to arrive (ticket counter) adds those
+// rows in slice order, so the result does not depend on the arrival order.  scratch: [kRedSlices][2 d] floats +
+// one counter per column group, zero before the first launch and left zero by every launch.
+constexpr int kRedSlices = 16;
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int d, const float *__restrict__ part,
-                                                                  float *__restrict__ out) {
+                                                                  float *__restrict__ out, float *__restrict__ part2,
+                                                                  unsigned int *__restrict__ tickets) {
   __shared__ float red[kWaves][64];
+  __shared__ int last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;           // column in [0, 2 d)
+  const int slices = gridDim.y;
+  const int per = (parts + slices - 1) / slices;
+  const int r_begin = blockIdx.y * per, r_end = min(parts, r_begin + per);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < 2 * d) {
     const int which = c / d, col = c - which * d;
     const float *p = part + (size_t)which * parts * d + col;
-    int r = wave;
-    for (; r + 7 * kWaves < parts; r += 8 * kWaves) {
+    int r = r_begin + wave;
+    for (; r + 7 * kWaves < r_end; r += 8 * kWaves) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] += p[(size_t)(r + u * kWaves) * d];
     }
-    for (; r < parts; r += kWaves) acc[0] += p[(size_t)r * d];
+    for (; r < r_end; r += kWaves) acc[0] += p[(size_t)r * d];
   }
   red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (wave == 0 && c < 2 * d) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (slices == 1) {
+    if (wave == 0 && c < 2 * d) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    return;
+  }
+  if (wave == 0) {
+    if (c < 2 * d) part2[(size_t)blockIdx.y * 2 * d + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t == (unsigned int)slices - 1u);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  __syncthreads();
+  if (!last || wave != 0 || c >= 2 * d) return;
+  float sum = 0.f;
+  for (int s = 0; s < slices; ++s)
+    sum += part2[(size_t)s * 2 * d + c];
+  out[c] = sum;
 }
 
 inline int grid_rows(int n_rows) {
@@ -243,10 +275,20 @@ extern "C" {
 
 int gps_ln_partial_rows(int n_rows) { return gps_ln::grid_rows(n_rows); }
 
-int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, gps_stream_t stream) {
+long long gps_ln_reduce_scratch_bytes(int d) {
+  return (long long)gps_ln::kRedSlices * 2 * d * 4 + (long long)((2 * d + 63) / 64) * 4;
+}
+
+int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, void *scratch, gps_stream_t stream) {
   if (parts < 1 || d < 1 || !part || !out) return GPS_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(gps_ln::reduce_partials_kernel, dim3((2 * d + 63) / 64), dim3(gps_ln::kBlock), 0,
-                     (hipStream_t)stream, parts, d, part, out);
+  const int groups = (2 * d + 63) / 64;
+  // few partial rows (or no scratch): one workgroup per column group does the whole sum
+  int slices = scratch ? (parts + 63) / 64 : 1;
+  if (slices > gps_ln::kRedSlices) slices = gps_ln::kRedSlices;
+  float *part2 = reinterpret_cast<float *>(scratch);
+  unsigned int *tickets = scratch ? reinterpret_cast<unsigned int *>(part2 + (size_t)gps_ln::kRedSlices * 2 * d) : nullptr;
+  hipLaunchKernelGGL(gps_ln::reduce_partials_kernel, dim3(groups, slices), dim3(gps_ln::kBlock), 0,
+                     (hipStream_t)stream, parts, d, part, out, part2, tickets);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

@@ -100,12 +100,14 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         txt_len, obj_len = txt_embeds.shape[1], obj_embeds.shape[1]
         joint_pad = torch.cat((txt_masks, obj_masks), dim=1).logical_not()
         type_txt = self.token_type_embeddings.weight[0]
-        # the same deterministic embedding is re-added every layer (ref :154-164): evaluate it once
+        # the same deterministic embeddings are re-added to both streams every layer (ref :154-164) and the
+        # streams are concatenated right after: build the joint (B, T, D) addend once and keep the sequence joint
+        # across layers -- the same elementwise sums, one add per layer instead of two adds + cat + split
         obj_extra = self.loc_layers[0](obj_locs) + self.token_type_embeddings.weight[1]
+        extra = torch.cat((type_txt.to(obj_extra.dtype).expand(txt_embeds.shape[0], txt_len, -1), obj_extra), dim=1)
+        joint = torch.cat((txt_embeds, obj_embeds), dim=1)
         for layer in self.unified_encoder:
-            obj_embeds = obj_embeds + obj_extra
-            txt_embeds = txt_embeds + type_txt
-            joint = torch.cat((txt_embeds, obj_embeds), dim=1)
+            joint = joint + extra
             joint, _ = layer(joint, tgt_key_padding_mask=joint_pad)
-            txt_embeds, obj_embeds = torch.split(joint, [txt_len, obj_len], dim=1)
+        txt_embeds, obj_embeds = torch.split(joint, [txt_len, obj_len], dim=1)
         return txt_embeds, obj_embeds

@@ -1,6 +1,7 @@
 """Masked-LM style pre-training heads (reference modules/heads/pretrain_head.py:8-56)."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ..build import HEADS_REGISTRY
 from ..utils import get_activation_fn
@@ -27,7 +28,9 @@ class BertLMPredictionHead(nn.Module):
         self.bias = nn.Parameter(torch.zeros(vocab_size))
 
     def forward(self, hidden_states):
-        return self.decoder(self.transform(hidden_states)) + self.bias
+        # decoder(h) + bias (ref :29) as ONE GEMM with the bias in its epilogue: under bf16 autocast the separate
+        # add promoted the (tokens x vocab) logits to fp32 (a 390 MB round trip forward, the same again backward)
+        return F.linear(self.transform(hidden_states), self.decoder.weight, self.bias)
 
 
 @HEADS_REGISTRY.register()

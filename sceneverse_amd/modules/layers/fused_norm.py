@@ -20,6 +20,20 @@ def set_fused_norm(flag: bool) -> None:
     _ENABLED = bool(flag)
 
 
+_REDUCE_SCRATCH = {}
+
+
+def _reduce_scratch(device: torch.device, d: int) -> torch.Tensor:
+    """Zero-initialised scratch of gps_ln_reduce_partials (second-level partial rows + arrival counters), one per
+    (device, width): every call leaves it zero again, and the launches of one device share one stream."""
+    key = (device.index, d)
+    buf = _REDUCE_SCRATCH.get(key)
+    if buf is None:
+        nbytes = int(_native.load().gps_ln_reduce_scratch_bytes(d))
+        buf = _REDUCE_SCRATCH[key] = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
+    return buf
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr() if t is not None else None
 
@@ -76,6 +90,7 @@ class _AddDropoutLN(torch.autograd.Function):
         sums = torch.empty((2, d), dtype=torch.float32, device=x2.device)
         with torch.cuda.device(x2.device):
             st = lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), sums.data_ptr(),
+                                            _reduce_scratch(x2.device, d).data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
         _native.check(st, "ln_reduce_partials")
         return (dx.view(x_shape), dh.view(h_shape), sums[0].to(g_dtype), sums[1].to(b_dtype),

@@ -97,3 +97,32 @@ def test_bf16_copy_output_and_its_gradient():
     ((yr * 0.5).sum() + (yr.to(torch.bfloat16).float() @ w).square().mean()).backward()
     for a, b in ((xg.grad, xr.grad), (hg.grad.float(), hr.grad)):
         assert (a - b).abs().max().item() <= 2 ** -6 * b.abs().max().item(), (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("parts,d", [(1024, 768), (1, 256), (63, 768), (65, 1024), (800, 2048), (130, 512)])
+def test_partial_row_reduction_is_exact_order_independent_and_reusable(parts, d):
+    """gps_ln_reduce_partials: two-level sum with an arrival counter.  Same bits on every call (fixed summation
+    order), counters left at zero (the scratch is reused by the next call), scratch-less form agrees."""
+    from sceneverse_amd import _native
+    from sceneverse_amd.modules.layers.fused_norm import _reduce_scratch
+    lib = _native.load()
+    g = torch.Generator().manual_seed(parts * 7 + d)
+    part = torch.randn(2, parts, d, generator=g).to(DEV)
+    ref = part.double().sum(1)
+    scratch = _reduce_scratch(torch.device(DEV, torch.cuda.current_device()), d)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for _ in range(4):
+        out = torch.full((2, d), float("nan"), device=DEV)
+        _native.check(lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), out.data_ptr(), scratch.data_ptr(), stream),
+                      "reduce")
+        outs.append(out)
+    torch.cuda.synchronize()
+    tickets = scratch[16 * 2 * d:]
+    assert int(tickets.abs().sum()) == 0
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert (outs[0].double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    plain = torch.empty((2, d), device=DEV)
+    _native.check(lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), plain.data_ptr(), None, stream), "reduce")
+    assert (plain.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--only", type=int, default=-1, help="index into LAYERS: time just that layer")
     ap.add_argument("--ablate", action="store_true", help="time variants 0/7 of the big forward shape with the copies or MFMAs skipped")
+    ap.add_argument("--split-sweep", action="store_true", help="weight-gradient form: time every split count 1..20")
     ap.add_argument("--pmc-loop", default=None,
                     help="form:variant -- run ONE kernel configuration of layer --only 30 times (for rocprofv3 --pmc)")
     args = ap.parse_args()
@@ -78,6 +79,31 @@ def main():
                     fns[f"v{v}_ab{ab}"] = (lambda v=v, ab=ab: G.gemm(_native.GEMM_NT, _native.EPI_BIAS, T, N, K, x, K, w, K, y, N, variant=v, ablate=ab))
             t = timeit(fns, args.rounds)
             print(json.dumps({"shape": [T, K, N], "us": {k: round(v, 1) for k, v in t.items()}}), flush=True)
+        return
+    if args.split_sweep:
+        res = []
+        for T, K, N in layers:
+            x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+            dy = torch.randn(T, N, device=dev).to(torch.bfloat16)
+            dw = torch.empty(N, K, device=dev)
+            db = torch.empty(N, device=dev)
+            nkt = (T + 63) // 64
+            fns = {}
+            for sp in range(1, 21):
+                if sp > 1 and sp > nkt // 4:
+                    break
+                ws = torch.empty(max(1, int(lib.gps_gemm_workspace_floats(_native.GEMM_TN, N, K, sp))), device=dev)
+                fns[f"s{sp}"] = (lambda sp=sp, ws=ws: G.gemm(_native.GEMM_TN, _native.EPI_F32, N, K, T, dy, N, x, K, dw, K,
+                                                             workspace=ws, colsum=db, splits=sp, variant=2))
+            t = timeit(fns, args.rounds)
+            tiles = ((N + 127) // 128) * ((K + 127) // 128)
+            row = {"tokens": T, "in": K, "out": N, "tiles": tiles, "default": int(lib.gps_gemm_pick_splits(_native.GEMM_TN, N, K, T)),
+                   "us": {k: round(v, 1) for k, v in t.items()}}
+            print(json.dumps(row), flush=True)
+            res.append(row)
+        if args.json:
+            with open(args.json, "w") as f:
+                json.dump(res, f, indent=1)
         return
     if args.pmc_loop:
         form, variant = args.pmc_loop.split(":")
