@@ -571,13 +571,16 @@ extern "C" {
 
 int gps_gemm_pick_splits(int form, int M, int N, int K) {
   if (form != GPS_GEMM_TN) return 1;
-  // weight gradient: M x N is small (a few dozen 128 x 128 tiles), K = tokens is long.  Eight splits measured
-  // best from 36 to 432 tiles (profiles/r2/gemm_bench_*.json), sixteen below that; every split keeps >= 8 stages.
+  // weight gradient: M x N is small (a few dozen 128 x 128 tiles), K = tokens is long.  The chip holds 512 of
+  // these workgroups at once (2 per CU); the time is a staircase in ceil(tiles * splits / 512), so take the largest
+  // split count that still fits ONE resident round, as long as every split keeps >= 8 stages of work
+  // (profiles/r2/split_sweep.json: 36 tiles -> 14, 96 -> 5, 108 / 114 -> 4, 144 -> 3; 50-stage K -> at most 6).
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
   const int nkt = (K + 63) / 64;
-  int s = tiles < 24 ? 16 : 8;
+  long long s = 512 / (tiles < 1 ? 1 : tiles);
+  if (s > 16) s = 16;
   if (s > nkt / 8) s = nkt / 8;
-  return s < 1 ? 1 : s;
+  return s < 1 ? 1 : (int)s;
 }
 
 long long gps_gemm_workspace_floats(int form, int M, int N, int splits) {
