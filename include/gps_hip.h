@@ -309,7 +309,7 @@ GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, c
  *   of GPS_GEMM_EPI_DGELU is recomputed from the same (seed, index), nothing is stored.  p_drop = 0: none.
  * splits (TN only): K is cut into `splits` ranges whose fp32 partial tiles go to `workspace`
  *   (gps_gemm_workspace_floats() floats) and are summed in split order by a second launch (deterministic);
- *   gps_gemm_pick_splits() gives the default.  variant: tile configuration 0..7, or -1 = chosen from the shape.
+ *   gps_gemm_pick_splits() gives the default.  variant: tile configuration 0..10 (8, 9, 10: persistent workgroups), or -1 = chosen from the shape.
  * Requirements (else GPS_ERR_UNSUPPORTED): lda, ldb multiples of 8, K too unless form TN; N, ldc, ldaux multiples of 4; for
  *   reduction-major operands their column count (N, and M in form TN) a multiple of 8; A, B, C, bias 16-byte aligned. */
 #define GPS_GEMM_NT 0
@@ -322,7 +322,7 @@ GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, c
 #define GPS_GEMM_EPI_DRELU 4
 #define GPS_GEMM_EPI_F32 5
 typedef struct gps_gemm_args {
-  int form, epilogue, M, N, K, splits, variant, reserved; /* reserved: 0 (timing experiments: bit 0 skips the stage copies, bit 1 the MFMAs) */
+  int form, epilogue, M, N, K, splits, variant, reserved; /* reserved: 0 */
   const void *A;
   long long lda;
   const void *B;

@@ -71,7 +71,6 @@ struct Params {
   unsigned int drop_thr;
   unsigned long long seed;
   const unsigned long long *seed_dev;
-  int ablate;              // timing experiments only (tools/gemm_bench.py): bit 0 = skip the stage copies, bit 1 = skip the MFMAs
 };
 
 __device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even (finite inputs)
@@ -137,7 +136,6 @@ struct Stager {
   static constexpr int NPIECE = ROWS / 8 / NW;      // pieces per wave and stage (tile = ROWS x 64 bf16 = ROWS / 8 KiB)
   static_assert(ROWS % (8 * NW) == 0, "tile rows must split evenly over the waves");
   unsigned int voff[NPIECE];
-  unsigned int kidx[NPIECE];                        // RM: k row inside the stage; KM: first k of the chunk (tail only)
   const unsigned char *base;
   unsigned int soff, step;
 
@@ -153,13 +151,11 @@ struct Stager {
         int row, chunk;
         km_stage_src(q, lane, row, chunk);
         const int r = min(r0 + row, rows - 1);
-        kidx[j] = 8u * chunk;
         voff[j] = (unsigned int)(((long long)r * ld + 8 * chunk) * 2);
       } else {
         int k, chunk;
         rm_stage_src<ROWS>(q, lane, k, chunk);
         const int c = min(r0 + 8 * chunk, rows - 8);
-        kidx[j] = (unsigned int)k;
         voff[j] = (unsigned int)(((long long)k * ld + c) * 2);
       }
     }
@@ -179,12 +175,20 @@ struct Stager {
     soff += step;
   }
   // the ragged last stage: only k_left (< 64) reduction indices are inside the matrix, the rest reads zeros
-  __device__ __forceinline__ void issue_tail(unsigned char *tile, int k_left, int wave) {
+  __device__ __forceinline__ void issue_tail(unsigned char *tile, int k_left, int wave, int lane) {
     const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_block;
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
-      const unsigned long long p = (unsigned long long)(uintptr_t)base + voff[j] + soff;
-      const unsigned long long full = ((int)kidx[j] < k_left) ? ~0ull : 0ull;
+      // reduction index of this lane's 16 bytes inside the stage (K-major: first k of the chunk), recomputed here
+      // rather than carried in registers through the main loop
+      int r_or_k, chunk;
+      if (!RM) km_stage_src(j * NW + wave, lane, r_or_k, chunk);
+      else rm_stage_src<ROWS>(j * NW + wave, lane, r_or_k, chunk);
+      const int kk = RM ? r_or_k : 8 * chunk;
+      unsigned int vo = voff[j];
+      asm volatile("" : "+v"(vo));      // opaque: keeps the 64-bit forms of this rare path out of the main loop's registers
+      const unsigned long long p = (unsigned long long)(uintptr_t)base + vo + soff;
+      const unsigned long long full = (kk < k_left) ? ~0ull : 0ull;
       glds16(reinterpret_cast<const void *>((uintptr_t)(zero + ((p - zero) & full))), tile + (j * NW + wave) * PIECE);
     }
     soff += step;
@@ -216,13 +220,13 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char *tile, int r0, i
 // one stage of both operands into the stage buffer at `base` (A tile, then B tile)
 template <int BM, int BN, bool ATR, bool BTR, int NW>
 __device__ __forceinline__ void issue_stage(Stager<BM, ATR, NW> &sa, Stager<BN, BTR, NW> &sb, unsigned char *base,
-                                            int &k_left, int wave) {
+                                            int &k_left, int wave, int lane) {
   if (k_left >= BK) {
     sa.issue_full(base, wave);
     sb.issue_full(base + BM * BK * 2, wave);
   } else {
-    sa.issue_tail(base, k_left, wave);
-    sb.issue_tail(base + BM * BK * 2, k_left, wave);
+    sa.issue_tail(base, k_left, wave, lane);
+    sb.issue_tail(base + BM * BK * 2, k_left, wave, lane);
   }
   k_left -= BK;
 }
@@ -259,6 +263,35 @@ __device__ __forceinline__ void compute_stage(const unsigned char *As, int wm0, 
 #pragma unroll
           for (int a = 0; a < TM; ++a) csum[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][a], csum[a], 0, 0, 0);
         }
+      }
+    }
+    return;
+  }
+  if constexpr (TM * TN >= 32) {
+    // big wave tiles (128 accumulator registers): walk the tile in groups of 4 A fragments against all B fragments
+    // of the K step, so that at most TN + 8 fragments are live (the next group's reads overlap this group's MFMAs);
+    // the scheduling barriers keep the compiler from hoisting every read of the stage to its top (which spills)
+    static_assert(TM % 4 == 0 && !COLSUM, "quadrant walk: 4 A fragments per group, no column sums");
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 bf[TN], af[2][4];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = read_frag<BN, BTR>(Bs, wn0 + 16 * b, ks, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[0][a] = read_frag<BM, ATR>(As, wm0 + 16 * a, ks, lane);
+#pragma unroll
+      for (int ag = 0; ag < TM / 4; ++ag) {
+        if (ag + 1 < TM / 4) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) af[(ag + 1) & 1][a] = read_frag<BM, ATR>(As, wm0 + 16 * (4 * (ag + 1) + a), ks, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[4 * ag + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[b], af[ag & 1][a], acc[4 * ag + a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     return;
@@ -307,67 +340,10 @@ constexpr int waves_per_simd(int BM, int BN, int NW, int NBUF) {
   return w < 1 ? 1 : (w > 2 ? 2 : w);     // the accumulators never leave room for more than 2
 }
 
-template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF, bool PF>
-__global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBUF)) void gemm_kernel(const Params P) {
-  constexpr int NW = WGM * WGN;
-  constexpr int WM = BM / WGM, WN = BN / WGN;
-  constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF * STAGE
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
-
-  // block -> (split, tile_m, tile_n).  The blocks of one XCD (block id mod 8) take a contiguous range of virtual
-  // ids; inside a split the tiles are walked in groups of GM tile rows, tile_m fastest, so that the workgroups
-  // resident on an XCD at any time share a few A row panels and a few B panels (both stay in its 4 MiB L2).
-  const int GM = P.gm;
-  const int ntiles = P.ntm * P.ntn;
-  const int vid = xcd_virtual_id(blockIdx.x, ntiles * P.splits);
-  const int split = vid / ntiles, tile = vid - split * ntiles;
-  const int group = tile / (GM * P.ntn), in_group = tile - group * (GM * P.ntn);
-  const int gm = min(GM, P.ntm - group * GM);
-  const int tile_n = in_group / gm, tile_m = group * GM + (in_group - tile_n * gm);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kt0 = split * P.kt_per_split;
-  const int nst = min(P.nkt, kt0 + P.kt_per_split) - kt0;
-
-  Stager<BM, ATR, NW> sa;
-  Stager<BN, BTR, NW> sb;
-  sa.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
-  sb.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
-  constexpr int NP = Stager<BM, ATR, NW>::NPIECE + Stager<BN, BTR, NW>::NPIECE;
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias gradient of the TN form: column sums of A over k via an all-ones operand (wave column 0 of tile_n 0)
-  const bool do_colsum = (EPI == EPI_F32) && P.colsum != nullptr && tile_n == 0 && wn0 == 0;
-  f32x4 csum[TM];
-#pragma unroll
-  for (int a = 0; a < TM; ++a) csum[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  int k_left = P.K - kt0 * BK;                       // reduction indices from the next stage to issue onwards
-  // ring of NBUF stage buffers: NBUF - 1 stages are in flight ahead of the one being computed; each wave waits for
-  // ITS OWN copies of the stage with a counted vmcnt, the (raw) barrier then makes every wave's copies visible and
-  // guarantees that the buffer about to be refilled (the one computed in the previous iteration) is no longer read
-#pragma unroll
-  for (int s = 0; s < NBUF - 1; ++s)
-    if (s < nst && !(P.ablate & 1)) issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + s * STAGE, k_left, wave);
-  int cur = 0, fill = NBUF - 1;
-  for (int it = 0; it < nst; ++it) {
-    wait_stages<NP, NBUF - 2>(min(nst - 1 - it, NBUF - 2));
-    __builtin_amdgcn_s_barrier();
-    if (it + NBUF - 1 < nst && !(P.ablate & 1)) issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + fill * STAGE, k_left, wave);
-    if (!(P.ablate & 2)) compute_stage<BM, BN, TM, TN, ATR, BTR, EPI == EPI_F32, PF>(smem + cur * STAGE, wm0, wn0, lane, acc, csum, do_colsum);
-    cur = (cur == NBUF - 1) ? 0 : cur + 1;
-    fill = (fill == NBUF - 1) ? 0 : fill + 1;
-  }
-
-  // ---- epilogue: lane (i, g) holds C[m0 + wm0 + 16 a + i][n0 + wn0 + 16 b + 4 g + 0..3] ---------------------------
+// ---- epilogue of one tile: lane (i, g) holds C[m0 + wm0 + 16 a + i][n0 + wn0 + 16 b + 4 g + 0..3] -----------------
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN], f32x4 (&csum)[TM], bool do_colsum,
+                                           int split, int m0, int n0, int wm0, int wn0, int lane) {
   const int i = lane & 15, g = lane >> 4;
   if (EPI == EPI_F32) {
     float *out = (P.splits > 1) ? P.partial + (size_t)split * P.M * P.N : reinterpret_cast<float *>(P.C);
@@ -458,6 +434,7 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
             if (row_ok && n_out < P.N) *reinterpret_cast<u32x4 *>(P.aux_out + (size_t)m * P.ldaux_out + n_out) = po;
           }
         }
+        if constexpr (TM * TN >= 32) __builtin_amdgcn_sched_barrier(0);    // 128 accumulators: no room to batch the rows
       }
     }
     return;
@@ -479,6 +456,115 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
       }
       *reinterpret_cast<u32x2 *>(C + (size_t)m * P.ldc + n) = o;
     }
+  }
+}
+
+// One workgroup = one output tile (PERSIST = false: grid = tiles x splits), or a resident workgroup that walks
+// every (workgroups per XCD)-th tile of its XCD's contiguous range (PERSIST = true: grid = what the chip holds at
+// once).  The persistent form keeps the stage ring running ACROSS tiles: the first stage(s) of the next tile are
+// issued before the last MFMAs of the current one, so its epilogue (conversions, activation, stores) overlaps the
+// next tile's first copies, and the per-workgroup launch cost is paid once.
+template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF, bool PF, bool PERSIST>
+__global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBUF)) void gemm_kernel(const Params P) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  static_assert(!PERSIST || EPI != EPI_F32, "the split-K form is one workgroup per (tile, split)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF * STAGE
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+
+  // block -> (split, tile_m, tile_n).  The blocks of one XCD (block id mod 8) take a contiguous range of virtual
+  // ids; inside a split the tiles are walked in groups of GM tile rows, tile_m fastest, so that the workgroups
+  // resident on an XCD at any time share a few A row panels and a few B panels (both stay in its 4 MiB L2).
+  const int GM = P.gm;
+  const int ntiles = P.ntm * P.ntn;
+  const int total = ntiles * P.splits;
+  int vid, vid_end, vid_step;
+  if (PERSIST) {
+    const int xcd = blockIdx.x & 7, per = (total + 7) >> 3;
+    vid = xcd * per + (int)(blockIdx.x >> 3);
+    vid_end = min(total, (xcd + 1) * per);
+    vid_step = (int)(gridDim.x >> 3);
+    if (vid >= vid_end) return;
+  } else {
+    vid = xcd_virtual_id(blockIdx.x, total);
+    vid_end = vid + 1;
+    vid_step = 1;
+  }
+  int split, m0, n0, tile_n;
+  auto decode = [&](int v) {
+    split = v / ntiles;
+    const int tile = v - split * ntiles;
+    const int group = tile / (GM * P.ntn), in_group = tile - group * (GM * P.ntn);
+    const int gm = min(GM, P.ntm - group * GM);
+    tile_n = in_group / gm;
+    m0 = (group * GM + (in_group - tile_n * gm)) * BM;
+    n0 = tile_n * BN;
+  };
+  decode(vid);
+  int kt0 = split * P.kt_per_split;
+  const int nst = min(P.nkt, kt0 + P.kt_per_split) - kt0;       // the same for every tile of a persistent walk
+
+  Stager<BM, ATR, NW> sa;
+  Stager<BN, BTR, NW> sb;
+  sa.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
+  sb.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
+  constexpr int NP = Stager<BM, ATR, NW>::NPIECE + Stager<BN, BTR, NW>::NPIECE;
+  int k_left = P.K - kt0 * BK;                       // reduction indices from the next stage to issue onwards
+
+  // ring of NBUF stage buffers: NBUF - 1 stages are in flight ahead of the one being computed; each wave waits for
+  // ITS OWN copies of the stage with a counted vmcnt, the (raw) barrier then makes every wave's copies visible and
+  // guarantees that the buffer about to be refilled (the one computed in the previous iteration) is no longer read
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s)
+    if (s < nst) issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + s * STAGE, k_left, wave, lane);
+  int cur = 0, fill = NBUF - 1;
+
+  for (;;) {
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient of the TN form: column sums of A over k via an all-ones operand (wave column 0 of tile_n 0)
+    const bool do_colsum = (EPI == EPI_F32) && P.colsum != nullptr && tile_n == 0 && wn0 == 0;
+    f32x4 csum[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) csum[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int split_c = split, m0_c = m0, n0_c = n0;
+    const int vnext = vid + vid_step;
+    const bool has_next = PERSIST && vnext < vid_end;
+
+    for (int it = 0; it < nst; ++it) {
+      // stages that may stay in flight behind the one about to be read; with a next tile the ring stays full (the
+      // epilogue's stores, issued after the prefetched copies, only make the count conservative)
+      wait_stages<NP, NBUF - 2>(has_next ? NBUF - 2 : min(nst - 1 - it, NBUF - 2));
+      __builtin_amdgcn_s_barrier();
+      {
+        if (it + NBUF - 1 < nst) {
+          issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + fill * STAGE, k_left, wave, lane);
+        } else if (PERSIST && has_next) {
+          if (it + NBUF - 1 == nst) {                 // first stage of the next tile: re-aim the stagers
+            decode(vnext);
+            kt0 = split * P.kt_per_split;
+            sa.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
+            sb.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
+            k_left = P.K - kt0 * BK;
+          }
+          if (it + NBUF - 1 - nst < nst) issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + fill * STAGE, k_left, wave, lane);
+        }
+      }
+      compute_stage<BM, BN, TM, TN, ATR, BTR, EPI == EPI_F32, PF>(smem + cur * STAGE, wm0, wn0, lane, acc, csum, do_colsum);
+      cur = (cur == NBUF - 1) ? 0 : cur + 1;
+      fill = (fill == NBUF - 1) ? 0 : fill + 1;
+    }
+    store_tile<TM, TN, EPI>(P, acc, csum, do_colsum, split_c, m0_c, n0_c, wm0, wn0, lane);
+    if (!has_next) break;
+    vid = vnext;
   }
 }
 
@@ -506,14 +592,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long lon
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF, bool PF = false>
+template <int BM, int BN, int WGM, int WGN, bool ATR, bool BTR, int EPI, int NBUF, bool PF = false, bool PERSIST = false>
 int launch_cfg(Params &P, hipStream_t s) {
   constexpr int LDS = lds_bytes(BM, BN, NBUF);
   static_assert(LDS <= 160 * 1024, "stage buffers exceed the LDS of a CU");
   P.ntm = (P.M + BM - 1) / BM;
   P.ntn = (P.N + BN - 1) / BN;
   P.gm = BM >= 256 ? 4 : 8;           // ~16 (128-row) panels of K = 768 bf16 stay under the 4 MiB L2 of an XCD
-  auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF, PF>;
+  auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF, PF, PERSIST>;
+  constexpr int THREADS = WGM * WGN * 64;
   static bool attr_done = false;
   if (LDS > 64 * 1024 && !attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
@@ -521,9 +608,24 @@ int launch_cfg(Params &P, hipStream_t s) {
       return GPS_ERR_LAUNCH;
     attr_done = true;
   }
-  const long long blocks = (long long)P.ntm * P.ntn * P.splits;
+  long long blocks = (long long)P.ntm * P.ntn * P.splits;
   if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WGM * WGN * 64), LDS, s, P);
+  if (PERSIST) {
+    // as many workgroups as the chip holds at once (a multiple of 8: the same number on every XCD)
+    static int slots = 0;
+    if (slots == 0) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), THREADS, LDS) != hipSuccess ||
+          hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
+        return GPS_ERR_LAUNCH;
+      slots = per_cu * prop.multiProcessorCount / 8 * 8;
+      if (slots < 8) slots = 8;
+    }
+    const long long want = (blocks + 7) / 8 * 8;
+    blocks = want < slots ? want : slots;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), LDS, s, P);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
@@ -532,9 +634,12 @@ int launch_cfg(Params &P, hipStream_t s) {
 //   0  128x128  2x2  2 bufs ( 64 KB)  2/CU      1  256x128  8x2  3 bufs (144 KB) 16 waves  2  128x128  4x2  2 bufs  PF
 //   3  128x64   2x2  3 bufs ( 72 KB)  2/CU      4  256x256  2x4  2 bufs (128 KB)  1/CU  5  256x128  4x2  2 bufs ( 96 KB) 1/CU
 //   6  128x64   2x2  2 bufs ( 48 KB)  3/CU      7  128x128  4x2  2 bufs ( 64 KB)  2/CU
-constexpr int kVariants = 8;
+//   8  = 7, persistent workgroups (stage ring runs across tiles)                  9  = 6, persistent
+//  10  = 4, persistent
+constexpr int kVariants = 11;
 struct VariantShape { int bm, bn; };
-constexpr VariantShape kShapes[kVariants] = {{128, 128}, {256, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128}};
+constexpr VariantShape kShapes[kVariants] = {{128, 128}, {256, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128},
+                                              {128, 128}, {128, 64}, {256, 256}};
 template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
@@ -552,6 +657,15 @@ int launch_variant(Params &P, int variant, hipStream_t s) {
       if constexpr (ATR) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
       else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 2>(P, s);
     case 7: return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+    case 8:                                                                            // 7, persistent
+      if constexpr (EPI == EPI_F32) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2, false, true>(P, s);
+    case 10:                                                                           // 4, persistent
+      if constexpr (EPI == EPI_F32 || ATR) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else return launch_cfg<256, 256, 2, 4, ATR, BTR, EPI, 2, false, true>(P, s);
+    case 9:                                                                            // 6, persistent
+      if constexpr (EPI == EPI_F32 || ATR) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 2, false, true>(P, s);
     default: return GPS_ERR_INVALID_ARGUMENT;
   }
 }
@@ -631,7 +745,6 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   P.keep_scale = a->p_drop > 0.f ? 1.f / (1.f - a->p_drop) : 1.f;
   P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
   P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
-  P.ablate = a->reserved;
   hipStream_t s = (hipStream_t)stream;
   if (a->K == 0) P.nkt = 0;
 

@@ -34,10 +34,11 @@ def _close16(got, ref, what):
 
 # (M, N, K): transformer shapes of the GPS step + ragged / tiny / tail cases
 NT_SHAPES = [(5120, 768, 768), (8320, 2304, 768), (5120, 2376, 768), (5120, 2048, 768), (8320, 768, 2048),
-             (3200, 3072, 768), (300, 72, 40), (129, 8, 8), (1, 768, 768), (257, 132, 200), (640, 640, 2376)]
+             (3200, 3072, 768), (300, 72, 40), (129, 8, 8), (1, 768, 768), (257, 132, 200), (640, 640, 2376),
+             (19200, 2304, 768), (8320, 1024, 64), (8200, 1032, 72)]      # persistent variants: 2 - 6 tiles per workgroup, 1- and 2-stage K
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_forward_nt(M, N, K, variant):
     x, w = _rand16(M, K, seed=1), _rand16(N, K, scale=0.05, seed=2)
@@ -62,7 +63,7 @@ NN_SHAPES = [(5120, 768, 768), (8320, 768, 2304), (5120, 768, 2376), (8320, 2048
              (300, 40, 72), (129, 8, 8), (257, 200, 136), (640, 2376, 640)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("M,N,K", NN_SHAPES)
 def test_dgrad_nn(M, N, K, variant):
     dy, w = _rand16(M, K, seed=5), _rand16(K, N, scale=0.05, seed=6)      # w is (out = K, in = N)
@@ -108,10 +109,20 @@ def _gelu_ref(pre16):
     return F.gelu(pre16.float())
 
 
+@pytest.fixture(params=[-1, 8, 9, 10])
+def forced_variant(request):
+    """-1 = the shape-based default; 8 / 9 = the persistent tile walks (several tiles per workgroup at T = 9000)"""
+    for form in (_native.GEMM_NT, _native.GEMM_NN):
+        G.set_gemm_variant(form, request.param)
+    yield request.param
+    for form in (_native.GEMM_NT, _native.GEMM_NN):
+        G.set_gemm_variant(form, -1)
+
+
 @pytest.mark.parametrize("act", ["gelu", "relu"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_activation_epilogues_forward_and_backward(act, p):
-    T, Kin, Hid = 1300, 136, 264
+def test_activation_epilogues_forward_and_backward(act, p, forced_variant):
+    T, Kin, Hid = (1300, 136, 264) if forced_variant < 0 else (9000, 136, 1032)
     x, w1 = _rand16(T, Kin, seed=11), _rand16(Hid, Kin, scale=0.2, seed=12)
     b1 = torch.randn(Hid, device=DEV)
     seed_dev = torch.tensor([123456789], dtype=torch.int64, device=DEV)
