@@ -303,6 +303,12 @@ GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, c
  *   GPS_GEMM_EPI_BIAS_RELU  C = dropout(relu(acc + bias))
  *   GPS_GEMM_EPI_DGELU      C = acc * gelu'(aux) * dropout-mask              (aux (M,N) bf16 = saved pre)
  *   GPS_GEMM_EPI_DRELU      C = acc * (aux != 0 ? 1/(1-p) : 0)               (aux (M,N) bf16 = saved dropout(relu()))
+ *   GPS_GEMM_EPI_RELU_SPLIT v = relu(acc + bias) written as a bf16 pair hi = rne(v), lo = rne(v - hi):
+ *                           C[m][n] = hi, C[m][N + n] = lo, C[m][2N + n] = hi (ldc >= 3N): the [hi | lo | hi] operand
+ *                           that, against weights laid out [W_hi | W_hi | W_lo] along K, gives the next layer's
+ *                           x W^T to ~2^-16 relative (fp32-accurate MLP chains on the bf16 MFMA path).  Form NT.
+ *   GPS_GEMM_EPI_RELU_MAX16 C fp32 (M / 16, N): max over each block of 16 consecutive rows of relu(acc + bias)
+ *                           (shared MLP + max-pool over a 16-point group).  Form NT, M % 16 == 0.
  *   GPS_GEMM_EPI_F32        C fp32 = acc; form TN only.  With colsum != NULL also colsum (M) fp32 = column sums of
  *                           A over K (the bias gradient when A = dY).
  * dropout: keep an element iff rng(seed + *seed_dev, m * N + n) >= p * 2^32, scale kept ones by 1/(1-p); the mask
@@ -321,6 +327,8 @@ GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, c
 #define GPS_GEMM_EPI_DGELU 3
 #define GPS_GEMM_EPI_DRELU 4
 #define GPS_GEMM_EPI_F32 5
+#define GPS_GEMM_EPI_RELU_SPLIT 6
+#define GPS_GEMM_EPI_RELU_MAX16 7
 typedef struct gps_gemm_args {
   int form, epilogue, M, N, K, splits, variant, reserved; /* reserved: 0 */
   const void *A;

@@ -38,6 +38,7 @@ class GemmArgs(ctypes.Structure):
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32 = 0, 1, 2, 3, 4, 5
+EPI_RELU_SPLIT, EPI_RELU_MAX16 = 6, 7
 
 # name -> argtypes, mirroring include/gps_hip.h one to one
 SIGNATURES = {

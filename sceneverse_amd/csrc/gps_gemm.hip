@@ -48,6 +48,8 @@ enum Epi : int {
   EPI_DGELU = 3,       // C bf16 = acc * gelu'(aux) * dropout-mask(idx)          (aux = saved pre-activation)
   EPI_DRELU = 4,       // C bf16 = acc * (aux != 0 ? keep_scale : 0)              (aux = saved FFN hidden)
   EPI_F32 = 5,         // C fp32 = acc (splits == 1) or partial[split] = acc; optional column sums of A
+  EPI_RELU_SPLIT = 6,  // v = relu(acc + bias) as a bf16 pair (hi, lo = v - hi): C[m][n | N + n | 2N + n] = hi | lo | hi
+  EPI_RELU_MAX16 = 7,  // C fp32 [m / 16][n] = max over the 16 rows of the block of relu(acc + bias)
 };
 
 struct Params {
@@ -360,6 +362,32 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
     }
     return;
   }
+  if (EPI == EPI_RELU_MAX16) {
+    // one 16-row fragment block = one group of 16 rows: its maximum lives in the 16 lanes i of a lane group
+    float *out = reinterpret_cast<float *>(P.C);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + wn0 + 16 * b + 4 * g;
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (P.bias && n < P.N) bias = *reinterpret_cast<const f32x4 *>(P.bias + n);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int mb = m0 + wm0 + 16 * a;
+        f32x4 v = acc[a][b] + bias;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = (mb + i < P.M) ? fmaxf(v[r], 0.f) : 0.f;      // rows past M: the neutral element of max(relu)
+          x = fmaxf(x, __shfl_xor(x, 1, 64));
+          x = fmaxf(x, __shfl_xor(x, 2, 64));
+          x = fmaxf(x, __shfl_xor(x, 4, 64));
+          x = fmaxf(x, __shfl_xor(x, 8, 64));
+          v[r] = x;
+        }
+        if (i == 0 && mb < P.M && n < P.N) *reinterpret_cast<f32x4 *>(out + (size_t)(mb >> 4) * P.ldc + n) = v;
+      }
+    }
+    return;
+  }
   const bool dropout = P.drop_thr != 0u;
   const unsigned long long seed = dropout ? P.seed + (P.seed_dev ? *P.seed_dev : 0ull) : 0ull;
   uint16_t *C = reinterpret_cast<uint16_t *>(P.C);
@@ -377,6 +405,18 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
     } else if (EPI == EPI_BIAS_RELU) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (EPI == EPI_RELU_SPLIT) {
+      // fp32 value carried as two bf16: hi = rne(v), lo = rne(v - hi) (exact difference); `pre` takes the lo words
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      const u32x2 hi = pack4(v);
+      f32x4 rest;
+      rest[0] = v[0] - bf2f((uint16_t)(hi[0] & 0xFFFFu));
+      rest[1] = v[1] - bf2f((uint16_t)(hi[0] >> 16));
+      rest[2] = v[2] - bf2f((uint16_t)(hi[1] & 0xFFFFu));
+      rest[3] = v[3] - bf2f((uint16_t)(hi[1] >> 16));
+      pre = pack4(rest);
+      return hi;
     } else if (EPI == EPI_DGELU) {
       const u32x2 a = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
       v[0] *= dgelu_f(bf2f((uint16_t)(a[0] & 0xFFFFu)));
@@ -396,7 +436,7 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
     }
     return pack4(v);
   };
-  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU;
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_RELU_SPLIT;
   // Pairs of adjacent 16-column fragments leave as 16-byte stores: inside a pair, the even lane groups (g = 0, 2)
   // send their 4 columns of fragment b + 1 to the odd group next to them and receive that group's 4 columns of
   // fragment b, so every lane ends up with 8 consecutive columns of one row -- half the store instructions of the
@@ -404,6 +444,7 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   // and 16-byte aligned rows; otherwise the 8-byte form below.
   const bool wide = (TN % 2 == 0) && (P.N % 8 == 0) && (P.ldc % 8 == 0) &&
                     (EPI != EPI_BIAS_GELU || P.aux_out == nullptr || P.ldaux_out % 8 == 0);
+  if (EPI == EPI_RELU_SPLIT && !wide) return;        // the C entry point only admits N % 8 == 0 == ldc % 8 for this form
   if (wide) {
     const bool odd = g & 1;
 #pragma unroll
@@ -426,6 +467,15 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
         const u32x2 recv = {(unsigned int)__shfl_xor((int)send[0], 16, 64), (unsigned int)__shfl_xor((int)send[1], 16, 64)};
         const u32x4 out = odd ? u32x4{recv[0], recv[1], o1[0], o1[1]} : u32x4{o0[0], o0[1], recv[0], recv[1]};
         if (row_ok && n_out < P.N) *reinterpret_cast<u32x4 *>(C + (size_t)m * P.ldc + n_out) = out;
+        if (EPI == EPI_RELU_SPLIT) {
+          const u32x2 sp = odd ? pre0 : pre1;
+          const u32x2 rp = {(unsigned int)__shfl_xor((int)sp[0], 16, 64), (unsigned int)__shfl_xor((int)sp[1], 16, 64)};
+          const u32x4 po = odd ? u32x4{rp[0], rp[1], pre1[0], pre1[1]} : u32x4{pre0[0], pre0[1], rp[0], rp[1]};
+          if (row_ok && n_out < P.N) {
+            *reinterpret_cast<u32x4 *>(C + (size_t)m * P.ldc + P.N + n_out) = po;
+            *reinterpret_cast<u32x4 *>(C + (size_t)m * P.ldc + 2 * P.N + n_out) = out;
+          }
+        }
         if (EPI == EPI_BIAS_GELU) {
           if (P.aux_out) {
             const u32x2 sp = odd ? pre0 : pre1;
@@ -705,7 +755,7 @@ long long gps_gemm_workspace_floats(int form, int M, int N, int splits) {
 int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   using namespace gps_gemm;
   if (!a || a->M < 0 || a->N < 0 || a->K < 0) return GPS_ERR_INVALID_ARGUMENT;
-  if (a->form < 0 || a->form > 2 || a->epilogue < 0 || a->epilogue > 5) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->form < 0 || a->form > 2 || a->epilogue < 0 || a->epilogue > 7) return GPS_ERR_INVALID_ARGUMENT;
   if (a->M == 0 || a->N == 0) return GPS_OK;
   if (!a->A || !a->B || !a->C) return GPS_ERR_INVALID_ARGUMENT;
   // 16-byte global chunks and 8 / 16-byte stores: leading dimensions in multiples of 8 elements, N of 4, K of 8
@@ -727,6 +777,11 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   if (a->aux_out && (a->ldaux_out & 3)) return GPS_ERR_UNSUPPORTED;
   if (a->p_drop < 0.f || a->p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
   if (a->bias && ((uintptr_t)a->bias & 15)) return GPS_ERR_UNSUPPORTED;
+  if (a->epilogue == GPS_GEMM_EPI_RELU_SPLIT || a->epilogue == GPS_GEMM_EPI_RELU_MAX16) {
+    if (a->form != GPS_GEMM_NT || a->p_drop != 0.f) return GPS_ERR_UNSUPPORTED;
+    if (a->epilogue == GPS_GEMM_EPI_RELU_SPLIT && ((a->N & 7) || (a->ldc & 7) || a->ldc < 3LL * a->N)) return GPS_ERR_UNSUPPORTED;
+    if (a->epilogue == GPS_GEMM_EPI_RELU_MAX16 && (a->M & 15)) return GPS_ERR_UNSUPPORTED;
+  }
 
   Params P = {};
   P.M = a->M; P.N = a->N; P.K = a->K;
@@ -758,6 +813,15 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
       case GPS_GEMM_EPI_BIAS: st = launch_variant<false, false, EPI_BIAS>(P, variant, s); break;
       case GPS_GEMM_EPI_BIAS_GELU: st = launch_variant<false, false, EPI_BIAS_GELU>(P, variant, s); break;
       case GPS_GEMM_EPI_BIAS_RELU: st = launch_variant<false, false, EPI_BIAS_RELU>(P, variant, s); break;
+      // the split-bf16 MLP forms exist for the two default tile configurations only
+      case GPS_GEMM_EPI_RELU_SPLIT:
+        st = variant == 6 ? launch_cfg<128, 64, 2, 2, false, false, EPI_RELU_SPLIT, 2>(P, s)
+                          : launch_cfg<128, 128, 4, 2, false, false, EPI_RELU_SPLIT, 2>(P, s);
+        break;
+      case GPS_GEMM_EPI_RELU_MAX16:
+        st = variant == 6 ? launch_cfg<128, 64, 2, 2, false, false, EPI_RELU_MAX16, 2>(P, s)
+                          : launch_cfg<128, 128, 4, 2, false, false, EPI_RELU_MAX16, 2>(P, s);
+        break;
       default: return GPS_ERR_UNSUPPORTED;
     }
   } else if (a->form == GPS_GEMM_NN) {

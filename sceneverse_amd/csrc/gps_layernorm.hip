@@ -258,9 +258,13 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int 
   }
   __syncthreads();
   if (!last || wave != 0 || c >= 2 * d) return;
-  float sum = 0.f;
-  for (int s = 0; s < slices; ++s)
-    sum += part2[(size_t)s * 2 * d + c];
+  // all slice rows are requested before the first add (16 independent loads in flight, not 16 round trips)
+  float v[kRedSlices];
+#pragma unroll
+  for (int s = 0; s < kRedSlices; ++s) v[s] = (s < slices) ? part2[(size_t)s * 2 * d + c] : 0.f;
+  float sum = v[0];
+#pragma unroll
+  for (int s = 1; s < kRedSlices; ++s) sum += v[s];
   out[c] = sum;
 }
 

@@ -27,7 +27,8 @@ from typing import Optional, Sequence
 import torch
 
 from ... import _native
-from ..._native import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32, GEMM_NN, GEMM_NT,
+from ..._native import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32, EPI_RELU_MAX16, EPI_RELU_SPLIT,
+                        GEMM_NN, GEMM_NT,
                         GEMM_TN, GemmArgs)
 
 _ENABLED = True
@@ -87,7 +88,7 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
     a.workspace, a.colsum, a.seed_dev = _ptr(workspace), _ptr(colsum), _ptr(seed_dev)
     a.seed, a.p_drop = 0, float(p_drop)
     from ...pointnet2._ext import _timed
-    nbytes = 2 * (M * K + N * K) + (4 if epilogue == EPI_F32 else 2) * M * N
+    nbytes = 2 * (M * K + N * K) + {EPI_F32: 4 * M * N, EPI_RELU_SPLIT: 6 * M * N, EPI_RELU_MAX16: M * N // 4}.get(epilogue, 2 * M * N)
     with torch.cuda.device(A.device), _timed(f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K},epi={epilogue})", nbytes,
                                              2 * M * N * K, "bf16"):
         st = _native.load().gps_gemm_bf16(ctypes.byref(a), _stream())
@@ -147,6 +148,52 @@ def linear_wgrad(dy16: torch.Tensor, x16: torch.Tensor, want_bias: bool = True):
     gemm(GEMM_TN, EPI_F32, N, K, T, dy16, dy16.stride(0), x16, x16.stride(0), dw, K, workspace=ws, colsum=db,
          splits=splits)
     return dw, db
+
+
+# ---- fp32-accurate MLP chains on the bf16 MFMA path (frozen point-encoder heads) ----------------------------------
+def split3_rows(x: torch.Tensor, k_pad: int) -> torch.Tensor:
+    """fp32 (M, K) -> bf16 (M, 3 k_pad) = [hi | lo | hi], hi = bf16(x), lo = bf16(x - hi), zero padding to k_pad."""
+    M, K = x.shape
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    out = torch.zeros((M, 3 * k_pad), dtype=torch.bfloat16, device=x.device) if k_pad != K else \
+        torch.empty((M, 3 * k_pad), dtype=torch.bfloat16, device=x.device)
+    out[:, :K] = hi
+    out[:, k_pad:k_pad + K] = lo
+    out[:, 2 * k_pad:2 * k_pad + K] = hi
+    return out
+
+
+def split3_weight(w: torch.Tensor, k_pad: int) -> torch.Tensor:
+    """fp32 (N, K) -> bf16 (N, 3 k_pad) = [W_hi | W_hi | W_lo]: against [x_hi | x_lo | x_hi] the K-sum is
+    x_hi W_hi + x_lo W_hi + x_hi W_lo = x W^T up to the dropped lo x lo term (2^-16 relative)."""
+    N, K = w.shape
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    out = torch.zeros((N, 3 * k_pad), dtype=torch.bfloat16, device=w.device)
+    out[:, :K] = hi
+    out[:, k_pad:k_pad + K] = hi
+    out[:, 2 * k_pad:2 * k_pad + K] = lo
+    return out
+
+
+def split3_mlp_max16(x: torch.Tensor, layers) -> torch.Tensor:
+    """relu(...relu(x W1^T + s1)... Wn^T + sn) followed by the max over every 16 consecutive rows, fp32-accurate,
+    as n MFMA GEMMs: x fp32 (M, K), M % 16 == 0; layers = [(split3_weight(W_i, k_pad_i), shift_i fp32), ...] with
+    k_pad_1 = K rounded up to 8 and k_pad_i = N_(i-1) (multiples of 8).  -> fp32 (M / 16, N_n)."""
+    M, K = x.shape
+    a = split3_rows(x, layers[0][0].shape[1] // 3)
+    for li, (w3, shift) in enumerate(layers):
+        N, K3 = w3.shape
+        assert a.shape[1] == K3
+        if li + 1 < len(layers):
+            c = torch.empty((M, 3 * N), dtype=torch.bfloat16, device=x.device)
+            gemm(GEMM_NT, EPI_RELU_SPLIT, M, N, K3, a, K3, w3, K3, c, 3 * N, bias=shift)
+            a = c
+        else:
+            out = torch.empty((M // 16, N), dtype=torch.float32, device=x.device)
+            gemm(GEMM_NT, EPI_RELU_MAX16, M, N, K3, a, K3, w3, K3, out, N, bias=shift)
+    return out
 
 
 # ---- bf16 shadows of the fp32 master weights ---------------------------------------------------------------

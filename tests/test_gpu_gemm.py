@@ -232,3 +232,42 @@ def test_unsupported_shapes_are_refused():
     y = torch.empty(16, 8, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(_native.GpsNativeError):
         G.gemm(_native.GEMM_NT, _native.EPI_BIAS, 16, 8, 12, x, 12, w, 12, y, 8)      # K not a multiple of 8
+
+
+def test_relu_split_epilogue_carries_fp32_values_as_bf16_pairs():
+    """GPS_GEMM_EPI_RELU_SPLIT: C = [hi | lo | hi] with hi + lo == relu(x W^T + b) to ~2^-16 relative."""
+    M, N, K = 1040, 264, 136
+    x, w = _rand16(M, K, seed=21), _rand16(N, K, scale=0.1, seed=22)
+    b = torch.randn(N, device=DEV)
+    c = torch.full((M, 3 * N + 8), 5.0, dtype=torch.bfloat16, device=DEV)
+    G.gemm(_native.GEMM_NT, _native.EPI_RELU_SPLIT, M, N, K, x, K, w, K, c, c.stride(0), bias=b)
+    ref = torch.relu(x.float() @ w.float().t() + b)
+    hi, lo, hi2 = c[:, :N].float(), c[:, N:2 * N].float(), c[:, 2 * N:3 * N].float()
+    assert torch.equal(hi, hi2) and torch.all(c[:, 3 * N:] == 5.0)
+    assert torch.equal(hi, ref.to(torch.bfloat16).float()) or (hi - ref).abs().max() <= 2 ** -8 * ref.abs().max()
+    err = (hi + lo - ref).abs().max().item()
+    assert err <= 3e-5 * ref.abs().max().item() + 1e-6, err        # fp32 accumulation order + 2^-16 of the pair
+
+
+@pytest.mark.parametrize("M,K", [(4112, 259), (16, 8), (81920, 259)])
+def test_split3_mlp_with_max_over_16_rows_is_fp32_accurate(M, K):
+    """Three-layer shared MLP + max over 16-row groups (PointNet++ group-all level) on the bf16 MFMA path with
+    split operands, against the same chain in fp64."""
+    g = torch.Generator().manual_seed(M + K)
+    chans = [256, 512, 768] if M > 16 else [8, 16, 8]
+    x = (torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    ws, ss, cin = [], [], K
+    for co in chans:
+        ws.append((torch.randn(co, cin, generator=g) * (2.0 / cin) ** 0.5).to(DEV))
+        ss.append((torch.randn(co, generator=g) * 0.1).to(DEV))
+        cin = co
+    k_pads = [(K + 7) // 8 * 8] + chans[:-1]
+    layers = [(G.split3_weight(w, kp), s) for w, s, kp in zip(ws, ss, k_pads)]
+    out = G.split3_mlp_max16(x, layers)
+    ref = x.double()
+    for w, s in zip(ws, ss):
+        ref = torch.relu(ref @ w.double().t() + s.double())
+    ref = ref.view(M // 16, 16, -1).amax(1)
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), (err, ref.abs().max().item())

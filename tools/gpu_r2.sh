@@ -64,7 +64,7 @@ if [[ $WHAT == *splitsweep* ]]; then
   ts splitsweep; timeout 600 python tools/gemm_bench.py --split-sweep --rounds 8 --json $OUT/split_sweep.json > $OUT/split_sweep.log 2>&1; echo "sweep exit $?"; tail -20 $OUT/split_sweep.log | cut -c1-400
 fi
 if [[ $WHAT == *lntest* ]]; then
-  ts lntest; timeout 600 python -m pytest tests/test_gpu_fused_norm.py tests/test_gpu_model.py tests/test_gpu_attention.py -m gpu -q -x > $OUT/pytest_ln.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_ln.log; tail -8 $OUT/pytest_ln.log | cut -c1-300
+  ts lntest; timeout 600 python -m pytest tests/test_gpu_fused_norm.py tests/test_gpu_model.py tests/test_gpu_sa_fused.py tests/test_gpu_gemm.py -m gpu -q -x > $OUT/pytest_ln.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_ln.log; tail -8 $OUT/pytest_ln.log | cut -c1-300
 fi
 if [[ $WHAT == *attrib* ]]; then
   ts attrib; timeout 600 python tools/step_attrib.py --out $OUT/step_attrib.txt > $OUT/step_attrib.log 2>&1; echo "attrib exit $?"; tail -5 $OUT/step_attrib.log
