@@ -351,6 +351,12 @@ typedef struct gps_gemm_args {
 } gps_gemm_args;
 GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
 GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
+/* First operand of a split-bf16 MLP chain over a group-all point level (reference: GroupAll in
+ * modules/third_party/pointnet2/pointnet2_utils.py -- cat of the grouped xyz and features): row (b, j) =
+ * [xyz (b, n, 3)[b][j] | feats (b, c, n)[b][:, j]] as bf16 [hi | lo | hi], each third k_pad >= 3 + c columns wide
+ * (k_pad % 8 == 0, padding columns zero).  out: (b * n, 3 * k_pad) bf16.  n * (4 + c) * 4 bytes of LDS <= 64 KiB. */
+GPS_API int gps_split3_points(int b, int n, int c, const float *xyz, const float *feats, int k_pad, void *out,
+                              gps_stream_t stream);
 GPS_API int gps_gemm_bf16(const gps_gemm_args *args, gps_stream_t stream);
 
 /* ---- optimizer step: gradient clipping + AdamW over all parameter tensors ------------------------------

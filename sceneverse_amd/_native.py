@@ -64,6 +64,7 @@ SIGNATURES = {
     "gps_embedding_grad": [_i, _i, _i, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_colsum_parts": [_i, _i],
     "gps_colsum_bf16": [_i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp],
+    "gps_split3_points": [_i, _i, _i, _vp, _vp, _i, _vp, _vp],
     "gps_masked_ce_forward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_masked_ce_backward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp],

@@ -639,6 +639,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long lon
   }
 }
 
+// Operand of the first split-bf16 layer of a group-all point level: row (b, j) = [xyz[b][j][0..2] | feats[b][0..C-1][j]]
+// (the reference's cat of grouped xyz and features, pointnet2_utils.py GroupAll), written as [hi | lo | hi] with
+// hi = rne_bf16(v), lo = rne_bf16(v - hi) and zeros in the k_pad - (3 + C) padding columns of each third.
+// One workgroup per object; the (C, n) feature block is staged through LDS so that both sides are coalesced.
+__global__ __launch_bounds__(256) void split3_points_kernel(int n, int C, const float *__restrict__ xyz,
+                                                            const float *__restrict__ feats, int k_pad,
+                                                            uint16_t *__restrict__ out) {
+  extern __shared__ float tile[];                    // [n][3 + C + 1]
+  const int b = blockIdx.x, K = 3 + C, ldt = K + 1;
+  for (int e = threadIdx.x; e < n * 3; e += 256) tile[(e / 3) * ldt + (e % 3)] = xyz[(size_t)b * n * 3 + e];
+  for (int e = threadIdx.x; e < C * n; e += 256) {   // feats[b][c][j], j fastest
+    const int c = e / n, j = e - c * n;
+    tile[j * ldt + 3 + c] = feats[(size_t)b * C * n + e];
+  }
+  __syncthreads();
+  uint16_t *o = out + (size_t)b * n * 3 * k_pad;
+  const int kp2 = k_pad >> 1;                         // two columns per thread: 4-byte stores
+  for (int e = threadIdx.x; e < n * kp2; e += 256) {
+    const int j = e / kp2, k = 2 * (e - j * kp2);
+    unsigned int hi = 0u, lo = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (k + t < K) {
+        const float v = tile[j * ldt + k + t];
+        const uint16_t h = f2bf(v);
+        hi |= (unsigned int)h << (16 * t);
+        lo |= (unsigned int)f2bf(v - bf2f(h)) << (16 * t);
+      }
+    }
+    unsigned int *row = reinterpret_cast<unsigned int *>(o + (size_t)j * 3 * k_pad);
+    row[k >> 1] = hi;
+    row[(k_pad + k) >> 1] = lo;
+    row[(2 * k_pad + k) >> 1] = hi;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -750,6 +786,18 @@ int gps_gemm_pick_splits(int form, int M, int N, int K) {
 long long gps_gemm_workspace_floats(int form, int M, int N, int splits) {
   if (form != GPS_GEMM_TN || splits <= 1) return 0;
   return (long long)splits * ((long long)M * N + M);
+}
+
+int gps_split3_points(int b, int n, int c, const float *xyz, const float *feats, int k_pad, void *out,
+                      gps_stream_t stream) {
+  if (b < 0 || n < 1 || c < 0 || k_pad < 3 + c || (k_pad & 7)) return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0) return GPS_OK;
+  if (!xyz || (c > 0 && !feats) || !out) return GPS_ERR_INVALID_ARGUMENT;
+  const size_t lds = (size_t)n * (3 + c + 1) * sizeof(float);
+  if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gps_gemm::split3_points_kernel, dim3(b), dim3(256), lds, (hipStream_t)stream, n, c, xyz, feats, k_pad,
+                     (uint16_t *)out);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
 int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {

@@ -242,18 +242,18 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int 
     if (wave == 0 && c < 2 * d) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     return;
   }
+  // Hand-off without L2 write-back / invalidate episodes (the previous kernel leaves > 100 MB dirty): the second-level
+  // rows are written through (agent-scope relaxed atomic stores = sc1), waited for, then the ticket is taken; the
+  // last arriver reads them with agent-scope loads.
   if (wave == 0) {
-    if (c < 2 * d) part2[(size_t)blockIdx.y * 2 * d + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (c < 2 * d)
+      __hip_atomic_store(part2 + (size_t)blockIdx.y * 2 * d + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned int t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last = (t == (unsigned int)slices - 1u);
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
@@ -261,7 +261,8 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int 
   // all slice rows are requested before the first add (16 independent loads in flight, not 16 round trips)
   float v[kRedSlices];
 #pragma unroll
-  for (int s = 0; s < kRedSlices; ++s) v[s] = (s < slices) ? part2[(size_t)s * 2 * d + c] : 0.f;
+  for (int s = 0; s < kRedSlices; ++s)
+    v[s] = (s < slices) ? __hip_atomic_load(part2 + (size_t)s * 2 * d + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
   float sum = v[0];
 #pragma unroll
   for (int s = 1; s < kRedSlices; ++s) sum += v[s];

@@ -177,12 +177,28 @@ def split3_weight(w: torch.Tensor, k_pad: int) -> torch.Tensor:
     return out
 
 
+def split3_points(xyz: torch.Tensor, feats: torch.Tensor, k_pad: int) -> torch.Tensor:
+    """xyz (B, n, 3) fp32, feats (B, C, n) fp32 -> bf16 (B * n, 3 k_pad) = [hi | lo | hi] of the rows
+    [xyz | feats^T] (one launch instead of cat + casts + three strided copies)."""
+    B, n, _ = xyz.shape
+    C = feats.shape[1]
+    xyz, feats = xyz.float().contiguous(), feats.float().contiguous()
+    out = torch.empty((B * n, 3 * k_pad), dtype=torch.bfloat16, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        st = _native.load().gps_split3_points(B, n, C, xyz.data_ptr(), feats.data_ptr(), k_pad, out.data_ptr(), _stream())
+    _native.check(st, "split3_points")
+    return out
+
+
 def split3_mlp_max16(x: torch.Tensor, layers) -> torch.Tensor:
     """relu(...relu(x W1^T + s1)... Wn^T + sn) followed by the max over every 16 consecutive rows, fp32-accurate,
-    as n MFMA GEMMs: x fp32 (M, K), M % 16 == 0; layers = [(split3_weight(W_i, k_pad_i), shift_i fp32), ...] with
+    as n MFMA GEMMs: x fp32 (M, K) (or the bf16 operand split3_points made), M % 16 == 0; layers = [(split3_weight(W_i, k_pad_i), shift_i fp32), ...] with
     k_pad_1 = K rounded up to 8 and k_pad_i = N_(i-1) (multiples of 8).  -> fp32 (M / 16, N_n)."""
-    M, K = x.shape
-    a = split3_rows(x, layers[0][0].shape[1] // 3)
+    if x.dtype == torch.bfloat16:           # already the [hi | lo | hi] operand of the first layer
+        a, M = x, x.shape[0]
+    else:
+        M = x.shape[0]
+        a = split3_rows(x, layers[0][0].shape[1] // 3)
     for li, (w3, shift) in enumerate(layers):
         N, K3 = w3.shape
         assert a.shape[1] == K3

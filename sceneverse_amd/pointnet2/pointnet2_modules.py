@@ -155,11 +155,13 @@ class _PointnetSAModuleBase(nn.Module):
                 return None
             ws, shifts, _ = folded
             with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
-                x = torch.cat([xyz.float(), features.float().transpose(1, 2)], dim=2)   # (B, N, 3 + C)
-                b, n, _ = x.shape
-                x = x.reshape(b * n, -1)
                 from ..modules.layers import gemm as G
-                if _SA_PRECISION == "bf16x3" and n == 16 and G.enabled() and all(w.shape[0] % 8 == 0 for w in ws):
+                b, n = xyz.shape[0], xyz.shape[1]
+                split = _SA_PRECISION == "bf16x3" and n == 16 and G.enabled() and all(w.shape[0] % 8 == 0 for w in ws)
+                if not split:
+                    x = torch.cat([xyz.float(), features.float().transpose(1, 2)], dim=2)   # (B, N, 3 + C)
+                    x = x.reshape(b * n, -1)
+                if split:
                     # split-bf16 (hi, lo) operands through libgps_hip.so's MFMA GEMM: ReLU + re-split in the
                     # epilogues of the first layers, ReLU + max over the 16 points of an object in the last
                     cache = mlp.__dict__.get("_gps_split3")
@@ -168,7 +170,8 @@ class _PointnetSAModuleBase(nn.Module):
                         cache = (folded, [(G.split3_weight(w, kp), s.float().contiguous())
                                           for w, s, kp in zip(ws, shifts, k_pads)])
                         mlp.__dict__["_gps_split3"] = cache
-                    return G.split3_mlp_max16(x.contiguous(), cache[1]).unsqueeze(-1)
+                    a = G.split3_points(xyz, features, cache[1][0][0].shape[1] // 3)
+                    return G.split3_mlp_max16(a, cache[1]).unsqueeze(-1)
                 for w, sft in zip(ws, shifts):
                     x = torch.relu_(torch.addmm(sft, x, w.t()))
                 return x.view(b, n, -1).amax(dim=1).unsqueeze(-1)

@@ -271,3 +271,15 @@ def test_split3_mlp_with_max_over_16_rows_is_fp32_accurate(M, K):
     assert out.shape == ref.shape and out.dtype == torch.float32
     err = (out.double() - ref).abs().max().item()
     assert err <= 1e-4 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+def test_split3_points_builds_the_first_operand():
+    """gps_split3_points == split3_rows(cat(xyz, feats^T)) bit for bit (same rne hi / lo, zero padding)."""
+    B, n, C = 37, 16, 256
+    g = torch.Generator().manual_seed(5)
+    xyz = torch.randn(B, n, 3, generator=g).to(DEV)
+    feats = torch.randn(B, C, n, generator=g).to(DEV)
+    k_pad = (3 + C + 7) // 8 * 8
+    got = G.split3_points(xyz, feats, k_pad)
+    ref = G.split3_rows(torch.cat([xyz, feats.transpose(1, 2)], dim=2).reshape(B * n, 3 + C), k_pad)
+    assert got.shape == ref.shape and torch.equal(got, ref)
