@@ -66,13 +66,13 @@ __device__ __forceinline__ unsigned long long effective_seed(const Params &P) {
   return P.seed + (P.seed_dev ? *P.seed_dev : 0ull);
 }
 
-__device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even
-  unsigned int u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even (hardware conversion)
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
-__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {     // v_cvt_pk_bf16_f32: round to nearest even
+  const bf16x2_t h = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned int, h);
 }
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ u32x4 zero4() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
@@ -83,11 +83,23 @@ __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 
 // counter-based RNG for attention dropout (splitmix64 finaliser): the same (seed, element) gives the
 // same keep decision in forward and backward
+// Counter-based dropout stream of the attention kernels: a 32-bit avalanche hash (two multiplies, three
+// xor-shifts; "lowbias32" constants) of the element (or key-pair) index folded with the seed.  All that matters is
+// that forward and backward draw the same bits for the same (seed, index) and that the keep rate is 1 - p; a
+// 64-bit splitmix per element cost ~30 vector instructions of the ~45 these kernels spent per score.
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {
+  x ^= x >> 16;
+  x *= 0x21F0AAADu;
+  x ^= x >> 15;
+  x *= 0x735A2D97u;
+  x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ unsigned int seed_fold(unsigned long long seed) {      // wave-uniform
+  return mix32((unsigned int)seed ^ mix32((unsigned int)(seed >> 32) + 0x9E3779B9u));
+}
 __device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (unsigned int)((z ^ (z >> 31)) >> 32);
+  return mix32(((unsigned int)idx + (unsigned int)(idx >> 32) * 0x85EBCA6Bu) ^ seed_fold(seed));
 }
 
 __device__ __forceinline__ void block_to_bh(const Params &P, int &b, int &h) {
@@ -775,12 +787,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // dropout of the streaming kernels: ONE hash per pair of adjacent keys (t even, t odd) of a query, its low / high
 // 16 bits decide the two elements (threshold p * 2^16: the drop probability is quantised to 1 / 65536).  The three
 // places that need the mask (forward pass B, both backward passes) evaluate the same function of (query, key pair).
-__device__ __forceinline__ unsigned int pair_rng(unsigned long long seed, unsigned long long row_base, int t) {
-  return rng_u32(seed ^ 0x5DEECE66DULL, (row_base + (unsigned long long)t) >> 1);
+// one hash decides the two keys of a pair (16-bit thresholds): index of the pair = (row base + key) / 2 with an even
+// row pitch, so that the lane holding keys (4 g + 0..3) of a query needs two hashes
+__device__ __forceinline__ unsigned int pair_rng(unsigned int seedmix, unsigned int row_pair_base, int t) {
+  return mix32((row_pair_base + (unsigned int)(t >> 1)) ^ seedmix);
 }
 __device__ __forceinline__ bool pair_keep(unsigned int r, int t, unsigned int thr16) {
   return ((t & 1) ? (r >> 16) : (r & 0xFFFFu)) >= thr16;
 }
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
 // B fragment (32 keys x 16 columns, K order of pack_tiles) from a row-major [key][KS] tile
 __device__ __forceinline__ bf16x8 frag_from_rows_tr(const uint16_t *rows, int ntile, int c, int lane) {
@@ -799,7 +815,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);       // [rows][KS]
   uint16_t *Vs = Ks + rows * KS;                            // [rows][KS]
-  uint8_t *s_mask = reinterpret_cast<uint8_t *>(Vs + rows * KS);
+  float *mb = reinterpret_cast<float *>(Vs + rows * KS);    // [rows] additive key term: 0, or -inf (padded / past L)
 
   int b, h;
   block_to_bh(P, b, h);
@@ -811,12 +827,14 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
   stage_rows(Ks, kb, P.ld_qkv, L, rows);
   stage_rows(Vs, vb, P.ld_qkv, L, rows);
-  for (int t = threadIdx.x; t < rows; t += blockDim.x) s_mask[t] = (t < L && P.mask) ? P.mask[row0 + t] : 0;
+  for (int t = threadIdx.x; t < rows; t += blockDim.x) mb[t] = (t < L && !(P.mask && P.mask[row0 + t])) ? 0.f : -INFINITY;
   __syncthreads();
 
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
-  const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
+  const unsigned int seedmix = dropout ? seed_fold(effective_seed(P)) : 0u;
+  const unsigned int thr16 = P.drop_thr >> 16;
+  const unsigned int pitch2 = (unsigned int)((L + 1) >> 1);       // key pairs per query row
 
   for (int s = wave; s < nt; s += nwaves) {
     const int qi = 16 * s + m;
@@ -833,47 +851,43 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
 #pragma unroll
       for (int d = 0; d < SD; ++d) w[d] = q_ok ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
     }
-    // logit of (query qi, key 16 j + 4 g + r); -inf for padded / out-of-range keys
-    auto logits = [&](int j, f32x4 &x) {
+    // base-2 logits of (query qi, keys 16 j + 4 g + 0..3): log2(e) * (q . k / 8 [+ spatial term]) + key term;
+    // one fused multiply-add per element in the plain form
+    auto logits2 = [&](int j, f32x4 &x) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
         acc = mfma(as_frag(a), bq[c], acc);
       }
+      const f32x4 kt = *reinterpret_cast<const f32x4 *>(mb + 16 * j + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = 16 * j + 4 * g + r;
-        const bool t_ok = t < L;
-        const bool km = t_ok && s_mask[t];
-        float v = acc[r] * 0.125f;
-        if (SPATIAL && t_ok && q_ok) {
-          float sig;
-          v += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+        if (SPATIAL) {
+          const int t = 16 * j + 4 * g + r;
+          float v = acc[r] * 0.125f;
+          if (t < L && q_ok) {
+            float sig;
+            v += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, kt[r] < 0.f, sig);
+          }
+          x[r] = fmaf(v, kLog2e, kt[r]);
+        } else {
+          x[r] = fmaf(acc[r], 0.125f * kLog2e, kt[r]);
         }
-        x[r] = (!t_ok || km) ? -INFINITY : v;
       }
     };
-    // pass A: running maximum and normaliser of this lane's keys
-    float mx = -INFINITY, sum = 0.f;
+    // pass A: the row maximum only (no exponentials)
+    float mx = -INFINITY;
     for (int j = 0; j < nt; ++j) {
       f32x4 x;
-      logits(j, x);
-      const float tm = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-      const float mn = fmaxf(mx, tm);
-      if (mn > -INFINITY) {
-        sum = sum * __expf(mx - mn) + __expf(x[0] - mn) + __expf(x[1] - mn) + __expf(x[2] - mn) + __expf(x[3] - mn);
-        mx = mn;
-      }
+      logits2(j, x);
+      mx = fmaxf(mx, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
     }
     const float gmx = xor_reduce_max_rows(mx);
-    sum = (mx > -INFINITY) ? sum * __expf(mx - gmx) : 0.f;
-    sum = xor_reduce_sum_rows(sum);
-    const float inv = 1.f / sum;                 // all keys masked -> NaN row, like torch
-    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * L + qi] = gmx + __logf(sum);
-    // pass B: probabilities chunk by chunk, O strip = P V
-    const unsigned long long rowbase = (((unsigned long long)b * P.H + h) * L + qi) * (unsigned long long)(L + (L & 1));
-    const unsigned int thr16 = P.drop_thr >> 16;
+    // pass B: p = 2^(x - max) chunk by chunk; the normaliser accumulates beside the P V product and is applied,
+    // with the dropout scale, to the 16 x 64 output strip at the end
+    const unsigned int rp = (((unsigned int)b * P.H + h) * L + qi) * pitch2;
+    float lsum = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -885,15 +899,17 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
         pt[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j < nt) {
           f32x4 x;
-          logits(j, x);
+          logits2(j, x);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pt[hh][r] = __expf(x[r] - gmx) * inv;
+          for (int r = 0; r < 4; ++r) pt[hh][r] = __builtin_amdgcn_exp2f(x[r] - gmx);
+          lsum += (pt[hh][0] + pt[hh][1]) + (pt[hh][2] + pt[hh][3]);
           if (dropout) {        // keys 16 j + 4 g + {0,1} and {2,3}: two hashes for the four elements
             const int t0 = 16 * j + 4 * g;
-            const unsigned int r01 = pair_rng(seed, rowbase, t0), r23 = pair_rng(seed, rowbase, t0 + 2);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              pt[hh][r] = pair_keep(r < 2 ? r01 : r23, t0 + r, thr16) ? pt[hh][r] * keep_scale : 0.f;
+            const unsigned int r01 = pair_rng(seedmix, rp, t0), r23 = pair_rng(seedmix, rp, t0 + 2);
+            pt[hh][0] = (r01 & 0xFFFFu) >= thr16 ? pt[hh][0] : 0.f;
+            pt[hh][1] = (r01 >> 16) >= thr16 ? pt[hh][1] : 0.f;
+            pt[hh][2] = (r23 & 0xFFFFu) >= thr16 ? pt[hh][2] : 0.f;
+            pt[hh][3] = (r23 >> 16) >= thr16 ? pt[hh][3] : 0.f;
           }
         }
       }
@@ -901,13 +917,17 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) o[n] = mfma(pa, frag_from_rows_tr(Vs, n, c, lane), o[n]);
     }
+    lsum = xor_reduce_sum_rows(lsum);             // all keys masked -> NaN row, like torch
+    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * L + qi] = (gmx + __builtin_amdgcn_logf(lsum)) * kLn2;
+    const float scale_q = keep_scale / lsum;      // of query 16 s + m; the output rows of this lane are 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qr = 16 * s + 4 * g + r;
+      const float sc = __shfl(scale_q, 4 * g + r, 64);
       if (qr < L) {
         uint16_t *op = P.out + (row0 + qr) * P.ld_o + h * DH + m;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r]);
+        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r] * sc);
       }
     }
   }
@@ -917,14 +937,15 @@ template <bool SPATIAL>
 __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;
-  // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (same storage): Qs [rows][KS] | dOs [rows][KS];  then
-  // delta [rows] and lse [rows] (fp32).  Every tile is ROW-major: A fragments are 16-byte reads, B fragments
-  // hardware-transposed reads of the same rows.
+  // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (same storage): Qs [rows][KS] | dOs [rows][KS];  then fp32 rows:
+  // delta, lse2 = log2(e) * lse (+inf past L: such queries get p = 0) and the additive key term (0 / -inf).
+  // Every tile is ROW-major: A fragments are 16-byte reads, B fragments hardware-transposed reads of the same rows.
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
   uint16_t *Vs = Ks + rows * KS;
   uint16_t *Qs = Ks, *dOs = Vs;
   float *delta_s = reinterpret_cast<float *>(smem + (size_t)2 * rows * KS * 2);
   float *lse_s = delta_s + rows;
+  float *mb = lse_s + rows;
 
   int b, h;
   block_to_bh(P, b, h);
@@ -939,10 +960,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   const float *lse = P.lse + ((size_t)b * P.H + h) * L;
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
-  const unsigned long long seed = dropout ? effective_seed(P) : 0ull;
+  const unsigned int seedmix = dropout ? seed_fold(effective_seed(P)) : 0u;
   const unsigned int thr16 = P.drop_thr >> 16;
-  const unsigned long long Leven = (unsigned long long)(L + (L & 1));
-  const unsigned long long bh_base = ((unsigned long long)b * P.H + h) * L;
+  const unsigned int pitch2 = (unsigned int)((L + 1) >> 1);
+  const unsigned int bh_base = ((unsigned int)b * P.H + h) * L;
 
   stage_rows(Ks, kb, P.ld_qkv, L, rows);
   stage_rows(Vs, vb, P.ld_qkv, L, rows);
@@ -962,7 +983,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
       }
     }
     delta_s[t] = d;
-    lse_s[t] = t < L ? lse[t] : 0.f;
+    lse_s[t] = t < L ? lse[t] * kLog2e : INFINITY;
+    mb[t] = (t < L && !(P.mask && P.mask[row0 + t])) ? 0.f : -INFINITY;
   }
   __syncthreads();
 
@@ -989,7 +1011,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
     }
     const float lse_q = lse_s[qi < rows ? qi : 0];
     const float delta = delta_s[qi < rows ? qi : 0];
-    const unsigned long long rowbase = (bh_base + qi) * Leven;
+    const unsigned int rp = (bh_base + qi) * pitch2;
     f32x4 o[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1009,37 +1031,42 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
             dacc = mfma(as_frag(av), bdo[cc], dacc);    // (dO V^T)^T
           }
           const int t0 = 16 * j + 4 * g;
-          unsigned int r01 = 0u, r23 = 0u;
+          const f32x4 kt = *reinterpret_cast<const f32x4 *>(mb + t0);
+          bool keep[4] = {true, true, true, true};
           if (dropout) {
-            r01 = pair_rng(seed, rowbase, t0);
-            r23 = pair_rng(seed, rowbase, t0 + 2);
+            const unsigned int r01 = pair_rng(seedmix, rp, t0), r23 = pair_rng(seedmix, rp, t0 + 2);
+            keep[0] = (r01 & 0xFFFFu) >= thr16;
+            keep[1] = (r01 >> 16) >= thr16;
+            keep[2] = (r23 & 0xFFFFu) >= thr16;
+            keep[3] = (r23 >> 16) >= thr16;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int t = t0 + r;
-            const bool t_ok = t < L && q_ok;
-            const bool km = t_ok && P.mask && P.mask[row0 + t];
-            float x = acc[r] * 0.125f;
-            float gt = 0.f;
-            if (SPATIAL && t_ok) {
-              float sig;
-              x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
-              gt = sig > 1e-6f ? 1.f - sig : 0.f;
+            float p, gt = 0.f;
+            if (SPATIAL) {
+              const int t = t0 + r;
+              float x = acc[r] * 0.125f;
+              if (t < L && q_ok) {
+                float sig;
+                x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, kt[r] < 0.f, sig);
+                gt = sig > 1e-6f ? 1.f - sig : 0.f;
+              }
+              p = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, kt[r]) - lse_q);
+            } else {
+              p = __builtin_amdgcn_exp2f(fmaf(acc[r], 0.125f * kLog2e, kt[r]) - lse_q);
             }
-            const float p = (t_ok && !km) ? __expf(x - lse_q) : 0.f;
-            float dp = dacc[r];
-            if (dropout) dp = pair_keep(r < 2 ? r01 : r23, t, thr16) ? dp * keep_scale : 0.f;
-            const float dlogit = p * (dp - delta);
+            const float dp = keep[r] ? dacc[r] : 0.f;                       // dropped gradient, before its 1/(1-p) scale
+            const float dlogit = p * fmaf(dp, keep_scale, -delta);
             if (SPATIAL) {
               const float dz = dlogit * gt;
               if (dz != 0.f) {
-                const float *plp = P.pl + ((row0 + qi) * L + t) * 5;
+                const float *plp = P.pl + ((row0 + qi) * L + t0 + r) * 5;
                 dw[0] += dz;
 #pragma unroll
                 for (int d = 0; d < 5; ++d) dw[1 + d] = fmaf(dz, plp[d], dw[1 + d]);
               }
             }
-            ds[hh][r] = dlogit * 0.125f;
+            ds[hh][r] = dlogit;                                             // the 1/8 of the logits goes onto dQ below
           }
         }
       }
@@ -1061,7 +1088,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
       if (qr < L) {
         uint16_t *op = P.dq + (row0 + qr) * P.ld_qkv + h * DH + m;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r]);
+        for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r] * 0.125f);
       }
     }
   }
@@ -1074,7 +1101,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   for (int js = wave; js < nt; js += nwaves) {
     const int t = 16 * js + m;            // this lane's key
     const bool t_ok = t < L;
-    const bool km = t_ok && P.mask && P.mask[row0 + t];
+    const float kt = mb[t < rows ? t : 0];
     bf16x8 bk[2], bv[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1108,42 +1135,45 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
             sacc = mfma(as_frag(v), bk[cc], sacc);    // S[query 16 i + 4 g + r][key t]
             dacc = mfma(as_frag(u), bv[cc], dacc);    // dO V^T
           }
-          // dropout hashes of (query 16 i + 4 g + r, key pair t >> 1): this lane computes two of the four, the
-          // lane of the other key of the pair (m ^ 1) the other two
-          unsigned int hr[4] = {0u, 0u, 0u, 0u};
+          const int q0 = 16 * i + 4 * g;
+          const f32x4 lq = *reinterpret_cast<const f32x4 *>(lse_s + q0);
+          const f32x4 dq4 = *reinterpret_cast<const f32x4 *>(delta_s + q0);
+          // dropout hashes of (query q0 + r, key pair t >> 1): this lane computes two of the four, the lane of
+          // the other key of the pair (m ^ 1) the other two
+          bool keep[4] = {true, true, true, true};
           if (dropout) {
             const int par = m & 1;
-            const int qa = 16 * i + 4 * g + 2 * par;
-            const unsigned int ha = pair_rng(seed, (bh_base + qa) * Leven, t);
-            const unsigned int hb = pair_rng(seed, (bh_base + qa + 1) * Leven, t);
+            const unsigned int qa = (unsigned int)(q0 + 2 * par);
+            const unsigned int ha = pair_rng(seedmix, (bh_base + qa) * pitch2, t);
+            const unsigned int hb = pair_rng(seedmix, (bh_base + qa + 1u) * pitch2, t);
             const unsigned int oa = (unsigned int)__shfl_xor((int)ha, 1, 64), ob2 = (unsigned int)__shfl_xor((int)hb, 1, 64);
-            hr[0] = par ? oa : ha;
-            hr[1] = par ? ob2 : hb;
-            hr[2] = par ? ha : oa;
-            hr[3] = par ? hb : ob2;
+            const unsigned int hr0 = par ? oa : ha, hr1 = par ? ob2 : hb, hr2 = par ? ha : oa, hr3 = par ? hb : ob2;
+            const unsigned int sh = par ? 16u : 0u;
+            keep[0] = ((hr0 >> sh) & 0xFFFFu) >= thr16;
+            keep[1] = ((hr1 >> sh) & 0xFFFFu) >= thr16;
+            keep[2] = ((hr2 >> sh) & 0xFFFFu) >= thr16;
+            keep[3] = ((hr3 >> sh) & 0xFFFFu) >= thr16;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int qi = 16 * i + 4 * g + r;
-            const bool ok = t_ok && qi < L;
-            float x = sacc[r] * 0.125f;
-            if (SPATIAL && ok) {
-              float w[SD];
+            float p;
+            if (SPATIAL) {
+              const int qi = q0 + r;
+              float x = sacc[r] * 0.125f;
+              if (t_ok && qi < L) {
+                float w[SD];
 #pragma unroll
-              for (int d = 0; d < SD; ++d) w[d] = P.sw[((row0 + qi) * P.H + h) * SD + d];
-              float sig;
-              x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, km, sig);
+                for (int d = 0; d < SD; ++d) w[d] = P.sw[((row0 + qi) * P.H + h) * SD + d];
+                float sig;
+                x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, kt < 0.f, sig);
+              }
+              p = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, kt) - lq[r]);
+            } else {
+              p = __builtin_amdgcn_exp2f(fmaf(sacc[r], 0.125f * kLog2e, kt) - lq[r]);
             }
-            const float p = (ok && !km) ? __expf(x - lse_s[qi]) : 0.f;
-            float dp = dacc[r], pd = p;
-            if (dropout) {
-              const bool keep = pair_keep(hr[r], t, thr16);
-              dp = keep ? dp * keep_scale : 0.f;
-              pd = keep ? p * keep_scale : 0.f;
-            }
-            const float dl = ok ? p * (dp - delta_s[qi]) : 0.f;
-            pt[hh][r] = pd;
-            ds[hh][r] = dl * 0.125f;
+            const float dp = keep[r] ? dacc[r] : 0.f;
+            pt[hh][r] = keep[r] ? p : 0.f;                                  // 1/(1-p) goes onto dV below
+            ds[hh][r] = p * fmaf(dp, keep_scale, -dq4[r]);                  // 1/8 goes onto dK below
           }
         }
       }
@@ -1163,8 +1193,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
         uint16_t *pv = P.dv + (row0 + tr) * P.ld_qkv + h * DH + m;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          pk[16 * n] = f2bf(dk[n][r]);
-          pv[16 * n] = f2bf(dv[n][r]);
+          pk[16 * n] = f2bf(dk[n][r] * 0.125f);
+          pv[16 * n] = f2bf(dv[n][r] * keep_scale);
         }
       }
     }
@@ -1173,11 +1203,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
 
 inline size_t stream_fwd_lds(int nt) {
   const size_t rows = (size_t)((nt + 1) / 2) * 32;
-  return 2 * (2 * rows * KS) + rows;
+  return 2 * (2 * rows * KS) + 4 * rows;
 }
 inline size_t stream_bwd_lds(int nt) {
   const size_t rows = (size_t)((nt + 1) / 2) * 32;
-  return 2 * (2 * rows * KS) + 8 * rows;
+  return 2 * (2 * rows * KS) + 12 * rows;
 }
 
 inline int pick_waves_stream(int nt) {        // up to 16 waves (one 1024-thread workgroup per (scene, head))

@@ -56,6 +56,23 @@ if [[ $WHAT == *gemmpmc* ]]; then
   done
   tail -n 12 $OUT/pmc_*.txt
 fi
+if [[ $WHAT == *attntest* ]]; then
+  ts attntest; timeout 600 python -m pytest tests/test_gpu_attention.py tests/test_gpu_model.py tests/test_a16_vs_golden.py -m gpu -q -x > $OUT/pytest_attn.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_attn.log; tail -8 $OUT/pytest_attn.log | cut -c1-300
+fi
+if [[ $WHAT == *attnpmc* ]]; then
+  ts attnpmc
+  for cfg in "300 0.1" "130 0.1"; do
+    set -- $cfg
+    for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM"; do
+      tag=L$1_${grp%% *}
+      rm -rf /tmp/pmc_$tag
+      (cd /tmp && timeout 120 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_$tag -o p --output-format csv -- python $REPO/tools/attn_pmc_loop.py --L $1 --p $2 > $OUT/pmc_$tag.log 2>&1; echo "pmc $tag exit $?")
+      f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
+      [ -n "$f" ] && python $REPO/tools/pmc_summary.py "$f" > $OUT/pmc_$tag.txt 2>&1
+    done
+  done
+  tail -n 14 $OUT/pmc_L*.txt | cut -c1-120
+fi
 if [[ $WHAT == *alltests* ]]; then
   ts pytest; timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
   grep -E "^(FAILED|ERROR)|passed|failed|exit" $OUT/pytest_gpu.log | head -40
