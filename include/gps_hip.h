@@ -190,6 +190,10 @@ GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, c
  * q, k, v) and dsw (B,L,H*6) fp32 (when sw != NULL).  pl and mask carry no gradient (inputs of the
  * data pipeline).  Probabilities are recomputed from lse.  out = the forward output (B,L,ld_o) bf16: required for
  * L > 256 (the streaming kernels take delta = rowsum(dout * out) from it), optional (may be NULL) below that. */
+/* Which kernel family serves a sequence length (in 16-token tiles: a row of L tokens has ceil(L / 16)): lengths of
+ * at least `plain` (no pairwise term) / `spatial` (with it) tiles take the streaming kernels, shorter ones the
+ * register-resident kernels.  Defaults 1 and 10.  Results agree to bf16 rounding either way; process-wide. */
+GPS_API void gps_attn_set_stream_min_tiles(int plain, int spatial);
 GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                               int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
                               float p_drop, unsigned long long seed, const void *seed_dev,

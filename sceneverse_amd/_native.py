@@ -115,6 +115,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_gemm_workspace_floats.argtypes = [_i, _i, _i, _i]
     lib.gps_adamw_chunk_elems.restype = _i
     lib.gps_adamw_chunk_elems.argtypes = []
+    lib.gps_attn_set_stream_min_tiles.restype = None
+    lib.gps_attn_set_stream_min_tiles.argtypes = [_i, _i]
     lib.gps_ln_partial_rows.restype = _i
     lib.gps_ln_partial_rows.argtypes = [_i]
     lib.gps_ln_reduce_scratch_bytes.restype = ctypes.c_longlong

@@ -1295,15 +1295,22 @@ int launch(const Params &P, bool backward, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
+static int g_stream_min_nt[2] = {-1, -1};      // [plain, spatial]; -1 = not read yet
+
 int dispatch(Params &P, bool backward, hipStream_t s) {
   P.nt = (P.L + 15) / 16;
-  // rows of up to 144 tokens: register-resident kernels (one launch holds a whole score row per query strip);
-  // GPS_ATTN_STREAM_MIN_NT (16-token tiles, default 10) moves the switch to the streaming kernels for experiments
-  static const int stream_min_nt = [] {
-    const char *e = getenv("GPS_ATTN_STREAM_MIN_NT");
-    const int v = e ? atoi(e) : 10;
-    return v < 1 ? 1 : v;
-  }();
+  // The streaming kernels (key / query chunks streamed, no whole score row in registers) serve every length of the
+  // plain form -- after their rewrite they beat the register-resident kernels at 50 and 130 tokens too
+  // (profiles/r2: 0.33 + 0.13 ms vs 0.48 + 0.29 ms per step) -- and the rows above 144 tokens of the spatial form,
+  // whose resident kernels (whole score row per query strip) stay ahead at 80 tokens.  The thresholds (in 16-token
+  // tiles) can be moved with gps_attn_set_stream_min_tiles (tests run both families against each other) or the
+  // environment (GPS_ATTN_STREAM_MIN_NT: spatial, GPS_ATTN_STREAM_MIN_NT_PLAIN).
+  if (g_stream_min_nt[0] < 0) {
+    const char *e0 = getenv("GPS_ATTN_STREAM_MIN_NT_PLAIN"), *e1 = getenv("GPS_ATTN_STREAM_MIN_NT");
+    g_stream_min_nt[0] = e0 ? (atoi(e0) < 1 ? 1 : atoi(e0)) : 1;
+    g_stream_min_nt[1] = e1 ? (atoi(e1) < 1 ? 1 : atoi(e1)) : 10;
+  }
+  const int stream_min_nt = g_stream_min_nt[P.pl != nullptr ? 1 : 0];
   if (P.nt >= stream_min_nt && P.nt <= 32 && (!backward || P.out != nullptr)) return launch_stream(P, backward, s);
   if (P.nt <= 5) return launch<5>(P, backward, s);
   if (P.nt <= 9) return launch<9>(P, backward, s);
@@ -1318,6 +1325,12 @@ int dispatch(Params &P, bool backward, hipStream_t s) {
 }  // namespace gps_attn
 
 extern "C" {
+
+void gps_attn_set_stream_min_tiles(int plain, int spatial) {
+  gps_attn::g_stream_min_nt[0] = plain < 1 ? 1 : plain;
+  gps_attn::g_stream_min_nt[1] = spatial < 1 ? 1 : spatial;
+}
+
 
 int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                      int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
