@@ -390,10 +390,9 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   }
   const bool dropout = P.drop_thr != 0u;
   const unsigned long long seed = dropout ? P.seed + (P.seed_dev ? *P.seed_dev : 0ull) : 0ull;
-  uint16_t *C = reinterpret_cast<uint16_t *>(P.C);
   // bias / activation / dropout of one 4-column group of row m -> the packed bf16 result (and the packed
-  // pre-activation through `pre` for the GELU form)
-  auto finish = [&](f32x4 v, int m, int n, const f32x4 &bias, u32x2 &pre) -> u32x2 {
+  // pre-activation / low halves through `pre` for the GELU and split forms); aux4 = this group's 4 saved values
+  auto finish = [&](f32x4 v, int m, int n, const f32x4 &bias, const u32x2 &aux4, u32x2 &pre) -> u32x2 {
     v = v + bias;
     const unsigned long long idx = (unsigned long long)m * (unsigned long long)P.N + (unsigned long long)n;
     if (EPI == EPI_BIAS_GELU) {
@@ -418,17 +417,15 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
       pre = pack4(rest);
       return hi;
     } else if (EPI == EPI_DGELU) {
-      const u32x2 a = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
-      v[0] *= dgelu_f(bf2f((uint16_t)(a[0] & 0xFFFFu)));
-      v[1] *= dgelu_f(bf2f((uint16_t)(a[0] >> 16)));
-      v[2] *= dgelu_f(bf2f((uint16_t)(a[1] & 0xFFFFu)));
-      v[3] *= dgelu_f(bf2f((uint16_t)(a[1] >> 16)));
+      v[0] *= dgelu_f(bf2f((uint16_t)(aux4[0] & 0xFFFFu)));
+      v[1] *= dgelu_f(bf2f((uint16_t)(aux4[0] >> 16)));
+      v[2] *= dgelu_f(bf2f((uint16_t)(aux4[1] & 0xFFFFu)));
+      v[3] *= dgelu_f(bf2f((uint16_t)(aux4[1] >> 16)));
     } else if (EPI == EPI_DRELU) {
-      const u32x2 h = *reinterpret_cast<const u32x2 *>(P.aux + (size_t)m * P.ldaux + n);
-      v[0] = (h[0] & 0x7FFFu) ? v[0] * P.keep_scale : 0.f;
-      v[1] = (h[0] & 0x7FFF0000u) ? v[1] * P.keep_scale : 0.f;
-      v[2] = (h[1] & 0x7FFFu) ? v[2] * P.keep_scale : 0.f;
-      v[3] = (h[1] & 0x7FFF0000u) ? v[3] * P.keep_scale : 0.f;
+      v[0] = (aux4[0] & 0x7FFFu) ? v[0] * P.keep_scale : 0.f;
+      v[1] = (aux4[0] & 0x7FFF0000u) ? v[1] * P.keep_scale : 0.f;
+      v[2] = (aux4[1] & 0x7FFFu) ? v[2] * P.keep_scale : 0.f;
+      v[3] = (aux4[1] & 0x7FFF0000u) ? v[3] * P.keep_scale : 0.f;
     }
     if (dropout && (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_DGELU)) {
 #pragma unroll
@@ -437,6 +434,19 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
     return pack4(v);
   };
   constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_RELU_SPLIT;
+  constexpr bool HAS_AUX = EPI == EPI_DGELU || EPI == EPI_DRELU;
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins: device pass only
+  // Everything goes through buffer descriptors with exact sizes: rows past M fall outside the descriptor and are
+  // dropped (stores) or read as zero (loads) by the hardware, columns past N are sent there on purpose (kOOB) --
+  // so the epilogue is straight-line code, and ALL its loads (bias, saved activations) are issued before its first
+  // store.  That matters: vmcnt retires loads and stores in one order, so a load placed behind a store makes the
+  // wave wait for the store's acknowledgement -- the first version did that once per 16-row fragment.
+  constexpr unsigned int kOOB = 0x80000000u;
+  const auto bytes_of = [&](long long ld) { return (unsigned int)((((long long)P.M - 1) * ld + P.N) * 2); };
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, bytes_of(P.ldc) + (EPI == EPI_RELU_SPLIT ? 4u * P.N : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(P.aux), 0, HAS_AUX ? bytes_of(P.ldaux) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rPre = __builtin_amdgcn_make_buffer_rsrc(P.aux_out, 0, (EPI == EPI_BIAS_GELU && P.aux_out) ? bytes_of(P.ldaux_out) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.bias), 0, (HAS_BIAS && P.bias) ? 4u * P.N : 0u, 0x00020000);
   // Pairs of adjacent 16-column fragments leave as 16-byte stores: inside a pair, the even lane groups (g = 0, 2)
   // send their 4 columns of fragment b + 1 to the odd group next to them and receive that group's 4 columns of
   // fragment b, so every lane ends up with 8 consecutive columns of one row -- half the store instructions of the
@@ -445,46 +455,51 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   const bool wide = (TN % 2 == 0) && (P.N % 8 == 0) && (P.ldc % 8 == 0) &&
                     (EPI != EPI_BIAS_GELU || P.aux_out == nullptr || P.ldaux_out % 8 == 0);
   if (EPI == EPI_RELU_SPLIT && !wide) return;        // the C entry point only admits N % 8 == 0 == ldc % 8 for this form
+  // ---- all loads first ----
+  f32x4 bias[TN];
+  u32x2 aux[TM][TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + wn0 + 16 * b + 4 * g;
+    bias[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBias, n < P.N ? 4u * n : kOOB, 0, 0));
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      aux[a][b] = u32x2{0u, 0u};
+      if (HAS_AUX) {
+        const int m = m0 + wm0 + 16 * a + i;
+        aux[a][b] = __builtin_amdgcn_raw_buffer_load_b64(rAux, n < P.N ? (unsigned int)(((long long)m * P.ldaux + n) * 2) : kOOB, 0, 0);
+      }
+    }
+  }
   if (wide) {
     const bool odd = g & 1;
 #pragma unroll
     for (int b = 0; b < TN; b += 2) {
       const int nb0 = n0 + wn0 + 16 * b + 4 * g, nb1 = nb0 + 16;       // this lane's 4 columns in fragments b, b + 1
-      f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
-      if (HAS_BIAS && P.bias) {
-        if (nb0 < P.N) bias0 = *reinterpret_cast<const f32x4 *>(P.bias + nb0);
-        if (nb1 < P.N) bias1 = *reinterpret_cast<const f32x4 *>(P.bias + nb1);
-      }
       const int n_out = n0 + wn0 + 16 * (b + (odd ? 1 : 0)) + 8 * (g >> 1);     // first of the 8 columns stored
+      const unsigned int col_ok = n_out < P.N ? 0u : kOOB;
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
         const int m = m0 + wm0 + 16 * a + i;
-        const bool row_ok = m < P.M;
-        u32x2 pre0 = {0u, 0u}, pre1 = {0u, 0u}, o0 = {0u, 0u}, o1 = {0u, 0u};
-        if (row_ok && nb0 < P.N) o0 = finish(acc[a][b], m, nb0, bias0, pre0);
-        if (row_ok && nb1 < P.N) o1 = finish(acc[a][b + 1], m, nb1, bias1, pre1);
+        u32x2 pre0 = {0u, 0u}, pre1 = {0u, 0u};
+        const u32x2 o0 = finish(acc[a][b], m, nb0, bias[b], aux[a][b], pre0);
+        const u32x2 o1 = finish(acc[a][b + 1], m, nb1, bias[b + 1], aux[a][b + 1], pre1);
         const u32x2 send = odd ? o0 : o1;
         const u32x2 recv = {(unsigned int)__shfl_xor((int)send[0], 16, 64), (unsigned int)__shfl_xor((int)send[1], 16, 64)};
         const u32x4 out = odd ? u32x4{recv[0], recv[1], o1[0], o1[1]} : u32x4{o0[0], o0[1], recv[0], recv[1]};
-        if (row_ok && n_out < P.N) *reinterpret_cast<u32x4 *>(C + (size_t)m * P.ldc + n_out) = out;
-        if (EPI == EPI_RELU_SPLIT) {
+        const unsigned int off = (unsigned int)(((long long)m * P.ldc + n_out) * 2) | col_ok;
+        __builtin_amdgcn_raw_buffer_store_b128(out, rC, off, 0, 0);
+        if (EPI == EPI_RELU_SPLIT || EPI == EPI_BIAS_GELU) {
           const u32x2 sp = odd ? pre0 : pre1;
           const u32x2 rp = {(unsigned int)__shfl_xor((int)sp[0], 16, 64), (unsigned int)__shfl_xor((int)sp[1], 16, 64)};
           const u32x4 po = odd ? u32x4{rp[0], rp[1], pre1[0], pre1[1]} : u32x4{pre0[0], pre0[1], rp[0], rp[1]};
-          if (row_ok && n_out < P.N) {
-            *reinterpret_cast<u32x4 *>(C + (size_t)m * P.ldc + P.N + n_out) = po;
-            *reinterpret_cast<u32x4 *>(C + (size_t)m * P.ldc + 2 * P.N + n_out) = out;
+          if (EPI == EPI_RELU_SPLIT) {
+            __builtin_amdgcn_raw_buffer_store_b128(po, rC, off + 2u * P.N, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(out, rC, off + 4u * P.N, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(po, rPre, (unsigned int)(((long long)m * P.ldaux_out + n_out) * 2) | col_ok, 0, 0);
           }
         }
-        if (EPI == EPI_BIAS_GELU) {
-          if (P.aux_out) {
-            const u32x2 sp = odd ? pre0 : pre1;
-            const u32x2 rp = {(unsigned int)__shfl_xor((int)sp[0], 16, 64), (unsigned int)__shfl_xor((int)sp[1], 16, 64)};
-            const u32x4 po = odd ? u32x4{rp[0], rp[1], pre1[0], pre1[1]} : u32x4{pre0[0], pre0[1], rp[0], rp[1]};
-            if (row_ok && n_out < P.N) *reinterpret_cast<u32x4 *>(P.aux_out + (size_t)m * P.ldaux_out + n_out) = po;
-          }
-        }
-        if constexpr (TM * TN >= 32) __builtin_amdgcn_sched_barrier(0);    // 128 accumulators: no room to batch the rows
       }
     }
     return;
@@ -492,21 +507,18 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int n = n0 + wn0 + 16 * b + 4 * g;
-    if (n >= P.N) continue;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (HAS_BIAS && P.bias) bias = *reinterpret_cast<const f32x4 *>(P.bias + n);
+    const unsigned int col_ok = n < P.N ? 0u : kOOB;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int m = m0 + wm0 + 16 * a + i;
-      if (m >= P.M) continue;
       u32x2 pre = {0u, 0u};
-      const u32x2 o = finish(acc[a][b], m, n, bias, pre);
-      if (EPI == EPI_BIAS_GELU) {
-        if (P.aux_out) *reinterpret_cast<u32x2 *>(P.aux_out + (size_t)m * P.ldaux_out + n) = pre;
-      }
-      *reinterpret_cast<u32x2 *>(C + (size_t)m * P.ldc + n) = o;
+      const u32x2 o = finish(acc[a][b], m, n, bias[b], aux[a][b], pre);
+      if (EPI == EPI_BIAS_GELU)
+        __builtin_amdgcn_raw_buffer_store_b64(pre, rPre, (unsigned int)(((long long)m * P.ldaux_out + n) * 2) | col_ok, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(o, rC, (unsigned int)(((long long)m * P.ldc + n) * 2) | col_ok, 0, 0);
     }
   }
+#endif
 }
 
 // One workgroup = one output tile (PERSIST = false: grid = tiles x splits), or a resident workgroup that walks
@@ -814,6 +826,14 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   {
     const long long ra = a->form == GPS_GEMM_TN ? a->K : a->M, rb = a->form == GPS_GEMM_NT ? a->N : a->K;
     if (ra * a->lda * 2 >= 0x7FFFFFFFLL || rb * a->ldb * 2 >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+  }
+  // 32-bit byte offsets into C and the saved-activation operands (buffer addressing in the epilogue; rows of the
+  // last tile past M are addressed too, and must not wrap)
+  if (a->epilogue != GPS_GEMM_EPI_F32 && a->epilogue != GPS_GEMM_EPI_RELU_MAX16) {
+    const long long rows = (long long)a->M + 256;
+    if (rows * a->ldc * 2 >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+    if (a->aux && rows * a->ldaux * 2 >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+    if (a->aux_out && rows * a->ldaux_out * 2 >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   }
   const bool f32out = a->epilogue == GPS_GEMM_EPI_F32;
   if (f32out != (a->form == GPS_GEMM_TN)) return GPS_ERR_UNSUPPORTED;       // fp32 sums <=> weight-gradient form
