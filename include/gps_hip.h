@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 2
+#define GPS_HIP_ABI_VERSION 3
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
