@@ -489,16 +489,66 @@ def main() -> None:
                 row.update({"bound": "hbm", "frac": row["frac_hbm"]})
             row.setdefault("algorithmic_flops", int(algo_flops))
             kernels.append(row)
-        # dominant kernel over ALL kernels of the step: native launch shapes (above) vs every other kernel name
-        # the profiler saw (library GEMMs, torch elementwise / optimizer kernels)
+        # dominant kernel over ALL kernels of the step.  Native launches are grouped the way rocprofv3 groups them --
+        # by kernel symbol = template instantiation: the GEMM by (form, epilogue), attention by direction -- so that
+        # `roofline` describes the symbol with the largest share of the step and its average launch agrees with the
+        # rocprofv3 --stats row of that symbol; the per-shape rows stay in `kernels`.  Compared against every other
+        # kernel name the profiler saw (library GEMMs, torch elementwise / reduce kernels).
+        import re as _re
+
+        def family(name: str) -> str:
+            mm = _re.match(r"gemm_(\w+)\(M=\d+,N=\d+,K=\d+,epi=(\d+)\)", name)
+            if mm:
+                return f"gemm_{mm.group(1)}(epi={mm.group(2)})"
+            mm = _re.match(r"(attn_\w+)\(L=\d+,spatial=(\d)\)", name)
+            if mm:
+                return f"{mm.group(1)}(spatial={mm.group(2)})"
+            mm = _re.match(r"(add_dropout_layernorm_\w+)\(", name)
+            if mm:
+                return mm.group(1)
+            return name
+
+        groups = {}
+        for r in kernels:
+            gk = groups.setdefault(family(r["kernel"]), {"kernel": family(r["kernel"]), "ms_per_step": 0.0, "launches_per_step": 0.0,
+                                                        "bytes": 0.0, "flops": 0.0, "mfma_dtype": r.get("mfma_dtype"),
+                                                        "split3": "bf16x3" in r["kernel"], "shapes": 0})
+            gk["ms_per_step"] += r["ms_per_step"]
+            gk["launches_per_step"] += r["launches_per_step"]
+            gk["bytes"] += r["algorithmic_bytes"] * r["launches_per_step"]
+            gk["flops"] += r.get("algorithmic_flops", 0) * r["launches_per_step"]
+            gk["mfma_dtype"] = gk["mfma_dtype"] or r.get("mfma_dtype")
+            gk["shapes"] += 1
+        for gk in groups.values():
+            sec = gk["ms_per_step"] * 1e-3
+            n_l = max(gk["launches_per_step"], 1e-9)
+            gk["avg_us"] = round(gk["ms_per_step"] * 1e3 / n_l, 2)
+            gbs = gk["bytes"] / sec / 1e9 if sec else 0.0
+            dt_name = "bf16" if gk["split3"] else (gk["mfma_dtype"] or "")
+            peak_tf = MFMA_PEAK_TFLOPS.get(dt_name, 0.0)
+            t_hbm = gk["bytes"] / (HBM_PEAK_GBS * 1e9)
+            t_mfma = gk["flops"] / (peak_tf * 1e12) if peak_tf else 0.0
+            if t_mfma > t_hbm:
+                tf = gk["flops"] / sec / 1e12
+                gk.update({"bound": "mfma", "mfma_dtype": dt_name, "achieved_TFLOPs": round(tf, 1), "frac": round(tf / peak_tf, 4)})
+                if gk["split3"]:
+                    gk["mfma_utilisation"] = round(3.0 * tf / peak_tf, 4)
+            else:
+                gk.update({"bound": "hbm", "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        ranked = sorted(groups.values(), key=lambda g_: -g_["ms_per_step"])
         native_names = ("gps_",)
         others = [r for r in step_kernels if not any(tag in r["name"] for tag in native_names)]
-        dom = kernels[0] if kernels else None
+        dom = ranked[0] if ranked else None
         dom_other = others[0] if others else None
         traffic = None
         if dom is not None and os.path.exists(PMC_TRAFFIC):
             with open(PMC_TRAFFIC) as f:
-                traffic = json.load(f).get("per_launch_hbm_bytes", {}).get(dom["kernel"])
+                per_launch = json.load(f).get("per_launch_hbm_bytes", {})
+            # PMC traffic is recorded per launch shape: report the largest shape of the family that has an entry
+            for r in kernels:
+                if family(r["kernel"]) == dom["kernel"] and r["kernel"] in per_launch:
+                    traffic = {"shape": r["kernel"], "hbm_bytes": per_launch[r["kernel"]], "algorithmic_bytes": r["algorithmic_bytes"]}
+                    break
         if dom is None:
             roofline = None
         elif dom_other is not None and dom_other["ms_per_step"] > dom["ms_per_step"]:
@@ -507,16 +557,23 @@ def main() -> None:
                         "note": "the kernel with the largest time per step is not a libgps_hip.so launch; its "
                                 "algorithmic work is not known to this script",
                         "largest_native": {"kernel": dom["kernel"], "bound": dom["bound"], "frac": dom["frac"],
-                                           "ms_per_step": dom["ms_per_step"]}}
+                                           "ms_per_step": round(dom["ms_per_step"], 4)}}
         elif dom["bound"] == "mfma":
             roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_TFLOPs"],
                         "peak": MFMA_PEAK_TFLOPS[dom["mfma_dtype"]], "unit": "TFLOP/s", "frac": dom["frac"],
-                        "dtype": dom["mfma_dtype"], "traffic": traffic, "ms_per_step": dom["ms_per_step"],
-                        **({"mfma_utilisation": dom["mfma_utilisation"]} if "mfma_utilisation" in dom else {})}
+                        "dtype": dom["mfma_dtype"], "traffic": traffic, "ms_per_step": round(dom["ms_per_step"], 4),
+                        "launches_per_step": dom["launches_per_step"], "avg_us": dom["avg_us"], "shapes": dom["shapes"],
+                        **({"mfma_utilisation": dom["mfma_utilisation"]} if "mfma_utilisation" in dom else {}),
+                        **({"note": "weight + bias gradient GEMMs of every Linear; avg_us is per gps_gemm_bf16 call = the split-K "
+                                    "kernel plus its partial-sum reduction launch (two rocprofv3 rows: gemm_kernel<..., true, true, 5, ...> "
+                                    "and splitk_reduce_kernel)"} if dom["kernel"].startswith("gemm_tn") else {})}
         else:
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
-                        "ms_per_step": dom["ms_per_step"]}
+                        "ms_per_step": round(dom["ms_per_step"], 4), "launches_per_step": dom["launches_per_step"],
+                        "avg_us": dom["avg_us"], "shapes": dom["shapes"]}
+        kernel_families = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in g_.items() if k not in ("bytes", "flops", "split3")}
+                           for g_ in ranked[:12]]
         attn = [r for r in kernels if r["kernel"].startswith("attn_")]
         attn_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in attn)
         attn_sec = sum(r["avg_us"] * 1e-6 * r["launches_per_step"] for r in attn)
@@ -571,6 +628,7 @@ def main() -> None:
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
             "headline": headline,
+            "kernel_families": kernel_families,
             "kernels": kernels,
             "step_kernels": step_kernels[:25],
         }

@@ -265,10 +265,10 @@ def sa_mlp_forward(xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Ten
     _, npoint, nsample = idx.shape
     c1, c2, c3 = (int(c) for c in channels)
     out = torch.empty((b, c3, npoint), dtype=torch.float32, device=xyz.device)
-    # algorithmic bytes of the UNFUSED reference API for the same work: two
-    # group_points calls (xyz, features) -- what this launch absorbs on the gather side
-    algo = 4 * (b * 3 * n + b * npoint * nsample + b * 3 * npoint * nsample) + \
-        4 * (b * c_feat * n + b * npoint * nsample + b * c_feat * npoint * nsample)
+    # algorithmic bytes of THIS launch: every input read once (points, centres, features, neighbour indices) and the
+    # pooled output written once.  (The unfused reference API moves 8x more for the same work -- two group_points
+    # outputs and three conv / BN / ReLU round trips -- which is what fusing removes, not this kernel's roof.)
+    algo = 4 * (b * 3 * n + b * 3 * npoint + b * c_feat * n + b * npoint * nsample + b * c3 * npoint)
     flops = 2 * b * npoint * nsample * ((3 + c_feat) * c1 + c1 * c2 + c2 * c3)
     x3 = precision == "bf16x3"
     fn = _native.load().gps_sa_mlp_forward_bf16x3 if x3 else _native.load().gps_sa_mlp_forward
