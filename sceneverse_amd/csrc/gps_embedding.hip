@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(int n, int d, int num_rows,
   int found = 1;
   // ids are scanned kAhead x 64 at a time: the loads of one trip are independent, so an id that occurs
   // across the whole batch ([CLS], [SEP]) costs n / (64 * kAhead) memory round trips, not n / 64
-  constexpr int kAhead = 8;
+  constexpr int kAhead = 16;
   for (int base = t + 1; base < n && found < want; base += 64 * kAhead) {
     unsigned long long masks[kAhead];
 #pragma unroll
@@ -66,18 +66,36 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(int n, int d, int num_rows,
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
       unsigned long long mask = masks[u];
-      while (mask) {                                                      // ascending token order
-        const int row = base + u * 64 + (__ffsll((long long)mask) - 1);
-        mask &= mask - 1ull;
+      while (mask) {                                                      // ascending token order, four rows per trip:
+        int rows[4];                                                      // their loads are issued together, the adds
+        int nr = 0;                                                       // stay in token order
 #pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c) {
-          const int col = c * 256 + lane * 4;
-          if (c < chunks && col < d) {
-            const float4 v = *reinterpret_cast<const float4 *>(dy + (size_t)row * ld + col);
-            acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+        for (int q = 0; q < 4; ++q) {
+          rows[q] = -1;
+          if (mask) {
+            rows[q] = base + u * 64 + (__ffsll((long long)mask) - 1);
+            mask &= mask - 1ull;
+            ++nr;
           }
         }
-        ++found;
+        float4 v[4][kMaxChunks];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < kMaxChunks; ++c) {
+            const int col = c * 256 + lane * 4;
+            v[q][c] = (rows[q] >= 0 && c < chunks && col < d) ? *reinterpret_cast<const float4 *>(dy + (size_t)rows[q] * ld + col)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (rows[q] < 0) continue;
+#pragma unroll
+          for (int c = 0; c < kMaxChunks; ++c) {
+            acc[c].x += v[q][c].x; acc[c].y += v[q][c].y; acc[c].z += v[q][c].z; acc[c].w += v[q][c].w;
+          }
+        }
+        found += nr;
       }
     }
   }

@@ -441,7 +441,9 @@ __global__ __launch_bounds__(kBlock) void group_points_kernel(int b, int c, int 
         const float *rowp = gp_tile + l * n;
         float4 v;
         v.x = rowp[id.x]; v.y = rowp[id.y]; v.z = rowp[id.z]; v.w = rowp[id.w];
-        reinterpret_cast<float4 *>(dst + (size_t)l * S)[s4] = v;
+        typedef __attribute__((ext_vector_type(4))) float f32x4_nt;
+        const f32x4_nt nv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(nv, reinterpret_cast<f32x4_nt *>(dst + (size_t)l * S) + s4);   // streamed once, never re-read here
       }
     }
   } else {
