@@ -284,6 +284,7 @@ __global__ __launch_bounds__(kBlock) void gather_points_grad_kernel(
 // stored with one coalesced write.  Chunks are visited in ascending order and a centre stops as
 // soon as nsample hits are found, so the output equals the reference's serial scan.
 // ------------------------------------------------------------------------------------------
+constexpr int kCentresPerLoad = 21;   // 63 lanes = 21 centres x 3 coordinates
 template <int R>  // R > 0: register-resident cloud of <= 64*R points; R == 0: streamed
 __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m, float radius,
                                                              int nsample,
@@ -340,10 +341,17 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
     const int row_len = nsample + 2 * kWave;
     int32_t *wrow = bq_rows + w * (row_len + kWave);
     int32_t *dummy = wrow + row_len + L;
-    for (int j = w; j < m; j += kWavesPerBlock) {
-      const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 0])));
-      const float c1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 1])));
-      const float c2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q[j * 3 + 2])));
+    // the wave's centres are fetched 21 at a time with ONE vector load (lane 3 jj + c = coordinate c of its jj-th
+    // centre) and broadcast from there: a load per centre put a memory round trip in front of every scan
+    for (int j0 = w; j0 < m; j0 += kCentresPerLoad * kWavesPerBlock) {
+     const int jl = j0 + (L / 3) * kWavesPerBlock;
+     const int cv = (L < 3 * kCentresPerLoad && jl < m) ? __float_as_int(q[jl * 3 + L % 3]) : 0;
+     for (int jj = 0; jj < kCentresPerLoad; ++jj) {
+      const int j = j0 + jj * kWavesPerBlock;
+      if (j >= m) break;
+      const float c0 = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 0));
+      const float c1 = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 1));
+      const float c2 = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 2));
       const f2 cx = {c0, c0}, cy = {c1, c1}, cz = {c2, c2};
       int cnt = 0;                                                          // wave-uniform (SGPR)
 #pragma unroll
@@ -365,6 +373,7 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
       // same-wave LDS write -> read: the compiler's lgkmcnt wait orders them, no barrier needed
       const int first = cnt > 0 ? wrow[0] : 0;
       for (int t = L; t < nsample; t += kWave) o[j * nsample + t] = t < cnt ? wrow[t] : first;
+     }
     }
     return;
   }
@@ -372,11 +381,15 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
   // R == 1: a single (possibly partial) chunk in registers; R == 0: streamed from L1/L2
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (R == 1 && L < n) { qx = p[L * 3 + 0]; qy = p[L * 3 + 1]; qz = p[L * 3 + 2]; }
-  for (int j = w; j < m; j += kWavesPerBlock) {
-    float cx = q[j * 3 + 0], cy = q[j * 3 + 1], cz = q[j * 3 + 2];
-    cx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx)));
-    cy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
-    cz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cz)));
+  for (int j0 = w; j0 < m; j0 += kCentresPerLoad * kWavesPerBlock) {
+   const int jl = j0 + (L / 3) * kWavesPerBlock;
+   const int cv = (L < 3 * kCentresPerLoad && jl < m) ? __float_as_int(q[jl * 3 + L % 3]) : 0;
+   for (int jj = 0; jj < kCentresPerLoad; ++jj) {
+    const int j = j0 + jj * kWavesPerBlock;
+    if (j >= m) break;
+    const float cx = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 0));
+    const float cy = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 1));
+    const float cz = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 2));
     int cnt = 0, first = 0;
     for (int i = 0; i < nchunks && cnt < nsample; ++i) {
       const int k = i * kWave + L;
@@ -395,6 +408,7 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
     }
     if (cnt > nsample) cnt = nsample;
     for (int t = L; t < nsample; t += kWave) o[j * nsample + t] = t < cnt ? row[t] : first;
+   }
   }
 }
 
