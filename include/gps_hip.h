@@ -352,6 +352,12 @@ typedef struct gps_gemm_args {
   unsigned long long seed;
   float p_drop;
   int reserved2;
+  /* optional device int32: the number of LEADING token rows that carry work.  Forms NT / NN: output rows at or
+   * past it are not computed (their tiles exit at once; rows of the last started tile may be written).  Form TN:
+   * the reduction stops at the end of the 64-row stage that contains row *extent_dev - 1 (operand rows between
+   * the extent and that stage end must hold zeros).  Lets a HIP-graph-captured step skip rows whose count is only
+   * known on the device (the unlabelled ~85 % of the masked-LM head's tokens).  NULL = all rows. */
+  const int *extent_dev;
 } gps_gemm_args;
 GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
 GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);

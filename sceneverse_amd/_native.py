@@ -33,7 +33,7 @@ class GemmArgs(ctypes.Structure):
                 ("C", _vp), ("ldc", ctypes.c_longlong), ("bias", _vp),
                 ("aux", _vp), ("ldaux", ctypes.c_longlong), ("aux_out", _vp), ("ldaux_out", ctypes.c_longlong),
                 ("workspace", _vp), ("colsum", _vp), ("seed_dev", _vp), ("seed", ctypes.c_ulonglong),
-                ("p_drop", _f), ("reserved2", _i)]
+                ("p_drop", _f), ("reserved2", _i), ("extent_dev", _vp)]
 
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2

@@ -73,6 +73,7 @@ struct Params {
   unsigned int drop_thr;
   unsigned long long seed;
   const unsigned long long *seed_dev;
+  const int *extent_dev;   // optional device count of leading token rows that carry work (rows of M for NT / NN, of K for TN)
 };
 
 __device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even (finite inputs)
@@ -569,7 +570,15 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   };
   decode(vid);
   int kt0 = split * P.kt_per_split;
-  const int nst = min(P.nkt, kt0 + P.kt_per_split) - kt0;       // the same for every tile of a persistent walk
+  int nst = min(P.nkt, kt0 + P.kt_per_split) - kt0;             // the same for every tile of a persistent walk
+  if (P.extent_dev) {
+    const int extent = *P.extent_dev;
+    if (ATR) {                                                   // TN: token rows are the reduction
+      nst = max(0, min(nst, (extent + BK - 1) / BK - kt0));
+    } else if (!PERSIST && m0 >= extent) {
+      return;                                                    // NT / NN: a tile of rows nobody reads
+    }
+  }
 
   Stager<BM, ATR, NW> sa;
   Stager<BN, BTR, NW> sb;
@@ -796,7 +805,7 @@ int gps_gemm_pick_splits(int form, int M, int N, int K) {
 }
 
 long long gps_gemm_workspace_floats(int form, int M, int N, int splits) {
-  if (form != GPS_GEMM_TN || splits <= 1) return 0;
+  if (form == GPS_GEMM_NT || splits <= 1) return 0;
   return (long long)splits * ((long long)M * N + M);
 }
 
@@ -836,7 +845,10 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
     if (a->aux_out && rows * a->ldaux_out * 2 >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   }
   const bool f32out = a->epilogue == GPS_GEMM_EPI_F32;
-  if (f32out != (a->form == GPS_GEMM_TN)) return GPS_ERR_UNSUPPORTED;       // fp32 sums <=> weight-gradient form
+  // fp32 sums (optionally split over K): the weight-gradient form, and the input-gradient form for long reductions
+  // over few rows (the masked-LM head: K = vocabulary); every other epilogue belongs to NT / NN
+  if (f32out ? a->form == GPS_GEMM_NT : a->form == GPS_GEMM_TN) return GPS_ERR_UNSUPPORTED;
+  if (f32out && a->form == GPS_GEMM_NN && a->colsum) return GPS_ERR_UNSUPPORTED;
   if (a->ldc & 3) return GPS_ERR_UNSUPPORTED;
   if (a->form == GPS_GEMM_TN && (a->M & 7)) return GPS_ERR_UNSUPPORTED;     // A is M-contiguous there
   if (a->form != GPS_GEMM_NT && (a->N & 7)) return GPS_ERR_UNSUPPORTED;     // B is N-contiguous there
@@ -861,13 +873,14 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   P.aux_out = (uint16_t *)a->aux_out; P.ldaux_out = a->ldaux_out;
   P.nkt = (a->K + BK - 1) / BK;
   P.splits = 1;
-  if (a->form == GPS_GEMM_TN && a->splits > 1) P.splits = a->splits < P.nkt ? a->splits : (P.nkt > 0 ? P.nkt : 1);
+  if (f32out && a->splits > 1) P.splits = a->splits < P.nkt ? a->splits : (P.nkt > 0 ? P.nkt : 1);
   P.kt_per_split = (P.nkt + P.splits - 1) / P.splits;
   P.splits = P.kt_per_split > 0 ? (P.nkt + P.kt_per_split - 1) / P.kt_per_split : 1;   // no empty split
   if (P.splits < 1) P.splits = 1;
   P.keep_scale = a->p_drop > 0.f ? 1.f / (1.f - a->p_drop) : 1.f;
   P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
   P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
+  P.extent_dev = a->extent_dev;
   hipStream_t s = (hipStream_t)stream;
   if (a->K == 0) P.nkt = 0;
 
@@ -897,6 +910,21 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
       case GPS_GEMM_EPI_BIAS: st = launch_variant<false, true, EPI_BIAS>(P, variant, s); break;
       case GPS_GEMM_EPI_DGELU: st = launch_variant<false, true, EPI_DGELU>(P, variant, s); break;
       case GPS_GEMM_EPI_DRELU: st = launch_variant<false, true, EPI_DRELU>(P, variant, s); break;
+      case GPS_GEMM_EPI_F32: {
+        if (P.splits > 1) {
+          if (!a->workspace) return GPS_ERR_INVALID_ARGUMENT;
+          P.partial = a->workspace;
+        }
+        st = launch_cfg<128, 128, 4, 2, false, true, EPI_F32, 2>(P, s);
+        if (st == GPS_OK && P.splits > 1) {
+          const long long elems = (long long)a->M * a->N;
+          const int main_blocks = (int)((elems / 4 + 255) / 256);
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3(main_blocks), dim3(256), 0, s, P.splits, elems, P.partial,
+                             reinterpret_cast<float *>(a->C), a->ldc, a->N, a->M, nullptr, nullptr, main_blocks);
+          st = hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+        }
+        break;
+      }
       default: return GPS_ERR_UNSUPPORTED;
     }
   } else {

@@ -52,7 +52,8 @@ class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
-                 native_gemm: bool = True, grad_compress: Optional[str] = "auto", native_optimizer: bool = True):
+                 native_gemm: bool = True, grad_compress: Optional[str] = "auto", native_optimizer: bool = True,
+                 fused_lm_loss: bool = True):
         self.cfg = cfg
         self.device = torch.device(device)
         # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
@@ -104,6 +105,7 @@ class GPSTrainStep:
         # gradient compression: bf16 on the wire (246 MB instead of 491 MB per step), fp32 accumulation of the
         # decompressed buckets; "auto" = on for RCCL, off for gloo (CPU tests compare against exact means)
         self.grad_compress = grad_compress
+        self.fused_lm_loss = bool(fused_lm_loss) and bool(native_gemm)
         self.frozen_unused: list = []
         self.global_step = 0
         if self.graph_dp and dist_utils.is_dist():
@@ -268,9 +270,16 @@ class GPSTrainStep:
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
 
     def _autocast(self):
+        """Context of every model / loss evaluation of the step: bf16 autocast, and (train mode, native GEMMs) the
+        masked-LM head in its fused linear + cross-entropy form (modules/heads/pretrain_head.py)."""
         if self.amp_dtype is None:
             return contextlib.nullcontext()
-        return torch.autocast(device_type="cuda", dtype=self.amp_dtype)
+        stack = contextlib.ExitStack()
+        stack.enter_context(torch.autocast(device_type="cuda", dtype=self.amp_dtype))
+        if self.fused_lm_loss:
+            from .modules.heads.pretrain_head import fused_lm_loss
+            stack.enter_context(fused_lm_loss(True))
+        return stack
 
     def _begin_step(self):
         # one tiny launch that advances the device-side dropout seed block; it sits inside every captured

@@ -1,10 +1,28 @@
 """Masked-LM style pre-training heads (reference modules/heads/pretrain_head.py:8-56)."""
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..build import HEADS_REGISTRY
 from ..utils import get_activation_fn
+
+
+_FUSED_LM_LOSS = False
+
+
+@contextlib.contextmanager
+def fused_lm_loss(flag: bool = True):
+    """Inside this context a TRAINING-mode `BertLMPredictionHead` on the GPU hands the loss a `LazyLMLogits`
+    (optim/loss/fused_lm_loss.py) instead of the (B, L, vocab) logits: the engine's train step turns it on,
+    everything else (evaluation, tests reading the logits) keeps the reference's tensor."""
+    global _FUSED_LM_LOSS
+    prev, _FUSED_LM_LOSS = _FUSED_LM_LOSS, bool(flag)
+    try:
+        yield
+    finally:
+        _FUSED_LM_LOSS = prev
 
 
 class BertPredictionHeadTransform(nn.Module):
@@ -28,6 +46,12 @@ class BertLMPredictionHead(nn.Module):
         self.bias = nn.Parameter(torch.zeros(vocab_size))
 
     def forward(self, hidden_states):
+        if _FUSED_LM_LOSS and self.training and hidden_states.is_cuda:
+            from ...optim.loss import fused_lm_loss as F_lm
+            h = self.transform(hidden_states)
+            if F_lm.usable(h, self.decoder.weight):
+                return F_lm.LazyLMLogits(h, self.decoder.weight, self.bias)
+            return F.linear(h, self.decoder.weight, self.bias)
         # decoder(h) + bias (ref :29) as ONE GEMM with the bias in its epilogue: under bf16 autocast the separate
         # add promoted the (tokens x vocab) logits to fp32 (a 390 MB round trip forward, the same again backward)
         return F.linear(self.transform(hidden_states), self.decoder.weight, self.bias)

@@ -75,7 +75,7 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
          ldaux: int = 0, aux_out: Optional[torch.Tensor] = None, ldaux_out: int = 0,
          workspace: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, p_drop: float = 0.0,
          seed_dev: Optional[torch.Tensor] = None, splits: int = 1, variant: Optional[int] = None,
-         ablate: int = 0) -> None:
+         ablate: int = 0, extent_dev: Optional[torch.Tensor] = None) -> None:
     """Thin checked call of gps_gemm_bf16 on the current stream (shapes in the header's convention)."""
     a = GemmArgs()
     a.form, a.epilogue, a.M, a.N, a.K = form, epilogue, M, N, K
@@ -86,6 +86,7 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
     a.bias = _ptr(bias)
     a.aux, a.ldaux, a.aux_out, a.ldaux_out = _ptr(aux), ldaux, _ptr(aux_out), ldaux_out
     a.workspace, a.colsum, a.seed_dev = _ptr(workspace), _ptr(colsum), _ptr(seed_dev)
+    a.extent_dev = _ptr(extent_dev)
     a.seed, a.p_drop = 0, float(p_drop)
     from ...pointnet2._ext import _timed
     nbytes = 2 * (M * K + N * K) + {EPI_F32: 4 * M * N, EPI_RELU_SPLIT: 6 * M * N, EPI_RELU_MAX16: M * N // 4}.get(epilogue, 2 * M * N)
@@ -214,7 +215,7 @@ def split3_mlp_max16(x: torch.Tensor, layers) -> torch.Tensor:
 
 # ---- bf16 shadows of the fp32 master weights ---------------------------------------------------------------
 class _Shadow:
-    __slots__ = ("w16", "b32", "versions", "weight_ids", "bias_ids", "row_offsets", "owners")
+    __slots__ = ("w16", "b32", "versions", "weight_ids", "bias_ids", "row_offsets", "row_counts", "owners", "b32_is_copy")
 
     def __init__(self):
         self.w16 = None
@@ -224,6 +225,8 @@ class _Shadow:
         self.weight_ids = ()
         self.bias_ids = ()
         self.row_offsets = ()
+        self.row_counts = ()
+        self.b32_is_copy = False
 
 
 _SHADOWS = {}
@@ -242,11 +245,11 @@ def shadow_targets() -> dict:
         if sh.w16 is None or sh.owners is None:
             continue
         alive = {id(t) for t in (r() for r in sh.owners) if t is not None}      # ids of dead masters may be recycled
-        for wid, bid, off, nxt in zip(sh.weight_ids, sh.bias_ids, sh.row_offsets, sh.row_offsets[1:] + (sh.w16.shape[0],)):
+        for wid, bid, off, cnt in zip(sh.weight_ids, sh.bias_ids, sh.row_offsets, sh.row_counts):
             if wid in alive:
-                out[wid] = (sh.w16[off:nxt], None)
-            if bid is not None and bid in alive and sh.b32 is not None and len(sh.weight_ids) > 1:
-                out[bid] = (None, sh.b32[off:nxt])
+                out[wid] = (sh.w16[off:off + cnt], None)
+            if bid is not None and bid in alive and sh.b32 is not None and sh.b32_is_copy:
+                out[bid] = (None, sh.b32[off:off + cnt])
     return out
 
 
@@ -254,11 +257,13 @@ def _versions(params) -> tuple:
     return tuple(p._version for p in params if p is not None)
 
 
-def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], pad_rows: int = 1):
     """(w16, b32): bf16 copy of the row-wise concatenation of `weights` and fp32 concatenation of `biases`,
     rebuilt only when one of the masters changed since the last call.  A single weight returns its own bias
-    tensor (no copy).  The optimizer kernel may write these buffers itself and call `mark_fresh`."""
-    key = tuple(id(w) for w in weights)
+    tensor (no copy).  The optimizer kernel may write these buffers itself and call `mark_fresh`.
+    pad_rows > 1: the row count is rounded up to that multiple (zero rows / zero bias entries behind the data),
+    for outputs whose width must be a multiple of 8 (the 30 522-row vocabulary decoder)."""
+    key = tuple(id(w) for w in weights) + ((("pad", pad_rows),) if pad_rows > 1 else ())
     sh = _SHADOWS.get(key)
     if sh is None:
         sh = _SHADOWS[key] = _Shadow()
@@ -269,10 +274,12 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
         sh.owners = tuple(weakref.ref(t) for t in masters)      # first use, or the ids now name other tensors
         sh.versions = None
     rows = sum(w.shape[0] for w in weights)
+    rows = (rows + pad_rows - 1) // pad_rows * pad_rows
+    padded = rows != sum(w.shape[0] for w in weights)
     if sh.w16 is None or sh.w16.device != dev or tuple(sh.w16.shape) != (rows, weights[0].shape[1]):
         global _REGISTRY_VERSION
         _REGISTRY_VERSION += 1
-        sh.w16 = torch.empty((rows, weights[0].shape[1]), dtype=torch.bfloat16, device=dev)
+        sh.w16 = (torch.zeros if padded else torch.empty)((rows, weights[0].shape[1]), dtype=torch.bfloat16, device=dev)
         sh.b32 = None
         sh.versions = None
         sh.weight_ids = tuple(id(w) for w in weights)
@@ -282,6 +289,7 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
             offs.append(r)
             r += w.shape[0]
         sh.row_offsets = tuple(offs)
+        sh.row_counts = tuple(w.shape[0] for w in weights)
     if sh.versions != ver:
         with torch.no_grad():
             r = 0
@@ -289,11 +297,13 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
                 sh.w16[r:r + w.shape[0]].copy_(w)
                 r += w.shape[0]
             if all(b is not None for b in biases):
-                if len(biases) == 1:
+                if len(biases) == 1 and not padded:
                     sh.b32 = biases[0].detach()
+                    sh.b32_is_copy = False
                 else:
                     if sh.b32 is None or sh.b32.data_ptr() in [b.data_ptr() for b in biases]:
-                        sh.b32 = torch.empty(sh.w16.shape[0], dtype=torch.float32, device=dev)
+                        sh.b32 = torch.zeros(sh.w16.shape[0], dtype=torch.float32, device=dev)
+                        sh.b32_is_copy = True
                         _REGISTRY_VERSION += 1
                     r = 0
                     for b in biases:

@@ -1,0 +1,127 @@
+"""Masked-LM head + cross-entropy over the LABELLED rows only (fused linear-cross-entropy).
+
+Reference: `BertLMPredictionHead.decoder` + bias (modules/heads/pretrain_head.py:22-30) produces (B, L, 30522) logits
+for every token, and `lm_cls_loss` (optim/loss/loss.py:56-61) then averages the cross-entropy over the ~15 % of tokens
+whose label is not `ignore_index`.  The other rows contribute nothing to the loss or to any gradient, so here they are
+never computed -- with static shapes, because the step is replayed as one HIP graph and the number of labelled tokens
+is only known on the device:
+
+  * the token rows are permuted so that the labelled ones come first (stable: original order inside each class);
+  * the three GEMMs of the head run on libgps_hip.so with a DEVICE-side row count (`gps_gemm_args.extent_dev`): forward
+    tiles past it exit at once, the weight gradient stops its reduction there, the input gradient (reduction over the
+    vocabulary, few rows) runs split-K into fp32;
+  * the vocabulary is padded to a multiple of 8 columns in a bf16 shadow of the decoder weight (zero rows) -- the
+    cross-entropy kernels (`gps_masked_ce_*`, row-sparse already) read the first V columns of each row.
+
+Loss value and every gradient equal the reference formulation's (to bf16 rounding of the logits); full logits exist
+only when somebody asks for them (`LazyLMLogits.materialize()`: evaluation, accuracy metrics).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ... import _native
+from ...modules.layers import gemm as G
+
+def _padded_shadow(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """bf16 copy of `weight` (V, D) with the rows padded to a multiple of 8 (zeros) + fp32 padded bias, from the
+    shadow registry of modules/layers/gemm.py (the clip + AdamW kernel writes it with the masters)."""
+    return G.shadow_of([weight], [bias], pad_rows=8)
+
+
+class _SparseLMLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, weight, bias, labels, ignore_index: int):
+        n, D = h.shape
+        V = weight.shape[0]
+        w16, b32 = _padded_shadow(weight, bias)
+        Vp = w16.shape[0]
+        lib = _native.load()
+        dev = h.device
+        labels = labels.reshape(-1).to(torch.int64)
+        valid = (labels != ignore_index) & (labels >= 0) & (labels < V)
+        n_valid = valid.sum(dtype=torch.int32).reshape(1)
+        perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)       # labelled rows first
+        hp = h.detach().to(torch.bfloat16).index_select(0, perm).contiguous()
+        lp = torch.where(valid, labels, torch.full_like(labels, ignore_index)).index_select(0, perm).contiguous()
+        logits = torch.empty((n, Vp), dtype=torch.bfloat16, device=dev)
+        G.gemm(_native.GEMM_NT, _native.EPI_BIAS, n, Vp, D, hp, D, w16, D, logits, Vp, bias=b32, extent_dev=n_valid)
+        rows = torch.empty(n, dtype=torch.float32, device=dev)
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = lib.gps_masked_ce_forward(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), int(ignore_index),
+                                           rows.data_ptr(), lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _native.check(st, "masked_ce_forward")
+        nv = n_valid.to(torch.float32)
+        loss = (rows.sum() / nv).reshape(())
+        ctx.save_for_backward(hp, w16, logits, lp, lse, perm, n_valid, nv)
+        ctx.meta = (n, D, V, Vp, int(ignore_index), h.dtype, bias is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        hp, w16, logits, lp, lse, perm, n_valid, nv = ctx.saved_tensors
+        n, D, V, Vp, ignore_index, h_dtype, has_bias = ctx.meta
+        lib = _native.load()
+        dev = hp.device
+        stream = torch.cuda.current_stream().cuda_stream
+        grad_rows = (g.reshape(1).float() / nv).expand(n).contiguous()
+        dlogits = torch.empty((n, Vp), dtype=torch.bfloat16, device=dev)
+        if Vp > V:
+            dlogits[:, V:].zero_()                         # padding columns meet zero weight rows, but must be finite
+        with torch.cuda.device(dev):
+            st = lib.gps_masked_ce_backward(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), ignore_index, lse.data_ptr(),
+                                            grad_rows.data_ptr(), dlogits.data_ptr(), Vp, stream)
+        _native.check(st, "masked_ce_backward")
+        dh = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dX = dlogits . W: a reduction over the vocabulary for a few hundred rows -> split-K into fp32
+            splits = 16
+            ws = G._workspace(dev, int(lib.gps_gemm_workspace_floats(_native.GEMM_NN, n, D, splits)))
+            dxp = torch.empty((n, D), dtype=torch.float32, device=dev)
+            G.gemm(_native.GEMM_NN, _native.EPI_F32, n, D, Vp, dlogits, Vp, w16, D, dxp, D, workspace=ws, splits=splits,
+                   extent_dev=n_valid)
+            live = (torch.arange(n, device=dev) < n_valid)[:, None]          # rows past the extent were never written
+            dxp = torch.where(live, dxp, torch.zeros((), dtype=torch.float32, device=dev))
+            dh = torch.empty((n, D), dtype=h_dtype, device=dev)
+            dh.index_copy_(0, perm, dxp.to(h_dtype))
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwp = torch.empty((Vp, D), dtype=torch.float32, device=dev)
+            dbp = torch.empty(Vp, dtype=torch.float32, device=dev)
+            G.gemm(_native.GEMM_TN, _native.EPI_F32, Vp, D, n, dlogits, Vp, hp, D, dwp, D, colsum=dbp, splits=1,
+                   extent_dev=n_valid)
+            dw = dwp[:V]
+            db = dbp[:V] if has_bias else None
+        return dh, dw, db, None, None
+
+
+def sparse_lm_loss(h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], labels: torch.Tensor,
+                   ignore_index: int = -1) -> torch.Tensor:
+    """mean over labelled tokens of CE(h W^T + b, labels); h (..., D), labels (...)."""
+    D = h.shape[-1]
+    return _SparseLMLoss.apply(h.reshape(-1, D), weight, bias, labels.reshape(-1), int(ignore_index))
+
+
+def usable(h: torch.Tensor, weight: torch.Tensor) -> bool:
+    return G.usable(h, weight.shape[1], (weight.shape[0] + 7) // 8 * 8) and weight.shape[1] % 8 == 0
+
+
+class LazyLMLogits:
+    """What the masked-LM head hands to the loss when the fused path is on: the transformed hidden states and the
+    decoder parameters.  `lm_cls_loss` turns it into the loss without full logits; anything else that wants the
+    (B, L, V) tensor calls `materialize()`."""
+
+    def __init__(self, hidden: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        self.hidden, self.weight, self.bias = hidden, weight, bias
+
+    @property
+    def shape(self):
+        return (*self.hidden.shape[:-1], self.weight.shape[0])
+
+    def materialize(self) -> torch.Tensor:
+        return torch.nn.functional.linear(self.hidden, self.weight, self.bias)
+
+    def loss(self, labels: torch.Tensor, ignore_index: int = -1) -> torch.Tensor:
+        return sparse_lm_loss(self.hidden, self.weight, self.bias, labels, ignore_index)

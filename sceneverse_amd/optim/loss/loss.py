@@ -68,6 +68,8 @@ def lm_cls_loss(data_dict):                                 # ref :56-61
     if labels.dim() == 3:
         labels = labels.view(-1, labels.size(-1))
     logits = data_dict["txt_lm_cls_logits"]
+    if hasattr(logits, "materialize"):          # LazyLMLogits: loss over the labelled rows, no (B, L, vocab) tensor
+        return logits.loss(labels, ignore_index=-1)
     if logits.is_cuda and logits.dtype in (torch.bfloat16, torch.float32):
         # row-sparse kernel: ignored positions (> 90 % of the rows) are never read
         from .masked_ce import masked_cross_entropy

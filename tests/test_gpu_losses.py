@@ -46,3 +46,38 @@ def test_lm_cls_loss_uses_it_and_handles_3d_labels():
     assert "masked_ce_forward" in rec
     ref = F.cross_entropy(logits.float().permute(0, 2, 1), labels, ignore_index=-1)
     assert abs(val.item() - ref.item()) < 1e-4
+
+
+@pytest.mark.parametrize("n,V,frac", [(3200, 30522, 0.15), (130, 607, 0.5), (640, 30522, 0.0), (256, 1000, 1.0)])
+def test_fused_lm_head_loss_matches_linear_plus_cross_entropy(n, V, frac):
+    """sparse_lm_loss (labelled rows only: permutation + device-side extents in the three GEMMs) against
+    F.cross_entropy(F.linear(h, W, b), labels, ignore_index=-1) on the same bf16-rounded operands: loss and the
+    gradients of h, W, b (rows without a label get exactly zero)."""
+    from sceneverse_amd.optim.loss.fused_lm_loss import sparse_lm_loss
+    D = 768
+    g = torch.Generator().manual_seed(n + V)
+    h = (torch.randn(n, D, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(V, D, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = (torch.randn(V, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, V, (n,), generator=g)
+    labels[torch.rand(n, generator=g) >= frac] = -1
+    labels = labels.to(DEV)
+    hf = h.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = sparse_lm_loss(hf, w, b, labels, -1)
+    if frac == 0.0:
+        assert torch.isnan(loss).item()                     # no labelled token: 0 / 0 like F.cross_entropy
+        return
+    loss.backward()
+    gh, gw, gb = hf.grad.float(), w.grad.clone(), b.grad.clone()
+    w.grad = b.grad = None
+    hr = h.float().clone().requires_grad_(True)
+    ref = F.cross_entropy(F.linear(hr, w.to(torch.bfloat16).float(), b), labels, ignore_index=-1)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-3 * abs(ref.item()) + 1e-4, (loss.item(), ref.item())
+
+    def rel(a, r):
+        return ((a - r).norm() / (r.norm() + 1e-12)).item()
+    assert rel(gh, hr.grad) <= 2e-2 and rel(gw, w.grad) <= 2e-2 and rel(gb, b.grad) <= 2e-2, \
+        (rel(gh, hr.grad), rel(gw, w.grad), rel(gb, b.grad))
+    assert gh[labels < 0].abs().max().item() == 0.0 if (labels < 0).any() else True

@@ -56,6 +56,9 @@ if [[ $WHAT == *gemmpmc* ]]; then
   done
   tail -n 12 $OUT/pmc_*.txt
 fi
+if [[ $WHAT == *losstest* ]]; then
+  ts losstest; timeout 600 python -m pytest tests/test_gpu_losses.py tests/test_gpu_model.py tests/test_gpu_optim.py tests/test_gpu_gemm.py -m gpu -q -x > $OUT/pytest_loss.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_loss.log; tail -8 $OUT/pytest_loss.log | cut -c1-300
+fi
 if [[ $WHAT == *attntest* ]]; then
   ts attntest; timeout 600 python -m pytest tests/test_gpu_attention.py tests/test_gpu_model.py tests/test_a16_vs_golden.py -m gpu -q -x > $OUT/pytest_attn.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_attn.log; tail -8 $OUT/pytest_attn.log | cut -c1-300
 fi
