@@ -91,11 +91,20 @@ __device__ __forceinline__ u32x2 pack4(const f32x4 &v) {     // v_cvt_pk_bf16_f3
   return __builtin_bit_cast(u32x2, h);
 }
 // counter-based dropout RNG shared with gps_layernorm.hip / gps_attention.hip (splitmix64 finaliser)
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {      // 32-bit avalanche hash ("lowbias32" constants)
+  x ^= x >> 16;
+  x *= 0x21F0AAADu;
+  x ^= x >> 15;
+  x *= 0x735A2D97u;
+  x ^= x >> 15;
+  return x;
+}
+// counter-based dropout stream: forward and backward draw the same bits for the same (seed, element index); the seed
+// part is wave-uniform (scalar unit), the element part costs 2 multiplies and 3 xor-shifts (the 64-bit splitmix of
+// the first version: ~30 vector instructions per element)
 __device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (unsigned int)((z ^ (z >> 31)) >> 32);
+  const unsigned int s = mix32((unsigned int)seed ^ mix32((unsigned int)(seed >> 32) + 0x9E3779B9u));
+  return mix32(((unsigned int)idx + (unsigned int)(idx >> 32) * 0x85EBCA6Bu) ^ s);
 }
 // erf GELU (the reference's F.gelu / HF "gelu") and its derivative.  erf through Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the bf16 rounding of the result) so that the epilogue costs ~15 VALU per element
@@ -647,15 +656,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long lon
   if ((int)blockIdx.x < main_blocks) {
     const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= elems) return;
-    f32x4 s = *reinterpret_cast<const f32x4 *>(partial + e);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(partial + (size_t)k * elems + e);
+    // the partial tiles of up to 16 splits are requested together (independent loads in flight, not one memory round
+    // trip per split) and then added in split order
+    f32x4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      v[k] = k < splits ? *reinterpret_cast<const f32x4 *>(partial + (size_t)k * elems + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += v[k];
+    for (int k = 16; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(partial + (size_t)k * elems + e);
     const long long r = e / ncols, c = e - r * ncols;
     *reinterpret_cast<f32x4 *>(out + r * ldo + c) = s;
   } else {
     const int m = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
     if (m >= m_rows) return;
-    float s = colsum_partial[m];
-    for (int k = 1; k < splits; ++k) s += colsum_partial[(size_t)k * m_rows + m];
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = k < splits ? colsum_partial[(size_t)k * m_rows + m] : 0.f;
+    float s = w[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += w[k];
+    for (int k = 16; k < splits; ++k) s += colsum_partial[(size_t)k * m_rows + m];
     colsum_out[m] = s;
   }
 }

@@ -25,21 +25,28 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxIter = 8;          // D <= 8 * 256 (ITERS = D / 256 is a template parameter)
 
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {      // 32-bit avalanche hash ("lowbias32" constants)
+  x ^= x >> 16;
+  x *= 0x21F0AAADu;
+  x ^= x >> 15;
+  x *= 0x735A2D97u;
+  x ^= x >> 15;
+  return x;
+}
+// counter-based dropout stream: forward and backward draw the same bits for the same (seed, element index); the seed
+// part is wave-uniform (scalar unit), the element part costs 2 multiplies and 3 xor-shifts (the 64-bit splitmix of
+// the first version: ~30 vector instructions per element)
 __device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (unsigned int)((z ^ (z >> 31)) >> 32);
+  const unsigned int s = mix32((unsigned int)seed ^ mix32((unsigned int)(seed >> 32) + 0x9E3779B9u));
+  return mix32(((unsigned int)idx + (unsigned int)(idx >> 32) * 0x85EBCA6Bu) ^ s);
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  unsigned int u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f2bf(float f) {      // round to nearest even (v_cvt_pk_bf16_f32)
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
 // 4 consecutive elements at p (element index e0), as fp32
 __device__ __forceinline__ float4 load4(const float *p, size_t e0) {
@@ -126,7 +133,8 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
 
 // dx = dz, dh = dz * keep * scale, partial dgamma/dbeta per workgroup ([gridDim.x][d] each)
 template <typename TX, typename TH, int ITERS>
-__global__ __launch_bounds__(kBlock) void add_dropout_ln_bwd_kernel(
+__global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd_kernel(   // d <= 768: 4 waves per SIMD
+   
     int n_rows, int d, const TX *__restrict__ dy, const uint16_t *__restrict__ dy16, const TX *__restrict__ x,
     const TH *__restrict__ h, const float *__restrict__ gamma, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, float p_drop, unsigned int thr, unsigned long long seed,
