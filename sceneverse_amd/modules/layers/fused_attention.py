@@ -52,7 +52,10 @@ class _FusedSelfAttention(torch.autograd.Function):
         if spatial:
             pl = pl.float().contiguous()
             assert pl.shape == (B, L, L, 5), pl.shape
-        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        # a bool tensor is one byte per element holding 0 / 1: the kernels read it in place (no conversion launch)
+        m8 = None
+        if mask is not None:
+            m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
         out = torch.empty((B, L, D), dtype=torch.bfloat16, device=packed.device)
         lse = torch.empty((B, n_head, L), dtype=torch.float32, device=packed.device)
         base, esz = packed.data_ptr(), packed.element_size()
