@@ -71,10 +71,16 @@ class OpenVocab(_GPSBase):
             data_dict['cur_step'] = 1
             data_dict['total_steps'] = 1
 
-        txt = self.lang_encoder(data_dict['txt_ids'], data_dict['txt_masks'])
-        if self.use_scene_cap:
-            scene_txt = self.lang_encoder(data_dict['scene_txt_ids'], data_dict['scene_txt_masks'])
+        if self.use_scene_cap and hasattr(self.lang_encoder, "forward_pair"):
+            # the sentence and the scene caption go through the text encoder's layers as one row batch
+            txt, scene_txt = self.lang_encoder.forward_pair(data_dict['txt_ids'], data_dict['txt_masks'],
+                                                            data_dict['scene_txt_ids'], data_dict['scene_txt_masks'])
             data_dict['scene_text_embed'] = scene_txt[:, 0]
+        else:
+            txt = self.lang_encoder(data_dict['txt_ids'], data_dict['txt_masks'])
+            if self.use_scene_cap:
+                scene_txt = self.lang_encoder(data_dict['scene_txt_ids'], data_dict['scene_txt_masks'])
+                data_dict['scene_text_embed'] = scene_txt[:, 0]
 
         obj, obj_pre, obj_cls_raw = self._encode_objects(data_dict)
         if self.use_scene_cap:

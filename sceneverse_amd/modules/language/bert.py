@@ -57,18 +57,34 @@ class BERTLanguageEncoder(nn.Module):
                 and getattr(cfg, "position_embedding_type", "absolute") == "absolute")
 
     def _fast_forward(self, txt_ids, txt_masks):
+        return self._fast_forward_multi([(txt_ids, txt_masks)])[0]
+
+    def _fast_forward_multi(self, texts):
+        """texts = [(ids (B_i, L_i), masks (B_i, L_i)), ...] -> [last hidden state (B_i, L_i, D), ...].
+        Every row-wise operation of a layer (QKV / output / FFN GEMMs, residual + LayerNorm) runs ONCE over the
+        token rows of all texts together -- the weights are the same, the rows independent -- and only the attention
+        core runs per text (its own length and padding mask).  One text: the reference's call.  Two (the sentence
+        and the 300-token scene caption of the pre-train step): the 3 200-row GEMMs of the short text, which alone
+        fill a fraction of the chip, ride along with the 19 200-row ones, and each parameter gets ONE gradient
+        instead of two that autograd then adds."""
         from ..layers import gemm
         from ..layers.fused_attention import fused_self_attention, supported as attn_supported
         from ..layers.fused_norm import add_dropout_layer_norm
         from . import fused_embedding
         m, H = self.model, self.bert_config.num_attention_heads
-        if _FAST_EMB and fused_embedding.supported(m.embeddings, txt_ids):
-            x = fused_embedding.bert_embeddings(m.embeddings, txt_ids)      # same values, sort-free backward
-        else:
-            x = m.embeddings(input_ids=txt_ids)                 # (B, L, D) fp32 under autocast
+        xs, shapes, pads = [], [], []
+        for ids, masks in texts:
+            if _FAST_EMB and fused_embedding.supported(m.embeddings, ids):
+                e = fused_embedding.bert_embeddings(m.embeddings, ids)      # same values, sort-free backward
+            else:
+                e = m.embeddings(input_ids=ids)                 # (B, L, D) fp32 under autocast
+            shapes.append(e.shape)
+            xs.append(e.reshape(-1, e.shape[-1]))
+            pads.append(masks == 0)
+        D = xs[0].shape[-1]
+        rows = [t.shape[0] for t in xs]
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)         # (sum of B_i L_i, D): the row batch of every GEMM / LN
         x16 = x                                                 # bf16 copy of x once a fused LN made one
-        B, L, D = x.shape
-        pad = txt_masks == 0
         training = self.training
         for layer in m.encoder.layer:
             sa, so = layer.attention.self, layer.attention.output
@@ -80,14 +96,20 @@ class BERTLanguageEncoder(nn.Module):
                     w = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0)
                     b = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0)
                     packed = F.linear(x16, w, b)
-                if attn_supported(D, H, L):
-                    ctx = fused_self_attention(packed, H, None, pad, dropout_p=sa.dropout.p, training=training)
-                else:   # long captions: torch SDPA (flash) on views of the packed projection
-                    q, k, v = packed.view(B, L, 3, H, D // H).permute(2, 0, 3, 1, 4)
-                    ctx = F.scaled_dot_product_attention(
-                        q, k, v, attn_mask=pad.logical_not()[:, None, None, :],
-                        dropout_p=sa.dropout.p if training else 0.0)
-                    ctx = ctx.transpose(1, 2).reshape(B, L, D)
+                ctxs, r0 = [], 0
+                for (B, L, _), pad, n in zip(shapes, pads, rows):
+                    pk = packed[r0:r0 + n].view(B, L, 3 * D)
+                    r0 += n
+                    if attn_supported(D, H, L):
+                        c = fused_self_attention(pk, H, None, pad, dropout_p=sa.dropout.p, training=training)
+                    else:   # beyond the fused core's length limit: torch SDPA on views of the packed projection
+                        q, k, v = pk.view(B, L, 3, H, D // H).permute(2, 0, 3, 1, 4)
+                        c = F.scaled_dot_product_attention(
+                            q, k, v, attn_mask=pad.logical_not()[:, None, None, :],
+                            dropout_p=sa.dropout.p if training else 0.0)
+                        c = c.transpose(1, 2).reshape(B, L, D)
+                    ctxs.append(c.reshape(n, D))
+                ctx = ctxs[0] if len(ctxs) == 1 else torch.cat(ctxs, 0)
                 attn_out = gemm.linear(ctx, so.dense.weight, so.dense.bias) if native else so.dense(ctx)
                 x, x16 = add_dropout_layer_norm(x, attn_out, so.LayerNorm, so.dropout.p, training, want_bf16=True)
                 if native:      # dense + GELU + dense as two GEMMs with fused epilogues (HF: no dropout in between)
@@ -97,7 +119,19 @@ class BERTLanguageEncoder(nn.Module):
                     ffn_out = layer.output.dense(inter)
                 x, x16 = add_dropout_layer_norm(x, ffn_out, layer.output.LayerNorm,
                                                 layer.output.dropout.p, training, want_bf16=True)
-        return x
+        outs, r0 = [], 0
+        for shp, n in zip(shapes, rows):
+            outs.append(x[r0:r0 + n].view(shp))
+            r0 += n
+        return outs
+
+    def forward_pair(self, ids_a, masks_a, ids_b, masks_b):
+        """Both texts of a pre-train pair through ONE walk of the encoder stack (see _fast_forward_multi); without
+        the fast path: two plain calls, as the reference makes them (model/openvocab.py:34-40)."""
+        if self._fast_ok(ids_a) and self._fast_ok(ids_b):
+            a, b = self._fast_forward_multi([(ids_a, masks_a), (ids_b, masks_b)])
+            return a, b
+        return self.forward(ids_a, masks_a), self.forward(ids_b, masks_b)
 
     def forward(self, txt_ids, txt_masks, **kwargs):
         if self._fast_ok(txt_ids):
