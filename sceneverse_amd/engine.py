@@ -256,10 +256,7 @@ class GPSTrainStep:
                 self._clip_and_step()
             self._graph, self._graph_out = (g1, g2, g3), (out, total, losses)
         else:
-            for k, v in tensors.items():
-                buf = self._static[k]
-                if buf.data_ptr() != v.data_ptr():
-                    buf.copy_(v, non_blocking=True)
+            self._fill_static(tensors)
         g1, g2, g3 = self._graph
         out, total, losses = self._graph_out
         g1.replay()
@@ -324,13 +321,25 @@ class GPSTrainStep:
                 total, losses = self._eager_body(static_dict)
             self._graph, self._graph_out = g, (total, losses)
         else:
-            for k, v in tensors.items():
-                buf = self._static[k]
-                if buf.data_ptr() != v.data_ptr():
-                    buf.copy_(v, non_blocking=True)
+            self._fill_static(tensors)
         self._graph.replay()
         total, losses = self._graph_out
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
+
+    def _fill_static(self, tensors) -> None:
+        """Copy a batch into the buffers the captured graph reads.  The graph was captured for ONE set of keys,
+        shapes and dtypes: anything else (a smaller last batch, a missing or extra tensor) would replay stale or
+        broadcast data, so it is an error here, not a silent copy."""
+        if tensors.keys() != self._static.keys():
+            raise ValueError("HIP-graph step: the batch has tensor keys "
+                             f"{sorted(tensors.keys() ^ self._static.keys())} that differ from the captured batch")
+        for k, v in tensors.items():
+            buf = self._static[k]
+            if v.shape != buf.shape or v.dtype != buf.dtype:
+                raise ValueError(f"HIP-graph step: batch['{k}'] is {tuple(v.shape)} {v.dtype}, the graph was captured "
+                                 f"for {tuple(buf.shape)} {buf.dtype} (drop the last partial batch or use graph=False)")
+            if buf.data_ptr() != v.data_ptr():
+                buf.copy_(v, non_blocking=True)
 
     def step(self, data_dict):
         """One optimisation step; returns (total_loss tensor, dict of loss tensors).  No host sync."""

@@ -1,6 +1,8 @@
 """Row-sparse cross-entropy on libgps_hip.so (gps_masked_ce_forward/backward): the masked-LM loss of
 the reference (optim/loss/loss.py:56-61) without touching the > 90 % of rows whose label is
-`ignore_index`.  GPU tensors only; `lm_cls_loss` keeps F.cross_entropy for CPU tensors."""
+`ignore_index`.  GPU tensors only; `lm_cls_loss` keeps F.cross_entropy for CPU tensors.
+Deviation from F.cross_entropy: a label outside [0, V) that is not `ignore_index` is treated as ignored (the kernels
+must not index outside the row) where torch raises a device assert; the data pipeline only produces -1 or valid ids."""
 from __future__ import annotations
 
 import torch

@@ -132,6 +132,8 @@ class _PointnetSAModuleBase(nn.Module):
         and the tensors live on the GPU, else None (the caller runs the op-by-op path)."""
         if not (_FUSED_SA and xyz.is_cuda and _is_frozen(mlp)):
             return None
+        if torch.is_grad_enabled() and (xyz.requires_grad or (features is not None and features.requires_grad)):
+            return None          # an earlier (trainable) level wants input gradients: the fused level computes none
         ext = pointnet2_utils._ext
         if isinstance(grouper, pointnet2_utils.QueryAndGroup):
             plain = not (grouper.sample_uniformly or grouper.normalize_xyz or grouper.ret_grouped_xyz
