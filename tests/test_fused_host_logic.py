@@ -3,6 +3,7 @@
   * the frozen/unfrozen decision and the cache key of the folded weights;
   * CPU tensors never reach the fused GPU-only wrappers (torch formulation is used);
   * the between-batch losses' gather protocol used by the split-graph data-parallel engine."""
+import pytest
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -210,3 +211,34 @@ def test_bench_rank_resolution_rules():
     cmd = bench.spawn_command(["--gpus", "4", "--steps", "3"], 4, 29511)
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+
+
+def test_graph_step_rejects_batches_that_do_not_match_the_capture():
+    """GPSTrainStep._fill_static: same keys, shapes and dtypes as the captured batch, or a clear error."""
+    import types
+
+    from sceneverse_amd.engine import GPSTrainStep
+    eng = types.SimpleNamespace(_static={"a": torch.zeros(4, 3), "b": torch.zeros(4, dtype=torch.int64)})
+    fill = lambda t: GPSTrainStep._fill_static(eng, t)  # noqa: E731
+    fill({"a": torch.ones(4, 3), "b": torch.arange(4)})
+    assert torch.equal(eng._static["a"], torch.ones(4, 3)) and torch.equal(eng._static["b"], torch.arange(4))
+    with pytest.raises(ValueError, match="keys"):
+        fill({"a": torch.ones(4, 3)})
+    with pytest.raises(ValueError, match="captured"):
+        fill({"a": torch.ones(2, 3), "b": torch.arange(4)})                # a smaller last batch
+    with pytest.raises(ValueError, match="captured"):
+        fill({"a": torch.ones(4, 3), "b": torch.arange(4).float()})
+
+
+def test_weight_gradient_split_rule_fills_one_resident_round():
+    """gps_gemm_pick_splits: largest split count with tiles * splits <= 512 resident workgroups and >= 8 stages per
+    split (profiles/r2/split_sweep.json)."""
+    from sceneverse_amd import _native
+    lib = _native.load()
+    pick = lambda M, N, K: lib.gps_gemm_pick_splits(_native.GEMM_TN, M, N, K)  # noqa: E731
+    assert pick(768, 768, 19200) == 14 and pick(768, 2048, 8320) == 5 and pick(768, 2304, 19200) == 4
+    assert pick(768, 3072, 19200) == 3 and pick(768, 768, 3200) == 6 and pick(30528, 768, 3200) == 1
+    for M, N, K in ((768, 768, 19200), (2376, 768, 5120), (768, 3072, 22400)):
+        s = pick(M, N, K)
+        tiles = -(-M // 128) * -(-N // 128)
+        assert tiles * s <= 512 and (K + 63) // 64 // s >= 8
