@@ -1,7 +1,7 @@
 // gps_gemm_layout.h -- LDS image and fragment index maps of the bf16 MFMA GEMM (gps_gemm.hip).
 //
 // Kept free of HIP constructs so that the SAME functions are compiled for the device (hipcc) and for the host
-// emulation that checks them end to end on a CPU (tests/test_gemm_layout.py builds tools/gemm_layout_emu.cpp
+// emulation that checks them end to end on a CPU (tests/test_gemm_layout.py builds tools/gemm_layout_shim.cpp
 // with g++): stage map -> LDS image -> fragment reads -> MFMA lane semantics -> C = op(A) op(B).
 //
 // One K step of a workgroup tile stages BK = 64 reduction indices of both operands into LDS with

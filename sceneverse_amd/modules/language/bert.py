@@ -11,7 +11,7 @@ from ..build import LANGUAGE_REGISTRY
 
 # GPU fast path of the encoder stack: the HuggingFace PARAMETERS and embedding
 # block are used as they are, but each BertLayer runs as
-#   one packed QKV GEMM -> fused attention core (libgps_hip.so; torch SDPA above 256 tokens)
+#   one packed QKV GEMM -> fused attention core (libgps_hip.so, up to 512 tokens; torch SDPA beyond)
 #   -> dense -> fused residual+dropout+LayerNorm -> dense+GELU -> dense -> fused residual+dropout+LN
 # instead of HF's op-by-op formulation (3 projection GEMMs, separate dropout/add/LayerNorm/casts).
 # Same mathematics as transformers.models.bert.modeling_bert.BertLayer (post-norm, exact GELU,
