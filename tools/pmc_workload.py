@@ -76,7 +76,7 @@ def main():
     # the optimizer pass; tools/pmc_traffic.py tells the launches of one kernel symbol apart by their grid size
     from sceneverse_amd import _native
     from sceneverse_amd.modules.layers import gemm as GM
-    T, K, N = 19200, 768, 3072
+    T, K, N = 22400, 768, 3072          # token rows of both BERT texts (3 200 + 19 200) in one GEMM
     x = torch.randn(T, K, device=dev).to(torch.bfloat16)
     w = (0.02 * torch.randn(N, K, device=dev)).to(torch.bfloat16)
     b = torch.randn(N, device=dev)
