@@ -242,3 +242,45 @@ def test_weight_gradient_split_rule_fills_one_resident_round():
         s = pick(M, N, K)
         tiles = -(-M // 128) * -(-N // 128)
         assert tiles * s <= 512 and (K + 63) // 64 // s >= 8
+
+
+def test_lazy_lm_logits_and_head_switch_on_cpu():
+    """The masked-LM head only hands out LazyLMLogits inside the engine's context, in training mode, on the GPU;
+    on the CPU (and in eval mode) it stays the reference's dense tensor.  materialize() is that tensor."""
+    from sceneverse_amd.modules.heads import pretrain_head as PH
+    from sceneverse_amd.optim.loss.fused_lm_loss import LazyLMLogits
+    torch.manual_seed(0)
+    head = PH.BertLMPredictionHead(32, 50)
+    h = torch.randn(2, 5, 32)
+    dense = head(h)
+    assert torch.is_tensor(dense) and dense.shape == (2, 5, 50)
+    with PH.fused_lm_loss(True):
+        assert torch.is_tensor(head(h))                      # CPU tensors: never lazy
+        assert PH._FUSED_LM_LOSS is True
+    assert PH._FUSED_LM_LOSS is False
+    lazy = LazyLMLogits(head.transform(h), head.decoder.weight, head.bias)
+    assert lazy.shape == (2, 5, 50)
+    torch.testing.assert_close(lazy.materialize(), dense)
+
+
+def test_padded_shadow_rows_and_optimizer_targets():
+    """shadow_of(pad_rows=8): zero rows behind the data, a padded fp32 bias copy, and optimizer targets that cover
+    exactly the parameter's own rows (the clip + AdamW kernel writes them with the masters)."""
+    import gc
+
+    from sceneverse_amd.modules.layers import gemm as G
+    G.clear_shadows()
+    lin = torch.nn.Linear(16, 13)
+    w16, b32 = G.shadow_of([lin.weight], [lin.bias], pad_rows=8)
+    assert w16.shape == (16, 16) and b32.shape == (16,)
+    assert torch.equal(w16[:13], lin.weight.to(torch.bfloat16)) and w16[13:].abs().sum() == 0 and b32[13:].abs().sum() == 0
+    tg = G.shadow_targets()
+    assert tg[id(lin.weight)][0].shape == (13, 16) and tg[id(lin.bias)][1].shape == (13,)
+    assert tg[id(lin.weight)][0].data_ptr() == w16.data_ptr() and tg[id(lin.bias)][1].data_ptr() == b32.data_ptr()
+    with torch.no_grad():
+        lin.weight.add_(1.0)                                # in-place update bumps the version: refreshed at next use
+    w16b, _ = G.shadow_of([lin.weight], [lin.bias], pad_rows=8)
+    assert w16b.data_ptr() == w16.data_ptr() and torch.equal(w16b[:13], lin.weight.to(torch.bfloat16))
+    del lin
+    gc.collect()
+    G.clear_shadows()
