@@ -75,13 +75,13 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
          ldaux: int = 0, aux_out: Optional[torch.Tensor] = None, ldaux_out: int = 0,
          workspace: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, p_drop: float = 0.0,
          seed_dev: Optional[torch.Tensor] = None, splits: int = 1, variant: Optional[int] = None,
-         ablate: int = 0, extent_dev: Optional[torch.Tensor] = None) -> None:
+         extent_dev: Optional[torch.Tensor] = None) -> None:
     """Thin checked call of gps_gemm_bf16 on the current stream (shapes in the header's convention)."""
     a = GemmArgs()
     a.form, a.epilogue, a.M, a.N, a.K = form, epilogue, M, N, K
     a.splits = splits
     a.variant = _VARIANT[form] if variant is None else variant
-    a.reserved = ablate
+    a.reserved = 0
     a.A, a.lda, a.B, a.ldb, a.C, a.ldc = A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc
     a.bias = _ptr(bias)
     a.aux, a.ldaux, a.aux_out, a.ldaux_out = _ptr(aux), ldaux, _ptr(aux_out), ldaux_out

@@ -59,7 +59,6 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--only", type=int, default=-1, help="index into LAYERS: time just that layer")
-    ap.add_argument("--ablate", action="store_true", help="time variants 0/7 of the big forward shape with the copies or MFMAs skipped")
     ap.add_argument("--split-sweep", action="store_true", help="weight-gradient form: time every split count 1..20")
     ap.add_argument("--pmc-loop", default=None,
                     help="form:variant -- run ONE kernel configuration of layer --only 30 times (for rocprofv3 --pmc)")
@@ -68,18 +67,6 @@ def main():
     lib = _native.load()
     out = []
     layers = LAYERS if args.only < 0 else [LAYERS[args.only]]
-    if args.ablate:
-        for T, K, N in [(19200, 768, 2304), (8320, 768, 2048)]:
-            x = torch.randn(T, K, device=dev).to(torch.bfloat16)
-            w = (0.02 * torch.randn(N, K, device=dev)).to(torch.bfloat16)
-            y = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
-            fns = {}
-            for v in (0, 7, 4, 5):
-                for ab in (0, 1, 2, 3):
-                    fns[f"v{v}_ab{ab}"] = (lambda v=v, ab=ab: G.gemm(_native.GEMM_NT, _native.EPI_BIAS, T, N, K, x, K, w, K, y, N, variant=v, ablate=ab))
-            t = timeit(fns, args.rounds)
-            print(json.dumps({"shape": [T, K, N], "us": {k: round(v, 1) for k, v in t.items()}}), flush=True)
-        return
     if args.split_sweep:
         res = []
         for T, K, N in layers:

@@ -39,9 +39,6 @@ if [[ $WHAT == *pointtest* ]]; then
   ts pointtest; timeout 900 python -m pytest tests/test_gpu_point_ops.py tests/test_gpu_vs_reference_ext.py tests/test_gpu_sa_fused.py -m gpu -q > $OUT/pytest_point.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_point.log
   tail -8 $OUT/pytest_point.log
 fi
-if [[ $WHAT == *ablate* ]]; then
-  ts ablate; timeout 300 python tools/gemm_bench.py --ablate > $OUT/gemm_ablate.log 2>&1; tail -4 $OUT/gemm_ablate.log
-fi
 if [[ $WHAT == *gemmpmc* ]]; then
   ts gemmpmc
   rocprofv3 -L > $OUT/pmc_list.txt 2>&1
