@@ -385,10 +385,9 @@ def main() -> None:
     torch.cuda.set_device(dev)
 
     cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world, workload=args.config)
-    # One GPU: the whole step as one HIP graph.  N > 1: torch DDP in eager mode -- since the BERT stack
-    # moved onto the fused kernels the eager step is GPU-bound too (28.6 ms eager vs 28.0 ms graph on one
-    # GPU), and DDP overlaps the 491 MB gradient all-reduce with backward, which the split-graph form
-    # (--graph-dp: 3 graphs around eager RCCL collectives, all-reduce exposed) cannot.
+    # One GPU: the whole step as one HIP graph (19.3 ms).  N > 1: torch DDP in eager mode (20.6 ms on one GPU):
+    # DDP overlaps the gradient all-reduce (246 MB as bf16) with backward, which the split-graph form
+    # (--graph-dp: 3 graphs around eager RCCL collectives, 20.1 ms + an exposed 491 MB fp32 all-reduce) cannot.
     use_graph = (world == 1 and not args.no_graph) or args.graph_dp
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
                         graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm)
