@@ -14,17 +14,16 @@ weights; inputs are resident in HBM before the timed region.  Weak scaling: per-
 `--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N
 ranks (reference behaviour: common/launch_utils.py:26-42); a WORLD_SIZE that disagrees with --gpus is an error.
 
-The single JSON line also carries
-  roofline      the kernel with the largest time per step among ALL kernels of the step (native launches by
+The single JSON line (< 4 KB, last line of stdout) also carries
+  roofline      the kernel family with the largest time per step among ALL kernels of the step (native launches by
                 HIP events, everything else by a torch.profiler pass): ALGORITHMIC flops (or bytes) / measured
-                duration vs the dense MFMA peak of its dtype (or 8 TB/s); executed-MFMA utilisation of the
-                split-bf16 point kernels is reported separately as `mfma_utilisation`
+                duration vs the dense MFMA peak of its dtype (or 8 TB/s), + PMC HBM traffic of its largest shape
   headline      the north-star fractions: unfused ball_query+group vs the HBM roof (the six launches of the
-                reference API timed here), in-scope transformer FLOPs vs the bf16 MFMA peak, attention core
-  kernels       per launch shape of libgps_hip.so: time, algorithmic work, roof fraction
-  step_kernels  top kernels of the whole step by time (torch.profiler), native or not
-  cpu_baseline  the oracle port (oracle/gps_torch_reference.py + C point ops + HF BERT, fp32, all
-                host cores) timed on a bounded sample of the same workload (rank 0, N=1 only)
+                reference API timed here), all native GEMMs and the attention core vs the bf16 MFMA peak
+  cpu_baseline  the oracle port (oracle/gps_torch_reference.py + C point ops + HF BERT, fp32, min(64, host cores)
+                threads) timed on a bounded sample of the same workload (rank 0, N=1 only)
+and gpurun_out/bench_detail.json (--detail PATH) holds what does not fit the line: `kernels` (per launch shape of
+libgps_hip.so: time, algorithmic work, roof fraction), `kernel_families`, `step_kernels` (torch.profiler's top kernels).
 """
 from __future__ import annotations
 
@@ -56,6 +55,29 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, same guide
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")   # rocprofv3 --pmc, see tools/pmc_traffic.py
 N_CLS = 607
+MAX_LINE_BYTES = 4000   # the driver keeps the last ~8 KB of stdout: the final JSON line must fit with room to spare
+
+
+def final_line(result: dict) -> str:
+    """The ONE JSON line the driver parses (last line of stdout), bounded in size."""
+    line = json.dumps(result)
+    if len(line) >= MAX_LINE_BYTES:
+        raise RuntimeError(f"bench line is {len(line)} bytes; the driver keeps only the last ~8 KB of stdout -- move "
+                           f"detail into write_detail()")
+    return line
+
+
+def write_detail(detail: dict, path=None) -> None:
+    """Per-launch-shape rows, kernel families and the profiler's view of the step: too large for the one JSON line the
+    driver parses, so they go to a file (default gpurun_out/bench_detail.json, merged back by gpurun)."""
+    path = path or os.environ.get("GPS_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        print(f"[bench] per-kernel detail written to {path}", file=sys.stderr)
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e}", file=sys.stderr)
 
 
 # workload presets: BASELINE.json configs[1] (default), configs[3] and configs[4]
@@ -179,38 +201,33 @@ def _cpu_baseline_inproc(batch_size: int, steps: int, n_obj: int, n_pts: int, th
     steps = done
     dt = time.perf_counter() - t0
     return {"value": batch_size * steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of the same fwd+loss+bwd+AdamW step at B={batch_size} "
-                      f"({n_obj} obj x {n_pts} pts, 50+300 tokens), fp32, torch {torch.__version__} "
-                      f"on {cores} host threads, after 1 warm-up step; {dt:.1f} s"}
+            "sample": f"{steps} steps of the same step at B={batch_size} ({n_obj} obj x {n_pts} pts, 50+300 tokens), "
+                      f"fp32 torch on {cores} threads, 1 warm-up; {dt:.1f} s"}
 
 
 def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
-    """Runs the CPU baseline in a child process with a wall-clock bound: first on ALL host cores; if that does not
-    finish in time (256 torch threads can thrash on the small operators of this model), once more on 64 threads.
-    The returned record says which of the two it is (`cores`)."""
+    """Runs the CPU baseline in a child process with a wall-clock bound, on min(64, host cores) torch threads: with all
+    256 threads of the GPU box's host the small operators of this model thrash and the sample does not finish in
+    120 s (measured in round 2), so that attempt only runs when GPS_CPU_BASELINE_THREADS asks for it.  The returned
+    record says how many threads were used (`cores`) and how many the host has (`host_cores`)."""
     import subprocess
     total = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    tries = [(int(os.environ.get("GPS_CPU_BASELINE_THREADS", str(total))), 120.0)]
-    if tries[0][0] > 64:
-        tries.append((64, 150.0))
-    note = []
-    for threads, limit in tries:
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
-               json.dumps([batch_size, steps, n_obj, n_pts, threads])]
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and lines:
-                out = json.loads(lines[-1])
-                out["host_cores"] = total
-                if note:
-                    out["note"] = "; ".join(note)
-                return out
-            note.append(f"{threads} threads: worker failed ({r.stderr[-200:]!r})")
-        except subprocess.TimeoutExpired:
-            note.append(f"{threads} threads: no result within {limit:.0f} s")
+    threads = int(os.environ.get("GPS_CPU_BASELINE_THREADS", str(min(64, total))))
+    limit = float(os.environ.get("GPS_CPU_BASELINE_LIMIT_S", "150"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
+           json.dumps([batch_size, steps, n_obj, n_pts, threads])]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            out = json.loads(lines[-1])
+            out["host_cores"] = total
+            return out
+        note = f"{threads} threads: worker failed ({r.stderr[-200:]!r})"
+    except subprocess.TimeoutExpired:
+        note = f"{threads} threads: no result within {limit:.0f} s"
     return {"value": None, "unit": "pairs/s", "cores": None, "kind": "port", "sample": "not measured", "host_cores": total,
-            "note": "; ".join(note)}
+            "note": note}
 
 
 def _free_port() -> int:
@@ -346,6 +363,9 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--detail", default=None, help="where the per-kernel detail JSON goes (default gpurun_out/bench_detail.json)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="attention-core products (QK^T, PV) on the OCP e4m3 MFMA path (BASELINE configs[4]: --config stress --fp8)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the reporting-only passes after the timed region (profiler, unfused point-op timing)")
     args = ap.parse_args()
@@ -540,11 +560,14 @@ def main() -> None:
         if dom is not None and os.path.exists(PMC_TRAFFIC):
             with open(PMC_TRAFFIC) as f:
                 per_launch = json.load(f).get("per_launch_hbm_bytes", {})
-            # PMC traffic is recorded per launch shape: report the largest shape of the family that has an entry
-            for r in kernels:
-                if family(r["kernel"]) == dom["kernel"] and r["kernel"] in per_launch:
-                    traffic = {"shape": r["kernel"], "hbm_bytes": per_launch[r["kernel"]], "algorithmic_bytes": r["algorithmic_bytes"]}
-                    break
+            # PMC traffic is recorded per launch shape (tools/pmc_workload.py): report the shape of the family with the
+            # largest time per step that has an entry; the counters are from the committed rocprofv3 --pmc passes
+            cands = [r for r in kernels if family(r["kernel"]) == dom["kernel"] and r["kernel"] in per_launch]
+            if cands:
+                r = max(cands, key=lambda r_: r_["ms_per_step"])
+                traffic = {"shape": r["kernel"], "hbm_bytes": per_launch[r["kernel"]], "algorithmic_bytes": r["algorithmic_bytes"],
+                           "ratio": round(per_launch[r["kernel"]] / max(1, r["algorithmic_bytes"]), 3),
+                           "source": os.path.relpath(PMC_TRAFFIC, ROOT)}
         if dom is None:
             roofline = None
         elif dom_other is not None and dom_other["ms_per_step"] > dom["ms_per_step"]:
@@ -560,9 +583,8 @@ def main() -> None:
                         "dtype": dom["mfma_dtype"], "traffic": traffic, "ms_per_step": round(dom["ms_per_step"], 4),
                         "launches_per_step": dom["launches_per_step"], "avg_us": dom["avg_us"], "shapes": dom["shapes"],
                         **({"mfma_utilisation": dom["mfma_utilisation"]} if "mfma_utilisation" in dom else {}),
-                        **({"note": "weight + bias gradient GEMMs of every Linear; avg_us is per gps_gemm_bf16 call = the split-K "
-                                    "kernel plus its partial-sum reduction launch (two rocprofv3 rows: gemm_kernel<..., true, true, 5, ...> "
-                                    "and splitk_reduce_kernel)"} if dom["kernel"].startswith("gemm_tn") else {})}
+                        **({"note": "weight+bias gradient GEMMs; avg_us per gps_gemm_bf16 call = split-K kernel + its "
+                                    "splitk_reduce_kernel launch (two rocprofv3 rows)"} if dom["kernel"].startswith("gemm_tn") else {})}
         else:
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
@@ -573,15 +595,16 @@ def main() -> None:
         attn = [r for r in kernels if r["kernel"].startswith("attn_")]
         attn_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in attn)
         attn_sec = sum(r["avg_us"] * 1e-6 * r["launches_per_step"] for r in attn)
+        attn_bytes = sum(r.get("algorithmic_bytes", 0) * r["launches_per_step"] for r in attn)
         gemm_rows = [r for r in kernels if r["kernel"].startswith("gemm_")]
         gemm_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in gemm_rows)
         gemm_sec = sum(r["avg_us"] * 1e-6 * r["launches_per_step"] for r in gemm_rows)
-        headline = {
+        in_scope_tf = IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR * pairs_per_s / 1e3
+        headline_full = {
             "ball_query_group_unfused": bqg,
             "transformer_in_scope": None if args.config != "pretrain" else {
-                "gflop_per_pair": IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR,
-                "achieved_TFLOPs": round(IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR * pairs_per_s / 1e3, 1),
-                "frac_of_bf16_mfma_peak": round(IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR * pairs_per_s / 1e3 / MFMA_PEAK_TFLOPS["bf16"], 4),
+                "gflop_per_pair": IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR, "achieved_TFLOPs": round(in_scope_tf, 1),
+                "frac_of_bf16_mfma_peak": round(in_scope_tf / MFMA_PEAK_TFLOPS["bf16"], 4),
                 "note": "in-scope transformer FLOPs per pair x whole-step pairs/s: the whole step (BERT, point "
                         "encoder, heads, optimizer) is in the denominator's time"},
             "native_gemms": None if not gemm_sec else {
@@ -589,8 +612,23 @@ def main() -> None:
                 "frac_of_bf16_mfma_peak": round(gemm_flops / gemm_sec / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4)},
             "attention_core": None if not attn_sec else {
                 "achieved_TFLOPs": round(attn_flops / attn_sec / 1e12, 1), "ms_per_step": round(attn_sec * 1e3, 3),
-                "frac_of_bf16_mfma_peak": round(attn_flops / attn_sec / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4)},
+                "frac_of_bf16_mfma_peak": round(attn_flops / attn_sec / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 4),
+                "achieved_GBps": round(attn_bytes / attn_sec / 1e9, 1),
+                "frac_hbm": round(attn_bytes / attn_sec / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        # the printed line carries the three north-star fractions only; everything else goes to the detail file
+        headline = {
+            "ball_query_group_unfused_frac_hbm": bqg["frac_hbm"] if bqg else None,
+            "ball_query_group_unfused_us": bqg["us"] if bqg else None,
+            "native_gemms_frac_bf16_mfma": headline_full["native_gemms"]["frac_of_bf16_mfma_peak"] if gemm_sec else None,
+            "native_gemms_ms_per_step": headline_full["native_gemms"]["ms_per_step"] if gemm_sec else None,
+            "attention_core_frac_bf16_mfma": headline_full["attention_core"]["frac_of_bf16_mfma_peak"] if attn_sec else None,
+            "attention_core_frac_hbm": headline_full["attention_core"]["frac_hbm"] if attn_sec else None,
+            "attention_core_ms_per_step": headline_full["attention_core"]["ms_per_step"] if attn_sec else None,
+        }
+        over = [r["kernel"] for r in kernels if (r.get("frac") or 0) > 1.0]
+        if over:
+            print(f"[bench] WARNING: launch shapes above their roof (work model wrong?): {over}", file=sys.stderr)
         result = {
             "metric": "GPS pre-train pairs/sec (fwd+bwd)" if args.config == "pretrain" else
                       f"GPS {args.config} pairs/sec (fwd+bwd)",
@@ -603,11 +641,10 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "fp32" if args.fp32 else "bf16",
+            "dtype": "fp32" if args.fp32 else ("bf16+fp8-attention" if args.fp8 else "bf16"),
             "data": "synthetic",
-            "config": {"workload": (f"GPS pre-train step (all_pretrain.yaml model, ScanNet-shaped synthetic "
-                                    f"scenes): {args.n_obj} obj x {args.n_pts} pts x 6 ch, 50-token sentence "
-                                    f"+ 300-token scene caption, fwd+loss+bwd+clip+AdamW") if args.config == "pretrain" else
+            "config": {"workload": (f"GPS pre-train step (all_pretrain.yaml model): {args.n_obj} obj x {args.n_pts} pts x 6 ch, "
+                                    f"50-token sentence + 300-token scene caption, fwd+loss+bwd+clip+AdamW") if args.config == "pretrain" else
                                    (f"GPS {args.config} step ({'finetune/scanrefer_finetune.yaml head + og3d_loss' if args.config == 'finetune' else 'BASELINE configs[4]'}): "
                                     f"{args.n_obj} obj x {args.n_pts} pts x 6 ch, {preset['txt_len']}-token text, "
                                     f"fwd+loss+bwd+clip+AdamW"),
@@ -615,20 +652,22 @@ def main() -> None:
                        **({"eval": eval_metrics} if eval_metrics is not None else {}),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
-                       "point_ops": "fp32-accurate split-bf16 MFMA (libgps_hip.so)",
-                       "gemms": "hipBLASLt (A/B run)" if args.no_native_gemm else "libgps_hip.so bf16 MFMA (gps_gemm_bf16)",
                        "launch": graph_note or "eager",
-                       "kernel_timing": "HIP events around each native launch in three eager steps right after the timed region",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
             "headline": headline,
-            "kernel_families": kernel_families,
-            "kernels": kernels,
-            "step_kernels": step_kernels[:25],
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "pretrain":
             result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.n_obj, args.n_pts)
-        print(json.dumps(result), flush=True)
+        detail = dict(result)
+        detail["config"] = dict(result["config"],
+                                point_ops="fp32-accurate split-bf16 MFMA (libgps_hip.so)",
+                                gemms="hipBLASLt (A/B run)" if args.no_native_gemm else "libgps_hip.so bf16 MFMA (gps_gemm_bf16)",
+                                kernel_timing="HIP events around each native launch in three eager steps right after the timed region")
+        detail.update({"headline": headline_full, "kernel_families": kernel_families, "kernels": kernels,
+                       "step_kernels": step_kernels[:25]})
+        write_detail(detail, args.detail)
+        print(final_line(result), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(kThreads) void sumsq_kernel(const gps_adamw_tensor 
   const long long end = min(t.numel, begin + kChunk);
   const float *g = reinterpret_cast<const float *>(t.grad);
   float s = 0.f;
-  if ((t.numel & 3) == 0) {
+  // 16-byte loads only for 16-byte aligned views: gradients that are slices of one flat buffer (DDP bucket views, the
+  // split-graph flat gradient) start wherever the preceding tensors end
+  if ((t.numel & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
     for (long long e = begin + threadIdx.x * 4; e < end; e += kThreads * 4) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(g + e);
       s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(kThreads) void adamw_kernel(const gps_adamw_tensor 
   const float *g = reinterpret_cast<const float *>(t.grad);
   uint16_t *sh = reinterpret_cast<uint16_t *>(t.shadow_bf16);
   float *mir = reinterpret_cast<float *>(t.mirror_f32);
-  if ((t.numel & 3) == 0) {
+  const uintptr_t align = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                          reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(mir) | (reinterpret_cast<uintptr_t>(sh) << 1);
+  if ((t.numel & 3) == 0 && (align & 15) == 0) {
     for (long long e = begin + threadIdx.x * 4; e < end; e += kThreads * 4) {
       f32x4 P = *reinterpret_cast<f32x4 *>(p + e), M = *reinterpret_cast<f32x4 *>(m + e), V = *reinterpret_cast<f32x4 *>(v + e);
       const f32x4 Gr = *reinterpret_cast<const f32x4 *>(g + e);

@@ -5,9 +5,10 @@
 
 Data parallelism is the reference's only strategy (Accelerate -> torch DDP over NCCL,
 trainer/build.py:66-75,121).  Here: one process per GPU, `torch.distributed` backend "nccl"
-(= RCCL over xGMI), torch DDP with gradient buckets viewed in place and all-reduced while backward
-is still running; `find_unused_parameters=True` for the same reason as the reference (13 trainable
-tensors never receive a gradient).
+(= RCCL over xGMI), torch DDP with gradient buckets viewed in place and all-reduced (fp32, like the
+reference) while backward is still running.  The reference sets `find_unused_parameters=True` because 13
+trainable tensors never receive a gradient; here those are found by one probe
+step, agreed across ranks and frozen, unless `find_unused_parameters=True` asks for the reference's setting.
 
 bf16: the transformer stack, BERT, heads and losses run under `torch.autocast(bfloat16)`;
 the point ops always compute in fp32 (indices must be bit-exact).
@@ -52,8 +53,8 @@ class GPSTrainStep:
     def __init__(self, cfg, device: torch.device | str = "cuda", total_steps: int = 100000,
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
-                 native_gemm: bool = True, grad_compress: Optional[str] = "auto", native_optimizer: bool = True,
-                 fused_lm_loss: bool = True):
+                 native_gemm: bool = True, grad_compress: Optional[str] = None, native_optimizer: bool = True,
+                 fused_lm_loss: bool = True, find_unused_parameters: bool = False):
         self.cfg = cfg
         self.device = torch.device(device)
         # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
@@ -102,9 +103,17 @@ class GPSTrainStep:
         # buckets hold exactly the tensors that are reduced.
         self._want_ddp = bool(use_ddp)
         self._ddp_kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
-        # gradient compression: bf16 on the wire (246 MB instead of 491 MB per step), fp32 accumulation of the
-        # decompressed buckets; "auto" = on for RCCL, off for gloo (CPU tests compare against exact means)
+        # gradient exchange.  None (default) = the reference's: fp32 buckets all-reduced in fp32 (trainer/build.py:66-75).
+        # Opt-in compression, used by bench.py and named in its config line:
+        #   "bf16_fp32acc"  bf16 on the wire (246 MB instead of 491 MB per step), every rank's contribution rounded to
+        #                   bf16 ONCE, the cross-rank sum accumulated in fp32 (all-to-all of bucket slices, local fp32
+        #                   sum, all-gather of the bf16 mean): common/dist_utils.bf16_wire_fp32_acc_hook
+        #   "bf16"          torch's bf16_compress_hook: all-reduce IN bf16 (the sum itself is accumulated in bf16,
+        #                   ~2^-8 relative per element, growing with world size)
         self.grad_compress = grad_compress
+        # True = the reference's DDP setting (per-step unused-parameter search, tolerates data-dependent branches);
+        # False = freeze the tensors no rank ever gives a gradient in the probe step and skip the search
+        self.find_unused_parameters = bool(find_unused_parameters)
         self.fused_lm_loss = bool(fused_lm_loss) and bool(native_gemm)
         self.frozen_unused: list = []
         self.global_step = 0
@@ -131,38 +140,61 @@ class GPSTrainStep:
     def _build_ddp(self, data_dict) -> None:
         from torch.nn.parallel import DistributedDataParallel as DDP
         self.model.train()
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        for p in params:
-            p.grad = None
+        if not self.find_unused_parameters:
+            self._freeze_never_used(data_dict)
+        kw = dict(self._ddp_kw, find_unused_parameters=self.find_unused_parameters,
+                  broadcast_buffers=self._needs_buffer_broadcast())
+        if self.device.type == "cuda":
+            self.net = DDP(self.model, device_ids=[self.device.index], **kw)
+        else:
+            self.net = DDP(self.model, **kw)
+        compress = self.grad_compress
+        if compress == "bf16_fp32acc":
+            self.net.register_comm_hook(state=None, hook=dist_utils.bf16_wire_fp32_acc_hook)
+        elif compress == "bf16":
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            self.net.register_comm_hook(state=None, hook=default_hooks.bf16_compress_hook)
+        elif compress is not None:
+            raise ValueError(f"grad_compress={compress!r}")
+        self._want_ddp = False
+
+    def _freeze_never_used(self, data_dict) -> None:
+        """One local forward + backward on the first batch; a trainable tensor is frozen only if NO rank gave it a
+        gradient (the per-rank masks are MAX-all-reduced, so every rank builds DDP over the same parameter list even
+        when a data-dependent branch fired on some ranks only).  Buffers (BatchNorm running statistics of an unfrozen
+        encoder) and the RNG streams are restored: the probe leaves no trace in the training state.  A tensor that is
+        unused in the probe on every rank but used by a later batch would stay untrained -- configurations with such
+        branches should pass find_unused_parameters=True (the reference's setting)."""
+        named = dict(self.model.named_parameters())
+        names = [n for n, p in named.items() if p.requires_grad]
+        for n in names:
+            named[n].grad = None
+        buffers = [(b, b.detach().clone()) for b in self.model.buffers()]
         rng_cpu = torch.get_rng_state()
         rng_dev = torch.cuda.get_rng_state(self.device) if self.device.type == "cuda" else None
         with self._autocast():
             out = self.model(dict(data_dict))
             total, _ = self.loss(out)
         total.backward()
-        named = dict(self.model.named_parameters())
-        self.frozen_unused = sorted(n for n, p in named.items() if p.requires_grad and p.grad is None)
+        got = torch.tensor([1 if named[n].grad is not None else 0 for n in names], dtype=torch.int32, device=self.device)
+        if dist_utils.is_dist() and dist_utils.get_world_size() > 1:
+            torch.distributed.all_reduce(got, op=torch.distributed.ReduceOp.MAX)
+        got = got.tolist()
+        self.frozen_unused = sorted(n for n, g in zip(names, got) if not g)
         for n in self.frozen_unused:
             named[n].requires_grad_(False)
-        for p in params:
-            p.grad = None
+        for n in names:
+            named[n].grad = None
+        with torch.no_grad():
+            for b, saved in buffers:
+                b.copy_(saved)
         torch.set_rng_state(rng_cpu)                       # the probe must not shift the training RNG streams
         if rng_dev is not None:
             torch.cuda.set_rng_state(rng_dev, self.device)
-        kw = dict(self._ddp_kw, find_unused_parameters=False, broadcast_buffers=self._needs_buffer_broadcast())
-        if self.device.type == "cuda":
-            self.net = DDP(self.model, device_ids=[self.device.index], **kw)
-        else:
-            self.net = DDP(self.model, **kw)
-        compress = self.grad_compress
-        if compress == "auto":
-            compress = "bf16" if torch.distributed.get_backend() == "nccl" else None
-        if compress == "bf16":
-            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-            self.net.register_comm_hook(state=None, hook=default_hooks.bf16_compress_hook)
-        elif compress is not None:
-            raise ValueError(f"grad_compress={compress!r}")
-        self._want_ddp = False
+        if self.frozen_unused and dist_utils.get_rank() == 0:
+            import logging
+            logging.getLogger("sceneverse_amd").info("DDP: %d trainable tensors receive no gradient on any rank and were "
+                                                     "frozen: %s", len(self.frozen_unused), ", ".join(self.frozen_unused))
 
     # ---- split-graph data parallelism ------------------------------------------------------------
     def _dist_losses(self):

@@ -88,10 +88,22 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
     a.workspace, a.colsum, a.seed_dev = _ptr(workspace), _ptr(colsum), _ptr(seed_dev)
     a.extent_dev = _ptr(extent_dev)
     a.seed, a.p_drop = 0, float(p_drop)
-    from ...pointnet2._ext import _timed
+    from ...pointnet2._ext import _timed, profiling
     nbytes = 2 * (M * K + N * K) + {EPI_F32: 4 * M * N, EPI_RELU_SPLIT: 6 * M * N, EPI_RELU_MAX16: M * N // 4}.get(epilogue, 2 * M * N)
+    work_fraction = None
+    if extent_dev is not None and profiling():
+        # the kernel stops at *extent_dev rows of the token dimension (M for NT / NN, K for TN): charge that share
+        # of the static shape's work.  Snapshot now (the word may be rewritten by the next step), read at profile_stop.
+        snap = extent_dev.detach().clone()
+        full = K if form == GEMM_TN else M
+        work_fraction = lambda: min(1.0, max(0.0, float(snap.item()) / full))  # noqa: E731
+        out_b = {EPI_F32: 4}.get(epilogue, 2)
+        if form == GEMM_TN:      # both operands lose token rows, the (M, N) result is written whole
+            nbytes = lambda f: int(2 * f * K * (M + N)) + out_b * M * N  # noqa: E731
+        else:                    # A and C lose rows, the weight operand is read whole
+            nbytes = lambda f: int(f * M * (2 * K + out_b * N)) + 2 * N * K  # noqa: E731
     with torch.cuda.device(A.device), _timed(f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K},epi={epilogue})", nbytes,
-                                             2 * M * N * K, "bf16"):
+                                             2 * M * N * K, "bf16", work_fraction):
         st = _native.load().gps_gemm_bf16(ctypes.byref(a), _stream())
     _native.check(st, f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K})")
 
@@ -266,6 +278,7 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
     key = tuple(id(w) for w in weights) + ((("pad", pad_rows),) if pad_rows > 1 else ())
     sh = _SHADOWS.get(key)
     if sh is None:
+        _prune_dead_shadows()
         sh = _SHADOWS[key] = _Shadow()
     ver = _versions(list(weights) + list(biases))
     dev = weights[0].device
@@ -296,7 +309,7 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
             for w in weights:
                 sh.w16[r:r + w.shape[0]].copy_(w)
                 r += w.shape[0]
-            if all(b is not None for b in biases):
+            if any(b is not None for b in biases):
                 if len(biases) == 1 and not padded:
                     sh.b32 = biases[0].detach()
                     sh.b32_is_copy = False
@@ -306,13 +319,27 @@ def shadow_of(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.T
                         sh.b32_is_copy = True
                         _REGISTRY_VERSION += 1
                     r = 0
-                    for b in biases:
-                        sh.b32[r:r + b.shape[0]].copy_(b)
-                        r += b.shape[0]
+                    for w, b in zip(weights, biases):      # a bias-free member of a packed group contributes zeros
+                        if b is not None:
+                            sh.b32[r:r + w.shape[0]].copy_(b)
+                        else:
+                            sh.b32[r:r + w.shape[0]].zero_()
+                        r += w.shape[0]
             else:
                 sh.b32 = None
         sh.versions = ver
     return sh.w16, sh.b32
+
+
+def _prune_dead_shadows() -> None:
+    """Drop the records whose masters are gone (a model that was deleted): their bf16 copies would otherwise stay
+    resident for the life of the process (two models live in A/B benches and in the tests)."""
+    global _REGISTRY_VERSION
+    dead = [k for k, sh in _SHADOWS.items() if sh.owners is not None and any(r() is None for r in sh.owners)]
+    for k in dead:
+        del _SHADOWS[k]
+    if dead:
+        _REGISTRY_VERSION += 1
 
 
 def shadow_entry(weights: Sequence[torch.Tensor]):

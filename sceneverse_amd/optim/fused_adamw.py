@@ -92,10 +92,19 @@ class GpsAdamW(torch.optim.Optimizer):
             if "step" in st:
                 self._steps[self._slot[id(p)]] = float(st["step"])
                 st["step"] = self._steps[self._slot[id(p)]]
+        if self._keep:
+            raise RuntimeError("GpsAdamW.load_state_dict after a HIP-graph capture: the captured tables point at the old "
+                               "learning-rate / state words -- load the checkpoint before the first captured step")
         for g in self.param_groups:
-            if not torch.is_tensor(g["lr"]):
-                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self._device)
+            # a checkpoint loaded with map_location='cpu' carries lr as a CPU tensor: the kernel dereferences the
+            # word on the device, so it must live there (fp32, 0-dim)
+            g["lr"] = self._device_lr(g["lr"])
         self._sig = None
+
+    def _device_lr(self, lr) -> torch.Tensor:
+        if torch.is_tensor(lr) and lr.device == self._device and lr.dtype == torch.float32:
+            return lr
+        return torch.full((), float(lr), dtype=torch.float32, device=self._device)
 
     def _build_tables(self, entries, targets):
         lib = _native.load()
@@ -166,9 +175,8 @@ class GpsAdamW(torch.optim.Optimizer):
                 entries.append((p, gi))
         if not entries:
             return loss
-        for g in self.param_groups:                 # a plain float assigned from outside (g["lr"] = 1e-4) moves onto
-            if not torch.is_tensor(g["lr"]):        # the device again: the kernel reads learning rates from device words
-                g["lr"] = torch.full((), float(g["lr"]), dtype=torch.float32, device=self._device)
+        for g in self.param_groups:                 # a plain float (g["lr"] = 1e-4) or a CPU tensor assigned from outside
+            g["lr"] = self._device_lr(g["lr"])      # moves onto the device: the kernel reads learning rates from device words
         sig = (gemm.registry_version(), tuple(g["lr"].data_ptr() for g in self.param_groups),
                tuple((p.data_ptr(), p.grad.data_ptr()) for p, _ in entries))
         if sig != self._sig:

@@ -26,6 +26,10 @@ def profile_start() -> None:
     _PROFILE = {}
 
 
+def profiling() -> bool:
+    return _PROFILE is not None
+
+
 def profile_stop() -> dict:
     """-> {op: {"launches": n, "avg_us": t, "bytes_per_launch": B, "flops_per_launch": F,
     "mfma_dtype": "fp32"|"bf16"|None}} (synchronises)."""
@@ -35,18 +39,26 @@ def profile_stop() -> dict:
     out = {}
     for name, evs in rec.items():
         ms = [s.elapsed_time(e) for s, e, *_ in evs]
+        # launches with a device-side extent (gps_gemm_args.extent_dev) did only `frac` of the work their static
+        # shape names: the snapshot of the extent word taken at launch time is read back here, once
+        fr = [ev[5]() if ev[5] is not None else 1.0 for ev in evs]
         out[name] = {"launches": len(evs), "avg_us": 1e3 * sum(ms) / len(ms),
-                     "bytes_per_launch": sum(ev[2] for ev in evs) / len(evs),
-                     "flops_per_launch": sum(ev[3] for ev in evs) / len(evs),
+                     "bytes_per_launch": sum((ev[2](f) if callable(ev[2]) else ev[2] * f) for ev, f in zip(evs, fr)) / len(evs),
+                     "flops_per_launch": sum(ev[3] * f for ev, f in zip(evs, fr)) / len(evs),
                      "mfma_dtype": evs[0][4]}
+        if any(ev[5] is not None for ev in evs):
+            out[name]["work_fraction"] = sum(fr) / len(fr)
     return out
 
 
 class _timed:
     """Brackets one native launch with two events on the current (= launch) stream."""
 
-    def __init__(self, name: str, algo_bytes: int, algo_flops: int = 0, mfma_dtype=None):
+    def __init__(self, name: str, algo_bytes: int, algo_flops: int = 0, mfma_dtype=None, work_fraction=None):
+        """work_fraction: None, or a callable evaluated at profile_stop() -> the share of the static shape's
+        algorithmic work this launch really did (device-side extents)."""
         self.name, self.bytes, self.flops, self.mfma = name, algo_bytes, algo_flops, mfma_dtype
+        self.work_fraction = work_fraction
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -58,7 +70,8 @@ class _timed:
     def __exit__(self, *exc):
         if _PROFILE is not None:
             self.e.record()
-            _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.bytes, self.flops, self.mfma))
+            _PROFILE.setdefault(self.name, []).append((self.s, self.e, self.bytes, self.flops, self.mfma,
+                                                       self.work_fraction))
         return False
 
 

@@ -8,7 +8,10 @@ layers/objects so two replicas fit the CPU suite's time budget):
   * after DDP steps on DIFFERENT per-rank shards the replicas hold identical parameters, and the
     gradient DDP leaves on each rank is the mean of the two single-process gradients;
   * the 13 never-used trainable tensors are found by the probe step and frozen, so the reducer runs with
-    find_unused_parameters=False; bf16-compressed gradient buckets keep the replicas identical.
+    find_unused_parameters=False; the per-rank "received a gradient" masks are MAX-reduced first, so a branch that
+    fires on one rank only is not frozen anywhere; the probe leaves RNG streams and buffers untouched;
+  * the opt-in gradient compression (bf16 on the wire, fp32 accumulation) is within two bf16 roundings of the exact
+    mean and keeps the replicas identical.
 
 Point ops are routed to the CPU oracle (tests only): libgps_hip.so has no CPU path by design.
 """
@@ -135,9 +138,44 @@ def _worker(rank, world, port, tmp):
         eng._allreduce_grads()
         result["graph_dp_allreduce_ok"] = bool(torch.allclose(eng._flat_grad, torch.full((10,), (world - 1) / 2.0)))
 
+        # -- the probe's "received a gradient" mask is agreed across ranks: on rank 0 the probe batch leaves the
+        #    masked-LM branch unused (its loss term is dropped there, a stand-in for a data-dependent branch); rank 1
+        #    uses it, so NO rank may freeze the LM head and both must build DDP over the same parameter list.  The
+        #    probe must also leave buffers and RNG streams untouched.
+        agree = GPSTrainStep(_small_cfg(lp, world, between_batch=False), device="cpu", ddp=True, seed=5)
+        if rank == 0:
+            agree.loss.selected_keys = [k for k in agree.loss.selected_keys if k != "lm_cls_loss"]
+        rng_before = torch.get_rng_state()
+        bufs_before = [b.clone() for b in agree.model.buffers()]
+        agree.prepare(dict(shards[rank], cur_step=0, total_steps=10))
+        result["probe_keeps_rng"] = bool(torch.equal(rng_before, torch.get_rng_state()))
+        result["probe_keeps_buffers"] = all(torch.equal(a, b) for a, b in zip(bufs_before, agree.model.buffers()))
+        names = [None] * world
+        dist.all_gather_object(names, list(agree.frozen_unused))
+        result["frozen_sets_equal"] = all(n == names[0] for n in names)
+        result["lm_head_kept"] = not any("lm_pred_head" in n or "lm_head" in n for n in agree.frozen_unused)
+        result["n_frozen_agreed"] = len(agree.frozen_unused)
+
+        # -- the opt-in gradient compression: bf16 on the wire, cross-rank sum in fp32 (two roundings per element
+        #    whatever the world size); checked against the exact fp32 mean of known per-rank buckets
+        class _Bucket:
+            def __init__(self, t):
+                self.t = t
+
+            def buffer(self):
+                return self.t
+        gen = torch.Generator().manual_seed(17 + rank)
+        mine = torch.randn(1001, generator=gen) * 3.0
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        got = dist_utils.bf16_wire_fp32_acc_hook(None, _Bucket(mine.clone())).wait()
+        want = sum(e.to(torch.bfloat16).float() for e in every) / world       # exact fp32 mean of the bf16 contributions
+        result["hook_vs_fp32_sum"] = float(((got - want).abs() / (want.abs() + 1e-3)).max())       # one final rounding: <= 2^-8
+        result["hook_vs_exact"] = float(((got - sum(every) / world).abs() / (sum(e.abs() for e in every) / world + 1e-3)).max())
+
         # -- two optimisation steps (full loss list) on different shards keep the replicas identical; gradients
-        #    travel as bf16 (the compression hook of the RCCL path), accumulate in fp32
-        ddp = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=True, seed=5, grad_compress="bf16")
+        #    travel as bf16 with fp32 accumulation (what bench.py asks for on the RCCL path)
+        ddp = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=True, seed=5, grad_compress="bf16_fp32acc")
         for i in range(2):
             ddp.step(dict(synth_batch(2, n_obj=6, n_pts=1024, scene_txt_len=40,
                                       seed=200 + 10 * i + rank, min_real=3)))
@@ -166,3 +204,6 @@ def test_ddp_world_size_2_gloo():
         assert r["wrapped"] == "DistributedDataParallel", r
         assert r["n_frozen_unused"] >= 13 and r["n_unused"] == 0, r     # found by the probe step, frozen before the wrap
         assert r["graph_dp_gather_ok"] and r["graph_dp_allreduce_ok"], r
+        assert r["frozen_sets_equal"] and r["lm_head_kept"] and r["n_frozen_agreed"] >= 13, r
+        assert r["probe_keeps_rng"] and r["probe_keeps_buffers"], r
+        assert r["hook_vs_fp32_sum"] <= 2.0 ** -8 and r["hook_vs_exact"] <= 2.0 ** -7, r
