@@ -352,6 +352,9 @@ def main() -> None:
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
+    ap.add_argument("--fp32-grads", action="store_true",
+                    help="N > 1: all-reduce fp32 gradient buckets like the reference (default here: bf16 on the wire, "
+                         "fp32 accumulation -- common/dist_utils.bf16_wire_fp32_acc_hook)")
     ap.add_argument("--graph-dp", action="store_true",
                     help="force the split-graph data-parallel form at world_size 1 (what N > 1 runs; for A/B)")
     ap.add_argument("--no-native-gemm", action="store_true",
@@ -410,7 +413,8 @@ def main() -> None:
     # (--graph-dp: 3 graphs around eager RCCL collectives, 20.1 ms + an exposed 491 MB fp32 all-reduce) cannot.
     use_graph = (world == 1 and not args.no_graph) or args.graph_dp
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
-                        graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm)
+                        graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm,
+                        grad_compress=(None if (world == 1 or share or args.fp32_grads) else "bf16_fp32acc"))
     use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank,
                         device=dev)
@@ -653,6 +657,8 @@ def main() -> None:
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
                        "launch": graph_note or "eager",
+                       **({"grad_exchange": "fp32 all-reduce" if (share or args.fp32_grads) else
+                           "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"} if world > 1 else {}),
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
             "headline": headline,
