@@ -352,9 +352,9 @@ def main() -> None:
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (debug)")
-    ap.add_argument("--fp32-grads", action="store_true",
-                    help="N > 1: all-reduce fp32 gradient buckets like the reference (default here: bf16 on the wire, "
-                         "fp32 accumulation -- common/dist_utils.bf16_wire_fp32_acc_hook)")
+    ap.add_argument("--bf16-grads", action="store_true",
+                    help="N > 1: gradient buckets as bf16 on the wire with fp32 accumulation (all-to-all + all-gather, "
+                         "common/dist_utils.bf16_wire_fp32_acc_hook) instead of the reference's fp32 all-reduce")
     ap.add_argument("--graph-dp", action="store_true",
                     help="force the split-graph data-parallel form at world_size 1 (what N > 1 runs; for A/B)")
     ap.add_argument("--no-native-gemm", action="store_true",
@@ -396,6 +396,10 @@ def main() -> None:
     if args.no_fused_emb:
         from sceneverse_amd.modules.language import bert as _bert
         _bert.set_fused_embedding(False)
+    if args.fp8:
+        # BASELINE configs[4]: Q K^T and P V of every bf16 attention call on the OCP e4m3 MFMA (forward)
+        from sceneverse_amd.modules.layers import fused_attention as _fa
+        _fa.set_fp8_products(True)
     # GPS_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 and the collectives go over gloo, so
     # the N > 1 code path can be exercised end to end on a one-GPU box (RCCL refuses two ranks on one GPU)
     share = os.environ.get("GPS_BENCH_SHARE_GPU") == "1"
@@ -414,7 +418,7 @@ def main() -> None:
     use_graph = (world == 1 and not args.no_graph) or args.graph_dp
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
                         graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm,
-                        grad_compress=(None if (world == 1 or share or args.fp32_grads) else "bf16_fp32acc"))
+                        grad_compress=("bf16_fp32acc" if (world > 1 and not share and args.bf16_grads) else None))
     use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank,
                         device=dev)
@@ -657,8 +661,8 @@ def main() -> None:
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
                        "launch": graph_note or "eager",
-                       **({"grad_exchange": "fp32 all-reduce" if (share or args.fp32_grads) else
-                           "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"} if world > 1 else {}),
+                       **({"grad_exchange": "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
+                           if (args.bf16_grads and not share) else "fp32 all-reduce (DDP buckets)"} if world > 1 else {}),
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
             "headline": headline,

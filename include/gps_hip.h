@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 3
+#define GPS_HIP_ABI_VERSION 4
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -199,6 +199,47 @@ GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, 
                               float p_drop, unsigned long long seed, const void *seed_dev,
                               const void *dout, int ld_o, const float *lse, const void *out, void *dq, void *dk,
                               void *dv, float *dsw, gps_stream_t stream);
+
+/* ---- general form of the attention core: cross-attention, fp32 operands, fp8 products ---------------
+ * One argument block for everything gps_attn_forward / gps_attn_backward do, plus
+ *   - CROSS-ATTENTION (queries from `tgt`, keys / values from `memory`, Lq != Lk): the core of
+ *       nn.MultiheadAttention(tgt, memory, memory, key_padding_mask=memory_key_padding_mask) in CrossAttentionLayer,
+ *       TransformerDecoderLayer and TransformerSpatialDecoderLayer (modules/layers/transformers.py:12-63, 66-112,
+ *       242-282).  q (B, Lq, ld_q), k / v (B, Lk, ld_kv), mask (B, Lk) over the keys, out (B, Lq, ld_o),
+ *       lse (B, H, Lq).  The spatial term (sw, pl) needs Lq == Lk.
+ *   - dtype GPS_ATTN_F32: q, k, v, out, dout, dq, dk, dv are fp32 and every product runs on the fp32 MFMA
+ *       (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain): the fp32 "master" path for parity runs against the
+ *       reference's fp32 mathematics (transformers.py:193-239).  Lq, Lk <= 256.
+ *   - compute GPS_ATTN_COMPUTE_FP8 (forward only, dtype bf16): Q K^T and P V on the OCP e4m3 MFMA
+ *       (v_mfma_f32_16x16x32_fp8_fp8) with per-query-row scales for Q, one scale per (scene, head) tile for K and
+ *       for V, probabilities quantised as 128 p; softmax, spatial term and accumulation stay fp32 (BASELINE
+ *       configs[4]: 256 objects + 256 tokens).  The backward call always runs its products in the operand dtype.
+ * Dropout / seeds / lse as in gps_attn_forward.  head_dim must be 64; bf16: Lq, Lk <= 512. */
+#define GPS_ATTN_BF16 0
+#define GPS_ATTN_F32 1
+#define GPS_ATTN_COMPUTE_NATIVE 0
+#define GPS_ATTN_COMPUTE_FP8 1
+typedef struct gps_attn_args {
+  int B, H, Lq, Lk, head_dim;
+  int dtype;                 /* GPS_ATTN_BF16 | GPS_ATTN_F32: element type of q, k, v, out, dout, dq, dk, dv */
+  int compute;               /* GPS_ATTN_COMPUTE_NATIVE | GPS_ATTN_COMPUTE_FP8 */
+  int reserved;              /* 0 */
+  const void *q;  int ld_q;  /* (B, Lq, ld_q), head h in columns [64 h, 64 h + 64) */
+  const void *k, *v; int ld_kv;   /* (B, Lk, ld_kv) */
+  const float *sw;           /* (B, Lq, H * 6) or NULL */
+  const float *pl;           /* (B, Lq, Lk, 5) or NULL (with sw) */
+  const unsigned char *mask; /* (B, Lk), 1 = padded key, or NULL */
+  float p_drop; unsigned long long seed; const void *seed_dev;
+  void *out; int ld_o;       /* forward: written; backward: the forward output (read) */
+  float *lse;                /* (B, H, Lq): written by forward, read by backward */
+  /* backward only */
+  const void *dout;          /* (B, Lq, ld_o) */
+  void *dq; int ld_dq;       /* (B, Lq, ld_dq) */
+  void *dk, *dv; int ld_dkv; /* (B, Lk, ld_dkv) */
+  float *dsw;                /* (B, Lq, H * 6) when sw != NULL */
+} gps_attn_args;
+GPS_API int gps_attn_forward_ex(const gps_attn_args *args, gps_stream_t stream);
+GPS_API int gps_attn_backward_ex(const gps_attn_args *args, gps_stream_t stream);
 
 /* ---- row-sparse cross-entropy (masked-LM head) ----------------------------------------------------
  * Replaces the F.cross_entropy(..., ignore_index=-1) of lm_cls_loss (optim/loss/loss.py:56-61) over

@@ -36,6 +36,19 @@ class GemmArgs(ctypes.Structure):
                 ("p_drop", _f), ("reserved2", _i), ("extent_dev", _vp)]
 
 
+class AttnArgs(ctypes.Structure):
+    """struct gps_attn_args of include/gps_hip.h, field for field."""
+    _fields_ = [("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("head_dim", _i), ("dtype", _i), ("compute", _i),
+                ("reserved", _i),
+                ("q", _vp), ("ld_q", _i), ("k", _vp), ("v", _vp), ("ld_kv", _i),
+                ("sw", _vp), ("pl", _vp), ("mask", _vp),
+                ("p_drop", _f), ("seed", ctypes.c_ulonglong), ("seed_dev", _vp),
+                ("out", _vp), ("ld_o", _i), ("lse", _vp),
+                ("dout", _vp), ("dq", _vp), ("ld_dq", _i), ("dk", _vp), ("dv", _vp), ("ld_dkv", _i), ("dsw", _vp)]
+
+
+ATTN_BF16, ATTN_F32 = 0, 1
+ATTN_COMPUTE_NATIVE, ATTN_COMPUTE_FP8 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32 = 0, 1, 2, 3, 4, 5
 EPI_RELU_SPLIT, EPI_RELU_MAX16 = 6, 7
@@ -72,6 +85,8 @@ SIGNATURES = {
     "gps_add_dropout_layernorm_forward": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_add_dropout_layernorm_backward": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i, _vp, _vp],
+    "gps_attn_forward_ex": [ctypes.POINTER(AttnArgs), _vp],
+    "gps_attn_backward_ex": [ctypes.POINTER(AttnArgs), _vp],
     "gps_attn_backward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i] + [_vp] * 7,
 }
 

@@ -99,24 +99,40 @@ def bf16_wire_fp32_acc_hook(state, bucket):
     mean16 = torch.empty(chunk, dtype=torch.bfloat16, device=buf.device)
     out = torch.empty_like(send)
 
-    # No callback may BLOCK on the second collective (gloo runs callbacks on its few worker threads: with several
-    # buckets in flight they would all sit in wait() and nothing could progress), so the chain is built from
-    # done-callbacks that only enqueue work, and completes a future of our own.
-    done = torch.futures.Future(devices=[buf.device]) if buf.is_cuda else torch.futures.Future()
-
-    def finish(_fut):
-        try:
-            buf.copy_(out[:n])
-            done.set_result(buf)
-        except Exception as e:  # noqa: BLE001 -- surfaces in DDP's wait on the bucket future
-            done.set_exception(e)
-
-    def reduce_and_gather(_fut):
-        try:
-            mean16.copy_(recv.view(world, chunk).sum(dim=0, dtype=torch.float32).mul_(1.0 / world))
-            dist.all_gather_into_tensor(out, mean16, group=group, async_op=True).get_future().add_done_callback(finish)
-        except Exception as e:  # noqa: BLE001
-            done.set_exception(e)
-
-    dist.all_to_all_single(recv, send, group=group, async_op=True).get_future().add_done_callback(reduce_and_gather)
+    if not buf.is_cuda:
+        # gloo (CPU tests): done-callbacks would run on gloo's worker threads in COMPLETION order, which may differ
+        # between ranks and would interleave the collectives of different buckets differently -> issue both
+        # collectives synchronously, in the (rank-consistent) order DDP hands out the buckets
+        dist.all_to_all_single(recv, send, group=group)
+        mean16.copy_(recv.view(world, chunk).sum(dim=0, dtype=torch.float32).mul_(1.0 / world))
+        dist.all_gather_into_tensor(out, mean16, group=group)
+        buf.copy_(out[:n])
+        done = torch.futures.Future()
+        done.set_result(buf)
+        return done
+    # RCCL: everything is issued in program order (same on every rank) on a SIDE stream, so the backward pass that is
+    # still running on the current stream is not held up; `work.wait()` only orders the side stream after the
+    # collective's stream.  The returned future carries the side stream's event (set_result records it), which is
+    # what DDP synchronises with before the optimizer reads the bucket.
+    cur = torch.cuda.current_stream(buf.device)
+    side = _hook_stream(buf.device)
+    side.wait_stream(cur)
+    send.record_stream(side), recv.record_stream(side), mean16.record_stream(side), out.record_stream(side)
+    with torch.cuda.stream(side):
+        dist.all_to_all_single(recv, send, group=group, async_op=True).wait()
+        mean16.copy_(recv.view(world, chunk).sum(dim=0, dtype=torch.float32).mul_(1.0 / world))
+        dist.all_gather_into_tensor(out, mean16, group=group, async_op=True).wait()
+        buf.copy_(out[:n])
+        done = torch.futures.Future(devices=[buf.device])
+        done.set_result(buf)
     return done
+
+
+_HOOK_STREAMS = {}
+
+
+def _hook_stream(device) -> "torch.cuda.Stream":
+    st = _HOOK_STREAMS.get(device)
+    if st is None:
+        st = _HOOK_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st

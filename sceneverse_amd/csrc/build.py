@@ -16,6 +16,7 @@ SOURCES = [
     ("gps_point_ops.hip", ["-ffp-contract=off"]),
     ("gps_sa_mlp.hip", []),
     ("gps_attention.hip", []),
+    ("gps_attention_ex.hip", []),
     ("gps_losses.hip", []),
     ("gps_layernorm.hip", []),
     ("gps_objects.hip", []),

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "gps_hip.h"
+#include "gps_attention_ex.h"
 
 namespace gps_attn {
 
@@ -43,9 +44,11 @@ constexpr int KS = DH + 8;    // LDS row pitch of row-major tiles, bf16 elements
 constexpr int SD = 6;         // conditioning vector per (token, head): bias + 5 weights
 
 struct Params {
-  int B, H, L, nt;            // nt = ceil(L / 16)
-  int ld_qkv, ld_o;           // row pitches in elements
-  const uint16_t *q, *k, *v;  // (B, L, ld_qkv) views, head h at column h * 64
+  int B, H, L, nt;            // L = number of KEYS (= queries in self-attention), nt = ceil(L / 16)
+  int Lq, ntq;                // number of QUERIES (cross-attention: q from `tgt`, k / v from `memory`, Lq != L allowed)
+  int ld_qkv, ld_o;           // row pitches in elements: k, v (and q, dq, dk, dv in self-attention) | out, dout
+  int ld_q, ld_dq, ld_dkv;    // pitches of q | dq | dk, dv (streaming kernels; = ld_qkv in the packed self-attention call)
+  const uint16_t *q, *k, *v;  // (B, Lq, ld_q) and (B, L, ld_qkv) views, head h at column h * 64
   const float *sw;            // (B, L, H * 6) or null
   const float *pl;            // (B, L, L, 5)  or null
   const uint8_t *mask;        // (B, L), 1 = padded key, or null
@@ -812,7 +815,8 @@ __device__ __forceinline__ bf16x8 frag_from_rows_tr(const uint16_t *rows, int nt
 template <bool SPATIAL>
 __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;
+  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;      // keys
+  const int Lq = P.Lq, ntq = P.ntq;                                        // queries
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);       // [rows][KS]
   uint16_t *Vs = Ks + rows * KS;                            // [rows][KS]
   float *mb = reinterpret_cast<float *>(Vs + rows * KS);    // [rows] additive key term: 0, or -inf (padded / past L)
@@ -821,8 +825,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   block_to_bh(P, b, h);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int m = lane & 15, g = lane >> 4;
-  const size_t row0 = (size_t)b * L;
-  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const size_t row0 = (size_t)b * L, row0q = (size_t)b * Lq;
+  const uint16_t *qb = P.q + row0q * P.ld_q + h * DH;
   const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
   const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
   stage_rows(Ks, kb, P.ld_qkv, L, rows);
@@ -836,20 +840,20 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   const unsigned int thr16 = P.drop_thr >> 16;
   const unsigned int pitch2 = (unsigned int)((L + 1) >> 1);       // key pairs per query row
 
-  for (int s = wave; s < nt; s += nwaves) {
+  for (int s = wave; s < ntq; s += nwaves) {
     const int qi = 16 * s + m;
-    const bool q_ok = qi < L;
+    const bool q_ok = qi < Lq;
     bf16x8 bq[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       u32x4 v = zero4();
-      if (q_ok) v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_qkv + 32 * c + 8 * g);
+      if (q_ok) v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_q + 32 * c + 8 * g);
       bq[c] = as_frag(v);
     }
     float w[SD];
     if (SPATIAL) {
 #pragma unroll
-      for (int d = 0; d < SD; ++d) w[d] = q_ok ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
+      for (int d = 0; d < SD; ++d) w[d] = q_ok ? P.sw[((row0q + qi) * P.H + h) * SD + d] : 0.f;
     }
     // base-2 logits of (query qi, keys 16 j + 4 g + 0..3): log2(e) * (q . k / 8 [+ spatial term]) + key term;
     // one fused multiply-add per element in the plain form
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
           float v = acc[r] * 0.125f;
           if (t < L && q_ok) {
             float sig;
-            v += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, kt[r] < 0.f, sig);
+            v += spatial_bias(P.pl + ((row0q + qi) * L + t) * 5, w, kt[r] < 0.f, sig);
           }
           x[r] = fmaf(v, kLog2e, kt[r]);
         } else {
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
     const float gmx = xor_reduce_max_rows(mx);
     // pass B: p = 2^(x - max) chunk by chunk; the normaliser accumulates beside the P V product and is applied,
     // with the dropout scale, to the 16 x 64 output strip at the end
-    const unsigned int rp = (((unsigned int)b * P.H + h) * L + qi) * pitch2;
+    const unsigned int rp = (((unsigned int)b * P.H + h) * Lq + qi) * pitch2;
     float lsum = 0.f;
     f32x4 o[4];
 #pragma unroll
@@ -918,14 +922,14 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
       for (int n = 0; n < 4; ++n) o[n] = mfma(pa, frag_from_rows_tr(Vs, n, c, lane), o[n]);
     }
     lsum = xor_reduce_sum_rows(lsum);             // all keys masked -> NaN row, like torch
-    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * L + qi] = (gmx + __builtin_amdgcn_logf(lsum)) * kLn2;
+    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * Lq + qi] = (gmx + __builtin_amdgcn_logf(lsum)) * kLn2;
     const float scale_q = keep_scale / lsum;      // of query 16 s + m; the output rows of this lane are 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qr = 16 * s + 4 * g + r;
       const float sc = __shfl(scale_q, 4 * g + r, 64);
-      if (qr < L) {
-        uint16_t *op = P.out + (row0 + qr) * P.ld_o + h * DH + m;
+      if (qr < Lq) {
+        uint16_t *op = P.out + (row0q + qr) * P.ld_o + h * DH + m;
 #pragma unroll
         for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r] * sc);
       }
@@ -936,41 +940,44 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
 template <bool SPATIAL>
 __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;
-  // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (same storage): Qs [rows][KS] | dOs [rows][KS];  then fp32 rows:
-  // delta, lse2 = log2(e) * lse (+inf past L: such queries get p = 0) and the additive key term (0 / -inf).
+  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;            // keys
+  const int Lq = P.Lq, ntq = P.ntq, ncq = (ntq + 1) / 2, rows_q = ncq * 32;      // queries
+  const int rows_max = rows > rows_q ? rows : rows_q;
+  // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (same storage): Qs [rows_q][KS] | dOs [rows_q][KS];  then fp32 rows:
+  // delta, lse2 = log2(e) * lse (+inf past Lq: such queries get p = 0) per query and the additive key term (0 / -inf).
   // Every tile is ROW-major: A fragments are 16-byte reads, B fragments hardware-transposed reads of the same rows.
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
   uint16_t *Vs = Ks + rows * KS;
-  uint16_t *Qs = Ks, *dOs = Vs;
-  float *delta_s = reinterpret_cast<float *>(smem + (size_t)2 * rows * KS * 2);
-  float *lse_s = delta_s + rows;
-  float *mb = lse_s + rows;
+  uint16_t *Qs = Ks, *dOs = Qs + rows_q * KS;
+  float *delta_s = reinterpret_cast<float *>(smem + (size_t)2 * rows_max * KS * 2);
+  float *lse_s = delta_s + rows_q;
+  float *mb = lse_s + rows_q;
 
   int b, h;
   block_to_bh(P, b, h);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int m = lane & 15, g = lane >> 4;
-  const size_t row0 = (size_t)b * L;
-  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const size_t row0 = (size_t)b * L, row0q = (size_t)b * Lq;
+  const uint16_t *qb = P.q + row0q * P.ld_q + h * DH;
   const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
   const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
-  const uint16_t *dob = P.dout + row0 * P.ld_o + h * DH;
-  const uint16_t *ob = P.out + row0 * P.ld_o + h * DH;
-  const float *lse = P.lse + ((size_t)b * P.H + h) * L;
+  const uint16_t *dob = P.dout + row0q * P.ld_o + h * DH;
+  const uint16_t *ob = P.out + row0q * P.ld_o + h * DH;
+  const float *lse = P.lse + ((size_t)b * P.H + h) * Lq;
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
   const unsigned int seedmix = dropout ? seed_fold(effective_seed(P)) : 0u;
   const unsigned int thr16 = P.drop_thr >> 16;
   const unsigned int pitch2 = (unsigned int)((L + 1) >> 1);
-  const unsigned int bh_base = ((unsigned int)b * P.H + h) * L;
+  const unsigned int bh_base = ((unsigned int)b * P.H + h) * Lq;
 
   stage_rows(Ks, kb, P.ld_qkv, L, rows);
   stage_rows(Vs, vb, P.ld_qkv, L, rows);
   // delta[q] = sum_d dO[q][d] O[q][d] = rowsum(P' dP') for the dropped, rescaled probabilities of the forward pass
-  for (int t = threadIdx.x; t < rows; t += blockDim.x) {
+  for (int t = threadIdx.x; t < rows; t += blockDim.x) mb[t] = (t < L && !(P.mask && P.mask[row0 + t])) ? 0.f : -INFINITY;
+  for (int t = threadIdx.x; t < rows_q; t += blockDim.x) {
     float d = 0.f;
-    if (t < L) {
+    if (t < Lq) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const u32x4 a = *reinterpret_cast<const u32x4 *>(dob + (size_t)t * P.ld_o + 8 * c);
@@ -983,21 +990,20 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
       }
     }
     delta_s[t] = d;
-    lse_s[t] = t < L ? lse[t] * kLog2e : INFINITY;
-    mb[t] = (t < L && !(P.mask && P.mask[row0 + t])) ? 0.f : -INFINITY;
+    lse_s[t] = t < Lq ? lse[t] * kLog2e : INFINITY;
   }
   __syncthreads();
 
   // ---------------- pass 1: query strips, key chunks streamed -> dQ, dsw ----------------
-  for (int s = wave; s < nt; s += nwaves) {
+  for (int s = wave; s < ntq; s += nwaves) {
     const int qi = 16 * s + m;
-    const bool q_ok = qi < L;
+    const bool q_ok = qi < Lq;
     bf16x8 bq[2], bdo[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       u32x4 v = zero4(), u = zero4();
       if (q_ok) {
-        v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_qkv + 32 * c + 8 * g);
+        v = *reinterpret_cast<const u32x4 *>(qb + (size_t)qi * P.ld_q + 32 * c + 8 * g);
         u = *reinterpret_cast<const u32x4 *>(dob + (size_t)qi * P.ld_o + 32 * c + 8 * g);
       }
       bq[c] = as_frag(v);
@@ -1006,11 +1012,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
     float w[SD], dw[SD];
 #pragma unroll
     for (int d = 0; d < SD; ++d) {
-      w[d] = (SPATIAL && q_ok) ? P.sw[((row0 + qi) * P.H + h) * SD + d] : 0.f;
+      w[d] = (SPATIAL && q_ok) ? P.sw[((row0q + qi) * P.H + h) * SD + d] : 0.f;
       dw[d] = 0.f;
     }
-    const float lse_q = lse_s[qi < rows ? qi : 0];
-    const float delta = delta_s[qi < rows ? qi : 0];
+    const float lse_q = lse_s[qi < rows_q ? qi : 0];
+    const float delta = delta_s[qi < rows_q ? qi : 0];
     const unsigned int rp = (bh_base + qi) * pitch2;
     f32x4 o[4];
 #pragma unroll
@@ -1048,7 +1054,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
               float x = acc[r] * 0.125f;
               if (t < L && q_ok) {
                 float sig;
-                x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, kt[r] < 0.f, sig);
+                x += spatial_bias(P.pl + ((row0q + qi) * L + t) * 5, w, kt[r] < 0.f, sig);
                 gt = sig > 1e-6f ? 1.f - sig : 0.f;
               }
               p = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, kt[r]) - lse_q);
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
             if (SPATIAL) {
               const float dz = dlogit * gt;
               if (dz != 0.f) {
-                const float *plp = P.pl + ((row0 + qi) * L + t0 + r) * 5;
+                const float *plp = P.pl + ((row0q + qi) * L + t0 + r) * 5;
                 dw[0] += dz;
 #pragma unroll
                 for (int d = 0; d < 5; ++d) dw[1 + d] = fmaf(dz, plp[d], dw[1 + d]);
@@ -1079,22 +1085,22 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
       for (int d = 0; d < SD; ++d) dw[d] = xor_reduce_sum_rows(dw[d]);
       if (g == 0 && q_ok) {
 #pragma unroll
-        for (int d = 0; d < SD; ++d) P.dsw[((row0 + qi) * P.H + h) * SD + d] = dw[d];
+        for (int d = 0; d < SD; ++d) P.dsw[((row0q + qi) * P.H + h) * SD + d] = dw[d];
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qr = 16 * s + 4 * g + r;
-      if (qr < L) {
-        uint16_t *op = P.dq + (row0 + qr) * P.ld_qkv + h * DH + m;
+      if (qr < Lq) {
+        uint16_t *op = P.dq + (row0q + qr) * P.ld_dq + h * DH + m;
 #pragma unroll
         for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r] * 0.125f);
       }
     }
   }
   __syncthreads();   // K / V tiles no longer needed: the same storage now takes Q and dO (row-major as well)
-  stage_rows(Qs, qb, P.ld_qkv, L, rows);
-  stage_rows(dOs, dob, P.ld_o, L, rows);
+  stage_rows(Qs, qb, P.ld_q, Lq, rows_q);
+  stage_rows(dOs, dob, P.ld_o, Lq, rows_q);
   __syncthreads();
 
   // ---------------- pass 2: key strips, query chunks streamed -> dK, dV ----------------
@@ -1119,14 +1125,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
       dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
       dv[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int c = 0; c < nc; ++c) {        // 32-query chunks
+    for (int c = 0; c < ncq; ++c) {       // 32-query chunks
       f32x4 pt[2], ds[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int i = 2 * c + hh;          // query tile
         pt[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
         ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < nt) {
+        if (i < ntq) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int cc = 0; cc < 2; ++cc) {
@@ -1160,12 +1166,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
             if (SPATIAL) {
               const int qi = q0 + r;
               float x = sacc[r] * 0.125f;
-              if (t_ok && qi < L) {
+              if (t_ok && qi < Lq) {
                 float w[SD];
 #pragma unroll
-                for (int d = 0; d < SD; ++d) w[d] = P.sw[((row0 + qi) * P.H + h) * SD + d];
+                for (int d = 0; d < SD; ++d) w[d] = P.sw[((row0q + qi) * P.H + h) * SD + d];
                 float sig;
-                x += spatial_bias(P.pl + ((row0 + qi) * L + t) * 5, w, kt < 0.f, sig);
+                x += spatial_bias(P.pl + ((row0q + qi) * L + t) * 5, w, kt < 0.f, sig);
               }
               p = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, kt) - lq[r]);
             } else {
@@ -1189,8 +1195,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
     for (int r = 0; r < 4; ++r) {
       const int tr = 16 * js + 4 * g + r;
       if (tr < L) {
-        uint16_t *pk = P.dk + (row0 + tr) * P.ld_qkv + h * DH + m;
-        uint16_t *pv = P.dv + (row0 + tr) * P.ld_qkv + h * DH + m;
+        uint16_t *pk = P.dk + (row0 + tr) * P.ld_dkv + h * DH + m;
+        uint16_t *pv = P.dv + (row0 + tr) * P.ld_dkv + h * DH + m;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           pk[16 * n] = f2bf(dk[n][r] * 0.125f);
@@ -1205,9 +1211,10 @@ inline size_t stream_fwd_lds(int nt) {
   const size_t rows = (size_t)((nt + 1) / 2) * 32;
   return 2 * (2 * rows * KS) + 4 * rows;
 }
-inline size_t stream_bwd_lds(int nt) {
-  const size_t rows = (size_t)((nt + 1) / 2) * 32;
-  return 2 * (2 * rows * KS) + 12 * rows;
+inline size_t stream_bwd_lds(int nt, int ntq) {
+  const size_t rows = (size_t)((nt + 1) / 2) * 32, rows_q = (size_t)((ntq + 1) / 2) * 32;
+  const size_t rows_max = rows > rows_q ? rows : rows_q;
+  return 2 * (2 * rows_max * KS) + 8 * rows_q + 4 * rows;
 }
 
 inline int pick_waves_stream(int nt) {        // up to 16 waves (one 1024-thread workgroup per (scene, head))
@@ -1216,10 +1223,11 @@ inline int pick_waves_stream(int nt) {        // up to 16 waves (one 1024-thread
 }
 
 int launch_stream(const Params &P, bool backward, hipStream_t s) {
-  const int nw = pick_waves_stream(P.nt);
+  // forward and backward pass 1 walk query strips, backward pass 2 key strips
+  const int nw = pick_waves_stream(backward ? (P.nt > P.ntq ? P.nt : P.ntq) : P.ntq);
   const dim3 grid(P.B * P.H), block(64 * nw);
   const bool spatial = P.sw != nullptr;
-  const size_t lds = backward ? stream_bwd_lds(P.nt) : stream_fwd_lds(P.nt);
+  const size_t lds = backward ? stream_bwd_lds(P.nt, P.ntq) : stream_fwd_lds(P.nt);
   if (lds > 160 * 1024) return GPS_ERR_UNSUPPORTED;
   const void *fn = backward ? (spatial ? (const void *)&attn_bwd_stream_kernel<true> : (const void *)&attn_bwd_stream_kernel<false>)
                             : (spatial ? (const void *)&attn_fwd_stream_kernel<true> : (const void *)&attn_fwd_stream_kernel<false>);
@@ -1299,6 +1307,17 @@ static int g_stream_min_nt[2] = {-1, -1};      // [plain, spatial]; -1 = not rea
 
 int dispatch(Params &P, bool backward, hipStream_t s) {
   P.nt = (P.L + 15) / 16;
+  if (P.Lq <= 0) P.Lq = P.L;
+  P.ntq = (P.Lq + 15) / 16;
+  if (P.ld_q <= 0) P.ld_q = P.ld_qkv;
+  if (P.ld_dq <= 0) P.ld_dq = P.ld_qkv;
+  if (P.ld_dkv <= 0) P.ld_dkv = P.ld_qkv;
+  // cross-attention (Lq != Lk) and operands with separate pitches are served by the streaming kernels only
+  const bool packed_self = P.Lq == P.L && P.ld_q == P.ld_qkv && P.ld_dq == P.ld_qkv && P.ld_dkv == P.ld_qkv;
+  if (!packed_self) {
+    if (P.nt > 32 || P.ntq > 32 || (backward && P.out == nullptr)) return GPS_ERR_UNSUPPORTED;
+    return launch_stream(P, backward, s);
+  }
   // The streaming kernels (key / query chunks streamed, no whole score row in registers) serve every length of the
   // plain form -- after their rewrite they beat the register-resident kernels at 50 and 130 tokens too
   // (profiles/r2: 0.33 + 0.13 ms vs 0.48 + 0.29 ms per step) -- and the rows above 144 tokens of the spatial form,
@@ -1322,9 +1341,52 @@ int dispatch(Params &P, bool backward, hipStream_t s) {
   return GPS_ERR_UNSUPPORTED;
 }
 
+// the general entry: argument checks, then bf16 -> the kernels of this file, fp32 / fp8 -> gps_attention_ex.hip
+int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
+  if (!a) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->B < 0 || a->H < 1 || a->Lq < 0 || a->Lk < 0 || a->ld_q < a->H * 64 || a->ld_kv < a->H * 64 || a->ld_o < a->H * 64 ||
+      a->p_drop < 0.f || a->p_drop >= 1.f)
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (a->head_dim != DH) return GPS_ERR_UNSUPPORTED;
+  if (a->B == 0 || a->Lq == 0) return GPS_OK;
+  if (a->Lk == 0) return GPS_ERR_INVALID_ARGUMENT;              // a softmax over no keys
+  if (!a->q || !a->k || !a->v || !a->out || !a->lse || ((a->sw == nullptr) != (a->pl == nullptr))) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->sw && a->Lq != a->Lk) return GPS_ERR_INVALID_ARGUMENT;  // the pairwise term is a self-attention term
+  if (backward && (!a->dout || !a->dq || !a->dk || !a->dv || a->ld_dq < a->H * 64 || a->ld_dkv < a->H * 64 || (a->sw && !a->dsw)))
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (a->dtype == GPS_ATTN_F32) {
+    if (a->compute != GPS_ATTN_COMPUTE_NATIVE) return GPS_ERR_UNSUPPORTED;
+    return run_f32(a, backward, s);
+  }
+  if (a->dtype != GPS_ATTN_BF16) return GPS_ERR_UNSUPPORTED;
+  if ((a->ld_q & 7) || (a->ld_kv & 7) || (a->ld_o & 7) || (backward && ((a->ld_dq & 7) || (a->ld_dkv & 7)))) return GPS_ERR_UNSUPPORTED;
+  if (a->compute == GPS_ATTN_COMPUTE_FP8 && !backward) return run_fp8_forward(a, s);
+  if (a->compute != GPS_ATTN_COMPUTE_NATIVE && a->compute != GPS_ATTN_COMPUTE_FP8) return GPS_ERR_UNSUPPORTED;
+  Params P = {};
+  P.B = a->B; P.H = a->H; P.L = a->Lk; P.Lq = a->Lq; P.ld_qkv = a->ld_kv; P.ld_q = a->ld_q; P.ld_o = a->ld_o;
+  P.q = (const uint16_t *)a->q; P.k = (const uint16_t *)a->k; P.v = (const uint16_t *)a->v;
+  P.sw = a->sw; P.pl = a->pl; P.mask = a->mask; P.out = (uint16_t *)a->out; P.lse = a->lse;
+  P.p_drop = a->p_drop; P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
+  P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
+  if (backward) {
+    P.dout = (const uint16_t *)a->dout; P.dq = (uint16_t *)a->dq; P.dk = (uint16_t *)a->dk; P.dv = (uint16_t *)a->dv;
+    P.ld_dq = a->ld_dq; P.ld_dkv = a->ld_dkv; P.dsw = a->dsw;
+  } else {
+    P.ld_dq = a->ld_q; P.ld_dkv = a->ld_kv;
+  }
+  return dispatch(P, backward, s);
+}
+
 }  // namespace gps_attn
 
 extern "C" {
+
+int gps_attn_forward_ex(const gps_attn_args *a, gps_stream_t stream) {
+  return gps_attn::run_ex(a, false, (hipStream_t)stream);
+}
+int gps_attn_backward_ex(const gps_attn_args *a, gps_stream_t stream) {
+  return gps_attn::run_ex(a, true, (hipStream_t)stream);
+}
 
 void gps_attn_set_stream_min_tiles(int plain, int spatial) {
   gps_attn::g_stream_min_nt[0] = plain < 1 ? 1 : plain;

@@ -11,8 +11,9 @@ in one launch per direction.  The input is the PACKED projection output
 
 so the projections are one GEMM, and the gradient comes back as one tensor of the same shape (the
 kernel writes dq/dk/dv straight into their column blocks: no chunk/cat copies in either direction).
-GPU + bf16 only; there is no CPU path (the torch formulation in transformers.attention_core is used
-for CPU tensors and fp32 inputs).
+Also here: the cross-attention core (q from `tgt`, [k | v] from `memory`: decoder / cross layers), fp32 operands on
+the fp32 MFMA (parity runs at fp32 tolerances, up to 256 tokens) and the fp8-product forward (set_fp8_products).
+GPU only; there is no CPU path (the torch formulation in transformers.attention_core is used for CPU tensors).
 """
 from __future__ import annotations
 
@@ -27,8 +28,14 @@ SPATIAL_VEC = 6
 MAX_LEN = 512
 
 
-def supported(d_model: int, n_head: int, length: int) -> bool:
-    return d_model == n_head * HEAD_DIM and 0 < length <= MAX_LEN
+MAX_LEN_F32 = 256
+
+
+def supported(d_model: int, n_head: int, length: int, dtype: torch.dtype = torch.bfloat16, kv_length: Optional[int] = None) -> bool:
+    """Does libgps_hip.so serve this attention call?  bf16: up to 512 tokens; fp32 operands (fp32 MFMA): up to 256."""
+    cap = MAX_LEN_F32 if dtype == torch.float32 else MAX_LEN
+    kv = length if kv_length is None else kv_length
+    return d_model == n_head * HEAD_DIM and 0 < length <= cap and 0 < kv <= cap
 
 
 def _stream() -> int:
@@ -39,7 +46,53 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr() if t is not None else None
 
 
+_FP8 = False        # attention-core products (Q K^T, P V) of the bf16 forward on the OCP e4m3 MFMA (bench.py --fp8)
+
+
+def set_fp8_products(flag: bool) -> None:
+    """BASELINE configs[4] ("fp8 MFMA attention path"): the forward products of every bf16 attention call run on
+    v_mfma_f32_16x16x32_fp8_fp8 (per-row / per-tile scales, fp32 softmax); backward products stay bf16."""
+    global _FP8
+    _FP8 = bool(flag)
+
+
+def fp8_products() -> bool:
+    return _FP8
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _native.ATTN_BF16
+    if t.dtype == torch.float32:
+        return _native.ATTN_F32
+    raise RuntimeError(f"fused attention serves bf16 and fp32 operands, not {t.dtype}")
+
+
+def _mask8(mask: Optional[torch.Tensor]):
+    # a bool tensor is one byte per element holding 0 / 1: the kernels read it in place (no conversion launch)
+    if mask is None:
+        return None
+    return mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+
+
+def _call(backward: bool, name: str, nbytes: int, flops: int, **f) -> None:
+    """One gps_attn_forward_ex / gps_attn_backward_ex launch on the current stream (tensors -> pointers and pitches)."""
+    import ctypes
+
+    from ...pointnet2._ext import _timed
+    a = _native.AttnArgs()
+    for k, v in f.items():
+        setattr(a, k, v.data_ptr() if torch.is_tensor(v) else v)
+    lib = _native.load()
+    fn = lib.gps_attn_backward_ex if backward else lib.gps_attn_forward_ex
+    with _timed(name, nbytes, flops, "fp32" if a.dtype == _native.ATTN_F32 else "bf16"):
+        st = fn(ctypes.byref(a), _stream())
+    _native.check(st, name)
+
+
 class _FusedSelfAttention(torch.autograd.Function):
+    """packed (B, L, 3 D [+ H 6]) = [q | k | v [| cond]] in bf16 or fp32 -> (B, L, D), same dtype."""
+
     @staticmethod
     def forward(ctx, packed: torch.Tensor, pl: Optional[torch.Tensor], mask: Optional[torch.Tensor],
                 n_head: int, p_drop: float, seed: int, seed_dev: Optional[torch.Tensor]) -> torch.Tensor:
@@ -47,28 +100,26 @@ class _FusedSelfAttention(torch.autograd.Function):
         D = n_head * HEAD_DIM
         spatial = pl is not None
         assert W == 3 * D + (n_head * SPATIAL_VEC if spatial else 0), (W, D, spatial)
-        assert packed.is_cuda and packed.dtype == torch.bfloat16 and packed.is_contiguous()
+        assert packed.is_cuda and packed.is_contiguous()
+        dt = _dtype_code(packed)
         sw = packed[..., 3 * D:].float().contiguous() if spatial else None
         if spatial:
             pl = pl.float().contiguous()
             assert pl.shape == (B, L, L, 5), pl.shape
-        # a bool tensor is one byte per element holding 0 / 1: the kernels read it in place (no conversion launch)
-        m8 = None
-        if mask is not None:
-            m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
-        out = torch.empty((B, L, D), dtype=torch.bfloat16, device=packed.device)
+        m8 = _mask8(mask)
+        out = torch.empty((B, L, D), dtype=packed.dtype, device=packed.device)
         lse = torch.empty((B, n_head, L), dtype=torch.float32, device=packed.device)
         base, esz = packed.data_ptr(), packed.element_size()
-        from ...pointnet2._ext import _timed
+        fp8 = _FP8 and dt == _native.ATTN_BF16
         # algorithmic work: q,k,v,out once (+ pairwise/cond vector), 2 x L x L x 64 MACs per head
-        nbytes = 2 * B * L * 4 * D + (B * L * L * 5 * 4 + B * L * n_head * 6 * 4 if spatial else 0)
-        with torch.cuda.device(packed.device), _timed(f"attn_forward(L={L},spatial={int(spatial)})", nbytes,
-                                                      4 * B * n_head * L * L * HEAD_DIM, "bf16"):
-            st = _native.load().gps_attn_forward(
-                B, n_head, L, HEAD_DIM, base, base + D * esz, base + 2 * D * esz, W,
-                _ptr(sw), _ptr(pl), _ptr(m8), float(p_drop), int(seed), _ptr(seed_dev), out.data_ptr(), D,
-                lse.data_ptr(), _stream())
-        _native.check(st, "attn_forward")
+        nbytes = esz * B * L * 4 * D + (B * L * L * 5 * 4 + B * L * n_head * 6 * 4 if spatial else 0)
+        with torch.cuda.device(packed.device):
+            _call(False, f"attn_forward(L={L},spatial={int(spatial)})" + ("[fp32]" if dt else "") + ("[fp8]" if fp8 else ""),
+                  nbytes, 4 * B * n_head * L * L * HEAD_DIM,
+                  B=B, H=n_head, Lq=L, Lk=L, head_dim=HEAD_DIM, dtype=dt,
+                  compute=_native.ATTN_COMPUTE_FP8 if fp8 else _native.ATTN_COMPUTE_NATIVE,
+                  q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W, sw=_ptr(sw), pl=_ptr(pl), mask=_ptr(m8),
+                  p_drop=float(p_drop), seed=int(seed), seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse)
         ctx.save_for_backward(packed, sw, pl, m8, lse, seed_dev, out)
         ctx.meta = (n_head, float(p_drop), int(seed), spatial)
         return out
@@ -79,29 +130,80 @@ class _FusedSelfAttention(torch.autograd.Function):
         n_head, p_drop, seed, spatial = ctx.meta
         B, L, W = packed.shape
         D = n_head * HEAD_DIM
-        dout = dout.to(torch.bfloat16).contiguous()
+        dt = _dtype_code(packed)
+        dout = dout.to(packed.dtype).contiguous()
         dpacked = torch.empty_like(packed)
         dsw = torch.empty_like(sw) if spatial else None
         base, esz = packed.data_ptr(), packed.element_size()
         gbase = dpacked.data_ptr()
-        from ...pointnet2._ext import _timed
-        nbytes = 2 * B * L * 8 * D + (B * L * L * 5 * 4 + 2 * B * L * n_head * 6 * 4 if spatial else 0)
-        with torch.cuda.device(packed.device), _timed(f"attn_backward(L={L},spatial={int(spatial)})", nbytes,
-                                                      10 * B * n_head * L * L * HEAD_DIM, "bf16"):
-            st = _native.load().gps_attn_backward(
-                B, n_head, L, HEAD_DIM, base, base + D * esz, base + 2 * D * esz, W,
-                _ptr(sw), _ptr(pl), _ptr(m8), p_drop, seed, _ptr(seed_dev), dout.data_ptr(), D, lse.data_ptr(),
-                out.data_ptr(), gbase, gbase + D * esz, gbase + 2 * D * esz, _ptr(dsw), _stream())
-        _native.check(st, "attn_backward")
+        nbytes = esz * B * L * 8 * D + (B * L * L * 5 * 4 + 2 * B * L * n_head * 6 * 4 if spatial else 0)
+        with torch.cuda.device(packed.device):
+            _call(True, f"attn_backward(L={L},spatial={int(spatial)})" + ("[fp32]" if dt else ""),
+                  nbytes, 10 * B * n_head * L * L * HEAD_DIM,
+                  B=B, H=n_head, Lq=L, Lk=L, head_dim=HEAD_DIM, dtype=dt, compute=_native.ATTN_COMPUTE_NATIVE,
+                  q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W, sw=_ptr(sw), pl=_ptr(pl), mask=_ptr(m8),
+                  p_drop=p_drop, seed=seed, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
+                  dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz, ld_dkv=W, dsw=_ptr(dsw))
         if spatial:
             dpacked[..., 3 * D:] = dsw
         return dpacked, None, None, None, None, None, None
 
 
+class _FusedCrossAttention(torch.autograd.Function):
+    """q (B, Lq, D) from `tgt`, kv (B, Lk, 2 D) = [k | v] from `memory`, bf16 or fp32 -> (B, Lq, D): the core of
+    nn.MultiheadAttention(tgt, memory, memory, key_padding_mask=...) in the reference's CrossAttentionLayer /
+    TransformerDecoderLayer / TransformerSpatialDecoderLayer (modules/layers/transformers.py:12-112, 242-282)."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, kv: torch.Tensor, mask: Optional[torch.Tensor], n_head: int, p_drop: float,
+                seed_dev: Optional[torch.Tensor]) -> torch.Tensor:
+        B, Lq, D = q.shape
+        Lk = kv.shape[1]
+        assert D == n_head * HEAD_DIM and kv.shape == (B, Lk, 2 * D), (q.shape, kv.shape)
+        assert q.is_cuda and q.is_contiguous() and kv.is_contiguous() and q.dtype == kv.dtype
+        dt = _dtype_code(q)
+        m8 = _mask8(mask)
+        out = torch.empty_like(q)
+        lse = torch.empty((B, n_head, Lq), dtype=torch.float32, device=q.device)
+        esz = q.element_size()
+        fp8 = _FP8 and dt == _native.ATTN_BF16
+        nbytes = esz * B * (2 * Lq + 2 * Lk) * D
+        with torch.cuda.device(q.device):
+            _call(False, f"xattn_forward(Lq={Lq},Lk={Lk})" + ("[fp32]" if dt else "") + ("[fp8]" if fp8 else ""),
+                  nbytes, 4 * B * n_head * Lq * Lk * HEAD_DIM,
+                  B=B, H=n_head, Lq=Lq, Lk=Lk, head_dim=HEAD_DIM, dtype=dt,
+                  compute=_native.ATTN_COMPUTE_FP8 if fp8 else _native.ATTN_COMPUTE_NATIVE,
+                  q=q, ld_q=D, k=kv.data_ptr(), v=kv.data_ptr() + D * esz, ld_kv=2 * D, mask=_ptr(m8),
+                  p_drop=float(p_drop), seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse)
+        ctx.save_for_backward(q, kv, m8, lse, seed_dev, out)
+        ctx.meta = (n_head, float(p_drop))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        q, kv, m8, lse, seed_dev, out = ctx.saved_tensors
+        n_head, p_drop = ctx.meta
+        B, Lq, D = q.shape
+        Lk = kv.shape[1]
+        dt = _dtype_code(q)
+        dout = dout.to(q.dtype).contiguous()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        esz = q.element_size()
+        nbytes = esz * B * (4 * Lq + 4 * Lk) * D
+        with torch.cuda.device(q.device):
+            _call(True, f"xattn_backward(Lq={Lq},Lk={Lk})" + ("[fp32]" if dt else ""),
+                  nbytes, 10 * B * n_head * Lq * Lk * HEAD_DIM,
+                  B=B, H=n_head, Lq=Lq, Lk=Lk, head_dim=HEAD_DIM, dtype=dt, compute=_native.ATTN_COMPUTE_NATIVE,
+                  q=q, ld_q=D, k=kv.data_ptr(), v=kv.data_ptr() + D * esz, ld_kv=2 * D, mask=_ptr(m8),
+                  p_drop=p_drop, seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
+                  dq=dq, ld_dq=D, dk=dkv.data_ptr(), dv=dkv.data_ptr() + D * esz, ld_dkv=2 * D)
+        return dq, dkv, None, None, None, None
+
+
 def fused_self_attention(packed: torch.Tensor, n_head: int, pairwise_locs: Optional[torch.Tensor] = None,
                          key_padding_mask: Optional[torch.Tensor] = None, dropout_p: float = 0.0,
                          training: bool = False) -> torch.Tensor:
-    """packed (B, L, 3*D [+ H*6]) bf16 -> (B, L, D) bf16 attention output (heads merged)."""
+    """packed (B, L, 3*D [+ H*6]) bf16 / fp32 -> (B, L, D) attention output (heads merged), same dtype."""
     p = float(dropout_p) if training else 0.0
     seed, seed_dev = 0, None
     if p > 0.0:
@@ -111,6 +213,14 @@ def fused_self_attention(packed: torch.Tensor, n_head: int, pairwise_locs: Optio
         seed_dev = _next_device_seed(packed.device)
     return _FusedSelfAttention.apply(packed.contiguous(), pairwise_locs, key_padding_mask, n_head, p, seed,
                                      seed_dev)
+
+
+def fused_cross_attention(q: torch.Tensor, kv: torch.Tensor, n_head: int, key_padding_mask: Optional[torch.Tensor] = None,
+                          dropout_p: float = 0.0, training: bool = False) -> torch.Tensor:
+    """q (B, Lq, D), kv (B, Lk, 2 D) = [k | v] (bf16 / fp32, projections already applied) -> (B, Lq, D)."""
+    p = float(dropout_p) if training else 0.0
+    seed_dev = _next_device_seed(q.device) if p > 0.0 else None
+    return _FusedCrossAttention.apply(q.contiguous(), kv.contiguous(), key_padding_mask, n_head, p, seed_dev)
 
 
 _SEED_INC = 0x632BE59BD9B4E019        # odd 63-bit increment; the stream wraps modulo 2^64

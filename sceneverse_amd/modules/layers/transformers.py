@@ -14,9 +14,11 @@ tuples, parameter names), re-built around one attention core:
     CrossAttentionLayer               ref :12-63
 
 Backends of the attention core (see `set_attention_backend`):
-    "hip"    fused gfx950 kernels from libgps_hip.so (GPU tensors; the default on a GPU),
-    "torch"  plain PyTorch ops; chosen automatically only for CPU tensors (tests / gloo runs) or
-             when attention probabilities are requested (`need_weights=True`).
+    "hip"    fused gfx950 kernels from libgps_hip.so (GPU tensors; the default on a GPU): self- and cross-attention,
+             bf16 (<= 512 tokens) and fp32 operands (<= 256 tokens, fp32 MFMA),
+    "torch"  plain PyTorch ops; chosen automatically only for CPU tensors (tests / gloo runs), when attention
+             probabilities are requested (`need_weights=True`), for an explicit `attn_mask`, for the spatial
+             fusions other than 'cond', or for fp32 rows above 256 tokens.
 
 Deviations from the reference, on purpose (DESIGN.md "reference quirks"):
   * no `assert torch.sum(torch.isnan(fused_attn) == 0)` host sync (ref :234);
@@ -56,16 +58,27 @@ def _bf16_mode(x: Tensor) -> bool:
         torch.get_autocast_dtype('cuda') == torch.bfloat16
 
 
-def _use_hip(x: Tensor, d_model: int, n_head: int) -> bool:
-    """The fused gfx950 attention core (libgps_hip.so) serves GPU self-attention in bf16."""
+def _use_hip(x: Tensor, d_model: int, n_head: int, kv_len: Optional[int] = None) -> bool:
+    """The fused gfx950 attention core (libgps_hip.so) serves GPU self- and cross-attention: bf16 (a bf16 tensor, or
+    fp32 under bf16 autocast) up to 512 tokens on the bf16 MFMA, plain fp32 up to 256 tokens on the fp32 MFMA."""
     if _BACKEND == "torch" or not x.is_cuda:
         return False
     from . import fused_attention
-    ok = x.dim() == 3 and fused_attention.supported(d_model, n_head, x.shape[1]) and _bf16_mode(x)
+    dtype = torch.bfloat16 if _bf16_mode(x) else x.dtype
+    ok = x.dim() == 3 and dtype in (torch.bfloat16, torch.float32) and \
+        fused_attention.supported(d_model, n_head, x.shape[1], dtype, kv_len)
     if _BACKEND == "hip" and not ok:
         raise RuntimeError("attention backend 'hip' requested for an unsupported call "
-                           f"(shape {tuple(x.shape)}, dtype {x.dtype}, d_model {d_model}, heads {n_head})")
+                           f"(shape {tuple(x.shape)}, dtype {x.dtype}, d_model {d_model}, heads {n_head}, keys {kv_len})")
     return ok
+
+
+def _proj_ctx(x: Tensor):
+    """Projections around the fused core when they go through F.linear: bf16 autocast in bf16 mode, plain fp32 else."""
+    import contextlib
+    if _bf16_mode(x):
+        return torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+    return contextlib.nullcontext()
 
 
 def _split_heads(x: Tensor, n_head: int) -> Tensor:
@@ -171,16 +184,18 @@ class MultiHeadAttentionSpatial(nn.Module):
         copy of the four weights) and one fused attention launch."""
         from . import gemm
         from .fused_attention import fused_self_attention
-        if gemm.usable(x, self.d_model, self.d_model):
+        if _bf16_mode(x) and gemm.usable(x, self.d_model, self.d_model):
             packed = gemm.packed_linear(x, [self.w_qs, self.w_ks, self.w_vs, self.lang_cond_fc])
             out = fused_self_attention(packed, self.n_head, pairwise_locs, key_padding_mask)
             return gemm.linear(out, self.fc.weight, self.fc.bias), None
+        # fp32 operands (the fp32 master path: fp32 MFMA core) or bf16 without the native GEMMs (A/B runs)
         w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.lang_cond_fc.weight], 0)
         bias = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias, self.lang_cond_fc.bias], 0)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with _proj_ctx(x):
             packed = F.linear(x, w, bias)
         out = fused_self_attention(packed, self.n_head, pairwise_locs, key_padding_mask)
-        return self.fc(out), None
+        with _proj_ctx(x):
+            return self.fc(out), None
 
     def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, txt_embeds=None):
         if (self.spatial_attn_fusion == 'cond' and k is q and v is q and not self.need_weights
@@ -255,18 +270,43 @@ class MultiheadSelfAttention(nn.Module):
                 and _use_hip(query, self.embed_dim, self.num_heads)):
             from . import gemm
             from .fused_attention import fused_self_attention
-            native = gemm.usable(query, self.embed_dim, self.embed_dim)
+            native = _bf16_mode(query) and gemm.usable(query, self.embed_dim, self.embed_dim)
             if native:
                 packed = gemm.linear(query, self.in_proj_weight, self.in_proj_bias)
             else:
-                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                with _proj_ctx(query):
                     packed = F.linear(query, self.in_proj_weight, self.in_proj_bias)
             out = fused_self_attention(packed, self.num_heads, None, key_padding_mask,
                                        dropout_p=self.dropout, training=self.training)
             if native:
                 return gemm.linear(out, self.out_proj.weight, self.out_proj.bias), None
-            return self.out_proj(out), None
+            with _proj_ctx(query):
+                return self.out_proj(out), None
         E = self.embed_dim
+        if (key is not query and attn_mask is None and not want and key.dim() == 3 and key.shape[1] == value.shape[1]
+                and _use_hip(query, self.embed_dim, self.num_heads, kv_len=key.shape[1])):
+            # cross-attention (decoder / cross layers, ref :12-112, 242-282) on the fused core: q from `query`,
+            # [k | v] from `key` / `value` (one GEMM when they are the same tensor, as every reference caller passes)
+            from .fused_attention import fused_cross_attention
+            bq_, bkv = self.in_proj_bias[:E], self.in_proj_bias[E:]
+            with _proj_ctx(query):
+                if self._same:
+                    q = F.linear(query, self.in_proj_weight[:E], bq_)
+                    if key is value:
+                        kv = F.linear(key, self.in_proj_weight[E:], bkv)
+                    else:
+                        kv = torch.cat([F.linear(key, self.in_proj_weight[E:2 * E], bkv[:E]),
+                                        F.linear(value, self.in_proj_weight[2 * E:], bkv[E:])], dim=-1)
+                else:
+                    q = F.linear(query, self.q_proj_weight, bq_)
+                    kv = torch.cat([F.linear(key, self.k_proj_weight, bkv[:E]),
+                                    F.linear(value, self.v_proj_weight, bkv[E:])], dim=-1)
+            if kv.dtype != q.dtype:
+                kv = kv.to(q.dtype)
+            out = fused_cross_attention(q, kv, self.num_heads, key_padding_mask, dropout_p=self.dropout,
+                                        training=self.training)
+            with _proj_ctx(query):
+                return self.out_proj(out), None
         bq, bk, bv = self.in_proj_bias[:E], self.in_proj_bias[E:2 * E], self.in_proj_bias[2 * E:]
         if self._same:
             if key is query and value is query:

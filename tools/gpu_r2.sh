@@ -130,4 +130,13 @@ if [[ $WHAT == *prof* ]]; then
   f=$(ls $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -40 "$f" | cut -c1-200
   tail -3 $OUT/prof_bench.log
 fi
+if [[ $WHAT == *attnex* ]]; then
+  ts attnex; timeout 900 python -m pytest tests/test_gpu_attention_ex.py tests/test_gpu_attention.py tests/test_a16_vs_golden.py tests/test_gpu_model.py -m gpu -q > $OUT/pytest_attnex.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_attnex.log
+  grep -E "^(FAILED|ERROR)|passed|failed|exit" $OUT/pytest_attnex.log | head -40 | cut -c1-400
+fi
+if [[ $WHAT == *stressfp8* ]]; then
+  ts stressfp8
+  timeout 600 python bench.py --config stress --steps 5 --warmup 2 --detail $OUT/bench_stress_detail.json > $OUT/bench_stress.json 2> $OUT/bench_stress.err; echo "stress exit $?"; tail -c 1500 $OUT/bench_stress.json; tail -3 $OUT/bench_stress.err
+  timeout 600 python bench.py --config stress --fp8 --steps 5 --warmup 2 --detail $OUT/bench_stress_fp8_detail.json > $OUT/bench_stress_fp8.json 2> $OUT/bench_stress_fp8.err; echo "stress fp8 exit $?"; tail -c 1500 $OUT/bench_stress_fp8.json; tail -3 $OUT/bench_stress_fp8.err
+fi
 ts done; du -sh $REPO/gpurun_out
