@@ -52,7 +52,7 @@ if os.path.exists(_TUNED.replace(".csv", "0.csv")) and not os.environ.get("GPS_N
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, same guide
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, same guide
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")   # rocprofv3 --pmc, see tools/pmc_traffic.py
 N_CLS = 607
 MAX_LINE_BYTES = 4000   # the driver keeps the last ~8 KB of stdout: the final JSON line must fit with room to spare
@@ -524,9 +524,9 @@ def main() -> None:
             mm = _re.match(r"gemm_(\w+)\(M=\d+,N=\d+,K=\d+,epi=(\d+)\)", name)
             if mm:
                 return f"gemm_{mm.group(1)}(epi={mm.group(2)})"
-            mm = _re.match(r"(attn_\w+)\(L=\d+,spatial=(\d)\)", name)
+            mm = _re.match(r"(attn_\w+)\(L=\d+,spatial=(\d)\)(\[\w+\])?", name)
             if mm:
-                return f"{mm.group(1)}(spatial={mm.group(2)})"
+                return f"{mm.group(1)}(spatial={mm.group(2)}){mm.group(3) or ''}"
             mm = _re.match(r"(add_dropout_layernorm_\w+)\(", name)
             if mm:
                 return mm.group(1)
@@ -625,7 +625,12 @@ def main() -> None:
                 "frac_hbm": round(attn_bytes / attn_sec / 1e9 / HBM_PEAK_GBS, 4)},
         }
         # the printed line carries the three north-star fractions only; everything else goes to the detail file
+        fp8_rows = [r for r in attn if r["kernel"].endswith("[fp8]")]
+        fp8_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in fp8_rows)
+        fp8_sec = sum(r["avg_us"] * 1e-6 * r["launches_per_step"] for r in fp8_rows)
         headline = {
+            **({"attention_fp8_forward_frac_fp8_mfma": round(fp8_flops / fp8_sec / 1e12 / MFMA_PEAK_TFLOPS["fp8"], 4),
+                "attention_fp8_forward_ms_per_step": round(fp8_sec * 1e3, 3)} if fp8_sec else {}),
             "ball_query_group_unfused_frac_hbm": bqg["frac_hbm"] if bqg else None,
             "ball_query_group_unfused_us": bqg["us"] if bqg else None,
             "native_gemms_frac_bf16_mfma": headline_full["native_gemms"]["frac_of_bf16_mfma_peak"] if gemm_sec else None,

@@ -85,7 +85,8 @@ def _call(backward: bool, name: str, nbytes: int, flops: int, **f) -> None:
         setattr(a, k, v.data_ptr() if torch.is_tensor(v) else v)
     lib = _native.load()
     fn = lib.gps_attn_backward_ex if backward else lib.gps_attn_forward_ex
-    with _timed(name, nbytes, flops, "fp32" if a.dtype == _native.ATTN_F32 else "bf16"):
+    mfma = "fp32" if a.dtype == _native.ATTN_F32 else ("fp8" if (a.compute == _native.ATTN_COMPUTE_FP8 and not backward) else "bf16")
+    with _timed(name, nbytes, flops, mfma):
         st = fn(ctypes.byref(a), _stream())
     _native.check(st, name)
 

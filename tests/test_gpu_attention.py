@@ -189,12 +189,23 @@ def test_layers_hip_backend_matches_torch_backend_under_autocast():
         _close(a, b, 5e-2, n)
 
 
-def test_fp32_inputs_keep_the_torch_formulation():
-    layer = T.TransformerEncoderLayer(768, 12, dropout=0.0).to(DEV)
+def test_fp32_inputs_run_the_fp32_core_not_the_bf16_one():
+    """fp32 tensors without autocast go to the fp32-operand kernels (fp32 MFMA): the result stays fp32 and agrees
+    with the torch formulation to fp32 rounding, far below what a detour through bf16 would leave."""
+    layer = T.TransformerEncoderLayer(768, 12, dropout=0.0).to(DEV).eval()
     x = torch.randn(2, 50, 768, device=DEV)
     from sceneverse_amd.pointnet2 import _ext
-    y, _ = layer(x)             # fp32, no autocast: must not be routed to the bf16 kernel
+    _ext.profile_start()
+    y, _ = layer(x)
+    seen = _ext.profile_stop()
     assert y.dtype == torch.float32
+    assert any(k.startswith("attn_forward") and k.endswith("[fp32]") for k in seen), sorted(seen)
+    T.set_attention_backend("torch")
+    try:
+        want, _ = layer(x)
+    finally:
+        T.set_attention_backend("auto")
+    _close(y, want, 1e-4, "fp32 layer")
 
 
 def test_full_bench_shapes_against_reference_on_sampled_scenes():
