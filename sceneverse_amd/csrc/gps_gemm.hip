@@ -186,6 +186,21 @@ struct Stager {
 #endif
     soff += step;
   }
+  // the same stage into REGISTERS (one 16-byte chunk per piece and lane) ...
+  __device__ __forceinline__ void load_regs(u32x4 (&r)[NPIECE]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) r[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], soff, 0));
+#endif
+    soff += step;
+  }
+  // ... and from there into the stage buffer: the image the LDS-DMA form writes (piece base + lane * 16)
+  __device__ __forceinline__ void store_regs(unsigned char *tile, const u32x4 (&r)[NPIECE], int wave, int lane) const {
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) *reinterpret_cast<u32x4 *>(tile + (j * NW + wave) * PIECE + lane * 16) = r[j];
+  }
   // the ragged last stage: only k_left (< 64) reduction indices are inside the matrix, the rest reads zeros
   __device__ __forceinline__ void issue_tail(unsigned char *tile, int k_left, int wave, int lane) {
     const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_block;
@@ -648,6 +663,130 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, FOUR waves (one per SIMD, 512 registers each: the 256 accumulators of a 128 x 128 wave tile live in
+// AGPRs), operands staged through REGISTERS two stages ahead.  Why: with LDS-resident staging a CU
+// never has more than one stage in flight (64 KB at this tile) and a stage's L2 -> LDS round trip under full-chip
+// load (1.1 - 2 us) exceeds its MFMA time (0.86 us); the 128 x 128 tiles have two workgroups per CU but need twice
+// the L2 bytes per flop (the eight L2s cannot deliver them).  Here stage s is requested into registers at the middle
+// of iteration s - 3, written to its LDS buffer at the middle of iteration s - 1 (the buffer was freed by the barrier
+// that opened that iteration) and read by the MFMAs of iteration s: two full iterations of latency cover, 128 KB of
+// operands in flight per CU besides the 64 KB being computed on.  Forms NT / NN (B_TR), K % 64 == 0; the LDS images,
+// fragment reads, tile walk and epilogues are those of gemm_kernel.
+// The MFMAs are inline asm with the accumulator tied in place ("+a"): left to the register allocator, the two
+// copies of the loop body (one per register set) get DIFFERENT accumulator assignments and every iteration pays
+// ~480 v_accvgpr moves and 46 scratch accesses (whose vmcnt waits also serialise the prefetch); pinned, the loop
+// is 256 MFMAs, 64 fragment reads, 32 buffer loads, 32 ds_write_b128 and nothing else.
+// ---------------------------------------------------------------------------------------------------------
+template <bool BTR, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm256_kernel(const Params P) {
+  constexpr int BM = 256, BN = 256, NW = 4, WGN = 2, WM = 128, WN = 128, TM = 8, TN = 8;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
+  constexpr int NPA = Stager<BM, false, NW>::NPIECE, NPB = Stager<BN, BTR, NW>::NPIECE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int GM = P.gm;
+  const int ntiles = P.ntm * P.ntn;
+  const int vid = xcd_virtual_id(blockIdx.x, ntiles);
+  const int group = vid / (GM * P.ntn), in_group = vid - group * (GM * P.ntn);
+  const int gmr = min(GM, P.ntm - group * GM);
+  const int tile_n = in_group / gmr;
+  const int m0 = (group * GM + (in_group - tile_n * gmr)) * BM, n0 = tile_n * BN;
+  if (P.extent_dev && m0 >= *P.extent_dev) return;                  // a tile of rows nobody reads
+  const int nst = P.nkt;
+
+  Stager<BM, false, NW> sa;
+  Stager<BN, BTR, NW> sb;
+  sa.init(P.A, P.lda, P.M, m0, 0, wave, lane);
+  sb.init(P.B, P.ldb, P.N, n0, 0, wave, lane);
+  u32x4 ra0[NPA], rb0[NPB], ra1[NPA], rb1[NPB];
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one K step (32 reduction indices) of the stage at `As`: quadrant walk, 4 A fragments x 8 B fragments per group
+  auto compute_ks = [&](const unsigned char *As, int ks) {
+    const unsigned char *Bs = As + A_BYTES;
+    bf16x8 bf[TN], af[2];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[b] = read_frag<BN, BTR>(Bs, wn0 + 16 * b, ks, lane);
+    af[0] = read_frag<BM, false>(As, wm0, ks, lane);
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      if (a + 1 < TM) af[(a + 1) & 1] = read_frag<BM, false>(As, wm0 + 16 * (a + 1), ks, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(bf[b]), "v"(af[a & 1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // iteration `it`: MFMAs of stage it; in its middle the registers holding stage it + 1 go to the other LDS buffer and
+  // are re-used for the request of stage it + 3 (the other register set holds stage it + 2, still in flight).
+  // Branch-free: requests past the last stage re-read the last one (soff is clamped) and are never consumed.
+  const unsigned int soff_last_a = (unsigned int)(nst - 1) * sa.step, soff_last_b = (unsigned int)(nst - 1) * sb.step;
+  auto request = [&](u32x4 (&ra)[NPA], u32x4 (&rb)[NPB]) {
+    sa.soff = min(sa.soff, soff_last_a);
+    sb.soff = min(sb.soff, soff_last_b);
+    sa.load_regs(ra);
+    sb.load_regs(rb);
+  };
+  auto body = [&](int it, u32x4 (&ra)[NPA], u32x4 (&rb)[NPB]) {
+    unsigned char *cur = smem + (it & 1) * STAGE, *nxt = smem + ((it + 1) & 1) * STAGE;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's ds_writes of stage `it` are in LDS
+    __builtin_amdgcn_s_barrier();                            // ... everybody's; and nobody still reads `nxt`
+    compute_ks(cur, 0);
+    sa.store_regs(nxt, ra, wave, lane);                      // the compiler's vmcnt wait for (ra, rb) sits here
+    sb.store_regs(nxt + A_BYTES, rb, wave, lane);
+    request(ra, rb);
+    compute_ks(cur, 1);
+  };
+  // prologue: stage 0 -> registers -> LDS buffer 0; stages 1 and 2 stay in flight in the two register sets
+  request(ra1, rb1);
+  request(ra0, rb0);
+  sa.store_regs(smem, ra1, wave, lane);
+  sb.store_regs(smem + A_BYTES, rb1, wave, lane);
+  request(ra1, rb1);
+  // even iterations hand over register set 0 (stages 1, 3, ...), odd ones set 1 (stages 2, 4, ...)
+  int it = 0;
+#pragma clang loop unroll(disable)
+  for (; it + 1 < nst; it += 2) {
+    body(it, ra0, rb0);
+    body(it + 1, ra1, rb1);
+  }
+  if (it < nst) body(it, ra0, rb0);
+  // the MFMAs above are inline asm: the compiler does not know their latency, so the wait states between the last
+  // of them and the first read of an accumulator are spelled out (8 passes of 4 cycles, guide: MFMA -> VALU read)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  f32x4 csum[TM];
+  store_tile<TM, TN, EPI>(P, acc, csum, false, 0, m0, n0, wm0, wn0, lane);
+}
+
+template <bool BTR, int EPI>
+int launch_256(Params &P, hipStream_t s) {
+  constexpr int LDS = 2 * 2 * 256 * BK * 2;              // two stages of (A | B) = 128 KB
+  P.ntm = (P.M + 255) / 256;
+  P.ntn = (P.N + 255) / 256;
+  P.gm = 4;
+  auto kern = &gemm256_kernel<BTR, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return GPS_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const long long blocks = (long long)P.ntm * P.ntn;
+  if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, s, P);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
 // out[e] = sum over splits of partial[s][e] in split order (deterministic); the same for the column sums
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long long elems, const float *__restrict__ partial,
                                                            float *__restrict__ out, long long ldo, int ncols,
@@ -764,11 +903,12 @@ int launch_cfg(Params &P, hipStream_t s) {
 //   3  128x64   2x2  3 bufs ( 72 KB)  2/CU      4  256x256  2x4  2 bufs (128 KB)  1/CU  5  256x128  4x2  2 bufs ( 96 KB) 1/CU
 //   6  128x64   2x2  2 bufs ( 48 KB)  3/CU      7  128x128  4x2  2 bufs ( 64 KB)  2/CU
 //   8  = 7, persistent workgroups (stage ring runs across tiles)                  9  = 6, persistent
-//  10  = 4, persistent
-constexpr int kVariants = 11;
+//  10  = 4, persistent                                                        11  256x256  2x2 (4 waves, 512 registers), operands
+//                                                                                register-staged two stages ahead (gemm256_kernel)
+constexpr int kVariants = 12;
 struct VariantShape { int bm, bn; };
 constexpr VariantShape kShapes[kVariants] = {{128, 128}, {256, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128},
-                                              {128, 128}, {128, 64}, {256, 256}};
+                                              {128, 128}, {128, 64}, {256, 256}, {256, 256}};
 template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
@@ -795,6 +935,9 @@ int launch_variant(Params &P, int variant, hipStream_t s) {
     case 9:                                                                            // 6, persistent
       if constexpr (EPI == EPI_F32 || ATR) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
       else return launch_cfg<128, 64, 2, 2, ATR, BTR, EPI, 2, false, true>(P, s);
+    case 11:      // 256 x 256, four waves, register-staged operands two stages ahead (gemm256_kernel): NT / NN, whole K stages
+      if constexpr (ATR || EPI == EPI_F32 || EPI == EPI_RELU_SPLIT || EPI == EPI_RELU_MAX16) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else return (P.K % BK == 0 && P.K >= BK && P.splits == 1) ? launch_256<BTR, EPI>(P, s) : launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
     default: return GPS_ERR_INVALID_ARGUMENT;
   }
 }

@@ -38,7 +38,7 @@ NT_SHAPES = [(5120, 768, 768), (8320, 2304, 768), (5120, 2376, 768), (5120, 2048
              (19200, 2304, 768), (8320, 1024, 64), (8200, 1032, 72)]      # persistent variants: 2 - 6 tiles per workgroup, 1- and 2-stage K
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_forward_nt(M, N, K, variant):
     x, w = _rand16(M, K, seed=1), _rand16(N, K, scale=0.05, seed=2)
@@ -63,7 +63,7 @@ NN_SHAPES = [(5120, 768, 768), (8320, 768, 2304), (5120, 768, 2376), (8320, 2048
              (300, 40, 72), (129, 8, 8), (257, 200, 136), (640, 2376, 640)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", NN_SHAPES)
 def test_dgrad_nn(M, N, K, variant):
     dy, w = _rand16(M, K, seed=5), _rand16(K, N, scale=0.05, seed=6)      # w is (out = K, in = N)
@@ -109,9 +109,10 @@ def _gelu_ref(pre16):
     return F.gelu(pre16.float())
 
 
-@pytest.fixture(params=[-1, 8, 9, 10])
+@pytest.fixture(params=[-1, 8, 9, 10, 11])
 def forced_variant(request):
-    """-1 = the shape-based default; 8 / 9 = the persistent tile walks (several tiles per workgroup at T = 9000)"""
+    """-1 = the shape-based default; 8 / 9 / 10 = the persistent tile walks (several tiles per workgroup at T = 9000);
+    11 = the four-wave 256 x 256 tile with register-staged operands (whole 64-wide K stages only: own shapes)"""
     for form in (_native.GEMM_NT, _native.GEMM_NN):
         G.set_gemm_variant(form, request.param)
     yield request.param
@@ -122,7 +123,7 @@ def forced_variant(request):
 @pytest.mark.parametrize("act", ["gelu", "relu"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_activation_epilogues_forward_and_backward(act, p, forced_variant):
-    T, Kin, Hid = (1300, 136, 264) if forced_variant < 0 else (9000, 136, 1032)
+    T, Kin, Hid = (1300, 136, 264) if forced_variant < 0 else ((9000, 128, 1024) if forced_variant == 11 else (9000, 136, 1032))
     x, w1 = _rand16(T, Kin, seed=11), _rand16(Hid, Kin, scale=0.2, seed=12)
     b1 = torch.randn(Hid, device=DEV)
     seed_dev = torch.tensor([123456789], dtype=torch.int64, device=DEV)
@@ -141,7 +142,7 @@ def test_activation_epilogues_forward_and_backward(act, p, forced_variant):
     ref_h = torch.where(keep, full / (1 - p), torch.zeros_like(full))
     _close16(h, ref_h, f"{act} hidden p={p}")
     # backward epilogue: dpre = (dy W2) * act'(pre) * mask / (1 - p), the mask recomputed from (seed, index)
-    Out = 72
+    Out = 128 if forced_variant == 11 else 72      # variant 11 needs whole 64-wide K stages
     dy, w2 = _rand16(T, Out, seed=13), _rand16(Out, Hid, scale=0.2, seed=14)
     dpre = G.linear_dgrad(dy, w2, act=act, aux=pre if act == "gelu" else h, p_drop=p, seed_dev=seed_dev)
     dh = dy.float() @ w2.float()

@@ -128,13 +128,13 @@ def main():
         row = {"tokens": T, "in": K, "out": N}
         # forward
         fns = {"lib": lambda: torch.nn.functional.linear(x, w, b16)}
-        for v in range(11):
+        for v in range(12):
             fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NT, _native.EPI_BIAS, T, N, K, x, K, w, K, y, N, bias=b, variant=v))
         t = timeit(fns, args.rounds)
         row["fwd_us"] = {k: round(v, 2) for k, v in t.items()}
         # dgrad
         fns = {"lib": lambda: torch.mm(dy, w)}
-        for v in range(11):
+        for v in range(12):
             fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NN, _native.EPI_BIAS, T, K, N, dy, N, w, K, dx, K, variant=v))
         t = timeit(fns, args.rounds)
         row["dgrad_us"] = {k: round(v, 2) for k, v in t.items()}

@@ -19,6 +19,10 @@ fi
 if [[ $WHAT == *gemmbench* ]]; then
   ts gemmbench; timeout 600 python tools/gemm_bench.py --json $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "gemm bench exit $?"; tail -20 $OUT/gemm_bench.log
 fi
+if [[ $WHAT == *gemmquick* ]]; then
+  ts gemmquick
+  for i in 8 10 11 4 0; do timeout 200 python tools/gemm_bench.py --only $i --rounds 8 >> $OUT/gemm_quick.log 2>&1; done; echo "gemm quick exit $?"; grep "^{" $OUT/gemm_quick.log | cut -c1-1200
+fi
 if [[ $WHAT == *newtests* ]]; then
   ts newtests; timeout 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_optim.py tests/test_a16_vs_golden.py tests/test_gpu_attention.py tests/test_gpu_model.py -m gpu -q -x > $OUT/pytest_new.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_new.log
   tail -15 $OUT/pytest_new.log | cut -c1-300
