@@ -19,6 +19,19 @@ fi
 if [[ $WHAT == *gemmbench* ]]; then
   ts gemmbench; timeout 600 python tools/gemm_bench.py --json $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "gemm bench exit $?"; tail -20 $OUT/gemm_bench.log
 fi
+if [[ $WHAT == *gpmc2* ]]; then
+  ts gpmc2
+  for cfg in ${GPMC_CFGS:-nt:7 nt:4 nt:11}; do
+    for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
+      tag=$(echo ${cfg}_${grp%% *} | tr ':' '_')
+      rm -rf /tmp/pmc_$tag
+      (cd /tmp && timeout 120 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_$tag -o p --output-format csv -- python $REPO/tools/gemm_bench.py --only 8 --pmc-loop $cfg > $OUT/pmc_$tag.log 2>&1; echo "pmc $tag exit $?")
+      f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
+      [ -n "$f" ] && python $REPO/tools/pmc_summary.py "$f" > $OUT/pmc_$tag.txt 2>&1
+    done
+  done
+  tail -n 12 $OUT/pmc_*.txt
+fi
 if [[ $WHAT == *gemmquick* ]]; then
   ts gemmquick
   for i in 8 10 11 4 0; do timeout 200 python tools/gemm_bench.py --only $i --rounds 8 >> $OUT/gemm_quick.log 2>&1; done; echo "gemm quick exit $?"; grep "^{" $OUT/gemm_quick.log | cut -c1-1200
