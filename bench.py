@@ -363,6 +363,8 @@ def main() -> None:
     ap.add_argument("--no-fused-emb", action="store_true",
                     help="BERT word-table gradient through torch's sort-based embedding backward (A/B of "
                          "modules/language/fused_embedding.py)")
+    ap.add_argument("--no-wgrad-overlap", action="store_true",
+                    help="weight-gradient GEMMs on the main stream (A/B of the side-stream overlap, modules/layers/gemm.py)")
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
@@ -418,7 +420,8 @@ def main() -> None:
     use_graph = (world == 1 and not args.no_graph) or args.graph_dp
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
                         graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm,
-                        grad_compress=("bf16_fp32acc" if (world > 1 and not share and args.bf16_grads) else None))
+                        grad_compress=("bf16_fp32acc" if (world > 1 and not share and args.bf16_grads) else None),
+                        wgrad_overlap=not args.no_wgrad_overlap)
     use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank,
                         device=dev)
@@ -453,6 +456,8 @@ def main() -> None:
     # replayed graph cannot host event pairs, and in the eager modes the ~1 200 event records per step would sit on
     # the host's launch path inside the number being reported.
     saved = (step.graph, step.graph_dp) if use_graph else None
+    saved_overlap = step.wgrad_overlap
+    step.wgrad_overlap = False      # per-kernel durations are taken with every launch alone on the GPU (one stream)
     if use_graph:
         step.graph = step.graph_dp = False
         step.step(dict(batch))
@@ -483,6 +488,7 @@ def main() -> None:
             bqg = bq_group_unfused(batch)
     if saved is not None:
         step.graph, step.graph_dp = saved
+    step.wgrad_overlap = saved_overlap
 
     if rank == 0:
         pairs_per_s = args.batch * world * args.steps / dt
@@ -665,7 +671,8 @@ def main() -> None:
                        **({"eval": eval_metrics} if eval_metrics is not None else {}),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
-                       "launch": graph_note or "eager",
+                       "launch": (graph_note or "eager") + ("" if args.no_wgrad_overlap or world > 1 and not args.graph_dp else
+                                                            "; weight-gradient GEMMs on a second stream"),
                        **({"grad_exchange": "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
                            if (args.bf16_grads and not share) else "fp32 all-reduce (DDP buckets)"} if world > 1 else {}),
                        "final_loss": round(final_loss, 4)},

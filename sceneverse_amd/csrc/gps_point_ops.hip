@@ -449,6 +449,45 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
   }
 }
 
+// [r3] Clouds of at most 64 points (SA2: 32 points, 16 centres): ONE WAVE per object, four objects per workgroup.
+// Lane L owns point L; for every centre the radius test gives one 64-bit mask, a hit lane's output slot is its
+// rank in the mask (mbcnt) and it stores its index straight to idx[j][slot]; lanes cnt <= t < nsample store the
+// first hit (or 0 when there is none).  No LDS, no barrier, a quarter of the workgroups of the block-per-object form
+// (whose 5120 launches of 256 threads each did ~30 instructions of work per wave).
+__global__ __launch_bounds__(kBlock) void ball_query_small_kernel(int b, int n, int m, float radius, int nsample,
+                                                                  const float *__restrict__ new_xyz,
+                                                                  const float *__restrict__ xyz, int32_t *__restrict__ idx) {
+  const int L = lane_id();
+  const int obj = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(wave_id());
+  if (obj >= b) return;
+  const float *p = xyz + (size_t)obj * n * 3;
+  const float *q = new_xyz + (size_t)obj * m * 3;
+  int32_t *o = idx + (size_t)obj * m * nsample;
+  const float radius2 = radius * radius;
+  const bool in = L < n;
+  const float px = in ? p[L * 3 + 0] : 0.f, py = in ? p[L * 3 + 1] : 0.f, pz = in ? p[L * 3 + 2] : 0.f;
+  for (int j0 = 0; j0 < m; j0 += kCentresPerLoad) {
+    const int jl = j0 + L / 3;
+    const int cv = (L < 3 * kCentresPerLoad && jl < m) ? __float_as_int(q[jl * 3 + L % 3]) : 0;
+    for (int jj = 0; jj < kCentresPerLoad && j0 + jj < m; ++jj) {
+      const int j = j0 + jj;
+      const float cx = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 0));
+      const float cy = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 1));
+      const float cz = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 2));
+      const float dx = cx - px, dy = cy - py, dz = cz - pz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const bool hit = in && (d2 < radius2);
+      const unsigned long long mask = __ballot(hit);
+      const int cnt = __popcll(mask);
+      const int first = cnt ? (__ffsll((long long)mask) - 1) : 0;
+      const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      if (hit && slot < nsample) o[j * nsample + slot] = L;
+      for (int t = L; t < nsample; t += kWave)
+        if (t >= cnt) o[j * nsample + t] = first;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // group_points: out[i,l,j,k] = points[i,l,idx[i,j,k]]     (src/group_points_gpu.cu:8-28)
 //
@@ -889,8 +928,10 @@ int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *
 #define GPS_BQ_CASE(R_)                                                                         \
   hipLaunchKernelGGL(gps::ball_query_kernel<R_>, grid, block, lds, s, b, n, m, radius, nsample, \
                      new_xyz, xyz, idx)
-  if (need <= 1) GPS_BQ_CASE(1);
-  else if (need <= 2) GPS_BQ_CASE(2);
+  if (need <= 1) {
+    hipLaunchKernelGGL(gps::ball_query_small_kernel, dim3((b + gps::kWavesPerBlock - 1) / gps::kWavesPerBlock), block, 0, s, b, n,
+                       m, radius, nsample, new_xyz, xyz, idx);
+  } else if (need <= 2) GPS_BQ_CASE(2);
   else if (need <= 4) GPS_BQ_CASE(4);
   else if (need <= 8) GPS_BQ_CASE(8);
   else if (need <= 16) GPS_BQ_CASE(16);

@@ -54,7 +54,7 @@ class GPSTrainStep:
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
                  native_gemm: bool = True, grad_compress: Optional[str] = None, native_optimizer: bool = True,
-                 fused_lm_loss: bool = True, find_unused_parameters: bool = False):
+                 fused_lm_loss: bool = True, find_unused_parameters: bool = False, wgrad_overlap: bool = True):
         self.cfg = cfg
         self.device = torch.device(device)
         # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
@@ -115,6 +115,9 @@ class GPSTrainStep:
         # False = freeze the tensors no rank ever gives a gradient in the probe step and skip the search
         self.find_unused_parameters = bool(find_unused_parameters)
         self.fused_lm_loss = bool(fused_lm_loss) and bool(native_gemm)
+        # weight-gradient GEMMs on a side stream beside the input-gradient chain (modules/layers/gemm.deferred_wgrads);
+        # never under torch DDP, whose reducer hooks need autograd's own gradient accumulation
+        self.wgrad_overlap = bool(wgrad_overlap) and bool(native_gemm) and self.device.type == "cuda"
         self.frozen_unused: list = []
         self.global_step = 0
         if self.graph_dp and dist_utils.is_dist():
@@ -244,7 +247,7 @@ class GPSTrainStep:
                 with self._autocast():
                     total, losses = self.loss(out)
                 self.optimizer.zero_grad(set_to_none=True)
-                total.backward()
+                self._backward(total)
                 grads = [p.grad for p in self.model.parameters() if p.grad is not None]
                 if dist_utils.is_dist() and self.world > 1:
                     flat = torch.cat([g.reshape(-1).float() for g in grads])
@@ -282,7 +285,7 @@ class GPSTrainStep:
                 self._flat_grad.zero_()
                 with self._autocast():
                     total, losses = self.loss(out)
-                total.backward()                      # accumulates into the flat views
+                self._backward(total)                 # accumulates into the flat views
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g3):
                 self._clip_and_step()
@@ -310,6 +313,17 @@ class GPSTrainStep:
             stack.enter_context(fused_lm_loss(True))
         return stack
 
+    def _backward(self, total) -> None:
+        """`total.backward()`; on a single GPU (or the split-graph form) with the weight gradients of the native
+        Linears overlapped on a side stream and joined before anything reads `param.grad`."""
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        if self.wgrad_overlap and not isinstance(self.net, DDP) and not self._want_ddp:
+            from .modules.layers.gemm import deferred_wgrads
+            with deferred_wgrads():
+                total.backward()
+        else:
+            total.backward()
+
     def _begin_step(self):
         # one tiny launch that advances the device-side dropout seed block; it sits inside every captured
         # region that runs the model, so each graph replay draws fresh masks
@@ -327,7 +341,7 @@ class GPSTrainStep:
     def _eager_body(self, data_dict):
         out, total, losses = self.forward_loss(data_dict)
         self.optimizer.zero_grad(set_to_none=True)
-        total.backward()
+        self._backward(total)
         self._clip_and_step()
         return total, losses
 
@@ -394,7 +408,7 @@ class GPSTrainStep:
             _gemm.invalidate_shadows()
         out, total, losses = self.forward_loss(data_dict)
         self.optimizer.zero_grad(set_to_none=True)
-        total.backward()
+        self._backward(total)
         self._clip_and_step()
         self.scheduler.step()
         self.global_step += 1

@@ -163,6 +163,84 @@ def linear_wgrad(dy16: torch.Tensor, x16: torch.Tensor, want_bias: bool = True):
     return dw, db
 
 
+# ---- weight gradients on a side stream ---------------------------------------------------------------------------
+# In the backward pass of a Linear, dX = dY W feeds the next backward op while dW = dY^T X (+ db) is only needed by the
+# optimizer.  Both GEMM forms leave most of the matrix pipe idle (stage-copy and epilogue stalls), so the
+# weight gradients are issued to a SECOND HIP stream and run beside the input-gradient chain; their results go
+# straight into `param.grad` (no AccumulateGrad copy) and the streams are joined once, after backward and before the
+# optimizer (`deferred_wgrads()` context, entered by sceneverse_amd/engine.py around `backward()`; a HIP-graph capture
+# records the fork / join as graph edges).  Off by default: plain `loss.backward()` callers get ordinary autograd
+# gradients.  Not used under torch DDP (its reducer hooks live on autograd's accumulation nodes).
+_DEFER = {"on": False, "side": {}, "keep": [], "joined": True}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _DEFER["side"].get(device)
+    if st is None:
+        st = _DEFER["side"][device] = torch.cuda.Stream(device=device)
+    return st
+
+
+class deferred_wgrads:
+    """with deferred_wgrads(): loss.backward()   -- weight / bias gradients of the native Linears are computed on a
+    side stream into `param.grad`; leaving the block makes the current stream wait for them."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _DEFER["on"]
+        _DEFER["on"] = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER["on"] = self.prev
+        join_wgrads()
+        return False
+
+
+def join_wgrads() -> None:
+    for dev, side in _DEFER["side"].items():
+        torch.cuda.current_stream(dev).wait_stream(side)
+    _DEFER["keep"].clear()
+
+
+def _wgrad_to_params(dy16: torch.Tensor, x16: torch.Tensor, weights, biases, rows) -> bool:
+    """Side-stream form of `linear_wgrad` for a (packed) Linear whose parameters are leaf tensors: dW / db land in
+    (or are added to) `param.grad`.  Returns False when the deferred form does not apply (the caller then returns
+    ordinary gradients to autograd)."""
+    if not _DEFER["on"]:
+        return False
+    params = [w for w in weights] + [b for b in biases if b is not None]
+    if not all(isinstance(t, torch.nn.Parameter) and t.is_leaf and t.requires_grad and t.dtype == torch.float32 for t in params):
+        return False
+    dev = dy16.device
+    cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    want_bias = any(b is not None for b in biases)
+    side.wait_stream(cur)                                   # dy16 / x16 (and a zeroed flat gradient buffer) are ready
+    with torch.cuda.stream(side):
+        single = len(weights) == 1 and weights[0].grad is None and (biases[0] is None or biases[0].grad is None)
+        dw, db = linear_wgrad(dy16, x16, want_bias=want_bias)
+        r = 0
+        for w, b, n in zip(weights, biases, rows):
+            gw = dw if single else dw[r:r + n]
+            if w.grad is None:
+                w.grad = gw if single else gw.clone()
+            else:
+                w.grad.add_(gw)
+            if b is not None:
+                gb = db if single else db[r:r + n]
+                if b.grad is None:
+                    b.grad = gb if single else gb.clone()
+                else:
+                    b.grad.add_(gb)
+            r += n
+    # operands and results stay referenced until the join: the caching allocator must not hand their memory to a
+    # later allocation of the main stream while the side stream still reads / writes it
+    _DEFER["keep"].append((dy16, x16, dw, db))
+    return True
+
+
 # ---- fp32-accurate MLP chains on the bf16 MFMA path (frozen point-encoder heads) ----------------------------------
 def split3_rows(x: torch.Tensor, k_pad: int) -> torch.Tensor:
     """fp32 (M, K) -> bf16 (M, 3 k_pad) = [hi | lo | hi], hi = bf16(x), lo = bf16(x - hi), zero padding to k_pad."""
@@ -385,6 +463,7 @@ class _LinearFn(torch.autograd.Function):
         y = linear_forward(x16, w16, b32)
         ctx.save_for_backward(x16, w16)
         ctx.meta = (x.shape, x.dtype, n, [w.shape[0] for w in weights], [b is not None for b in biases])
+        ctx.params = (weights, biases)                       # the parameter OBJECTS (deferred weight gradients)
         return y.view(*x.shape[:-1], w16.shape[0])
 
     @staticmethod
@@ -394,13 +473,16 @@ class _LinearFn(torch.autograd.Function):
         dy16 = _as_rows16(dy)
         need_w = any(ctx.needs_input_grad[2:2 + n])
         need_b = any(ctx.needs_input_grad[2 + n:])
+        dws, dbs = [None] * n, [None] * n
+        deferred = False
+        if need_w and all(ctx.needs_input_grad[2:2 + n]) and all((not hb) or g for hb, g in zip(has_b, ctx.needs_input_grad[2 + n:])):
+            deferred = _wgrad_to_params(dy16, x16, ctx.params[0], ctx.params[1], rows)      # side stream, first
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(dy16, w16).view(x_shape)
             if dx.dtype != x_dtype:
                 dx = dx.to(x_dtype)
-        dws, dbs = [None] * n, [None] * n
-        if need_w or need_b:
+        if (need_w or need_b) and not deferred:
             dw, db = linear_wgrad(dy16, x16, want_bias=need_b)
             r = 0
             for i in range(n):
@@ -433,6 +515,7 @@ class _FFNFn(torch.autograd.Function):
         y = linear_forward(h, w2_16, b2_32)
         ctx.save_for_backward(x16, w1_16, w2_16, h, pre, seed_dev)
         ctx.meta = (x.shape, x.dtype, act, float(p_drop), b1 is not None, b2 is not None)
+        ctx.params = (w1, b1, w2, b2)
         return y.view(*x.shape[:-1], w2_16.shape[0])
 
     @staticmethod
@@ -440,9 +523,15 @@ class _FFNFn(torch.autograd.Function):
         x16, w1_16, w2_16, h, pre, seed_dev = ctx.saved_tensors
         x_shape, x_dtype, act, p_drop, has_b1, has_b2 = ctx.meta
         dy16 = _as_rows16(dy)
-        dw2, db2 = linear_wgrad(dy16, h, want_bias=has_b2)
+        w1, b1, w2, b2 = ctx.params
+        all_w = all(ctx.needs_input_grad[1:5][i] for i in (0, 2)) and (not has_b1 or ctx.needs_input_grad[2]) and \
+            (not has_b2 or ctx.needs_input_grad[4])
+        dw1 = db1 = dw2 = db2 = None
+        if not (all_w and _wgrad_to_params(dy16, h, (w2,), (b2,), (w2.shape[0],))):
+            dw2, db2 = linear_wgrad(dy16, h, want_bias=has_b2)
         dpre = linear_dgrad(dy16, w2_16, act=act, aux=pre if act == "gelu" else h, p_drop=p_drop, seed_dev=seed_dev)
-        dw1, db1 = linear_wgrad(dpre, x16, want_bias=has_b1)
+        if not (all_w and _wgrad_to_params(dpre, x16, (w1,), (b1,), (w1.shape[0],))):
+            dw1, db1 = linear_wgrad(dpre, x16, want_bias=has_b1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(dpre, w1_16).view(x_shape)

@@ -284,3 +284,42 @@ def test_split3_points_builds_the_first_operand():
     got = G.split3_points(xyz, feats, k_pad)
     ref = G.split3_rows(torch.cat([xyz, feats.transpose(1, 2)], dim=2).reshape(B * n, 3 + C), k_pad)
     assert got.shape == ref.shape and torch.equal(got, ref)
+
+
+def test_deferred_weight_gradients_equal_the_autograd_ones():
+    """modules/layers/gemm.deferred_wgrads: dW / db computed on a side stream straight into param.grad must equal the
+    gradients autograd accumulates on the main stream -- single Linears, a packed group, an FFN, a weight used twice
+    in one backward (accumulation), and pre-existing .grad tensors (flat-buffer views of the split-graph step)."""
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(768, 768).to(DEV)
+    pack = [torch.nn.Linear(768, n).to(DEV) for n in (768, 768, 72)]
+    l1, l2 = torch.nn.Linear(768, 2048).to(DEV), torch.nn.Linear(2048, 768).to(DEV)
+    mods = [lin, l1, l2] + pack
+    x = torch.randn(16, 80, 768, device=DEV)
+
+    def loss_fn():
+        a = G.linear(x.to(torch.bfloat16), lin.weight, lin.bias)
+        a = G.linear(a, lin.weight, lin.bias)                      # second use of the same weight
+        b = G.packed_linear(a, pack)
+        c = G.ffn(a, l1, l2, "gelu", 0.0, False)
+        return b.float().square().mean() + c.float().square().mean()
+
+    def grads(deferred, preset):
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+            if preset:
+                for p in m.parameters():
+                    p.grad = torch.full_like(p, 0.25)
+        if deferred:
+            with G.deferred_wgrads():
+                loss_fn().backward()
+        else:
+            loss_fn().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for m in mods for p in m.parameters()]
+
+    for preset in (False, True):
+        want, got = grads(False, preset), grads(True, preset)
+        for a, b in zip(got, want):
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-7, (preset, (a - b).abs().max().item())

@@ -415,15 +415,11 @@ def test_bench_config_step_against_the_fp32_oracle_port():
     ref_out = R.openvocab_forward(sd, cpu, lang)
     ref_losses = R.pretrain_losses(ref_out, cpu, logit_scale)
     ref_losses["total_loss"].backward()
-    probes = ["point_encoder.obj_loc_encoding.0.weight" if "point_encoder.obj_loc_encoding.0.weight" in sd else None,
-              "point_encoder.spatial_encoder.0.self_attn.w_qs.weight", "point_encoder.spatial_encoder.3.linear2.weight",
+    probes = ["point_encoder.loc_layers.0.0.weight", "point_encoder.spatial_encoder.0.self_attn.w_qs.weight",
+              "point_encoder.spatial_encoder.0.self_attn.lang_cond_fc.weight", "point_encoder.spatial_encoder.3.linear2.weight",
               "unified_encoder.unified_encoder.0.self_attn.in_proj_weight", "unified_encoder.unified_encoder.3.linear1.weight",
               "unified_encoder.unified_encoder.3.norm2.weight"]
-    probes = [p for p in probes if p is not None and p in sd and sd[p].grad is not None]
-    if len(probes) < 4:                                  # names differ: fall back to a spread of what does have gradients
-        with_grad = [k for k, t in sd.items() if torch.is_tensor(t) and t.requires_grad and t.grad is not None and t.dim() == 2]
-        probes = with_grad[:: max(1, len(with_grad) // 6)][:6]
-    assert len(probes) >= 4, probes
+    assert all(p in sd and sd[p].grad is not None for p in probes), [p for p in probes if p not in sd or sd[p].grad is None]
     ref_grads = {p: sd[p].grad.clone() for p in probes}
     bert_probe = "encoder.layer.0.attention.self.query.weight"
     ref_bert_grad = dict(bert.named_parameters())[bert_probe].grad.clone()

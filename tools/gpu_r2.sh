@@ -32,6 +32,22 @@ if [[ $WHAT == *gpmc2* ]]; then
   done
   tail -n 12 $OUT/pmc_*.txt
 fi
+if [[ $WHAT == *bqpmc* ]]; then
+  ts bqpmc
+  for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES"; do
+    tag=bq_${grp%% *}
+    rm -rf /tmp/pmc_$tag
+    (cd /tmp && timeout 120 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_$tag -o p --output-format csv -- python $REPO/tools/bq_pmc_loop.py > $OUT/pmc_$tag.log 2>&1; echo "pmc $tag exit $?")
+    f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && python $REPO/tools/pmc_summary.py "$f" > $OUT/pmc_$tag.txt 2>&1
+  done
+  tail -n 22 $OUT/pmc_bq_*.txt
+fi
+if [[ $WHAT == *benchoverlap* ]]; then
+  ts benchoverlap
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --detail $OUT/bench_overlap_detail.json > $OUT/bench_overlap.json 2> $OUT/bench_overlap.err; echo "bench overlap exit $?"; tail -c 1200 $OUT/bench_overlap.json | head -c 700; echo; tail -2 $OUT/bench_overlap.err
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-wgrad-overlap > $OUT/bench_nooverlap.json 2> $OUT/bench_nooverlap.err; echo "bench no-overlap exit $?"; tail -c 1200 $OUT/bench_nooverlap.json | head -c 400; echo; tail -2 $OUT/bench_nooverlap.err
+fi
 if [[ $WHAT == *gemmquick* ]]; then
   ts gemmquick
   for i in 8 10 11 4 0; do timeout 200 python tools/gemm_bench.py --only $i --rounds 8 >> $OUT/gemm_quick.log 2>&1; done; echo "gemm quick exit $?"; grep "^{" $OUT/gemm_quick.log | cut -c1-1200
