@@ -5,7 +5,14 @@ modules/third_party/pointnet2/pointnet2_modules.py:
     PointnetSAModuleMSG             ref :78-124  (note ref :121-122: `mlp_spec[0] += 3` mutates the
                                                   caller's list when use_xyz -- reproduced)
     PointnetSAModule                ref :127-161
+    PointnetSAModuleVotes           ref :164-274 single-scale level that also returns the sampled indices; max / avg /
+                                                  RBF pooling, optional radius-normalised xyz
+    PointnetSAModuleMSGVotes        ref :276-353 multi-scale level returning the sampled indices
     PointnetFPModule                ref :356-416 three_nn + inverse-distance interpolation + MLP
+    PointnetLFPModuleMSG            ref :418-496 learnable feature propagation (ball-query grouping + post MLP)
+
+The three `*Votes` / `LFP` classes are not used by any GPS configuration (VoteNet heritage of the third-party
+package); they are provided so that the package's public names all resolve, on the same native ops.
 
 State-dict layout is the reference's (`groupers.i`, `mlps.i.layer{j}.conv|bn.bn`).
 """
@@ -230,3 +237,123 @@ class PointnetFPModule(nn.Module):
         new_features = (torch.cat([interpolated, unknow_feats], dim=1)
                         if unknow_feats is not None else interpolated)
         return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
+
+
+def _sample_centres(xyz: torch.Tensor, npoint: Optional[int], inds: Optional[torch.Tensor]):
+    """FPS (unless the caller brings its own indices) + gather of the sampled centres: (inds, new_xyz (B, npoint, 3)).
+    npoint None (group-all): nothing is sampled (the reference would call FPS with npoint = None there and fail)."""
+    if npoint is None:
+        return inds, None
+    if inds is None:
+        inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    centres = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds)
+    return inds, centres.transpose(1, 2).contiguous()
+
+
+def _bump_for_xyz(spec: List[int], use_xyz: bool) -> List[int]:
+    # the reference adds the 3 xyz channels to the CALLER's list in place (ref :201-203, :311-313, :446-448)
+    if use_xyz and len(spec) > 0:
+        spec[0] += 3
+    return spec
+
+
+class PointnetSAModuleVotes(nn.Module):
+    """Set-abstraction level that also hands back the indices of the sampled points (ref :164-274).
+
+    forward(xyz (B,N,3), features (B,C,N), inds (B,npoint) or None)
+        -> (new_xyz (B,npoint,3), new_features (B,mlp[-1],npoint), inds[, unique_cnt])
+    pooling: 'max' | 'avg' | 'rbf' (Gaussian of the centre-relative xyz with width sigma, divided by nsample)."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pooling: str = 'max', sigma: float = None,
+                 normalize_xyz: bool = False, sample_uniformly: bool = False, ret_unique_cnt: bool = False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.pooling, self.use_xyz = pooling, use_xyz
+        self.sigma = radius / 2 if sigma is None else sigma
+        self.normalize_xyz, self.ret_unique_cnt = normalize_xyz, ret_unique_cnt
+        if npoint is not None:
+            self.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                                                         normalize_xyz=normalize_xyz, sample_uniformly=sample_uniformly,
+                                                         ret_unique_cnt=ret_unique_cnt)
+        else:
+            self.grouper = pointnet2_utils.GroupAll(use_xyz, ret_grouped_xyz=True)
+        self.mlp_module = pt_utils.SharedMLP(_bump_for_xyz(mlp, use_xyz), bn=bn)
+
+    def forward(self, xyz, features=None, inds=None):
+        if inds is not None:
+            assert inds.shape[1] == self.npoint
+        inds, new_xyz = _sample_centres(xyz, self.npoint, inds)
+        grouped = self.grouper(xyz, new_xyz, features)
+        unique_cnt = None
+        if self.ret_unique_cnt:
+            grouped_features, grouped_xyz, unique_cnt = grouped
+        else:
+            grouped_features, grouped_xyz = grouped
+        new_features = self.mlp_module(grouped_features)                     # (B, mlp[-1], npoint, nsample)
+        if self.pooling == 'max':
+            new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+        elif self.pooling == 'avg':
+            new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+        elif self.pooling == 'rbf':
+            rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1, keepdim=False) / (self.sigma ** 2) / 2)
+            new_features = torch.sum(new_features * rbf.unsqueeze(1), -1, keepdim=True) / float(self.nsample)
+        new_features = new_features.squeeze(-1)
+        if self.ret_unique_cnt:
+            return new_xyz, new_features, inds, unique_cnt
+        return new_xyz, new_features, inds
+
+
+class PointnetSAModuleMSGVotes(nn.Module):
+    """Multi-scale set abstraction returning the sampled indices (ref :276-353): one (ball query, SharedMLP, max-pool)
+    branch per radius, channel-concatenated."""
+
+    def __init__(self, *, mlps: List[List[int]], npoint: int, radii: List[float], nsamples: List[int],
+                 bn: bool = True, use_xyz: bool = True, sample_uniformly: bool = False):
+        super().__init__()
+        assert len(mlps) == len(nsamples) == len(radii)
+        self.npoint = npoint
+        self.groupers, self.mlps = nn.ModuleList(), nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz,
+                                                               sample_uniformly=sample_uniformly)
+                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+    def forward(self, xyz, features=None, inds=None):
+        inds, new_xyz = _sample_centres(xyz, self.npoint, inds)
+        pooled = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            f = mlp(grouper(xyz, new_xyz, features))
+            pooled.append(F.max_pool2d(f, kernel_size=[1, f.size(3)]).squeeze(-1))
+        return new_xyz, torch.cat(pooled, dim=1), inds
+
+
+class PointnetLFPModuleMSG(nn.Module):
+    """Learnable feature propagation (ref :418-496): for every radius, group the features of set 1 around the points of
+    set 2, SharedMLP + max-pool, concatenate set 2's own features, `post_mlp`; branches channel-concatenated."""
+
+    def __init__(self, *, mlps: List[List[int]], radii: List[float], nsamples: List[int], post_mlp: List[int],
+                 bn: bool = True, use_xyz: bool = True, sample_uniformly: bool = False):
+        super().__init__()
+        assert len(mlps) == len(nsamples) == len(radii)
+        self.post_mlp = pt_utils.SharedMLP(post_mlp, bn=bn)
+        self.groupers, self.mlps = nn.ModuleList(), nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz,
+                                                               sample_uniformly=sample_uniformly))
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+    def forward(self, xyz2, xyz1, features2, features1):
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            f = mlp(grouper(xyz1, xyz2, features1))                          # (B, mlp[-1], N2, nsample)
+            f = F.max_pool2d(f, kernel_size=[1, f.size(3)]).squeeze(-1)      # (B, mlp[-1], N2)
+            if features2 is not None:
+                f = torch.cat([f, features2], dim=1)
+            outs.append(self.post_mlp(f.unsqueeze(-1)))
+        return torch.cat(outs, dim=1).squeeze(-1)
