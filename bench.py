@@ -363,8 +363,9 @@ def main() -> None:
     ap.add_argument("--no-fused-emb", action="store_true",
                     help="BERT word-table gradient through torch's sort-based embedding backward (A/B of "
                          "modules/language/fused_embedding.py)")
-    ap.add_argument("--no-wgrad-overlap", action="store_true",
-                    help="weight-gradient GEMMs on the main stream (A/B of the side-stream overlap, modules/layers/gemm.py)")
+    ap.add_argument("--wgrad-overlap", action="store_true",
+                    help="weight-gradient GEMMs on a second stream beside the input-gradient chain (modules/layers/gemm.py "
+                         "deferred_wgrads; measured slower on one GPU, off by default)")
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
@@ -421,7 +422,7 @@ def main() -> None:
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
                         graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm,
                         grad_compress=("bf16_fp32acc" if (world > 1 and not share and args.bf16_grads) else None),
-                        wgrad_overlap=not args.no_wgrad_overlap)
+                        wgrad_overlap=args.wgrad_overlap)
     use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank,
                         device=dev)
@@ -671,8 +672,7 @@ def main() -> None:
                        **({"eval": eval_metrics} if eval_metrics is not None else {}),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
-                       "launch": (graph_note or "eager") + ("" if args.no_wgrad_overlap or world > 1 and not args.graph_dp else
-                                                            "; weight-gradient GEMMs on a second stream"),
+                       "launch": (graph_note or "eager") + ("; weight-gradient GEMMs on a second stream" if step.wgrad_overlap else ""),
                        **({"grad_exchange": "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
                            if (args.bf16_grads and not share) else "fp32 all-reduce (DDP buckets)"} if world > 1 else {}),
                        "final_loss": round(final_loss, 4)},

@@ -337,10 +337,11 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
       py[i].x = in0 ? p[k0 * 3 + 1] : 0.f;  py[i].y = in1 ? p[k1 * 3 + 1] : 0.f;
       pz[i].x = in0 ? p[k0 * 3 + 2] : 0.f;  pz[i].y = in1 ? p[k1 * 3 + 2] : 0.f;
     }
-    // per-wave LDS: row of nsample + 128 slots (a pair of chunks may overshoot nsample by < 128) + 64 dummy words
-    const int row_len = nsample + 2 * kWave;
+    // per-wave LDS: row of nsample + 512 slots (a block of 8 chunks may overshoot nsample by < 512) + 64 dummy words
+    const int row_len = nsample + 8 * kWave;
     int32_t *wrow = bq_rows + w * (row_len + kWave);
     int32_t *dummy = wrow + row_len + L;
+    const int dummy_at = row_len + L;
     // the wave's centres are fetched 21 at a time with ONE vector load (lane 3 jj + c = coordinate c of its jj-th
     // centre) and broadcast from there: a load per centre put a memory round trip in front of every scan
     for (int j0 = w; j0 < m; j0 += kCentresPerLoad * kWavesPerBlock) {
@@ -374,17 +375,23 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
               mk[2 * i] = __ballot(hit[2 * i]);
               mk[2 * i + 1] = __ballot(hit[2 * i + 1]);
             }
+            // The CU has ONE scalar unit for its four SIMDs: the counters of the previous form (profiles/r3:
+            // 23.3 M scalar against 19.0 M vector instructions per launch, scalar pipe saturated) say the per-chunk
+            // scalar tests (empty? still below nsample?) cost more than the vector work they skipped.  So the
+            // compaction of a block is unconditional and purely vector: slot = base + rank in the mask (2 mbcnt), the
+            // store address is SELECTED by the lane's hit bit (hit -> row[slot], miss -> a private dummy word), no
+            // exec masking, no branch; the scalar unit only keeps the running count (popcount + add per chunk) and
+            // takes one decision per block.  Slots past nsample land in the overshoot area of the row and are ignored.
             int base[9];
             base[0] = cnt;
 #pragma unroll
             for (int i = 0; i < 8; ++i) base[i + 1] = base[i] + __popcll(mk[i]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              if (mk[i] != 0ull && base[i] < nsample) {                     // wave-uniform
-                const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[i] >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((unsigned)mk[i], (unsigned)base[i]));
-                *(hit[i] ? wrow + slot : dummy) = (8 * blk + i) * kWave + L;
-              }
+              const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[i] >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mk[i], (unsigned)base[i]));
+              const int at = hit[i] ? slot : dummy_at;                      // v_cndmask on the compare's own SGPR pair
+              wrow[at] = (8 * blk + i) * kWave + L;
             }
             cnt = base[8];
           }
@@ -920,8 +927,8 @@ int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *
   if ((long long)b * m * nsample == 0) return GPS_OK;
   if (!new_xyz || !idx || (n > 0 && !xyz)) return GPS_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
-  // per wave: a row of nsample slots (+ 128 overshoot slots + 64 dummy words of the register-resident form)
-  const size_t lds = (size_t)gps::kWavesPerBlock * (nsample + 3 * gps::kWave) * sizeof(int32_t);
+  // per wave: a row of nsample slots (+ 512 overshoot slots + 64 dummy words of the register-resident form)
+  const size_t lds = (size_t)gps::kWavesPerBlock * (nsample + 9 * gps::kWave) * sizeof(int32_t);
   if (lds > (size_t)kLdsBudget) return GPS_ERR_UNSUPPORTED;
   const dim3 grid(b), block(gps::kBlock);
   const int need = (n + gps::kWave - 1) / gps::kWave;

@@ -54,7 +54,7 @@ class GPSTrainStep:
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
                  native_gemm: bool = True, grad_compress: Optional[str] = None, native_optimizer: bool = True,
-                 fused_lm_loss: bool = True, find_unused_parameters: bool = False, wgrad_overlap: bool = True):
+                 fused_lm_loss: bool = True, find_unused_parameters: bool = False, wgrad_overlap: bool = False):
         self.cfg = cfg
         self.device = torch.device(device)
         # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
@@ -116,7 +116,10 @@ class GPSTrainStep:
         self.find_unused_parameters = bool(find_unused_parameters)
         self.fused_lm_loss = bool(fused_lm_loss) and bool(native_gemm)
         # weight-gradient GEMMs on a side stream beside the input-gradient chain (modules/layers/gemm.deferred_wgrads);
-        # never under torch DDP, whose reducer hooks need autograd's own gradient accumulation
+        # never under torch DDP, whose reducer hooks need autograd's own gradient accumulation.  OFF by default:
+        # measured slower on one MI355X (profiles/r3/bench_overlap_ab.json: 20.5 vs 19.3 ms per step) -- both GEMM
+        # forms already occupy every CU's LDS with two workgroups, so a second stream's workgroups queue behind them
+        # instead of filling idle matrix-pipe time, and the two kernels evict each other's L2 panels
         self.wgrad_overlap = bool(wgrad_overlap) and bool(native_gemm) and self.device.type == "cuda"
         self.frozen_unused: list = []
         self.global_step = 0

@@ -73,9 +73,11 @@ class BERTLanguageEncoder(nn.Module):
         from . import fused_embedding
         m, H = self.model, self.bert_config.num_attention_heads
         xs, shapes, pads = [], [], []
-        for ids, masks in texts:
-            if _FAST_EMB and fused_embedding.supported(m.embeddings, ids):
-                e = fused_embedding.bert_embeddings(m.embeddings, ids)      # same values, sort-free backward
+        fused_emb = _FAST_EMB and all(fused_embedding.supported(m.embeddings, ids) for ids, _ in texts)
+        embs = fused_embedding.bert_embeddings_multi(m.embeddings, [ids for ids, _ in texts]) if fused_emb else None
+        for ti, (ids, masks) in enumerate(texts):
+            if fused_emb:
+                e = embs[ti]                                    # same values, ONE sort-free table gradient for all texts
             else:
                 e = m.embeddings(input_ids=ids)                 # (B, L, D) fp32 under autocast
             shapes.append(e.shape)

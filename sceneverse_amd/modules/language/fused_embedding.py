@@ -74,3 +74,21 @@ def bert_embeddings(emb, input_ids: torch.Tensor) -> torch.Tensor:
     x = x + emb.token_type_embeddings.weight[0]          # every token has type 0 (the HF buffer of zeros)
     x = x + emb.position_embeddings.weight[:L]
     return emb.dropout(emb.LayerNorm(x))
+
+
+def bert_embeddings_multi(emb, texts) -> list:
+    """The same block for several id tensors [(B_i, L_i), ...] with ONE word-table lookup over all their tokens, so
+    that the backward pass fills the (30 522 x 768) table gradient once (one zero-fill + one gps_embedding_grad launch
+    over every token of the step) instead of once per text; positions, type row, LayerNorm and dropout per text."""
+    pad = emb.word_embeddings.padding_idx
+    flat = torch.cat([ids.reshape(-1) for ids in texts]) if len(texts) > 1 else texts[0].reshape(-1)
+    words = _WordLookup.apply(flat, emb.word_embeddings.weight, -1 if pad is None else int(pad))
+    outs, r0 = [], 0
+    for ids in texts:
+        B, L = ids.shape
+        x = words[r0:r0 + B * L].view(B, L, -1)
+        r0 += B * L
+        x = x + emb.token_type_embeddings.weight[0]
+        x = x + emb.position_embeddings.weight[:L]
+        outs.append(emb.dropout(emb.LayerNorm(x)))
+    return outs

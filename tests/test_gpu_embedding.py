@@ -88,6 +88,32 @@ def test_bert_embedding_block_matches_huggingface():
         assert torch.allclose(p.grad, ref, rtol=1e-4, atol=1e-5 * max(1.0, ref.abs().max().item())), n
 
 
+def test_bert_embedding_block_for_two_texts_with_one_table_gradient():
+    """bert_embeddings_multi: the sentence and the scene caption share ONE word lookup (one table gradient launch);
+    values and every gradient equal two separate HF embedding calls."""
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(1)
+    emb = BertModel(BertConfig(hidden_size=768, num_hidden_layers=1, num_attention_heads=12,
+                               type_vocab_size=2)).embeddings.to(DEV)
+    emb.train()
+    emb.dropout.p = 0.0
+    a = torch.randint(1000, 30522, (8, 50), device=DEV)
+    b = torch.randint(1000, 30522, (8, 300), device=DEV)
+    b[:, :20] = a[:, :20]                                  # tokens shared between the two texts: duplicates across them
+    ga, gb = torch.randn(8, 50, 768, device=DEV), torch.randn(8, 300, 768, device=DEV)
+    ya, yb = emb(input_ids=a), emb(input_ids=b)
+    (ya * ga).sum().backward()
+    (yb * gb).sum().backward()
+    want = {n: p.grad.clone() for n, p in emb.named_parameters()}
+    emb.zero_grad(set_to_none=True)
+    za, zb = FE.bert_embeddings_multi(emb, [a, b])
+    ((za * ga).sum() + (zb * gb).sum()).backward()
+    assert torch.equal(ya, za) and torch.equal(yb, zb)
+    for n, p in emb.named_parameters():
+        ref = want[n]
+        assert torch.allclose(p.grad, ref, rtol=1e-4, atol=1e-5 * max(1.0, ref.abs().max().item())), n
+
+
 def test_argument_errors():
     from sceneverse_amd import _native
     ids = torch.zeros(4, dtype=torch.int64, device=DEV)
