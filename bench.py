@@ -363,6 +363,9 @@ def main() -> None:
     ap.add_argument("--no-fused-emb", action="store_true",
                     help="BERT word-table gradient through torch's sort-based embedding backward (A/B of "
                          "modules/language/fused_embedding.py)")
+    ap.add_argument("--no-varlen", action="store_true",
+                    help="BERT on the padded (B, L) row batch instead of the compacted valid tokens (A/B of "
+                         "modules/language/bert.py's variable-length fast path)")
     ap.add_argument("--wgrad-overlap", action="store_true",
                     help="weight-gradient GEMMs on a second stream beside the input-gradient chain (modules/layers/gemm.py "
                          "deferred_wgrads; measured slower on one GPU, off by default)")
@@ -399,6 +402,9 @@ def main() -> None:
     if args.no_fused_emb:
         from sceneverse_amd.modules.language import bert as _bert
         _bert.set_fused_embedding(False)
+    if args.no_varlen:
+        from sceneverse_amd.modules.language import bert as _bert
+        _bert.set_varlen(False)
     if args.fp8:
         # BASELINE configs[4]: Q K^T and P V of every bf16 attention call on the OCP e4m3 MFMA (forward)
         from sceneverse_amd.modules.layers import fused_attention as _fa
@@ -672,6 +678,7 @@ def main() -> None:
                        **({"eval": eval_metrics} if eval_metrics is not None else {}),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
+                       "text_rows": "padded (B, L) batch" if args.no_varlen else "valid tokens only (variable-length BERT path)",
                        "launch": (graph_note or "eager") + ("; weight-gradient GEMMs on a second stream" if step.wgrad_overlap else ""),
                        **({"grad_exchange": "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
                            if (args.bf16_grads and not share) else "fp32 all-reduce (DDP buckets)"} if world > 1 else {}),

@@ -237,6 +237,11 @@ typedef struct gps_attn_args {
   void *dq; int ld_dq;       /* (B, Lq, ld_dq) */
   void *dk, *dv; int ld_dkv; /* (B, Lk, ld_dkv) */
   float *dsw;                /* (B, Lq, H * 6) when sw != NULL */
+  /* packed VARIABLE-LENGTH self-attention (bf16, plain form, no mask needed): B sequences stored back to back, sequence
+   * b = rows [cu_rows[b], cu_rows[b + 1]) of q / k / v / out / dout / dq / dk / dv (B + 1 int32 on the device, lengths
+   * may be 0); Lq == Lk = the CAPACITY (an upper bound of every length; sizes LDS and is the pitch of lse (B, H, Lq)).
+   * NULL = fixed-length batch.  Work and traffic scale with the real lengths (sum L_b^2), not with B * Lq^2. */
+  const int *cu_rows;
 } gps_attn_args;
 GPS_API int gps_attn_forward_ex(const gps_attn_args *args, gps_stream_t stream);
 GPS_API int gps_attn_backward_ex(const gps_attn_args *args, gps_stream_t stream);
@@ -288,6 +293,22 @@ GPS_API int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, in
                                                float p_drop, unsigned long long seed, const void *seed_dev,
                                                void *dx, void *dh, float *dgamma_part, float *dbeta_part,
                                                gps_stream_t stream);
+
+/* The same two calls with a DEVICE-side row count: only the first min(n_rows, *rows_dev) rows are read / written and
+ * enter the dgamma / dbeta partial sums (rows_dev NULL = all n_rows).  For row batches whose number of live rows is
+ * only known on the device (text tokens compacted valid-first: modules/language/bert.py), with static launch shapes
+ * so that the step stays one replayable HIP graph. */
+GPS_API int gps_add_dropout_layernorm_forward_rows(int n_rows, int d, int x_bf16, int h_bf16, const void *x,
+                                                   const void *h, const float *gamma, const float *beta, float eps,
+                                                   float p_drop, unsigned long long seed, const void *seed_dev,
+                                                   void *y, void *y_bf16, float *mean, float *rstd,
+                                                   const int *rows_dev, gps_stream_t stream);
+GPS_API int gps_add_dropout_layernorm_backward_rows(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                                    const void *dy_bf16, const void *x, const void *h,
+                                                    const float *gamma, const float *mean, const float *rstd,
+                                                    float p_drop, unsigned long long seed, const void *seed_dev,
+                                                    void *dx, void *dh, float *dgamma_part, float *dbeta_part,
+                                                    const int *rows_dev, gps_stream_t stream);
 
 /* ---- per-object input processing of the data loader ------------------------------------------------
  * Replaces ScanBase._obj_processing_post (data/datasets/base.py:697-740: optional rotation, centre/size

@@ -44,7 +44,8 @@ class AttnArgs(ctypes.Structure):
                 ("sw", _vp), ("pl", _vp), ("mask", _vp),
                 ("p_drop", _f), ("seed", ctypes.c_ulonglong), ("seed_dev", _vp),
                 ("out", _vp), ("ld_o", _i), ("lse", _vp),
-                ("dout", _vp), ("dq", _vp), ("ld_dq", _i), ("dk", _vp), ("dv", _vp), ("ld_dkv", _i), ("dsw", _vp)]
+                ("dout", _vp), ("dq", _vp), ("ld_dq", _i), ("dk", _vp), ("dv", _vp), ("ld_dkv", _i), ("dsw", _vp),
+                ("cu_rows", _vp)]
 
 
 ATTN_BF16, ATTN_F32 = 0, 1
@@ -84,6 +85,8 @@ SIGNATURES = {
     "gps_ln_reduce_partials": [_i, _i, _vp, _vp, _vp, _vp],
     "gps_add_dropout_layernorm_forward": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_add_dropout_layernorm_backward": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 6,
+    "gps_add_dropout_layernorm_forward_rows": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 7,
+    "gps_add_dropout_layernorm_backward_rows": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 7,
     "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i, _vp, _vp],
     "gps_attn_forward_ex": [ctypes.POINTER(AttnArgs), _vp],
     "gps_attn_backward_ex": [ctypes.POINTER(AttnArgs), _vp],

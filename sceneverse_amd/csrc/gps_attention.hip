@@ -63,6 +63,9 @@ struct Params {
   unsigned long long seed;
   const unsigned long long *seed_dev;   // optional device word added to `seed` (HIP-graph replays
                                         // get fresh dropout masks by advancing it on the device)
+  const int *cu_rows;                   // optional (B + 1) row offsets of VARIABLE-LENGTH sequences packed back to back
+                                        // (self-attention, streaming kernels): sequence b = rows [cu[b], cu[b + 1]),
+                                        // L / Lq are then the CAPACITY (longest sequence; LDS sizing, lse pitch)
 };
 
 __device__ __forceinline__ unsigned long long effective_seed(const Params &P) {
@@ -815,17 +818,25 @@ __device__ __forceinline__ bf16x8 frag_from_rows_tr(const uint16_t *rows, int nt
 template <bool SPATIAL>
 __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;      // keys
-  const int Lq = P.Lq, ntq = P.ntq;                                        // queries
+  int b, h;
+  block_to_bh(P, b, h);
+  // fixed-length batch: sequence b = rows [b L, b L + L); packed variable-length batch: rows [cu[b], cu[b + 1])
+  int L = P.L, Lq = P.Lq;
+  size_t row0 = (size_t)b * P.L, row0q = (size_t)b * P.Lq;
+  if (P.cu_rows) {
+    row0 = row0q = (size_t)P.cu_rows[b];
+    L = Lq = P.cu_rows[b + 1] - P.cu_rows[b];
+    if (L <= 0) return;                                     // workgroup-uniform: an empty sequence has no rows at all
+  }
+  const int nt = (L + 15) / 16, nc = (nt + 1) / 2, rows = nc * 32;       // keys
+  const int ntq = (Lq + 15) / 16;                                         // queries
+  const int Lq_cap = P.Lq;                                                // pitch of lse and of the dropout counter
   uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);       // [rows][KS]
   uint16_t *Vs = Ks + rows * KS;                            // [rows][KS]
   float *mb = reinterpret_cast<float *>(Vs + rows * KS);    // [rows] additive key term: 0, or -inf (padded / past L)
 
-  int b, h;
-  block_to_bh(P, b, h);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int m = lane & 15, g = lane >> 4;
-  const size_t row0 = (size_t)b * L, row0q = (size_t)b * Lq;
   const uint16_t *qb = P.q + row0q * P.ld_q + h * DH;
   const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
   const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
   const unsigned int seedmix = dropout ? seed_fold(effective_seed(P)) : 0u;
   const unsigned int thr16 = P.drop_thr >> 16;
-  const unsigned int pitch2 = (unsigned int)((L + 1) >> 1);       // key pairs per query row
+  const unsigned int pitch2 = (unsigned int)((P.L + 1) >> 1);     // key pairs per query row (capacity: the same in backward)
 
   for (int s = wave; s < ntq; s += nwaves) {
     const int qi = 16 * s + m;
@@ -890,7 +901,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
     const float gmx = xor_reduce_max_rows(mx);
     // pass B: p = 2^(x - max) chunk by chunk; the normaliser accumulates beside the P V product and is applied,
     // with the dropout scale, to the 16 x 64 output strip at the end
-    const unsigned int rp = (((unsigned int)b * P.H + h) * Lq + qi) * pitch2;
+    const unsigned int rp = (((unsigned int)b * P.H + h) * Lq_cap + qi) * pitch2;
     float lsum = 0.f;
     f32x4 o[4];
 #pragma unroll
@@ -922,7 +933,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
       for (int n = 0; n < 4; ++n) o[n] = mfma(pa, frag_from_rows_tr(Vs, n, c, lane), o[n]);
     }
     lsum = xor_reduce_sum_rows(lsum);             // all keys masked -> NaN row, like torch
-    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * Lq + qi] = (gmx + __builtin_amdgcn_logf(lsum)) * kLn2;
+    if (g == 0 && q_ok) P.lse[((size_t)b * P.H + h) * Lq_cap + qi] = (gmx + __builtin_amdgcn_logf(lsum)) * kLn2;
     const float scale_q = keep_scale / lsum;      // of query 16 s + m; the output rows of this lane are 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -940,9 +951,19 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
 template <bool SPATIAL>
 __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int L = P.L, nt = P.nt, nc = (nt + 1) / 2, rows = nc * 32;            // keys
-  const int Lq = P.Lq, ntq = P.ntq, ncq = (ntq + 1) / 2, rows_q = ncq * 32;      // queries
+  int b, h;
+  block_to_bh(P, b, h);
+  int L = P.L, Lq = P.Lq;
+  size_t row0 = (size_t)b * P.L, row0q = (size_t)b * P.Lq;
+  if (P.cu_rows) {                                           // packed variable-length sequences (see the forward kernel)
+    row0 = row0q = (size_t)P.cu_rows[b];
+    L = Lq = P.cu_rows[b + 1] - P.cu_rows[b];
+    if (L <= 0) return;
+  }
+  const int nt = (L + 15) / 16, nc = (nt + 1) / 2, rows = nc * 32;               // keys
+  const int ntq = (Lq + 15) / 16, ncq = (ntq + 1) / 2, rows_q = ncq * 32;         // queries
   const int rows_max = rows > rows_q ? rows : rows_q;
+  const int Lq_cap = P.Lq;
   // pass 1: Ks [rows][KS] | Vs [rows][KS];  pass 2 (same storage): Qs [rows_q][KS] | dOs [rows_q][KS];  then fp32 rows:
   // delta, lse2 = log2(e) * lse (+inf past Lq: such queries get p = 0) per query and the additive key term (0 / -inf).
   // Every tile is ROW-major: A fragments are 16-byte reads, B fragments hardware-transposed reads of the same rows.
@@ -953,23 +974,20 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   float *lse_s = delta_s + rows_q;
   float *mb = lse_s + rows_q;
 
-  int b, h;
-  block_to_bh(P, b, h);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int m = lane & 15, g = lane >> 4;
-  const size_t row0 = (size_t)b * L, row0q = (size_t)b * Lq;
   const uint16_t *qb = P.q + row0q * P.ld_q + h * DH;
   const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
   const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
   const uint16_t *dob = P.dout + row0q * P.ld_o + h * DH;
   const uint16_t *ob = P.out + row0q * P.ld_o + h * DH;
-  const float *lse = P.lse + ((size_t)b * P.H + h) * Lq;
+  const float *lse = P.lse + ((size_t)b * P.H + h) * Lq_cap;
   const bool dropout = P.drop_thr != 0u;
   const float keep_scale = dropout ? 1.f / (1.f - P.p_drop) : 1.f;
   const unsigned int seedmix = dropout ? seed_fold(effective_seed(P)) : 0u;
   const unsigned int thr16 = P.drop_thr >> 16;
-  const unsigned int pitch2 = (unsigned int)((L + 1) >> 1);
-  const unsigned int bh_base = ((unsigned int)b * P.H + h) * Lq;
+  const unsigned int pitch2 = (unsigned int)((P.L + 1) >> 1);
+  const unsigned int bh_base = ((unsigned int)b * P.H + h) * Lq_cap;
 
   stage_rows(Ks, kb, P.ld_qkv, L, rows);
   stage_rows(Vs, vb, P.ld_qkv, L, rows);
@@ -1313,7 +1331,7 @@ int dispatch(Params &P, bool backward, hipStream_t s) {
   if (P.ld_dq <= 0) P.ld_dq = P.ld_qkv;
   if (P.ld_dkv <= 0) P.ld_dkv = P.ld_qkv;
   // cross-attention (Lq != Lk) and operands with separate pitches are served by the streaming kernels only
-  const bool packed_self = P.Lq == P.L && P.ld_q == P.ld_qkv && P.ld_dq == P.ld_qkv && P.ld_dkv == P.ld_qkv;
+  const bool packed_self = P.Lq == P.L && P.ld_q == P.ld_qkv && P.ld_dq == P.ld_qkv && P.ld_dkv == P.ld_qkv && !P.cu_rows;
   if (!packed_self) {
     if (P.nt > 32 || P.ntq > 32 || (backward && P.out == nullptr)) return GPS_ERR_UNSUPPORTED;
     return launch_stream(P, backward, s);
@@ -1352,6 +1370,8 @@ int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
   if (a->Lk == 0) return GPS_ERR_INVALID_ARGUMENT;              // a softmax over no keys
   if (!a->q || !a->k || !a->v || !a->out || !a->lse || ((a->sw == nullptr) != (a->pl == nullptr))) return GPS_ERR_INVALID_ARGUMENT;
   if (a->sw && a->Lq != a->Lk) return GPS_ERR_INVALID_ARGUMENT;  // the pairwise term is a self-attention term
+  if (a->cu_rows && (a->Lq != a->Lk || a->sw || a->mask || a->dtype != GPS_ATTN_BF16 || a->compute != GPS_ATTN_COMPUTE_NATIVE))
+    return GPS_ERR_UNSUPPORTED;                                  // packed variable-length form: plain bf16 self-attention
   if (backward && (!a->dout || !a->dq || !a->dk || !a->dv || a->ld_dq < a->H * 64 || a->ld_dkv < a->H * 64 || (a->sw && !a->dsw)))
     return GPS_ERR_INVALID_ARGUMENT;
   if (a->dtype == GPS_ATTN_F32) {
@@ -1368,6 +1388,7 @@ int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
   P.sw = a->sw; P.pl = a->pl; P.mask = a->mask; P.out = (uint16_t *)a->out; P.lse = a->lse;
   P.p_drop = a->p_drop; P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
   P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
+  P.cu_rows = a->cu_rows;
   if (backward) {
     P.dout = (const uint16_t *)a->dout; P.dq = (uint16_t *)a->dq; P.dk = (uint16_t *)a->dk; P.dv = (uint16_t *)a->dv;
     P.ld_dq = a->ld_dq; P.ld_dkv = a->ld_dkv; P.dsw = a->dsw;

@@ -595,10 +595,19 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   decode(vid);
   int kt0 = split * P.kt_per_split;
   int nst = min(P.nkt, kt0 + P.kt_per_split) - kt0;             // the same for every tile of a persistent walk
+  int k_eff = P.K;                                               // reduction indices that carry work
   if (P.extent_dev) {
     const int extent = *P.extent_dev;
-    if (ATR) {                                                   // TN: token rows are the reduction
-      nst = max(0, min(nst, (extent + BK - 1) / BK - kt0));
+    if (ATR) {
+      // TN: token rows are the reduction.  Only the first `extent` of them exist: the live stages are spread evenly
+      // over the splits (a static partition would leave the later splits idle), and the stage that contains row
+      // `extent` takes the ragged-tail path, which reads zeros past it -- rows beyond the extent may hold anything
+      // (they were never written by the extent-aware producers) and must not reach the sums.
+      k_eff = min(P.K, max(extent, 0));
+      const int nkt_eff = (k_eff + BK - 1) / BK;
+      const int per = (nkt_eff + P.splits - 1) / P.splits;
+      kt0 = split * per;
+      nst = max(0, min(nkt_eff, kt0 + per) - kt0);
     } else if (!PERSIST && m0 >= extent) {
       return;                                                    // NT / NN: a tile of rows nobody reads
     }
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   sa.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
   sb.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
   constexpr int NP = Stager<BM, ATR, NW>::NPIECE + Stager<BN, BTR, NW>::NPIECE;
-  int k_left = P.K - kt0 * BK;                       // reduction indices from the next stage to issue onwards
+  int k_left = k_eff - kt0 * BK;                     // reduction indices from the next stage to issue onwards
 
   // ring of NBUF stage buffers: NBUF - 1 stages are in flight ahead of the one being computed; each wave waits for
   // ITS OWN copies of the stage with a counted vmcnt, the (raw) barrier then makes every wave's copies visible and

@@ -86,8 +86,9 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
     int n_rows, int d, const TX *__restrict__ x, const TH *__restrict__ h, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, float p_drop, unsigned int thr, unsigned long long seed,
     const unsigned long long *__restrict__ seed_dev, TX *__restrict__ y, uint16_t *__restrict__ y16,
-    float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+    float *__restrict__ mean_out, float *__restrict__ rstd_out, const int *__restrict__ rows_dev) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (rows_dev) n_rows = min(n_rows, *rows_dev);        // device-side count of leading rows that carry work
   constexpr int iters = ITERS;
   Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
   const float inv_d = 1.f / (float)d;
@@ -139,9 +140,10 @@ __global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd
     const TH *__restrict__ h, const float *__restrict__ gamma, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, float p_drop, unsigned int thr, unsigned long long seed,
     const unsigned long long *__restrict__ seed_dev, TX *__restrict__ dx, TH *__restrict__ dh,
-    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part) {
+    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, const int *__restrict__ rows_dev) {
   extern __shared__ float red[];      // [kWaves][d] reused for dgamma then dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (rows_dev) n_rows = min(n_rows, *rows_dev);        // rows past it contribute nothing to dgamma / dbeta either
   constexpr int iters = ITERS;
   Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
   const float inv_d = 1.f / (float)d;
@@ -309,6 +311,14 @@ int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int h_bf16,
                                       const float *gamma, const float *beta, float eps, float p_drop,
                                       unsigned long long seed, const void *seed_dev, void *y, void *y_bf16,
                                       float *mean, float *rstd, gps_stream_t stream) {
+  return gps_add_dropout_layernorm_forward_rows(n_rows, d, x_bf16, h_bf16, x, h, gamma, beta, eps, p_drop, seed, seed_dev, y,
+                                                y_bf16, mean, rstd, nullptr, stream);
+}
+
+int gps_add_dropout_layernorm_forward_rows(int n_rows, int d, int x_bf16, int h_bf16, const void *x, const void *h,
+                                           const float *gamma, const float *beta, float eps, float p_drop,
+                                           unsigned long long seed, const void *seed_dev, void *y, void *y_bf16,
+                                           float *mean, float *rstd, const int *rows_dev, gps_stream_t stream) {
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
   if ((d & 255) || d > 256 * gps_ln::kMaxIter || ((d >> 8) > 4 && (d >> 8) != 8)) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
@@ -319,7 +329,7 @@ int gps_add_dropout_layernorm_forward(int n_rows, int d, int x_bf16, int h_bf16,
   const unsigned long long *sd = (const unsigned long long *)seed_dev;
 #define GPS_LN_FWD_I(TX, TH, IT)                                                                                  \
   hipLaunchKernelGGL((gps_ln::add_dropout_ln_fwd_kernel<TX, TH, IT>), grid, block, 0, s, n_rows, d, (const TX *)x, \
-                     (const TH *)h, gamma, beta, eps, p_drop, thr, seed, sd, (TX *)y, (uint16_t *)y_bf16, mean, rstd)
+                     (const TH *)h, gamma, beta, eps, p_drop, thr, seed, sd, (TX *)y, (uint16_t *)y_bf16, mean, rstd, rows_dev)
 #define GPS_LN_FWD(TX, TH)                          \
   do { switch (d >> 8) {                            \
     case 1: GPS_LN_FWD_I(TX, TH, 1); break;         \
@@ -343,6 +353,16 @@ int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, int h_bf16
                                        const float *mean, const float *rstd, float p_drop,
                                        unsigned long long seed, const void *seed_dev, void *dx, void *dh,
                                        float *dgamma_part, float *dbeta_part, gps_stream_t stream) {
+  return gps_add_dropout_layernorm_backward_rows(n_rows, d, x_bf16, h_bf16, dy, dy_bf16, x, h, gamma, mean, rstd, p_drop, seed,
+                                                 seed_dev, dx, dh, dgamma_part, dbeta_part, nullptr, stream);
+}
+
+int gps_add_dropout_layernorm_backward_rows(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                            const void *dy_bf16, const void *x, const void *h, const float *gamma,
+                                            const float *mean, const float *rstd, float p_drop,
+                                            unsigned long long seed, const void *seed_dev, void *dx, void *dh,
+                                            float *dgamma_part, float *dbeta_part, const int *rows_dev,
+                                            gps_stream_t stream) {
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
   if ((d & 255) || d > 256 * gps_ln::kMaxIter || ((d >> 8) > 4 && (d >> 8) != 8)) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
@@ -356,7 +376,7 @@ int gps_add_dropout_layernorm_backward(int n_rows, int d, int x_bf16, int h_bf16
 #define GPS_LN_BWD_I(TX, TH, IT)                                                                                    \
   hipLaunchKernelGGL((gps_ln::add_dropout_ln_bwd_kernel<TX, TH, IT>), grid, block, lds, s, n_rows, d, (const TX *)dy, \
                      (const uint16_t *)dy_bf16, (const TX *)x, (const TH *)h, gamma, mean, rstd, p_drop, thr,       \
-                     seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part)
+                     seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part, rows_dev)
 #define GPS_LN_BWD(TX, TH)                          \
   do { switch (d >> 8) {                            \
     case 1: GPS_LN_BWD_I(TX, TH, 1); break;         \

@@ -74,7 +74,8 @@ class OpenVocab(_GPSBase):
         if self.use_scene_cap and hasattr(self.lang_encoder, "forward_pair"):
             # the sentence and the scene caption go through the text encoder's layers as one row batch
             txt, scene_txt = self.lang_encoder.forward_pair(data_dict['txt_ids'], data_dict['txt_masks'],
-                                                            data_dict['scene_txt_ids'], data_dict['scene_txt_masks'])
+                                                            data_dict['scene_txt_ids'], data_dict['scene_txt_masks'],
+                                                            cls_second=True)
             data_dict['scene_text_embed'] = scene_txt[:, 0]
         else:
             txt = self.lang_encoder(data_dict['txt_ids'], data_dict['txt_masks'])

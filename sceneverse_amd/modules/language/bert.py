@@ -18,11 +18,41 @@ from ..build import LANGUAGE_REGISTRY
 # key-padding mask from the attention mask, dropout on probabilities and on both branches).
 _FAST = True
 _FAST_EMB = True
+# Variable-length form of the fast path: the VALID tokens of all texts are compacted to the front of one row batch
+# (stable: every sequence stays contiguous), and every kernel of the stack works on those rows only -- GEMMs and
+# LayerNorms through a device-side row count, attention through per-sequence row offsets.  The reference runs BERT on
+# the padded (B, L) batch (modules/language/bert.py:21-26) and then only ever reads valid positions (padded keys are
+# masked in every attention, padded text rows carry label -1, the caption is read at [CLS] only), so nothing
+# observable changes; at the bench workload 45 % of the text rows are padding (sentence 6..50 of 50, caption 30..300
+# of 300 tokens).  Shapes stay static (the counts live on the device): the step remains one replayable HIP graph.
+_VARLEN = True
 
 
 def set_fast_bert(flag: bool) -> None:
     global _FAST
     _FAST = bool(flag)
+
+
+def set_varlen(flag: bool) -> None:
+    """False: the fast path keeps the padded (B, L) row batch (A/B runs, parity tests against the padded form)."""
+    global _VARLEN
+    _VARLEN = bool(flag)
+
+
+class _ZeroDeadRows(torch.autograd.Function):
+    """Identity on (T, D) rows whose backward zeroes the rows >= *n_valid: gradients of rows no kernel ever wrote
+    (undefined memory) must not reach the embedding tables."""
+
+    @staticmethod
+    def forward(ctx, x, n_valid):
+        ctx.save_for_backward(n_valid)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (n_valid,) = ctx.saved_tensors
+        live = torch.arange(dy.shape[0], device=dy.device, dtype=torch.int32)[:, None] < n_valid
+        return torch.where(live, dy, torch.zeros((), dtype=dy.dtype, device=dy.device)), None
 
 
 def set_fused_embedding(flag: bool) -> None:
@@ -59,7 +89,75 @@ class BERTLanguageEncoder(nn.Module):
     def _fast_forward(self, txt_ids, txt_masks):
         return self._fast_forward_multi([(txt_ids, txt_masks)])[0]
 
-    def _fast_forward_multi(self, texts):
+    def _varlen_ok(self, texts) -> bool:
+        from ..layers import gemm
+        from ..layers.fused_attention import MAX_LEN
+        from . import fused_embedding
+        D = self.bert_config.hidden_size
+        probe = torch.empty(0, dtype=torch.bfloat16, device=texts[0][0].device)
+        return (gemm.enabled() and gemm.usable(probe, D, D) and self.bert_config.intermediate_size % 8 == 0
+                and _FAST_EMB and all(ids.dim() == 2 and ids.shape[1] <= MAX_LEN
+                                      and fused_embedding.supported(self.model.embeddings, ids) for ids, _ in texts))
+
+    def _fast_forward_varlen(self, texts, cls_only=()):
+        """The encoder stack over the VALID tokens only (see _VARLEN above).  texts = [(ids (B_i, L_i), masks), ...];
+        -> per text the last hidden state as (B_i, L_i, D) with zeros at padded positions, or (B_i, 1, D) = the
+        [CLS] rows for the texts listed in `cls_only`."""
+        from ..layers import gemm
+        from ..layers.fused_attention import fused_varlen_self_attention
+        from ..layers.fused_norm import add_dropout_layer_norm
+        from .fused_embedding import _WordLookup
+        m, H = self.model, self.bert_config.num_attention_heads
+        emb = m.embeddings
+        dev = texts[0][0].device
+        ids_all = torch.cat([ids.reshape(-1) for ids, _ in texts])
+        valid = torch.cat([(masks != 0).reshape(-1) for _, masks in texts])
+        lens = torch.cat([(masks != 0).sum(dim=1) for _, masks in texts]).to(torch.int32)
+        pos = torch.cat([torch.arange(ids.shape[1], device=dev).repeat(ids.shape[0]) for ids, _ in texts])
+        T, S, cap = ids_all.numel(), lens.numel(), max(ids.shape[1] for ids, _ in texts)
+        n_valid = valid.sum(dtype=torch.int32).reshape(1)
+        perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)      # compact row r <- flat row perm[r]
+        cu = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+        cu[1:] = torch.cumsum(lens, 0)
+        # embedding block on the compacted tokens (HF BertEmbeddings with token type 0): rows past n_valid hold pad ids
+        pad = emb.word_embeddings.padding_idx
+        x = _WordLookup.apply(ids_all.index_select(0, perm), emb.word_embeddings.weight, -1 if pad is None else int(pad))
+        x = x + emb.token_type_embeddings.weight[0]
+        x = x + emb.position_embeddings.weight.index_select(0, pos.index_select(0, perm))
+        x = emb.dropout(emb.LayerNorm(x))
+        x = _ZeroDeadRows.apply(x, n_valid)
+        x16 = x
+        training = self.training
+        for layer in m.encoder.layer:
+            sa, so = layer.attention.self, layer.attention.output
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                packed = gemm.packed_linear(x16, [sa.query, sa.key, sa.value], rows_dev=n_valid)
+                ctx = fused_varlen_self_attention(packed, cu, S, cap, H, dropout_p=sa.dropout.p, training=training)
+                attn_out = gemm.linear(ctx, so.dense.weight, so.dense.bias, rows_dev=n_valid)
+                x, x16 = add_dropout_layer_norm(x, attn_out, so.LayerNorm, so.dropout.p, training, want_bf16=True,
+                                                rows_dev=n_valid)
+                ffn_out = gemm.ffn(x16, layer.intermediate.dense, layer.output.dense, "gelu", 0.0, training,
+                                   rows_dev=n_valid)
+                x, x16 = add_dropout_layer_norm(x, ffn_out, layer.output.LayerNorm, layer.output.dropout.p, training,
+                                                want_bf16=True, rows_dev=n_valid)
+        # back to the callers' layouts
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(T, device=dev)
+        outs, r0, s0 = [], 0, 0
+        for ti, (ids, masks) in enumerate(texts):
+            B, L = ids.shape
+            if ti in cls_only:
+                first = cu[s0:s0 + B].long()                                 # compact row of every sequence's first token
+                outs.append(x.index_select(0, first).view(B, 1, -1))
+            else:
+                rows = x.index_select(0, inv[r0:r0 + B * L])
+                live = valid[r0:r0 + B * L, None]
+                outs.append(torch.where(live, rows, torch.zeros((), dtype=rows.dtype, device=dev)).view(B, L, -1))
+            r0 += B * L
+            s0 += B
+        return outs
+
+    def _fast_forward_multi(self, texts, cls_only=()):
         """texts = [(ids (B_i, L_i), masks (B_i, L_i)), ...] -> [last hidden state (B_i, L_i, D), ...].
         Every row-wise operation of a layer (QKV / output / FFN GEMMs, residual + LayerNorm) runs ONCE over the
         token rows of all texts together -- the weights are the same, the rows independent -- and only the attention
@@ -72,6 +170,8 @@ class BERTLanguageEncoder(nn.Module):
         from ..layers.fused_norm import add_dropout_layer_norm
         from . import fused_embedding
         m, H = self.model, self.bert_config.num_attention_heads
+        if _VARLEN and self._varlen_ok(texts):
+            return self._fast_forward_varlen(texts, cls_only)
         xs, shapes, pads = [], [], []
         fused_emb = _FAST_EMB and all(fused_embedding.supported(m.embeddings, ids) for ids, _ in texts)
         embs = fused_embedding.bert_embeddings_multi(m.embeddings, [ids for ids, _ in texts]) if fused_emb else None
@@ -127,11 +227,13 @@ class BERTLanguageEncoder(nn.Module):
             r0 += n
         return outs
 
-    def forward_pair(self, ids_a, masks_a, ids_b, masks_b):
+    def forward_pair(self, ids_a, masks_a, ids_b, masks_b, cls_second: bool = False):
         """Both texts of a pre-train pair through ONE walk of the encoder stack (see _fast_forward_multi); without
         the fast path: two plain calls, as the reference makes them (model/openvocab.py:34-40)."""
         if self._fast_ok(ids_a) and self._fast_ok(ids_b):
-            a, b = self._fast_forward_multi([(ids_a, masks_a), (ids_b, masks_b)])
+            # the second text (the scene caption) is only ever read at [CLS] (model/openvocab.py: scene_txt[:, 0]):
+            # the variable-length form hands back just those rows, as a (B, 1, D) tensor
+            a, b = self._fast_forward_multi([(ids_a, masks_a), (ids_b, masks_b)], cls_only=(1,) if cls_second else ())
             return a, b
         return self.forward(ids_a, masks_a), self.forward(ids_b, masks_b)
 

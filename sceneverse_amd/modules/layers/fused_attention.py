@@ -75,7 +75,7 @@ def _mask8(mask: Optional[torch.Tensor]):
     return mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
 
 
-def _call(backward: bool, name: str, nbytes: int, flops: int, **f) -> None:
+def _call(backward: bool, name: str, nbytes: int, flops: int, work_fraction=None, **f) -> None:
     """One gps_attn_forward_ex / gps_attn_backward_ex launch on the current stream (tensors -> pointers and pitches)."""
     import ctypes
 
@@ -86,7 +86,7 @@ def _call(backward: bool, name: str, nbytes: int, flops: int, **f) -> None:
     lib = _native.load()
     fn = lib.gps_attn_backward_ex if backward else lib.gps_attn_forward_ex
     mfma = "fp32" if a.dtype == _native.ATTN_F32 else ("fp8" if (a.compute == _native.ATTN_COMPUTE_FP8 and not backward) else "bf16")
-    with _timed(name, nbytes, flops, mfma):
+    with _timed(name, nbytes, flops, mfma, work_fraction):
         st = fn(ctypes.byref(a), _stream())
     _native.check(st, name)
 
@@ -199,6 +199,73 @@ class _FusedCrossAttention(torch.autograd.Function):
                   p_drop=p_drop, seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
                   dq=dq, ld_dq=D, dk=dkv.data_ptr(), dv=dkv.data_ptr() + D * esz, ld_dkv=2 * D)
         return dq, dkv, None, None, None, None
+
+
+class _FusedVarlenSelfAttention(torch.autograd.Function):
+    """Plain self-attention over B VARIABLE-LENGTH sequences stored back to back: packed (T, 3 D) = [q | k | v] rows,
+    cu_rows (B + 1) int32 row offsets on the device (sequence b = rows [cu[b], cu[b + 1])), cap = an upper bound of
+    every length.  -> (T, D).  Rows outside every sequence (>= cu[B]) are neither read nor written.  No padding mask:
+    there are no padded keys inside a sequence.  Work scales with sum L_b^2 (include/gps_hip.h gps_attn_args.cu_rows)."""
+
+    @staticmethod
+    def forward(ctx, packed: torch.Tensor, cu_rows: torch.Tensor, n_seq: int, cap: int, n_head: int, p_drop: float,
+                seed_dev: Optional[torch.Tensor]) -> torch.Tensor:
+        T, W = packed.shape
+        D = n_head * HEAD_DIM
+        assert W == 3 * D and packed.is_cuda and packed.dtype == torch.bfloat16 and packed.is_contiguous()
+        assert cu_rows.dtype == torch.int32 and cu_rows.numel() == n_seq + 1 and cu_rows.is_cuda
+        out = torch.empty((T, D), dtype=torch.bfloat16, device=packed.device)
+        lse = torch.empty((n_seq, n_head, cap), dtype=torch.float32, device=packed.device)
+        base, esz = packed.data_ptr(), packed.element_size()
+        frac = _varlen_fraction(cu_rows, n_seq, cap)
+        with torch.cuda.device(packed.device):
+            _call(False, f"attn_forward(L<={cap},varlen,seqs={n_seq})", esz * n_seq * cap * 4 * D,
+                  4 * n_seq * n_head * cap * cap * HEAD_DIM, work_fraction=frac,
+                  B=n_seq, H=n_head, Lq=cap, Lk=cap, head_dim=HEAD_DIM, dtype=_native.ATTN_BF16,
+                  compute=_native.ATTN_COMPUTE_NATIVE, q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W,
+                  p_drop=float(p_drop), seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, cu_rows=cu_rows)
+        ctx.save_for_backward(packed, cu_rows, lse, seed_dev, out)
+        ctx.meta = (n_seq, cap, n_head, float(p_drop))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        packed, cu_rows, lse, seed_dev, out = ctx.saved_tensors
+        n_seq, cap, n_head, p_drop = ctx.meta
+        T, W = packed.shape
+        D = n_head * HEAD_DIM
+        dout = dout.to(torch.bfloat16).contiguous()
+        dpacked = torch.empty_like(packed)
+        base, esz, gbase = packed.data_ptr(), packed.element_size(), dpacked.data_ptr()
+        frac = _varlen_fraction(cu_rows, n_seq, cap)
+        with torch.cuda.device(packed.device):
+            _call(True, f"attn_backward(L<={cap},varlen,seqs={n_seq})", esz * n_seq * cap * 8 * D,
+                  10 * n_seq * n_head * cap * cap * HEAD_DIM, work_fraction=frac,
+                  B=n_seq, H=n_head, Lq=cap, Lk=cap, head_dim=HEAD_DIM, dtype=_native.ATTN_BF16,
+                  compute=_native.ATTN_COMPUTE_NATIVE, q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W,
+                  p_drop=p_drop, seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
+                  dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz, ld_dkv=W, cu_rows=cu_rows)
+        return dpacked, None, None, None, None, None, None
+
+
+def _varlen_fraction(cu_rows: torch.Tensor, n_seq: int, cap: int):
+    """bench accounting: sum L_b^2 / (B cap^2), read back at profile_stop() from a snapshot of the offsets."""
+    from ...pointnet2._ext import profiling
+    if not profiling():
+        return None
+    snap = cu_rows.detach().clone()
+
+    def frac():
+        lens = (snap[1:] - snap[:-1]).double()
+        return float((lens * lens).sum().item()) / float(n_seq * cap * cap)
+    return frac
+
+
+def fused_varlen_self_attention(packed: torch.Tensor, cu_rows: torch.Tensor, n_seq: int, cap: int, n_head: int,
+                                dropout_p: float = 0.0, training: bool = False) -> torch.Tensor:
+    p = float(dropout_p) if training else 0.0
+    seed_dev = _next_device_seed(packed.device) if p > 0.0 else None
+    return _FusedVarlenSelfAttention.apply(packed.contiguous(), cu_rows, int(n_seq), int(cap), n_head, p, seed_dev)
 
 
 def fused_self_attention(packed: torch.Tensor, n_head: int, pairwise_locs: Optional[torch.Tensor] = None,

@@ -38,9 +38,18 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr() if t is not None else None
 
 
+def _row_fraction(rows_dev: Optional[torch.Tensor], n: int):
+    """bench accounting: share of the static row count a launch with a device-side row count really touches."""
+    from ...pointnet2._ext import profiling
+    if rows_dev is None or not profiling() or n == 0:
+        return None
+    snap = rows_dev.detach().clone()
+    return lambda: min(1.0, max(0.0, float(snap.item()) / n))
+
+
 class _AddDropoutLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev, want_bf16: bool):
+    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev, want_bf16: bool, rows_dev=None):
         d = x.shape[-1]
         x2 = x.reshape(-1, d).contiguous()
         h2 = h.reshape(-1, d).contiguous()
@@ -52,13 +61,15 @@ class _AddDropoutLN(torch.autograd.Function):
         rstd = torch.empty(n, dtype=torch.float32, device=x.device)
         from ...pointnet2._ext import _timed
         nbytes = n * d * (2 * x2.element_size() + h2.element_size())
-        with torch.cuda.device(x.device), _timed(f"add_dropout_layernorm_forward(rows={n},d={d})", nbytes):
-            st = _native.load().gps_add_dropout_layernorm_forward(
+        with torch.cuda.device(x.device), _timed(f"add_dropout_layernorm_forward(rows={n},d={d})", nbytes,
+                                                 work_fraction=_row_fraction(rows_dev, n)):
+            st = _native.load().gps_add_dropout_layernorm_forward_rows(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), x2.data_ptr(),
                 h2.data_ptr(), g32.data_ptr(), b32.data_ptr(), float(eps), float(p_drop), 0, _ptr(seed_dev),
-                y.data_ptr(), _ptr(y16), mean.data_ptr(), rstd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                y.data_ptr(), _ptr(y16), mean.data_ptr(), rstd.data_ptr(), _ptr(rows_dev),
+                torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_forward")
-        ctx.save_for_backward(x2, h2, g32, mean, rstd, seed_dev)
+        ctx.save_for_backward(x2, h2, g32, mean, rstd, seed_dev, rows_dev)
         ctx.meta = (float(p_drop), x.shape, h.shape, gamma.dtype, beta.dtype)
         if want_bf16:
             return y.view(x.shape), y16.view(x.shape)
@@ -66,7 +77,7 @@ class _AddDropoutLN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dy16=None):
-        x2, h2, g32, mean, rstd, seed_dev = ctx.saved_tensors
+        x2, h2, g32, mean, rstd, seed_dev, rows_dev = ctx.saved_tensors
         p_drop, x_shape, h_shape, g_dtype, b_dtype = ctx.meta
         n, d = x2.shape
         if dy is None:
@@ -80,11 +91,12 @@ class _AddDropoutLN(torch.autograd.Function):
         part = torch.empty((2, parts, d), dtype=torch.float32, device=x2.device)
         from ...pointnet2._ext import _timed
         nbytes = n * d * (3 * x2.element_size() + 2 * h2.element_size())
-        with torch.cuda.device(x2.device), _timed(f"add_dropout_layernorm_backward(rows={n},d={d})", nbytes):
-            st = lib.gps_add_dropout_layernorm_backward(
+        with torch.cuda.device(x2.device), _timed(f"add_dropout_layernorm_backward(rows={n},d={d})", nbytes,
+                                                  work_fraction=_row_fraction(rows_dev, n)):
+            st = lib.gps_add_dropout_layernorm_backward_rows(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), dy2.data_ptr(),
                 _ptr(dy16_2), x2.data_ptr(), h2.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, 0,
-                _ptr(seed_dev), dx.data_ptr(), dh.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
+                _ptr(seed_dev), dx.data_ptr(), dh.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), _ptr(rows_dev),
                 torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_backward")
         sums = torch.empty((2, d), dtype=torch.float32, device=x2.device)
@@ -94,7 +106,7 @@ class _AddDropoutLN(torch.autograd.Function):
                                             torch.cuda.current_stream().cuda_stream)
         _native.check(st, "ln_reduce_partials")
         return (dx.view(x_shape), dh.view(h_shape), sums[0].to(g_dtype), sums[1].to(b_dtype),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def supported(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm) -> bool:
@@ -106,16 +118,20 @@ def supported(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm) -> bool:
 
 
 def add_dropout_layer_norm(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm, p_drop: float = 0.0,
-                           training: bool = False, want_bf16: bool = False):
+                           training: bool = False, want_bf16: bool = False, rows_dev: Optional[torch.Tensor] = None):
     """norm(x + dropout(h, p_drop, training)); y has x's dtype on the fused path.
     want_bf16: also return a bf16 copy of y written by the same launch (what the next GEMM reads
-    under autocast; its gradient is added inside the fused backward) -> (y, y_bf16)."""
+    under autocast; its gradient is added inside the fused backward) -> (y, y_bf16).
+    rows_dev: int32 device word = number of leading rows (of the flattened (rows, d) view) that carry work; the other
+    rows are neither read nor written (their content is undefined) and do not enter the dgamma / dbeta sums."""
     p = float(p_drop) if training else 0.0
     if not supported(x, h, norm):
+        if rows_dev is not None:
+            raise RuntimeError("add_dropout_layer_norm: a device-side row count needs the fused kernel")
         y = norm(x + F.dropout(h, p, training=p > 0.0))
         return (y, y) if want_bf16 else y
     seed_dev = None
     if p > 0.0:
         from .fused_attention import _next_device_seed
         seed_dev = _next_device_seed(x.device)
-    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev, bool(want_bf16))
+    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev, bool(want_bf16), rows_dev)

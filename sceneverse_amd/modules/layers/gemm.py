@@ -110,20 +110,24 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
 
 # ---- the three contractions of a Linear -------------------------------------------------------------------
 def linear_forward(x16: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str] = None,
-                   p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None, want_pre: bool = False):
-    """x16 (T, K) bf16, w16 (N, K) bf16, bias (N) fp32 -> y (T, N) bf16 [, pre-activation (T, N) bf16]."""
+                   p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None, want_pre: bool = False,
+                   rows_dev: Optional[torch.Tensor] = None):
+    """x16 (T, K) bf16, w16 (N, K) bf16, bias (N) fp32 -> y (T, N) bf16 [, pre-activation (T, N) bf16].
+    rows_dev (all three contractions): int32 device word, the number of leading token rows that carry work; tiles of
+    rows past it are skipped (their output rows stay unwritten), the weight gradient sums the live rows only."""
     T, K = x16.shape
     N = w16.shape[0]
     y = torch.empty((T, N), dtype=torch.bfloat16, device=x16.device)
     pre = torch.empty_like(y) if (want_pre and act == "gelu") else None
     epi = {None: EPI_BIAS, "gelu": EPI_BIAS_GELU, "relu": EPI_BIAS_RELU}[act]
     gemm(GEMM_NT, epi, T, N, K, x16, x16.stride(0), w16, w16.stride(0), y, N, bias=bias, aux_out=pre, ldaux_out=N,
-         p_drop=p_drop if act else 0.0, seed_dev=seed_dev)
+         p_drop=p_drop if act else 0.0, seed_dev=seed_dev, extent_dev=rows_dev)
     return (y, pre) if want_pre else y
 
 
 def linear_dgrad(dy16: torch.Tensor, w16: torch.Tensor, act: Optional[str] = None, aux: Optional[torch.Tensor] = None,
-                 p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None,
+                 rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy16 (T, N) bf16, w16 (N, K) bf16 -> dx (T, K) bf16 = dy W, optionally times the derivative of the
     activation that PRODUCED this layer's input (aux = its saved pre-activation (gelu) / output (relu))."""
     T, N = dy16.shape
@@ -131,7 +135,8 @@ def linear_dgrad(dy16: torch.Tensor, w16: torch.Tensor, act: Optional[str] = Non
     dx = torch.empty((T, K), dtype=torch.bfloat16, device=dy16.device)
     epi = {None: EPI_BIAS, "gelu": EPI_DGELU, "relu": EPI_DRELU}[act]
     gemm(GEMM_NN, epi, T, K, N, dy16, dy16.stride(0), w16, w16.stride(0), dx, K, aux=aux,
-         ldaux=aux.stride(0) if aux is not None else 0, p_drop=p_drop if act else 0.0, seed_dev=seed_dev)
+         ldaux=aux.stride(0) if aux is not None else 0, p_drop=p_drop if act else 0.0, seed_dev=seed_dev,
+         extent_dev=rows_dev)
     return dx
 
 
@@ -147,7 +152,7 @@ def _workspace(device, floats: int) -> torch.Tensor:
     return buf
 
 
-def linear_wgrad(dy16: torch.Tensor, x16: torch.Tensor, want_bias: bool = True):
+def linear_wgrad(dy16: torch.Tensor, x16: torch.Tensor, want_bias: bool = True, rows_dev: Optional[torch.Tensor] = None):
     """dy16 (T, N) bf16, x16 (T, K) bf16 -> dW (N, K) fp32 = dy^T x, db (N) fp32 = column sums of dy."""
     T, N = dy16.shape
     K = x16.shape[1]
@@ -159,7 +164,7 @@ def linear_wgrad(dy16: torch.Tensor, x16: torch.Tensor, want_bias: bool = True):
     if splits > 1:
         ws = _workspace(dy16.device, int(lib.gps_gemm_workspace_floats(GEMM_TN, N, K, splits)))
     gemm(GEMM_TN, EPI_F32, N, K, T, dy16, dy16.stride(0), x16, x16.stride(0), dw, K, workspace=ws, colsum=db,
-         splits=splits)
+         splits=splits, extent_dev=rows_dev)
     return dw, db
 
 
@@ -205,7 +210,7 @@ def join_wgrads() -> None:
     _DEFER["keep"].clear()
 
 
-def _wgrad_to_params(dy16: torch.Tensor, x16: torch.Tensor, weights, biases, rows) -> bool:
+def _wgrad_to_params(dy16: torch.Tensor, x16: torch.Tensor, weights, biases, rows, rows_dev=None) -> bool:
     """Side-stream form of `linear_wgrad` for a (packed) Linear whose parameters are leaf tensors: dW / db land in
     (or are added to) `param.grad`.  Returns False when the deferred form does not apply (the caller then returns
     ordinary gradients to autograd)."""
@@ -220,7 +225,7 @@ def _wgrad_to_params(dy16: torch.Tensor, x16: torch.Tensor, weights, biases, row
     side.wait_stream(cur)                                   # dy16 / x16 (and a zeroed flat gradient buffer) are ready
     with torch.cuda.stream(side):
         single = len(weights) == 1 and weights[0].grad is None and (biases[0] is None or biases[0].grad is None)
-        dw, db = linear_wgrad(dy16, x16, want_bias=want_bias)
+        dw, db = linear_wgrad(dy16, x16, want_bias=want_bias, rows_dev=rows_dev)
         r = 0
         for w, b, n in zip(weights, biases, rows):
             gw = dw if single else dw[r:r + n]
@@ -457,10 +462,14 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n, *wb):
+        rows_dev = None
+        if len(wb) == 2 * n + 1:                             # optional trailing device-side row count
+            rows_dev, wb = wb[-1], wb[:-1]
         weights, biases = wb[:n], wb[n:]
         w16, b32 = shadow_of(weights, biases)
         x16 = _as_rows16(x)
-        y = linear_forward(x16, w16, b32)
+        y = linear_forward(x16, w16, b32, rows_dev=rows_dev)
+        ctx.rows_dev = rows_dev
         ctx.save_for_backward(x16, w16)
         ctx.meta = (x.shape, x.dtype, n, [w.shape[0] for w in weights], [b is not None for b in biases])
         ctx.params = (weights, biases)                       # the parameter OBJECTS (deferred weight gradients)
@@ -476,14 +485,14 @@ class _LinearFn(torch.autograd.Function):
         dws, dbs = [None] * n, [None] * n
         deferred = False
         if need_w and all(ctx.needs_input_grad[2:2 + n]) and all((not hb) or g for hb, g in zip(has_b, ctx.needs_input_grad[2 + n:])):
-            deferred = _wgrad_to_params(dy16, x16, ctx.params[0], ctx.params[1], rows)      # side stream, first
+            deferred = _wgrad_to_params(dy16, x16, ctx.params[0], ctx.params[1], rows, ctx.rows_dev)      # side stream, first
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(dy16, w16).view(x_shape)
+            dx = linear_dgrad(dy16, w16, rows_dev=ctx.rows_dev).view(x_shape)
             if dx.dtype != x_dtype:
                 dx = dx.to(x_dtype)
         if (need_w or need_b) and not deferred:
-            dw, db = linear_wgrad(dy16, x16, want_bias=need_b)
+            dw, db = linear_wgrad(dy16, x16, want_bias=need_b, rows_dev=ctx.rows_dev)
             r = 0
             for i in range(n):
                 if ctx.needs_input_grad[2 + i]:
@@ -491,28 +500,33 @@ class _LinearFn(torch.autograd.Function):
                 if has_b[i] and ctx.needs_input_grad[2 + n + i]:
                     dbs[i] = db[r:r + rows[i]]
                 r += rows[i]
-        return (dx, None, *dws, *dbs)
+        return (dx, None, *dws, *dbs) + ((None,) if ctx.rows_dev is not None else ())
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+           rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if rows_dev is not None:
+        return _LinearFn.apply(x, 1, weight, bias, rows_dev)
     return _LinearFn.apply(x, 1, weight, bias)
 
 
-def packed_linear(x: torch.Tensor, layers: Sequence[torch.nn.Linear]) -> torch.Tensor:
+def packed_linear(x: torch.Tensor, layers: Sequence[torch.nn.Linear], rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One GEMM for several Linears that read the same input; output columns in the order given."""
-    return _LinearFn.apply(x, len(layers), *[m.weight for m in layers], *[m.bias for m in layers])
+    extra = (rows_dev,) if rows_dev is not None else ()
+    return _LinearFn.apply(x, len(layers), *[m.weight for m in layers], *[m.bias for m in layers], *extra)
 
 
 class _FFNFn(torch.autograd.Function):
     """y = dropout(act(x W1^T + b1)) W2^T + b2 : two forward GEMMs, four backward GEMMs, no elementwise launch."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act, p_drop, seed_dev):
+    def forward(ctx, x, w1, b1, w2, b2, act, p_drop, seed_dev, rows_dev=None):
         w1_16, b1_32 = shadow_of((w1,), (b1,))
         w2_16, b2_32 = shadow_of((w2,), (b2,))
         x16 = _as_rows16(x)
-        h, pre = linear_forward(x16, w1_16, b1_32, act=act, p_drop=p_drop, seed_dev=seed_dev, want_pre=True)
-        y = linear_forward(h, w2_16, b2_32)
+        h, pre = linear_forward(x16, w1_16, b1_32, act=act, p_drop=p_drop, seed_dev=seed_dev, want_pre=True, rows_dev=rows_dev)
+        y = linear_forward(h, w2_16, b2_32, rows_dev=rows_dev)
+        ctx.rows_dev = rows_dev
         ctx.save_for_backward(x16, w1_16, w2_16, h, pre, seed_dev)
         ctx.meta = (x.shape, x.dtype, act, float(p_drop), b1 is not None, b2 is not None)
         ctx.params = (w1, b1, w2, b2)
@@ -527,28 +541,29 @@ class _FFNFn(torch.autograd.Function):
         all_w = all(ctx.needs_input_grad[1:5][i] for i in (0, 2)) and (not has_b1 or ctx.needs_input_grad[2]) and \
             (not has_b2 or ctx.needs_input_grad[4])
         dw1 = db1 = dw2 = db2 = None
-        if not (all_w and _wgrad_to_params(dy16, h, (w2,), (b2,), (w2.shape[0],))):
-            dw2, db2 = linear_wgrad(dy16, h, want_bias=has_b2)
-        dpre = linear_dgrad(dy16, w2_16, act=act, aux=pre if act == "gelu" else h, p_drop=p_drop, seed_dev=seed_dev)
-        if not (all_w and _wgrad_to_params(dpre, x16, (w1,), (b1,), (w1.shape[0],))):
-            dw1, db1 = linear_wgrad(dpre, x16, want_bias=has_b1)
+        rd = ctx.rows_dev
+        if not (all_w and _wgrad_to_params(dy16, h, (w2,), (b2,), (w2.shape[0],), rd)):
+            dw2, db2 = linear_wgrad(dy16, h, want_bias=has_b2, rows_dev=rd)
+        dpre = linear_dgrad(dy16, w2_16, act=act, aux=pre if act == "gelu" else h, p_drop=p_drop, seed_dev=seed_dev, rows_dev=rd)
+        if not (all_w and _wgrad_to_params(dpre, x16, (w1,), (b1,), (w1.shape[0],), rd)):
+            dw1, db1 = linear_wgrad(dpre, x16, want_bias=has_b1, rows_dev=rd)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(dpre, w1_16).view(x_shape)
+            dx = linear_dgrad(dpre, w1_16, rows_dev=rd).view(x_shape)
             if dx.dtype != x_dtype:
                 dx = dx.to(x_dtype)
-        return dx, dw1, db1, dw2, db2, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
 def ffn(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear, act: str, p_drop: float,
-        training: bool) -> torch.Tensor:
+        training: bool, rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act in {"gelu", "relu"}; dropout between activation and linear2 as the reference's layers apply it."""
     p = float(p_drop) if training else 0.0
     seed_dev = None
     if p > 0.0:
         from .fused_attention import _next_device_seed
         seed_dev = _next_device_seed(x.device)
-    return _FFNFn.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, act, p, seed_dev)
+    return _FFNFn.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, act, p, seed_dev, rows_dev)
 
 
 def activation_name(fn) -> Optional[str]:

@@ -1,0 +1,120 @@
+"""Variable-length form of the BERT fast path (modules/language/bert.py `_VARLEN`): valid tokens compacted to the
+front of one row batch, GEMMs / LayerNorms bounded by a device-side row count, attention over per-sequence row offsets
+(gps_attn_args.cu_rows) -- against the padded form of the same fast path and against HuggingFace's own BertModel.
+Everything the model reads (valid positions; [CLS] of the caption) and every parameter gradient must agree:
+  * outputs at valid positions: |diff| <= 0.06 vs HF (the bound of tests/test_gpu_model.py's BERT check), <= 2e-2 vs the
+    padded fast path (same kernels, same bf16 roundings; only reduction splits differ);
+  * parameter gradients: relative L2 <= 2e-2 vs the padded fast path;
+  * padded positions of the returned (B, L, D) tensor are exactly zero; rows past the valid count never leak NaNs
+    (the scratch rows are poisoned with NaN before the run)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _encoder(seed=0):
+    from sceneverse_amd.common.config import ConfigNode
+    from sceneverse_amd.modules.language.bert import BERTLanguageEncoder
+    torch.manual_seed(seed)
+    enc = BERTLanguageEncoder(ConfigNode({}), weights=None, hidden_size=768, num_hidden_layers=2,
+                              num_attention_heads=12, type_vocab_size=2).to(DEV)
+    enc.train()
+    for m in enc.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return enc
+
+
+def _texts(B=8, La=50, Lb=300, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for L, lo in ((La, 6), (Lb, 30)):
+        lens = torch.randint(lo, L + 1, (B,), generator=g)
+        lens[0] = L                                            # one full row
+        ids = torch.randint(1000, 30522, (B, L), generator=g)
+        ids[:, 0] = 101
+        mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+        out.append(((ids * mask).to(DEV), mask.to(DEV)))
+    return out
+
+
+def _run(enc, texts, varlen, probe_w):
+    from sceneverse_amd.modules.language import bert as B
+    B.set_varlen(varlen)
+    try:
+        enc.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            a, b = enc.forward_pair(texts[0][0], texts[0][1], texts[1][0], texts[1][1], cls_second=True)
+        loss = (a.float() * probe_w[0]).sum() + (b[:, 0].float() * probe_w[1]).sum()
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.grad is not None}
+        return a.detach().float(), b[:, 0].detach().float(), grads
+    finally:
+        B.set_varlen(True)
+
+
+def test_varlen_bert_matches_the_padded_fast_path_and_huggingface():
+    enc = _encoder()
+    texts = _texts()
+    g = torch.Generator().manual_seed(5)
+    valid_a = texts[0][1].bool()
+    probe_w = (torch.randn(8, 50, 768, generator=g).to(DEV) * valid_a[..., None], torch.randn(8, 768, generator=g).to(DEV))
+    # poison the allocator's free memory: rows the variable-length kernels must never read as data
+    junk = torch.full((64, 1024, 1024), float("nan"), device=DEV)
+    del junk
+    a_v, c_v, g_v = _run(enc, texts, True, probe_w)
+    a_p, c_p, g_p = _run(enc, texts, False, probe_w)
+    assert torch.isfinite(a_v).all() and torch.isfinite(c_v).all()
+    assert a_v[~valid_a].abs().max().item() == 0.0                     # padded positions: exact zeros
+    assert (a_v - a_p)[valid_a].abs().max().item() <= 2e-2
+    assert (c_v - c_p).abs().max().item() <= 2e-2
+    assert set(g_v) == set(g_p)
+    for n in g_p:
+        assert torch.isfinite(g_v[n]).all(), n
+        rel = ((g_v[n].float() - g_p[n].float()).norm() / (g_p[n].float().norm() + 1e-12)).item()
+        assert rel <= 2e-2, (n, rel)
+    # HuggingFace's own forward (fp32) on the padded batch
+    with torch.no_grad():
+        hf_a = enc.model(texts[0][0], texts[0][1]).last_hidden_state
+        hf_c = enc.model(texts[1][0], texts[1][1]).last_hidden_state[:, 0]
+    assert (a_v - hf_a)[valid_a].abs().max().item() <= 0.06
+    assert (c_v - hf_c).abs().max().item() <= 0.06
+
+
+def test_varlen_bert_with_dropout_runs_and_is_finite():
+    enc = _encoder(seed=2)
+    for m in enc.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.1
+    texts = _texts(B=4, seed=3)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        a, b = enc.forward_pair(texts[0][0], texts[0][1], texts[1][0], texts[1][1], cls_second=True)
+    (a.float().square().mean() + b.float().square().mean()).backward()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    for n, p in enc.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+
+
+def test_gemm_weight_gradient_ignores_rows_past_the_device_extent():
+    """TN form with extent_dev: rows past the extent may hold NaN; dW / db must equal the sums over the live rows, for
+    extents on and off a 64-row stage boundary and for every split count the heuristic picks."""
+    from sceneverse_amd import _native
+    from sceneverse_amd.modules.layers import gemm as G
+    T, N, K = 3000, 768, 768
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(T, N, generator=g).to(torch.bfloat16).to(DEV)
+    x = torch.randn(T, K, generator=g).to(torch.bfloat16).to(DEV)
+    for ext in (0, 1, 63, 64, 1000, 1984, 2999, 3000):
+        dy2, x2 = dy.clone(), x.clone()
+        dy2[ext:] = float("nan")
+        x2[ext:] = float("nan")
+        rows = torch.tensor([ext], dtype=torch.int32, device=DEV)
+        dw, db = G.linear_wgrad(dy2, x2, want_bias=True, rows_dev=rows)
+        ref = dy[:ext].float().t() @ x[:ext].float()
+        refb = dy[:ext].float().sum(0)
+        assert torch.isfinite(dw).all() and torch.isfinite(db).all(), ext
+        assert (dw - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), ext
+        assert (db - refb).abs().max().item() <= 1e-4 * max(1.0, refb.abs().max().item()), ext

@@ -48,6 +48,13 @@ if [[ $WHAT == *benchoverlap* ]]; then
   timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --detail $OUT/bench_overlap_detail.json > $OUT/bench_overlap.json 2> $OUT/bench_overlap.err; echo "bench overlap exit $?"; tail -c 1200 $OUT/bench_overlap.json | head -c 700; echo; tail -2 $OUT/bench_overlap.err
   timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-wgrad-overlap > $OUT/bench_nooverlap.json 2> $OUT/bench_nooverlap.err; echo "bench no-overlap exit $?"; tail -c 1200 $OUT/bench_nooverlap.json | head -c 400; echo; tail -2 $OUT/bench_nooverlap.err
 fi
+if [[ $WHAT == *varlen* ]]; then
+  ts varlen
+  timeout 900 python -m pytest tests/test_gpu_bert_varlen.py tests/test_gpu_fused_norm.py tests/test_gpu_model.py tests/test_gpu_attention.py tests/test_gpu_gemm.py tests/test_gpu_losses.py -m gpu -q -x > $OUT/pytest_varlen.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_varlen.log
+  grep -E "^(FAILED|ERROR)|passed|failed|exit|Error|assert" $OUT/pytest_varlen.log | head -30 | cut -c1-400
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --detail $OUT/bench_varlen_detail.json > $OUT/bench_varlen.json 2> $OUT/bench_varlen.err; echo "bench varlen exit $?"; tail -c 2200 $OUT/bench_varlen.json; echo; tail -2 $OUT/bench_varlen.err
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-varlen > $OUT/bench_padded.json 2> $OUT/bench_padded.err; echo "bench padded exit $?"; tail -c 2200 $OUT/bench_padded.json | head -c 300; echo; tail -2 $OUT/bench_padded.err
+fi
 if [[ $WHAT == *gemmquick* ]]; then
   ts gemmquick
   for i in 8 10 11 4 0; do timeout 200 python tools/gemm_bench.py --only $i --rounds 8 >> $OUT/gemm_quick.log 2>&1; done; echo "gemm quick exit $?"; grep "^{" $OUT/gemm_quick.log | cut -c1-1200
