@@ -242,6 +242,9 @@ typedef struct gps_attn_args {
    * may be 0); Lq == Lk = the CAPACITY (an upper bound of every length; sizes LDS and is the pitch of lse (B, H, Lq)).
    * NULL = fixed-length batch.  Work and traffic scale with the real lengths (sum L_b^2), not with B * Lq^2. */
   const int *cu_rows;
+  /* with cu_rows: optional (B) int32 permutation of the sequences (device); workgroups are dispatched in block order,
+   * so listing the longest sequences first balances the tail of the launch.  NULL = natural order. */
+  const int *seq_order;
 } gps_attn_args;
 GPS_API int gps_attn_forward_ex(const gps_attn_args *args, gps_stream_t stream);
 GPS_API int gps_attn_backward_ex(const gps_attn_args *args, gps_stream_t stream);

@@ -63,6 +63,9 @@ struct Params {
   unsigned long long seed;
   const unsigned long long *seed_dev;   // optional device word added to `seed` (HIP-graph replays
                                         // get fresh dropout masks by advancing it on the device)
+  const int *seq_order;                 // optional (B) permutation: workgroups visit the sequences in this order
+                                        // (longest first: the dispatcher hands out workgroups in block order, so the
+                                        // long ones start early and the short ones fill the tail)
   const int *cu_rows;                   // optional (B + 1) row offsets of VARIABLE-LENGTH sequences packed back to back
                                         // (self-attention, streaming kernels): sequence b = rows [cu[b], cu[b + 1]),
                                         // L / Lq are then the CAPACITY (longest sequence; LDS sizing, lse pitch)
@@ -820,6 +823,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int b, h;
   block_to_bh(P, b, h);
+  if (P.seq_order) b = P.seq_order[b];
   // fixed-length batch: sequence b = rows [b L, b L + L); packed variable-length batch: rows [cu[b], cu[b + 1])
   int L = P.L, Lq = P.Lq;
   size_t row0 = (size_t)b * P.L, row0q = (size_t)b * P.Lq;
@@ -953,6 +957,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int b, h;
   block_to_bh(P, b, h);
+  if (P.seq_order) b = P.seq_order[b];
   int L = P.L, Lq = P.Lq;
   size_t row0 = (size_t)b * P.L, row0q = (size_t)b * P.Lq;
   if (P.cu_rows) {                                           // packed variable-length sequences (see the forward kernel)
@@ -1389,6 +1394,7 @@ int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
   P.p_drop = a->p_drop; P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
   P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
   P.cu_rows = a->cu_rows;
+  P.seq_order = a->cu_rows ? a->seq_order : nullptr;
   if (backward) {
     P.dout = (const uint16_t *)a->dout; P.dq = (uint16_t *)a->dq; P.dk = (uint16_t *)a->dk; P.dv = (uint16_t *)a->dv;
     P.ld_dq = a->ld_dq; P.ld_dkv = a->ld_dkv; P.dsw = a->dsw;

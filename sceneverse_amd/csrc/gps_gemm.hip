@@ -568,9 +568,15 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
   // ids; inside a split the tiles are walked in groups of GM tile rows, tile_m fastest, so that the workgroups
   // resident on an XCD at any time share a few A row panels and a few B panels (both stay in its 4 MiB L2).
   const int GM = P.gm;
-  const int ntiles = P.ntm * P.ntn;
+  // NT / NN with a device-side row extent: only the tile rows below it exist.  The LIVE tiles are re-enumerated (and
+  // spread over the XCDs) as if the matrix ended there: with the static enumeration the dead tiles -- the last tile
+  // rows -- are exactly the virtual-id range of the last XCDs, which then idle while the first ones do all the work.
+  int ntm = P.ntm;
+  if (!ATR && !PERSIST && P.extent_dev) ntm = min(P.ntm, max(0, (*P.extent_dev + BM - 1) / BM));
+  const int ntiles = ntm * P.ntn;
   const int total = ntiles * P.splits;
   int vid, vid_end, vid_step;
+  if (!PERSIST && (int)blockIdx.x >= total) return;
   if (PERSIST) {
     const int xcd = blockIdx.x & 7, per = (total + 7) >> 3;
     vid = xcd * per + (int)(blockIdx.x >> 3);
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
     split = v / ntiles;
     const int tile = v - split * ntiles;
     const int group = tile / (GM * P.ntn), in_group = tile - group * (GM * P.ntn);
-    const int gm = min(GM, P.ntm - group * GM);
+    const int gm = min(GM, ntm - group * GM);
     tile_n = in_group / gm;
     m0 = (group * GM + (in_group - tile_n * gm)) * BM;
     n0 = tile_n * BN;
@@ -698,10 +704,13 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(const Params P) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int GM = P.gm;
-  const int ntiles = P.ntm * P.ntn;
+  int ntm = P.ntm;
+  if (P.extent_dev) ntm = min(P.ntm, max(0, (*P.extent_dev + BM - 1) / BM));      // live tile rows only (see gemm_kernel)
+  const int ntiles = ntm * P.ntn;
+  if ((int)blockIdx.x >= ntiles) return;
   const int vid = xcd_virtual_id(blockIdx.x, ntiles);
   const int group = vid / (GM * P.ntn), in_group = vid - group * (GM * P.ntn);
-  const int gmr = min(GM, P.ntm - group * GM);
+  const int gmr = min(GM, ntm - group * GM);
   const int tile_n = in_group / gmr;
   const int m0 = (group * GM + (in_group - tile_n * gmr)) * BM, n0 = tile_n * BN;
   if (P.extent_dev && m0 >= *P.extent_dev) return;                  // a tile of rows nobody reads

@@ -119,6 +119,7 @@ class BERTLanguageEncoder(nn.Module):
         perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)      # compact row r <- flat row perm[r]
         cu = torch.zeros(S + 1, dtype=torch.int32, device=dev)
         cu[1:] = torch.cumsum(lens, 0)
+        order = torch.argsort(lens, descending=True).to(torch.int32)               # longest sequences dispatched first
         # embedding block on the compacted tokens (HF BertEmbeddings with token type 0): rows past n_valid hold pad ids
         pad = emb.word_embeddings.padding_idx
         x = _WordLookup.apply(ids_all.index_select(0, perm), emb.word_embeddings.weight, -1 if pad is None else int(pad))
@@ -132,7 +133,8 @@ class BERTLanguageEncoder(nn.Module):
             sa, so = layer.attention.self, layer.attention.output
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 packed = gemm.packed_linear(x16, [sa.query, sa.key, sa.value], rows_dev=n_valid)
-                ctx = fused_varlen_self_attention(packed, cu, S, cap, H, dropout_p=sa.dropout.p, training=training)
+                ctx = fused_varlen_self_attention(packed, cu, S, cap, H, dropout_p=sa.dropout.p, training=training,
+                                                  order=order)
                 attn_out = gemm.linear(ctx, so.dense.weight, so.dense.bias, rows_dev=n_valid)
                 x, x16 = add_dropout_layer_norm(x, attn_out, so.LayerNorm, so.dropout.p, training, want_bf16=True,
                                                 rows_dev=n_valid)
