@@ -53,7 +53,16 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, same guide
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")   # rocprofv3 --pmc, see tools/pmc_traffic.py
+def _latest_pmc_traffic() -> str:
+    """profiles/r<N>/pmc_traffic.json of the latest round that has one (rocprofv3 --pmc passes, tools/pmc_traffic.py)."""
+    import glob
+    import re as _r
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")),
+                   key=lambda p_: int(_r.search(r"r(\d+)", os.path.basename(os.path.dirname(p_))).group(1)))
+    return cands[-1] if cands else os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
+
+
+PMC_TRAFFIC = _latest_pmc_traffic()
 N_CLS = 607
 MAX_LINE_BYTES = 4000   # the driver keeps the last ~8 KB of stdout: the final JSON line must fit with room to spare
 

@@ -24,10 +24,11 @@ NAMES = [
     (r"fps_resident_kernel<1>", "furthest_point_sampling(n=32,m=16)"),
     (r"ball_query_kernel<16>", "ball_query(n=1024,m=32,ns=32)"),
     (r"ball_query_kernel<1>", "ball_query(n=32,m=16,ns=32)"),
+    (r"ball_query_small_kernel", "ball_query(n=32,m=16,ns=32)"),
     (r"add_dropout_ln_bwd_kernel", "add_dropout_layernorm_backward"),
     (r"add_dropout_ln_fwd_kernel", "add_dropout_layernorm_forward"),
-    (r"attn_bwd_stream_kernel", "attn_backward(L=300,spatial=0)"),
-    (r"attn_fwd_stream_kernel", "attn_forward(L=300,spatial=0)"),
+    (r"attn_bwd_stream_kernel", "attn_backward(L<=300,varlen,seqs=128)"),
+    (r"attn_fwd_stream_kernel", "attn_forward(L<=300,varlen,seqs=128)"),
     (r"gemm_kernel<128, 128, 4, 2, false, false, 1,", "gemm_nt(M=22400,N=3072,K=768,epi=1)"),
     (r"gemm_kernel<128, 128, 4, 2, false, true, 0,", "gemm_nn(M=22400,N=768,K=3072,epi=0)"),
     (r"gemm_kernel<128, 128, 4, 2, true, true, 5,", "gemm_tn(M=3072,N=768,K=22400,epi=5)"),
@@ -74,9 +75,20 @@ def main(fetch_csv, write_csv, out):
                 wb = w_unit * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
                 if name in ("group_points", "gather_points") or (" grid=" in k and "stream" not in k):
                     name = f"{name}#{len(res['per_launch_detail'])}" + (k[k.rfind(" grid="):] if " grid=" in k else "")
+                if name in res["per_launch_hbm_bytes"] and " grid=" in k:      # the same symbol at another shape
+                    # keep the launch with MORE workgroups under the plain name (the step's dominant shape)
+                    prev_grid = res["per_launch_detail"][name].get("grid", 0)
+                    this_grid = int(k[k.rfind(" grid=") + 6:] or 0)
+                    if this_grid <= prev_grid:
+                        name = name + k[k.rfind(" grid="):]
+                    else:
+                        old_name = name + f" grid={prev_grid}"
+                        res["per_launch_hbm_bytes"][old_name] = res["per_launch_hbm_bytes"].pop(name)
+                        res["per_launch_detail"][old_name] = res["per_launch_detail"].pop(name)
                 res["per_launch_hbm_bytes"][name] = int(fb + wb)
                 res["per_launch_detail"][name] = {"symbol": k[:100], "read_bytes": int(fb), "write_bytes": int(wb),
-                                                  "launches": len(fetch[k])}
+                                                  "launches": len(fetch[k]),
+                                                  "grid": int(k[k.rfind(" grid=") + 6:]) if " grid=" in k else 0}
                 break
     with open(out, "w") as f:
         json.dump(res, f, indent=1)

@@ -65,13 +65,25 @@ def main():
         h = torch.randn(rows, 768, device=dev).to(torch.bfloat16).requires_grad_(True)
         for _ in range(3):
             add_dropout_layer_norm(x, h, norm, 0.1, True).sum().backward()
-    for L, spatial in ((80, True), (130, False), (300, False)):
+    for L, spatial in ((80, True), (130, False)):
         W = 3 * 768 + (72 if spatial else 0)
         packed = torch.randn(64, L, W, device=dev).to(torch.bfloat16).requires_grad_(True)
         pl = torch.rand(64, L, L, 5, device=dev) if spatial else None
         mask = torch.zeros(64, L, dtype=torch.bool, device=dev)
         for _ in range(3):
             _FusedSelfAttention.apply(packed, pl, mask, 12, 0.0, 0, None).float().sum().backward()
+    # [r3] the variable-length text attention of the step: 64 sentences (6..50 tokens) + 64 captions (30..300 tokens)
+    # packed back to back, the lengths of bench.py's batch (synth_batch(64, seed=42))
+    from sceneverse_amd.modules.layers.fused_attention import fused_varlen_self_attention
+    lens = torch.cat([d["txt_masks"].sum(1), d["scene_txt_masks"].sum(1)]).to(torch.int32).to(dev)
+    cu = torch.zeros(lens.numel() + 1, dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    n_valid = cu[-1:].clone()
+    order = torch.argsort(lens, descending=True).to(torch.int32)
+    rows_all = 64 * 350
+    packed = torch.randn(rows_all, 3 * 768, device=dev).to(torch.bfloat16).requires_grad_(True)
+    for _ in range(3):
+        fused_varlen_self_attention(packed, cu, 128, 300, 12, order=order).float().sum().backward()
     # the MFMA GEMMs of the largest Linears of the step (forward GELU, input gradient x GELU', weight gradient) and
     # the optimizer pass; tools/pmc_traffic.py tells the launches of one kernel symbol apart by their grid size
     from sceneverse_amd import _native
@@ -81,10 +93,11 @@ def main():
     w = (0.02 * torch.randn(N, K, device=dev)).to(torch.bfloat16)
     b = torch.randn(N, device=dev)
     dyb = torch.randn(T, N, device=dev).to(torch.bfloat16)
-    for _ in range(3):
-        h, pre = GM.linear_forward(x, w, b, act="gelu", want_pre=True)
-        GM.linear_dgrad(dyb, w, None)
-        GM.linear_wgrad(dyb, x)
+    for _ in range(3):                 # with the step's device-side row count (valid text tokens of the bench batch)
+        h, pre = GM.linear_forward(x, w, b, act="gelu", want_pre=True, rows_dev=n_valid)
+        GM.linear_dgrad(dyb, w, None, rows_dev=n_valid)
+        GM.linear_wgrad(dyb, x, rows_dev=n_valid)
+    print("valid text rows", int(n_valid), "of", rows_all, flush=True)
     ps = [torch.nn.Parameter(torch.randn(4096, 768, device=dev)) for _ in range(8)]
     from sceneverse_amd.optim.fused_adamw import GpsAdamW
     opt = GpsAdamW(ps, lr=1e-3)
