@@ -284,3 +284,24 @@ def test_padded_shadow_rows_and_optimizer_targets():
     del lin
     gc.collect()
     G.clear_shadows()
+
+
+def test_bench_final_line_is_bounded():
+    """The driver keeps only the last ~8 KB of stdout: the ONE JSON line bench.py prints must stay far below that
+    (round 2's 28 KB line could not be parsed); everything bulky goes to the detail file."""
+    import json
+
+    import bench
+    small = {"metric": "GPS pre-train pairs/sec (fwd+bwd)", "value": 1.0, "unit": "pairs/s", "roofline": {"frac": 0.2},
+             "headline": {}, "cpu_baseline": {"value": 1.9, "cores": 64, "kind": "port", "sample": "x" * 200}}
+    line = bench.final_line(small)
+    assert json.loads(line)["value"] == 1.0 and len(line) < bench.MAX_LINE_BYTES <= 4000
+    big = dict(small, kernels=[{"kernel": f"gemm_nt(M={i})", "avg_us": 1.0} for i in range(400)])
+    with pytest.raises(RuntimeError):
+        bench.final_line(big)
+    # the line of this round's own GPU run (profiles/r3/bench_h.json) respects the bound
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3", "bench_h.json")
+    if os.path.exists(path):
+        last = open(path).read().strip().splitlines()[-1]
+        assert len(last) < bench.MAX_LINE_BYTES and "roofline" in json.loads(last)
