@@ -457,8 +457,8 @@ def main() -> None:
             step.step(dict(batch))
         torch.cuda.synchronize()
         graph_note = ("whole step replayed as one HIP graph" if step.graph else
-                      "3 HIP graphs per step (forward | losses+backward | clip+AdamW) around eager RCCL "
-                      "all-gather / all-reduce")
+                      "4 HIP graphs per step (forward | losses + top backward | bottom backward | clip+AdamW) around "
+                      "the eager RCCL all-gather and two all-reduces")
     for _ in range(args.warmup):
         step.step(dict(batch))
     barrier()
@@ -689,7 +689,9 @@ def main() -> None:
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
                        "text_rows": "padded (B, L) batch" if args.no_varlen else "valid tokens only (variable-length BERT path)",
                        "launch": (graph_note or "eager") + ("; weight-gradient GEMMs on a second stream" if step.wgrad_overlap else ""),
-                       **({"grad_exchange": "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
+                       **({"grad_exchange": "fp32 all-reduce of the top / bottom segment of one flat buffer, the first beside "
+                                            "the bottom backward graph" if step.graph_dp
+                           else "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
                            if (args.bf16_grads and not share) else "fp32 all-reduce (DDP buckets)"} if world > 1 else {}),
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,

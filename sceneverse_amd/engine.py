@@ -27,12 +27,15 @@ box, so the step is split at its two exchange points instead and the collectives
 
     graph 1  model forward                                        (replay)
     eager    all-gather of the contrastive features (C2)          RCCL, into static buffers
-    graph 2  losses + backward into ONE flat fp32 gradient buffer  (replay; shares graph 1's pool)
-    eager    all-reduce of the flat gradient buffer, / world (C1)  RCCL, one collective of ~491 MB
+    graph 2a losses + backward of the TOP segment (joint encoder, heads) into the flat fp32 gradient buffer
+    eager    all-reduce of the top range of the buffer (C1, part 1)  RCCL, asynchronous: runs beside graph 2b
+    graph 2b backward of the BOTTOM segment (text + object encoders) from the boundary gradients
+    eager    all-reduce of the bottom range (C1, part 2), wait for both, / world
     graph 3  gradient clipping + AdamW                             (replay)
 
-The all-reduce is not overlapped with backward (backward is one graph launch); at ~3 ms over xGMI
-against a ~31 ms step that costs less than the ~13 ms of launch gaps the eager DDP step carries.
+[r3] The backward pass is cut at the outputs of the text and object encoders (model._stage_boundary;
+torch.autograd.backward(inputs=...) restricts each segment to its own parameters), so about half of the 491 MB
+gradient exchange overlaps the bottom segment's ~5 ms of backward; only the bottom range's all-reduce is exposed.
 Parameters are broadcast from rank 0 once.  The same code runs with world_size 1 (collectives are
 no-ops), which is how tests/test_gpu_model.py exercises it on one GPU.
 """
@@ -221,10 +224,25 @@ class GPSTrainStep:
                     buf.copy_(t)
 
     def _allreduce_grads(self):
-        """Eager C1: one all-reduce of the flat gradient buffer, then the mean."""
-        if dist_utils.is_dist() and self.world > 1:
-            torch.distributed.all_reduce(self._flat_grad)
-            self._flat_grad.mul_(1.0 / self.world)
+        """Eager C1: all-reduce of the flat gradient buffer, then the mean."""
+        self._wait_allreduce(self._allreduce_async(0, self._flat_grad.numel()))
+
+    def _allreduce_async(self, lo: int, hi: int):
+        """Start the all-reduce of `_flat_grad[lo:hi]` (the gradients of one backward segment) and return a handle for
+        `_wait_allreduce`.  With RCCL the collective runs on the process group's own stream, ordered after what the
+        current stream has issued so far -- i.e. beside the next backward segment, which is launched right after."""
+        if not (dist_utils.is_dist() and self.world > 1) or hi <= lo:
+            return None
+        seg = self._flat_grad[lo:hi]
+        return (torch.distributed.all_reduce(seg, async_op=True), seg)
+
+    def _wait_allreduce(self, *handles) -> None:
+        for h in handles:
+            if h is None:
+                continue
+            work, seg = h
+            work.wait()                                  # the current stream waits; the host does not
+            seg.mul_(1.0 / self.world)
 
     def _clip_and_step(self):
         from .optim.fused_adamw import GpsAdamW
@@ -270,37 +288,68 @@ class GPSTrainStep:
             # gradients live as views of ONE flat fp32 buffer (only for parameters that do receive a
             # gradient: the never-used ones keep grad None, as under DDP / eager AdamW)
             used = [p for p in self.model.parameters() if p.grad is not None]
+            # [r3] two backward segments: "top" = joint encoder, heads, loss parameters; "bottom" = the text and the
+            # object encoder.  Their gradients sit in two contiguous ranges of the flat buffer, so the all-reduce of
+            # the top range travels over xGMI while the bottom segment's backward graph replays.
+            bottom_ids = set()
+            for name in ("lang_encoder", "point_encoder"):
+                sub = getattr(self.model, name, None)
+                if sub is not None:
+                    bottom_ids.update(id(p) for p in sub.parameters())
+            top = [p for p in used if id(p) not in bottom_ids]
+            bottom = [p for p in used if id(p) in bottom_ids]
+            used = top + bottom
             self._flat_grad = torch.zeros(sum(p.numel() for p in used), dtype=torch.float32, device=self.device)
+            self._n_top = sum(p.numel() for p in top)
             off = 0
             self.optimizer.zero_grad(set_to_none=True)
             for p in used:
                 p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
                 off += p.numel()
             torch.cuda.synchronize(self.device)
-            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
             with torch.cuda.graph(g1):
                 self._begin_step()
                 with self._autocast():
                     out = self.net(static_dict)
             self._gather_features(out)
+            boundary = list(getattr(self.model, "_stage_boundary", None) or [])
+            segmented = bool(boundary) and bool(top) and bool(bottom) and not self.wgrad_overlap
             torch.cuda.synchronize(self.device)
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2a, pool=g1.pool()):
                 self._flat_grad.zero_()
                 with self._autocast():
                     total, losses = self.loss(out)
-                self._backward(total)                 # accumulates into the flat views
+                if segmented:
+                    # gradients of the top parameters (into their flat views) and of the boundary tensors
+                    torch.autograd.backward(total, inputs=top + boundary, retain_graph=True)
+                else:
+                    self._backward(total)             # accumulates into the flat views
             torch.cuda.synchronize(self.device)
+            if segmented:
+                with torch.cuda.graph(g2b, pool=g1.pool()):
+                    live = [t for t in boundary if t.grad is not None]
+                    torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bottom)
+                torch.cuda.synchronize(self.device)
+            else:
+                g2b = None
             with torch.cuda.graph(g3):
                 self._clip_and_step()
-            self._graph, self._graph_out = (g1, g2, g3), (out, total, losses)
+            self._graph, self._graph_out = (g1, g2a, g2b, g3), (out, total, losses)
         else:
             self._fill_static(tensors)
-        g1, g2, g3 = self._graph
+        g1, g2a, g2b, g3 = self._graph
         out, total, losses = self._graph_out
         g1.replay()
         self._gather_features(out)
-        g2.replay()
-        self._allreduce_grads()
+        g2a.replay()
+        if g2b is not None:
+            h_top = self._allreduce_async(0, self._n_top)              # overlaps the bottom segment's backward
+            g2b.replay()
+            h_bot = self._allreduce_async(self._n_top, self._flat_grad.numel())
+            self._wait_allreduce(h_top, h_bot)
+        else:
+            self._allreduce_grads()
         g3.replay()
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
 

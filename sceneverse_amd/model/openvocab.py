@@ -71,6 +71,7 @@ class OpenVocab(_GPSBase):
             data_dict['cur_step'] = 1
             data_dict['total_steps'] = 1
 
+        scene_txt = None
         if self.use_scene_cap and hasattr(self.lang_encoder, "forward_pair"):
             # the sentence and the scene caption go through the text encoder's layers as one row batch
             txt, scene_txt = self.lang_encoder.forward_pair(data_dict['txt_ids'], data_dict['txt_masks'],
@@ -86,6 +87,13 @@ class OpenVocab(_GPSBase):
         obj, obj_pre, obj_cls_raw = self._encode_objects(data_dict)
         if self.use_scene_cap:
             data_dict["scene_embed"] = self.object_pool(obj)
+        # outputs of the two bottom encoders (text, objects): where sceneverse_amd.engine cuts the backward pass of the
+        # split-graph data-parallel step (gradients of everything above are exchanged while the part below still runs).
+        # A valid cut holds no tensor that is an ancestor of another one: `obj_pre` feeds `obj`, so the cut exists only
+        # when nothing above reads `obj_pre` (the grounding head does; the pre-train heads do not).
+        reads_obj_pre = getattr(self, "ground_head", None) is not None
+        self._stage_boundary = [] if reads_obj_pre else \
+            [t for t in (txt, scene_txt, obj) if torch.is_tensor(t) and t.requires_grad]
 
         before = self.cfg.model.inter == "before"
         if before:

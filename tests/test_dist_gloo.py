@@ -137,6 +137,36 @@ def _worker(rank, world, port, tmp):
         eng._flat_grad = torch.full((10,), float(rank))
         eng._allreduce_grads()
         result["graph_dp_allreduce_ok"] = bool(torch.allclose(eng._flat_grad, torch.full((10,), (world - 1) / 2.0)))
+        # the two asynchronous segment exchanges of the split backward (top range while the bottom segment still runs)
+        eng._flat_grad = torch.arange(10.0) * (rank + 1)
+        h_top = eng._allreduce_async(0, 4)
+        h_bot = eng._allreduce_async(4, 10)
+        eng._wait_allreduce(h_top, h_bot)
+        result["graph_dp_segments_ok"] = bool(torch.allclose(eng._flat_grad, torch.arange(10.0) * (world + 1) / 2.0))
+        # staged backward = one backward: gradients of the top parameters and of the boundary tensors first, then the
+        # bottom parameters from the boundary gradients (what graphs 2a / 2b capture)
+        stage = GPSTrainStep(_small_cfg(lp, world, between_batch=False), device="cpu", ddp=False, seed=5)
+        stage.net.eval()
+        batch = dict(shards[rank], cur_step=0, total_steps=10)
+        stage.model.zero_grad(set_to_none=True)
+        _, total_s, _ = stage.forward_loss(dict(batch))
+        total_s.backward()
+        want_g = {n: p.grad.clone() for n, p in stage.model.named_parameters() if p.grad is not None}
+        stage.model.zero_grad(set_to_none=True)
+        _, total_s, _ = stage.forward_loss(dict(batch))
+        bottom_ids = {id(p) for sub in (stage.model.lang_encoder, stage.model.point_encoder) for p in sub.parameters()}
+        used = [p for n, p in stage.model.named_parameters() if n in want_g]
+        top = [p for p in used if id(p) not in bottom_ids]
+        bottom = [p for p in used if id(p) in bottom_ids]
+        boundary = list(stage.model._stage_boundary)
+        torch.autograd.backward(total_s, inputs=top + boundary, retain_graph=True)
+        assert all(p.grad is None for p in bottom)
+        live = [t for t in boundary if t.grad is not None]
+        torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bottom)
+        worst = max((p.grad - want_g[n]).abs().max().item() / (want_g[n].abs().max().item() + 1e-12)
+                    for n, p in stage.model.named_parameters() if n in want_g)
+        result["staged_backward_rel_err"] = worst
+        result["staged_counts"] = (len(top), len(bottom), len(boundary))
 
         # -- the probe's "received a gradient" mask is agreed across ranks: on rank 0 the probe batch leaves the
         #    masked-LM branch unused (its loss term is dropped there, a stand-in for a data-dependent branch); rank 1
@@ -203,7 +233,8 @@ def test_ddp_world_size_2_gloo():
         assert r["between_batch_err"] < 1e-6, r
         assert r["wrapped"] == "DistributedDataParallel", r
         assert r["n_frozen_unused"] >= 13 and r["n_unused"] == 0, r     # found by the probe step, frozen before the wrap
-        assert r["graph_dp_gather_ok"] and r["graph_dp_allreduce_ok"], r
+        assert r["graph_dp_gather_ok"] and r["graph_dp_allreduce_ok"] and r["graph_dp_segments_ok"], r
+        assert r["staged_backward_rel_err"] <= 1e-6 and min(r["staged_counts"]) > 0, r
         assert r["frozen_sets_equal"] and r["lm_head_kept"] and r["n_frozen_agreed"] >= 13, r
         assert r["probe_keeps_rng"] and r["probe_keeps_buffers"], r
         assert r["hook_vs_fp32_sum"] <= 2.0 ** -8 and r["hook_vs_exact"] <= 2.0 ** -7, r

@@ -307,11 +307,13 @@ def test_ddp_wrapper_runs_on_the_fused_path_with_rccl():
         dist.destroy_process_group()
 
 
-def test_bench_n2_code_path_on_one_gpu():
+@pytest.mark.parametrize("extra", [[], ["--graph-dp"]], ids=["ddp", "segmented_graphs"])
+def test_bench_n2_code_path_on_one_gpu(extra):
     """bench.py launched exactly as the driver launches it for N = 2 (torch.distributed.run, one process
     per rank), except that both ranks share cuda:0 and talk over gloo (GPS_BENCH_SHARE_GPU=1; RCCL refuses
     two ranks on one GPU).  Checks the N > 1 flow end to end: DDP wrap, between-batch all-gather,
-    max-over-ranks timing, one JSON line from rank 0 with the aggregate over both ranks."""
+    max-over-ranks timing, one JSON line from rank 0 with the aggregate over both ranks.  `--graph-dp`: the same
+    with the step as forward / top-backward / bottom-backward / optimizer graphs around two eager all-reduces."""
     import json
     import os
     import socket
@@ -325,7 +327,7 @@ def test_bench_n2_code_path_on_one_gpu():
     env = dict(os.environ, GPS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"]
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"] + extra
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

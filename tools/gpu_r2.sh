@@ -180,3 +180,9 @@ if [[ $WHAT == *stressfp8* ]]; then
   timeout 600 python bench.py --config stress --fp8 --steps 5 --warmup 2 --detail $OUT/bench_stress_fp8_detail.json > $OUT/bench_stress_fp8.json 2> $OUT/bench_stress_fp8.err; echo "stress fp8 exit $?"; tail -c 1500 $OUT/bench_stress_fp8.json; tail -3 $OUT/bench_stress_fp8.err
 fi
 ts done; du -sh $REPO/gpurun_out
+if [[ $WHAT == *dpgraph* ]]; then
+  ts dpgraph
+  timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -x > $OUT/pytest_dpgraph.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_dpgraph.log
+  grep -E "^(FAILED|ERROR)|passed|failed|exit|Error|assert" $OUT/pytest_dpgraph.log | head -30 | cut -c1-400
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --graph-dp > $OUT/bench_dpgraph.json 2> $OUT/bench_dpgraph.err; echo "bench dp exit $?"; tail -c 2200 $OUT/bench_dpgraph.json | head -c 400; echo; tail -3 $OUT/bench_dpgraph.err
+fi
