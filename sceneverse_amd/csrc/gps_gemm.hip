@@ -805,6 +805,256 @@ int launch_256(Params &P, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, EIGHT waves in two groups of four that alternate on the matrix pipe (the guide's "8-phase" schedule,
+// here with 4 phases per 64-deep K tile and the buffer parity at run time).  One workgroup per CU, two waves per SIMD
+// (one of each group).  A phase of a wave = [fragment reads of one 64 x 32 output quadrant | LDS-DMA of one half-tile
+// of a later K tile] barrier [16 MFMAs] barrier; group 1 runs ONE BARRIER behind group 0, so while one group's waves
+// issue their 16 MFMAs (256 cycles of its SIMD) the other group's waves read fragments and issue copies -- the matrix
+// pipe of every SIMD always has a wave in its MFMA segment.  Per wave and K tile: 24 ds_read_b128 (or 48 tr reads) for
+// 64 MFMAs, a quarter of the LDS bytes per flop of the 32 x 64 wave tiles of gemm_kernel.
+//
+// LDS: two buffers of four half-tile images (A rows 0..127 | A rows 128..255 | B cols 0..127 | B cols 128..255, 16 KB
+// each, the images of gemm_kernel's 128-row tiles).  Wave (wr, wc) owns output rows {64 wr + [0, 64)} of BOTH A halves
+// and columns {32 wc + [0, 32)} of BOTH B halves, i.e. four 64 x 32 quadrants C[qa][qb]; the phases walk
+// C00 (reads Bq0, Aq0) -> C01 (reads Bq1) -> C11 (reads Aq1) -> C10 (Bq0 kept in registers), so that half B0 is read in
+// phase 1 only, B1 in phase 2, A0 in phase 1, A1 in phase 3, and each half can be refilled early:
+//   phase 1 of tile t : copy A1(t + 1) -> other buffer     (last read: phase 3 of tile t - 1)
+//   phase 2           : copy B0(t + 2) -> this buffer       (read in phase 1, retired by lgkmcnt(8) BEFORE that phase's
+//                                                            first barrier: safe one phase later)
+//   phase 3           : copy A0(t + 2) -> this buffer       (read in phase 1: two phases later)
+//   phase 4           : copy B1(t + 2) -> this buffer       (read in phase 2); vmcnt(6): everything up to A1(t + 1) has
+//                                                            landed, the three halves of tile t + 2 stay in flight
+// RAW: a wave's counted vmcnt precedes the first barrier of its phase 4, the reads of tile t + 1 start after the
+// second one (for group 0: after group 1's wait as well, because group 1's first barrier of a phase IS group 0's second).
+// Forms NT / NN; K a multiple of 64; no split-K.
+// ---------------------------------------------------------------------------------------------------------
+template <bool ATR, bool BTR, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Params P) {
+  constexpr int HALF = 128 * BK * 2, BUF = 4 * HALF;
+  constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+  constexpr bool COLSUM = EPI == EPI_F32 && ATR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * BUF = 128 KB
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int GM = P.gm;
+  int ntm = P.ntm;
+  if (!ATR && P.extent_dev) ntm = min(P.ntm, max(0, (*P.extent_dev + 255) / 256));   // live tile rows only (see gemm_kernel)
+  const int ntiles = ntm * P.ntn;
+  const int total = ntiles * P.splits;
+  if ((int)blockIdx.x >= total) return;
+  const int vid = xcd_virtual_id(blockIdx.x, total);
+  const int split = vid / ntiles, tile = vid - split * ntiles;
+  const int group = tile / (GM * P.ntn), in_group = tile - group * (GM * P.ntn);
+  const int gmr = min(GM, ntm - group * GM);
+  const int tile_n = in_group / gmr;
+  const int m0 = (group * GM + (in_group - tile_n * gmr)) * 256, n0 = tile_n * 256;
+  // reduction range of this workgroup: K tiles kt0 .. kt0 + nst - 1; TN (ATR) with a device-side extent: only the
+  // first `extent` token rows exist, their K tiles are spread evenly over the splits and the tile that contains
+  // row `extent` reads zeros past it (gemm_kernel's rule)
+  int kt0 = split * P.kt_per_split;
+  int nst = min(P.nkt, kt0 + P.kt_per_split) - kt0;
+  int k_eff = P.K;
+  if (ATR && P.extent_dev) {
+    k_eff = min(P.K, max(*P.extent_dev, 0));
+    const int nkt_eff = (k_eff + BK - 1) / BK;
+    const int per = (nkt_eff + P.splits - 1) / P.splits;
+    kt0 = split * per;
+    nst = max(0, min(nkt_eff, kt0 + per) - kt0);
+  }
+  const int k_span = k_eff - kt0 * BK;                      // reduction indices from this workgroup's first K tile on
+
+  Stager<128, ATR, 8> sa0, sa1;
+  Stager<128, BTR, 8> sb0, sb1;
+  sa0.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
+  sa1.init(P.A, P.lda, P.M, m0 + 128, kt0 * BK, wave, lane);
+  sb0.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
+  sb1.init(P.B, P.ldb, P.N, n0 + 128, kt0 * BK, wave, lane);
+  // half-tile of K tile `tj` (relative to kt0) into `dst`; only a reduction-major (token-row) K can be ragged
+  auto issue = [&](auto &st, unsigned char *dst, int tj) {
+    if constexpr (ATR) {
+      const int kl = k_span - tj * BK;
+      if (kl < BK) {
+        st.issue_tail(dst, kl, wave, lane);
+        return;
+      }
+    }
+    st.issue_full(dst, wave);
+  };
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[q >> 1][q & 1][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient of the TN form: column sums of A over k, on the vector ALU beside the MFMAs (wave column 0 of tile
+  // column 0 only): lane (i, g) adds the 8 k values it holds of row i of every A fragment with four v_dot2c against
+  // bf16 ones (exact products, fp32 sums) -- one register per fragment row block instead of an MFMA accumulator
+  const bool do_colsum = COLSUM && P.colsum != nullptr && tile_n == 0 && wc == 0;
+  float csum[2][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) csum[a >> 2][a & 3] = 0.f;
+  bf16x8 aq[2][4], bq0[2][2], bq1[2][2];
+
+  auto read_a = [&](const unsigned char *half) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) aq[ks][a] = read_frag<128, ATR>(half, 64 * wr + 16 * a, ks, lane);
+  };
+  auto read_b = [&](const unsigned char *half, bf16x8 (&bq)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bq[ks][b] = read_frag<128, BTR>(half, 32 * wc + 16 * b, ks, lane);
+  };
+  auto mfma16 = [&](f32x4 (&c)[4][2], const bf16x8 (&bq)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][b], aq[ks][a], c[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto colsum8 = [&](float (&cs)[4]) {
+    if constexpr (COLSUM) {
+      if (do_colsum) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const bf16x8 f = aq[ks][a];
+            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, cs[a], false);
+            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, cs[a], false);
+            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, cs[a], false);
+            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, cs[a], false);
+          }
+      }
+    }
+  };
+
+  if (nst > 0) {
+    unsigned char *cur = smem, *oth = smem + BUF;
+    // prologue: tile 0 complete in buffer 0, the first three halves of tile 1 in flight into buffer 1
+    issue(sb0, cur + OFF_B0, 0);
+    issue(sa0, cur + OFF_A0, 0);
+    issue(sb1, cur + OFF_B1, 0);
+    issue(sa1, cur + OFF_A1, 0);
+    if (nst > 1) {
+      issue(sb0, oth + OFF_B0, 1);
+      issue(sa0, oth + OFF_A0, 1);
+      issue(sb1, oth + OFF_B1, 1);
+      wait_vmcnt<6>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind
+
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < nst; ++t) {
+      const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
+      // ---- phase 1: C00 ----
+      read_b(cur + OFF_B0, bq0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(cur + OFF_A0);
+      if (n1) issue(sa1, oth + OFF_A1, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // the B reads (issued first) are done: B0 may be refilled one phase from now
+      if constexpr (ATR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (tr reads: two per fragment; wait for all)
+      else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(acc[0][0], bq0);
+      colsum8(csum[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2: C01 ----
+      read_b(cur + OFF_B1, bq1);
+      if (n2) issue(sb0, cur + OFF_B0, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(acc[0][1], bq1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 3: C11 ----
+      read_a(cur + OFF_A1);
+      if (n2) issue(sa0, cur + OFF_A0, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(acc[1][1], bq1);
+      colsum8(csum[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 4: C10 ----
+      if (n2) {
+        issue(sb1, cur + OFF_B1, t + 2);
+        wait_vmcnt<6>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mfma16(acc[1][0], bq0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      unsigned char *tmp = cur;
+      cur = oth;
+      oth = tmp;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+  }
+
+  if constexpr (COLSUM) {
+    if (do_colsum) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        float v = csum[a >> 2][a & 3];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int m = m0 + 128 * (a >> 2) + 64 * wr + 16 * (a & 3) + (lane & 15);
+        if (lane < 16 && m < P.M) P.colsum[(size_t)split * P.M + m] = v;
+      }
+    }
+  }
+  f32x4 unused[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    store_tile<4, 2, EPI>(P, acc[q >> 1][q & 1], unused, false, split, m0, n0, 128 * (q >> 1) + 64 * wr, 128 * (q & 1) + 32 * wc, lane);
+}
+
+template <bool ATR, bool BTR, int EPI>
+int launch_8p(Params &P, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * BK * 2;              // two buffers of four half-tile images = 128 KB
+  P.ntm = (P.M + 255) / 256;
+  P.ntn = (P.N + 255) / 256;
+  P.gm = 4;
+  auto kern = &gemm8p_kernel<ATR, BTR, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return GPS_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const long long blocks = (long long)P.ntm * P.ntn * P.splits;
+  if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS, s, P);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
 // out[e] = sum over splits of partial[s][e] in split order (deterministic); the same for the column sums
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long long elems, const float *__restrict__ partial,
                                                            float *__restrict__ out, long long ldo, int ncols,
@@ -923,10 +1173,10 @@ int launch_cfg(Params &P, hipStream_t s) {
 //   8  = 7, persistent workgroups (stage ring runs across tiles)                  9  = 6, persistent
 //  10  = 4, persistent                                                        11  256x256  2x2 (4 waves, 512 registers), operands
 //                                                                                register-staged two stages ahead (gemm256_kernel)
-constexpr int kVariants = 12;
+constexpr int kVariants = 13;
 struct VariantShape { int bm, bn; };
 constexpr VariantShape kShapes[kVariants] = {{128, 128}, {256, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128},
-                                              {128, 128}, {128, 64}, {256, 256}, {256, 256}};
+                                              {128, 128}, {128, 64}, {256, 256}, {256, 256}, {256, 256}};
 template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
@@ -956,6 +1206,10 @@ int launch_variant(Params &P, int variant, hipStream_t s) {
     case 11:      // 256 x 256, four waves, register-staged operands two stages ahead (gemm256_kernel): NT / NN, whole K stages
       if constexpr (ATR || EPI == EPI_F32 || EPI == EPI_RELU_SPLIT || EPI == EPI_RELU_MAX16) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
       else return (P.K % BK == 0 && P.K >= BK && P.splits == 1) ? launch_256<BTR, EPI>(P, s) : launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+    case 12:      // 256 x 256, eight waves in two alternating groups (gemm8p_kernel): NT / NN with whole K stages, TN
+      if constexpr (ATR && BTR && EPI == EPI_F32) return launch_8p<ATR, BTR, EPI>(P, s);
+      else if constexpr (ATR || EPI == EPI_F32 || EPI == EPI_RELU_SPLIT || EPI == EPI_RELU_MAX16) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else return (P.K % BK == 0 && P.K >= BK && P.splits == 1) ? launch_8p<ATR, BTR, EPI>(P, s) : launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
     default: return GPS_ERR_INVALID_ARGUMENT;
   }
 }
@@ -963,8 +1217,23 @@ int launch_variant(Params &P, int variant, hipStream_t s) {
 // default variant from the per-shape timings of profiles/r2/gemm_bench_*.json: the 8-wave 128 x 128 tile (two
 // workgroups = 16 waves per CU) once there are enough tiles to fill the chip more than once, else 128 x 64 tiles at
 // three workgroups per CU; weight gradients: 8 waves with the fragment reads of a stage issued up front
-inline int pick_variant(int form, int M, int N, int splits) {
-  if (form == GPS_GEMM_TN) return 2;
+// weight gradients with >= 18 output tiles of 256 x 256 and a long token reduction: the two-group 256 x 256 kernel with one
+// workgroup per CU, the reduction split so that (nearly) every CU gets one (profiles/r3/gemm_8p_*.log)
+inline int tn_8p_splits(int M, int N, int K) {
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const int nkt = (K + 63) / 64;
+  if (tiles < 18 || tiles > 256 || nkt < 64) return 0;
+  long long s = 256 / tiles;
+  if (s > nkt / 24) s = nkt / 24;        // >= 24 K tiles per workgroup: below that the fp32 partial tiles and the prologue dominate
+  return tiles * s >= 160 ? (int)s : 0;
+}
+inline int pick_variant(int form, int M, int N, int K, int splits) {
+  const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if (form == GPS_GEMM_TN) return (tiles256 >= 18 && tiles256 * splits >= 160 && tiles256 * splits <= 256) ? 12 : 2;
+  // long reductions over >= 140 tiles of 256 x 256 (more than half the CUs busy in the last round): the two-group kernel
+  // (12 608 x 768 x 3072: 62.5 vs 71.7 us forward, 71.1 vs 86.0 us input gradient; at K = 768 its per-tile prologue and
+  // 128 KB store tail cancel the gain -- profiles/r3/gemm_8p_shapes.log)
+  if (K % 64 == 0 && K >= 1536 && tiles256 >= 140) return 12;
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * splits;
   return tiles >= 384 ? 7 : 6;
 }
@@ -975,6 +1244,7 @@ extern "C" {
 
 int gps_gemm_pick_splits(int form, int M, int N, int K) {
   if (form != GPS_GEMM_TN) return 1;
+  if (const int s8 = gps_gemm::tn_8p_splits(M, N, K)) return s8;
   // weight gradient: M x N is small (a few dozen 128 x 128 tiles), K = tokens is long.  The chip holds 512 of
   // these workgroups at once (2 per CU); the time is a staircase in ceil(tiles * splits / 512), so take the largest
   // split count that still fits ONE resident round, as long as every split keeps >= 8 stages of work
@@ -1068,7 +1338,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   if (a->K == 0) P.nkt = 0;
 
   int variant = a->variant;
-  if (variant < 0) variant = pick_variant(a->form, a->M, a->N, P.splits);
+  if (variant < 0) variant = pick_variant(a->form, a->M, a->N, a->K, P.splits);
   if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
 
   int st;
@@ -1077,14 +1347,16 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
       case GPS_GEMM_EPI_BIAS: st = launch_variant<false, false, EPI_BIAS>(P, variant, s); break;
       case GPS_GEMM_EPI_BIAS_GELU: st = launch_variant<false, false, EPI_BIAS_GELU>(P, variant, s); break;
       case GPS_GEMM_EPI_BIAS_RELU: st = launch_variant<false, false, EPI_BIAS_RELU>(P, variant, s); break;
-      // the split-bf16 MLP forms exist for the two default tile configurations only
+      // the split-bf16 MLP forms exist for the two default tile configurations and the two-group 256 x 256 kernel only
       case GPS_GEMM_EPI_RELU_SPLIT:
-        st = variant == 6 ? launch_cfg<128, 64, 2, 2, false, false, EPI_RELU_SPLIT, 2>(P, s)
-                          : launch_cfg<128, 128, 4, 2, false, false, EPI_RELU_SPLIT, 2>(P, s);
+        st = (variant == 12 && P.K % BK == 0 && P.K >= BK) ? launch_8p<false, false, EPI_RELU_SPLIT>(P, s)
+             : variant == 6 ? launch_cfg<128, 64, 2, 2, false, false, EPI_RELU_SPLIT, 2>(P, s)
+                            : launch_cfg<128, 128, 4, 2, false, false, EPI_RELU_SPLIT, 2>(P, s);
         break;
       case GPS_GEMM_EPI_RELU_MAX16:
-        st = variant == 6 ? launch_cfg<128, 64, 2, 2, false, false, EPI_RELU_MAX16, 2>(P, s)
-                          : launch_cfg<128, 128, 4, 2, false, false, EPI_RELU_MAX16, 2>(P, s);
+        st = (variant == 12 && P.K % BK == 0 && P.K >= BK) ? launch_8p<false, false, EPI_RELU_MAX16>(P, s)
+             : variant == 6 ? launch_cfg<128, 64, 2, 2, false, false, EPI_RELU_MAX16, 2>(P, s)
+                            : launch_cfg<128, 128, 4, 2, false, false, EPI_RELU_MAX16, 2>(P, s);
         break;
       default: return GPS_ERR_UNSUPPORTED;
     }

@@ -98,16 +98,18 @@ def test_varlen_bert_with_dropout_runs_and_is_finite():
             assert torch.isfinite(p.grad).all(), n
 
 
-def test_gemm_weight_gradient_ignores_rows_past_the_device_extent():
+@pytest.mark.parametrize("T,N,K", [(3000, 768, 768), (6000, 768, 3072), (5000, 2376, 768)],
+                         ids=["128x128_tiles", "two_group_256x256", "two_group_ragged_M"])
+def test_gemm_weight_gradient_ignores_rows_past_the_device_extent(T, N, K):
     """TN form with extent_dev: rows past the extent may hold NaN; dW / db must equal the sums over the live rows, for
-    extents on and off a 64-row stage boundary and for every split count the heuristic picks."""
+    extents on and off a 64-row stage boundary and for every split count the heuristic picks (the small shape runs the
+    128 x 128 kernel, the wide ones the two-group 256 x 256 kernel with one workgroup per CU)."""
     from sceneverse_amd import _native
     from sceneverse_amd.modules.layers import gemm as G
-    T, N, K = 3000, 768, 768
     g = torch.Generator().manual_seed(9)
     dy = torch.randn(T, N, generator=g).to(torch.bfloat16).to(DEV)
     x = torch.randn(T, K, generator=g).to(torch.bfloat16).to(DEV)
-    for ext in (0, 1, 63, 64, 1000, 1984, 2999, 3000):
+    for ext in (0, 1, 63, 64, 1000, 1984, T - 1, T):
         dy2, x2 = dy.clone(), x.clone()
         dy2[ext:] = float("nan")
         x2[ext:] = float("nan")

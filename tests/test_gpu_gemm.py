@@ -38,7 +38,7 @@ NT_SHAPES = [(5120, 768, 768), (8320, 2304, 768), (5120, 2376, 768), (5120, 2048
              (19200, 2304, 768), (8320, 1024, 64), (8200, 1032, 72)]      # persistent variants: 2 - 6 tiles per workgroup, 1- and 2-stage K
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_forward_nt(M, N, K, variant):
     x, w = _rand16(M, K, seed=1), _rand16(N, K, scale=0.05, seed=2)
@@ -63,7 +63,7 @@ NN_SHAPES = [(5120, 768, 768), (8320, 768, 2304), (5120, 768, 2376), (8320, 2048
              (300, 40, 72), (129, 8, 8), (257, 200, 136), (640, 2376, 640)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("M,N,K", NN_SHAPES)
 def test_dgrad_nn(M, N, K, variant):
     dy, w = _rand16(M, K, seed=5), _rand16(K, N, scale=0.05, seed=6)      # w is (out = K, in = N)
@@ -86,7 +86,7 @@ def test_wgrad_tn(T, N, K, splits):
     dw = torch.empty(N, K, device=DEV)
     db = torch.empty(N, device=DEV)
     ws = torch.empty(max(1, int(lib.gps_gemm_workspace_floats(_native.GEMM_TN, N, K, s))), device=DEV)
-    for variant in (0, 1, 2, 5, 7):
+    for variant in (0, 1, 2, 5, 7, 12):
         dw.fill_(float("nan"))
         db.fill_(float("nan"))
         G.gemm(_native.GEMM_TN, _native.EPI_F32, N, K, T, dy, N, x, K, dw, K, workspace=ws, colsum=db, splits=s,
@@ -109,10 +109,11 @@ def _gelu_ref(pre16):
     return F.gelu(pre16.float())
 
 
-@pytest.fixture(params=[-1, 8, 9, 10, 11])
+@pytest.fixture(params=[-1, 8, 9, 10, 11, 12])
 def forced_variant(request):
     """-1 = the shape-based default; 8 / 9 / 10 = the persistent tile walks (several tiles per workgroup at T = 9000);
-    11 = the four-wave 256 x 256 tile with register-staged operands (whole 64-wide K stages only: own shapes)"""
+    11 = the four-wave 256 x 256 tile with register-staged operands, 12 = the eight-wave two-group 256 x 256 tile
+    (both: whole 64-wide K stages only, hence their own shapes)"""
     for form in (_native.GEMM_NT, _native.GEMM_NN):
         G.set_gemm_variant(form, request.param)
     yield request.param
@@ -123,7 +124,7 @@ def forced_variant(request):
 @pytest.mark.parametrize("act", ["gelu", "relu"])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_activation_epilogues_forward_and_backward(act, p, forced_variant):
-    T, Kin, Hid = (1300, 136, 264) if forced_variant < 0 else ((9000, 128, 1024) if forced_variant == 11 else (9000, 136, 1032))
+    T, Kin, Hid = (1300, 136, 264) if forced_variant < 0 else ((9000, 128, 1024) if forced_variant in (11, 12) else (9000, 136, 1032))
     x, w1 = _rand16(T, Kin, seed=11), _rand16(Hid, Kin, scale=0.2, seed=12)
     b1 = torch.randn(Hid, device=DEV)
     seed_dev = torch.tensor([123456789], dtype=torch.int64, device=DEV)
@@ -142,7 +143,7 @@ def test_activation_epilogues_forward_and_backward(act, p, forced_variant):
     ref_h = torch.where(keep, full / (1 - p), torch.zeros_like(full))
     _close16(h, ref_h, f"{act} hidden p={p}")
     # backward epilogue: dpre = (dy W2) * act'(pre) * mask / (1 - p), the mask recomputed from (seed, index)
-    Out = 128 if forced_variant == 11 else 72      # variant 11 needs whole 64-wide K stages
+    Out = 128 if forced_variant in (11, 12) else 72      # variants 11 / 12 need whole 64-wide K stages
     dy, w2 = _rand16(T, Out, seed=13), _rand16(Out, Hid, scale=0.2, seed=14)
     dpre = G.linear_dgrad(dy, w2, act=act, aux=pre if act == "gelu" else h, p_drop=p, seed_dev=seed_dev)
     dh = dy.float() @ w2.float()
@@ -235,13 +236,15 @@ def test_unsupported_shapes_are_refused():
         G.gemm(_native.GEMM_NT, _native.EPI_BIAS, 16, 8, 12, x, 12, w, 12, y, 8)      # K not a multiple of 8
 
 
-def test_relu_split_epilogue_carries_fp32_values_as_bf16_pairs():
-    """GPS_GEMM_EPI_RELU_SPLIT: C = [hi | lo | hi] with hi + lo == relu(x W^T + b) to ~2^-16 relative."""
-    M, N, K = 1040, 264, 136
+@pytest.mark.parametrize("K,variant", [(136, -1), (192, 12), (136, 6)])
+def test_relu_split_epilogue_carries_fp32_values_as_bf16_pairs(K, variant):
+    """GPS_GEMM_EPI_RELU_SPLIT: C = [hi | lo | hi] with hi + lo == relu(x W^T + b) to ~2^-16 relative (default tile, the
+    two-group 256 x 256 kernel, the 128 x 64 tile)."""
+    M, N = 1040, 264
     x, w = _rand16(M, K, seed=21), _rand16(N, K, scale=0.1, seed=22)
     b = torch.randn(N, device=DEV)
     c = torch.full((M, 3 * N + 8), 5.0, dtype=torch.bfloat16, device=DEV)
-    G.gemm(_native.GEMM_NT, _native.EPI_RELU_SPLIT, M, N, K, x, K, w, K, c, c.stride(0), bias=b)
+    G.gemm(_native.GEMM_NT, _native.EPI_RELU_SPLIT, M, N, K, x, K, w, K, c, c.stride(0), bias=b, variant=variant)
     ref = torch.relu(x.float() @ w.float().t() + b)
     hi, lo, hi2 = c[:, :N].float(), c[:, N:2 * N].float(), c[:, 2 * N:3 * N].float()
     assert torch.equal(hi, hi2) and torch.all(c[:, 3 * N:] == 5.0)

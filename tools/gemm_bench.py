@@ -25,7 +25,9 @@ from sceneverse_amd.modules.layers import gemm as G  # noqa: E402
 LAYERS = [(5120, 768, 2376), (5120, 768, 768), (5120, 768, 2048), (5120, 2048, 768),
           (8320, 768, 2304), (8320, 768, 768), (8320, 768, 2048), (8320, 2048, 768),
           (19200, 768, 2304), (19200, 768, 768), (19200, 768, 3072), (19200, 3072, 768),
-          (3200, 768, 2304), (3200, 768, 768), (3200, 768, 3072), (3200, 3072, 768)]
+          (3200, 768, 2304), (3200, 768, 768), (3200, 768, 3072), (3200, 3072, 768),
+          # the 22 400-row text batch with only its valid tokens (variable-length path, synthetic bench batch)
+          (12608, 768, 2304), (12608, 768, 768), (12608, 768, 3072), (12608, 3072, 768)]
 
 
 def timeit(fns, rounds=12, inner=10):
@@ -128,21 +130,26 @@ def main():
         row = {"tokens": T, "in": K, "out": N}
         # forward
         fns = {"lib": lambda: torch.nn.functional.linear(x, w, b16)}
-        for v in range(12):
+        for v in range(13):
             fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NT, _native.EPI_BIAS, T, N, K, x, K, w, K, y, N, bias=b, variant=v))
         t = timeit(fns, args.rounds)
         row["fwd_us"] = {k: round(v, 2) for k, v in t.items()}
         # dgrad
         fns = {"lib": lambda: torch.mm(dy, w)}
-        for v in range(12):
+        for v in range(13):
             fns[f"v{v}"] = (lambda v=v: G.gemm(_native.GEMM_NN, _native.EPI_BIAS, T, K, N, dy, N, w, K, dx, K, variant=v))
         t = timeit(fns, args.rounds)
         row["dgrad_us"] = {k: round(v, 2) for k, v in t.items()}
         # wgrad (+ bias gradient): library = mm + fp32 cast + column sum, as autograd runs it under autocast
         fns = {"lib": lambda: (torch.mm(dy.t(), x).float(), dy.sum(0, dtype=torch.float32))}
-        for s in sorted({int(lib.gps_gemm_pick_splits(_native.GEMM_TN, N, K, T))}):
+        # the 128 x 128 forms at their own split rule (<= 512 resident workgroups), the 256 x 256 two-group form at the
+        # library's default for it (one workgroup per CU)
+        t128 = ((N + 127) // 128) * ((K + 127) // 128)
+        s_old = max(1, min(512 // t128, 16, ((T + 63) // 64) // 8))
+        s_new = int(lib.gps_gemm_pick_splits(_native.GEMM_TN, N, K, T))
+        for s, vs in ((s_old, (0, 2, 7)), (s_new, (12,))):
             ws = torch.empty(max(1, int(lib.gps_gemm_workspace_floats(_native.GEMM_TN, N, K, s))), device=dev)
-            for v in (0, 2, 7):
+            for v in vs:
                 fns[f"v{v}s{s}"] = (lambda v=v, s=s, ws=ws: G.gemm(_native.GEMM_TN, _native.EPI_F32, N, K, T, dy, N, x, K, dw, K,
                                                                   workspace=ws, colsum=db, splits=s, variant=v))
         t = timeit(fns, args.rounds)

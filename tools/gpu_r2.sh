@@ -186,3 +186,28 @@ if [[ $WHAT == *dpgraph* ]]; then
   grep -E "^(FAILED|ERROR)|passed|failed|exit|Error|assert" $OUT/pytest_dpgraph.log | head -30 | cut -c1-400
   timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --graph-dp > $OUT/bench_dpgraph.json 2> $OUT/bench_dpgraph.err; echo "bench dp exit $?"; tail -c 2200 $OUT/bench_dpgraph.json | head -c 400; echo; tail -3 $OUT/bench_dpgraph.err
 fi
+if [[ $WHAT == *g8p* ]]; then
+  ts g8p
+  timeout 600 python -m pytest tests/test_gpu_gemm.py -m gpu -q -x -k "12 or forced" > $OUT/pytest_g8p.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_g8p.log
+  tail -8 $OUT/pytest_g8p.log | cut -c1-300
+  for i in ${G8P_LAYERS:-8 10 11 4}; do timeout 200 python tools/gemm_bench.py --only $i --rounds 8 >> $OUT/gemm_quick.log 2>&1; done; echo "gemm quick exit $?"; grep "^{" $OUT/gemm_quick.log | cut -c1-1300
+fi
+if [[ $WHAT == *g8tn* ]]; then
+  ts g8tn
+  timeout 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_bert_varlen.py -m gpu -q -x -k "wgrad or extent or determin" > $OUT/pytest_g8tn.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_g8tn.log
+  tail -8 $OUT/pytest_g8tn.log | cut -c1-400
+  for i in ${G8P_LAYERS:-10 11 8 4 6 0}; do timeout 200 python tools/gemm_bench.py --only $i --rounds 8 >> $OUT/gemm_quick.log 2>&1; done; echo "gemm quick exit $?"; grep "^{" $OUT/gemm_quick.log | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print(r['tokens'], r['in'], r['out'], 'wgrad', r['wgrad_us'], 'fwd12', r['fwd_us']['v12'], 'lib', r['fwd_us']['lib'])"
+fi
+if [[ $WHAT == *fullcheck* ]]; then
+  ts fullcheck
+  timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  grep -E "^(FAILED|ERROR)|passed|failed|exit" $OUT/pytest_gpu.log | head -20 | cut -c1-300
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; tail -c 2200 $OUT/bench.json; echo; tail -2 $OUT/bench.err
+fi
+if [[ $WHAT == *attrib* ]]; then
+  ts attrib
+  timeout 600 python tools/step_attrib.py --steps 2 --out $OUT/step_attrib.txt > $OUT/step_attrib.log 2>&1; echo "attrib exit $?"; tail -5 $OUT/step_attrib.log
+fi
