@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 4
+#define GPS_HIP_ABI_VERSION 5
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -354,6 +354,31 @@ GPS_API int gps_colsum_bf16(int rows, int cols, const void *x, long long ld, flo
  * scratch: 2 * num_rows int32.  d and ld multiples of 4, d <= 2048, dy / out 16-byte aligned. */
 GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, const float *dy, long long ld,
                                long long padding_idx, int32_t *scratch, float *out, gps_stream_t stream);
+
+/* ---- embedding block of the BERT text encoder: lookups + LayerNorm + dropout in one launch per direction ----
+ * Replaces HF BertEmbeddings.forward as the language encoder calls it (modules/language/bert.py:21-26: input_ids only,
+ * i.e. token type 0 everywhere and caller-supplied positions):
+ *     y[r] = dropout(LayerNorm(word[ids[r]] + type_row + pos_table[pos[r]]) * gamma + beta)        r < n_rows
+ * ids / pos (n_rows) int64 (ids in [0, vocabulary), pos in [0, positions): NOT checked); tables fp32 with row pitch d;
+ * y fp32 and, if y_bf16 is not null, the same values as bf16; mean / rstd (n_rows) fp32 are the only saved state: the
+ * backward pass gathers the three rows again.  rows_dev (optional, device int32): only the first min(n_rows, *rows_dev)
+ * rows are computed, the others are not written.  Dropout: the counter-based stream of
+ * gps_add_dropout_layernorm_forward (element index r * d + c, seed + *seed_dev).
+ * backward: dz (n_rows, d) fp32 = gradient of the pre-LayerNorm sum for dy (+ dy_bf16 if not null) -- the operand of
+ * gps_embedding_grad for the word table (ids) and the position table (pos); rows past the device row count get zeros;
+ * the type-row gradient is the column sum of the position-table gradient.  dgamma_part / dbeta_part:
+ * (gps_bert_embed_partial_rows(n_rows), d) fp32 per-workgroup partial sums for gps_ln_reduce_partials.
+ * d a multiple of 256, <= 1024; all fp32 / bf16 pointers 16-byte aligned. */
+GPS_API int gps_bert_embed_partial_rows(int n_rows);
+GPS_API int gps_bert_embed_forward(int n_rows, int d, const long long *ids, const long long *pos, const float *word,
+                                   const float *pos_table, const float *type_row, const float *gamma, const float *beta,
+                                   float eps, float p_drop, unsigned long long seed, const void *seed_dev, float *y,
+                                   void *y_bf16, float *mean, float *rstd, const int *rows_dev, gps_stream_t stream);
+GPS_API int gps_bert_embed_backward(int n_rows, int d, const float *dy, const void *dy_bf16, const long long *ids,
+                                    const long long *pos, const float *word, const float *pos_table, const float *type_row,
+                                    const float *gamma, const float *mean, const float *rstd, float p_drop,
+                                    unsigned long long seed, const void *seed_dev, float *dz, float *dgamma_part,
+                                    float *dbeta_part, const int *rows_dev, gps_stream_t stream);
 
 /* ---- bf16 MFMA GEMMs of the transformer projections / FFNs -------------------------------------------
  * Replaces the nn.Linear contractions of the GPS transformer layers -- w_qs / w_ks / w_vs / fc / lang_cond_fc

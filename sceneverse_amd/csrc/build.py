@@ -22,6 +22,7 @@ SOURCES = [
     ("gps_objects.hip", []),
     ("gps_reduce.hip", []),
     ("gps_embedding.hip", []),
+    ("gps_bert_embed.hip", []),
     ("gps_gemm.hip", []),
     ("gps_optim.hip", []),
 ]

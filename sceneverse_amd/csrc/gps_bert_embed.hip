@@ -1,0 +1,267 @@
+// gps_bert_embed.hip -- the embedding block of the BERT text encoder as one launch per direction on MI355X (gfx950).
+//
+// Reference: HF BertEmbeddings.forward behind modules/language/bert.py:21-26 (token_type_ids = None, position_ids =
+// None):   e = word[id] + type[0] + pos[p];   y = dropout(LayerNorm(e))
+// which torch runs as gather, gather, add, add, layer_norm, dropout (+ the fp32 -> bf16 copy the first GEMM wants) and,
+// backward, dropout_backward, layer_norm_backward (2 kernels), a 22 400-row column sum for the type row, index_add for
+// the position table and the word-table scatter: ~0.5 ms of the 15.6 ms pre-train step in a dozen launches
+// (profiles/r3/step_attrib_o.txt).  Here:
+//   forward   one wave per token row: the three table rows are summed in registers, mean / variance two-pass from
+//             registers, y (fp32) and its bf16 copy written once; mean and rstd (2 floats per row) are all that is
+//             saved -- the pre-LayerNorm sum is NOT written: the backward pass gathers it again (the position and type
+//             rows hit L2, the word rows are the same 3 KB per token a saved copy would cost to read, without the write)
+//   backward  dz = LayerNorm'(dy * keep / (1 - p)) per row -> dz (fp32, the operand of the two table-gradient scatters,
+//             gps_embedding_grad) + per-workgroup partial column sums for dgamma / dbeta (summed by
+//             gps_ln_reduce_partials); rows past the device-side row count get dz = 0.
+// The type-row gradient is the column sum of the position-table gradient (every row has exactly one position).
+// Dropout: the counter-based stream of gps_layernorm.hip (element index = row * d + column), recomputed in backward.
+// HBM-bound: forward reads 3 KB (word row) and writes 4.5 KB per live row at d = 768; backward reads 6 KB, writes 3 KB.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gps_hip.h"
+
+namespace gps_bert_embed {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {      // as in gps_layernorm.hip
+  x ^= x >> 16;
+  x *= 0x21F0AAADu;
+  x ^= x >> 15;
+  x *= 0x735A2D97u;
+  x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigned long long idx) {
+  const unsigned int s = mix32((unsigned int)seed ^ mix32((unsigned int)(seed >> 32) + 0x9E3779B9u));
+  return mix32(((unsigned int)idx + (unsigned int)(idx >> 32) * 0x85EBCA6Bu) ^ s);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
+  return (unsigned int)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((unsigned int)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
+}
+// keep * scale of the 4 elements starting at element index e0 (1 everywhere without dropout)
+__device__ __forceinline__ float4 keep4(unsigned int thr, float scale, unsigned long long seed, unsigned long long e0) {
+  if (thr == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
+  return make_float4(rng_u32(seed, e0 + 0) >= thr ? scale : 0.f, rng_u32(seed, e0 + 1) >= thr ? scale : 0.f,
+                     rng_u32(seed, e0 + 2) >= thr ? scale : 0.f, rng_u32(seed, e0 + 3) >= thr ? scale : 0.f);
+}
+// (word[id] + type) + pos[p] for the 4 columns at c0: HF's order of the two additions
+__device__ __forceinline__ float4 gather4(const float *__restrict__ w, const float *__restrict__ p, const float *__restrict__ t,
+                                          int c0) {
+  const float4 a = *reinterpret_cast<const float4 *>(w + c0);
+  const float4 b = *reinterpret_cast<const float4 *>(t + c0);
+  const float4 c = *reinterpret_cast<const float4 *>(p + c0);
+  return make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
+}
+
+template <int ITERS>
+__global__ __launch_bounds__(kBlock) void fwd_kernel(int n_rows, int d, const int64_t *__restrict__ ids,
+                                                     const int64_t *__restrict__ pos, const float *__restrict__ word,
+                                                     const float *__restrict__ pos_tab, const float *__restrict__ type_row,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                     float p_drop, unsigned int thr, unsigned long long seed,
+                                                     const unsigned long long *__restrict__ seed_dev, float *__restrict__ y,
+                                                     uint16_t *__restrict__ y16, float *__restrict__ mean_out,
+                                                     float *__restrict__ rstd_out, const int *__restrict__ rows_dev) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (rows_dev) n_rows = min(n_rows, *rows_dev);        // device-side count of leading rows that carry work
+  const float scale = thr ? 1.f / (1.f - p_drop) : 1.f;
+  const unsigned long long sd = seed + ((thr && seed_dev) ? *seed_dev : 0ull);
+  const float inv_d = 1.f / (float)d;
+  for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
+    const float *w = word + (size_t)ids[row] * d, *p = pos_tab + (size_t)pos[row] * d;
+    float4 z[ITERS];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      z[i] = gather4(w, p, type_row, (i * 64 + lane) * 4);
+      s += (z[i].x + z[i].y) + (z[i].z + z[i].w);
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const float a = z[i].x - mean, b = z[i].y - mean, c = z[i].z - mean, e = z[i].w - mean;
+      v += (a * a + b * b) + (c * c + e * e);
+    }
+    const float rstd = rsqrtf(wave_sum(v) * inv_d + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const size_t base = (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c0);
+      const float4 bt = *reinterpret_cast<const float4 *>(beta + c0);
+      const float4 k = keep4(thr, scale, sd, base + c0);
+      float4 o;
+      o.x = ((z[i].x - mean) * rstd * g.x + bt.x) * k.x;
+      o.y = ((z[i].y - mean) * rstd * g.y + bt.y) * k.y;
+      o.z = ((z[i].z - mean) * rstd * g.z + bt.z) * k.z;
+      o.w = ((z[i].w - mean) * rstd * g.w + bt.w) * k.w;
+      *reinterpret_cast<float4 *>(y + base + c0) = o;
+      if (y16) *reinterpret_cast<uint2 *>(y16 + base + c0) = make_uint2(pack2(o.x, o.y), pack2(o.z, o.w));
+    }
+  }
+}
+
+template <int ITERS>
+__global__ __launch_bounds__(kBlock) void bwd_kernel(int n_rows, int d, const float *__restrict__ dy,
+                                                     const uint16_t *__restrict__ dy16, const int64_t *__restrict__ ids,
+                                                     const int64_t *__restrict__ pos, const float *__restrict__ word,
+                                                     const float *__restrict__ pos_tab, const float *__restrict__ type_row,
+                                                     const float *__restrict__ gamma, const float *__restrict__ mean_in,
+                                                     const float *__restrict__ rstd_in, float p_drop, unsigned int thr,
+                                                     unsigned long long seed, const unsigned long long *__restrict__ seed_dev,
+                                                     float *__restrict__ dz_out, float *__restrict__ dgamma_part,
+                                                     float *__restrict__ dbeta_part, const int *__restrict__ rows_dev) {
+  extern __shared__ float red[];      // [kWaves][d], used for dgamma then dbeta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_live = rows_dev ? min(n_rows, *rows_dev) : n_rows;
+  const float scale = thr ? 1.f / (1.f - p_drop) : 1.f;
+  const unsigned long long sd = seed + ((thr && seed_dev) ? *seed_dev : 0ull);
+  const float inv_d = 1.f / (float)d;
+  float4 gacc[ITERS], bacc[ITERS], gm[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    gacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
+  }
+  for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
+    const size_t base = (size_t)row * d;
+    if (row >= n_live) {               // rows nobody computed: their gradient is zero for the table scatters
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) *reinterpret_cast<float4 *>(dz_out + base + (i * 64 + lane) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const float *w = word + (size_t)ids[row] * d, *p = pos_tab + (size_t)pos[row] * d;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 zh[ITERS], a[ITERS];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      float4 g = *reinterpret_cast<const float4 *>(dy + base + c0);
+      if (dy16) {                      // gradient that arrived through the bf16 copy of y
+        const uint2 u = *reinterpret_cast<const uint2 *>(dy16 + base + c0);
+        g.x += __uint_as_float(u.x << 16); g.y += __uint_as_float(u.x & 0xFFFF0000u);
+        g.z += __uint_as_float(u.y << 16); g.w += __uint_as_float(u.y & 0xFFFF0000u);
+      }
+      const float4 k = keep4(thr, scale, sd, base + c0);
+      g = make_float4(g.x * k.x, g.y * k.y, g.z * k.z, g.w * k.w);         // gradient of the LayerNorm output
+      const float4 e = gather4(w, p, type_row, c0);
+      zh[i] = make_float4((e.x - mean) * rstd, (e.y - mean) * rstd, (e.z - mean) * rstd, (e.w - mean) * rstd);
+      a[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
+      s1 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+      s2 += (a[i].x * zh[i].x + a[i].y * zh[i].y) + (a[i].z * zh[i].z + a[i].w * zh[i].w);
+      gacc[i].x += g.x * zh[i].x; gacc[i].y += g.y * zh[i].y; gacc[i].z += g.z * zh[i].z; gacc[i].w += g.w * zh[i].w;
+      bacc[i].x += g.x; bacc[i].y += g.y; bacc[i].z += g.z; bacc[i].w += g.w;
+    }
+    s1 = wave_sum(s1) * inv_d;
+    s2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      float4 dz;
+      dz.x = rstd * (a[i].x - s1 - zh[i].x * s2);
+      dz.y = rstd * (a[i].y - s1 - zh[i].y * s2);
+      dz.z = rstd * (a[i].z - s1 - zh[i].z * s2);
+      dz.w = rstd * (a[i].w - s1 - zh[i].w * s2);
+      *reinterpret_cast<float4 *>(dz_out + base + (i * 64 + lane) * 4) = dz;
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {      // cross-wave reduction of the column sums, one partial row per workgroup
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) *reinterpret_cast<float4 *>(red + wave * d + (i * 64 + lane) * 4) = pass == 0 ? gacc[i] : bacc[i];
+    __syncthreads();
+    float *dst = (pass == 0 ? dgamma_part : dbeta_part) + (size_t)blockIdx.x * d;
+    for (int c = threadIdx.x; c < d; c += kBlock) {
+      float t = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < kWaves; ++w2) t += red[w2 * d + c];
+      dst[c] = t;
+    }
+  }
+}
+
+inline int grid_rows(int n_rows) {
+  int g = (n_rows + kWaves - 1) / kWaves;
+  return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+
+}  // namespace gps_bert_embed
+
+extern "C" {
+
+int gps_bert_embed_partial_rows(int n_rows) { return gps_bert_embed::grid_rows(n_rows); }
+
+int gps_bert_embed_forward(int n_rows, int d, const long long *ids, const long long *pos, const float *word,
+                           const float *pos_table, const float *type_row, const float *gamma, const float *beta, float eps,
+                           float p_drop, unsigned long long seed, const void *seed_dev, float *y, void *y_bf16, float *mean,
+                           float *rstd, const int *rows_dev, gps_stream_t stream) {
+  using namespace gps_bert_embed;
+  if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
+  if ((d & 255) || d > 1024) return GPS_ERR_UNSUPPORTED;
+  if (n_rows == 0) return GPS_OK;
+  if (!ids || !pos || !word || !pos_table || !type_row || !gamma || !beta || !y || !mean || !rstd) return GPS_ERR_INVALID_ARGUMENT;
+  const uintptr_t align = (uintptr_t)word | (uintptr_t)pos_table | (uintptr_t)type_row | (uintptr_t)gamma | (uintptr_t)beta |
+                          (uintptr_t)y | (uintptr_t)y_bf16;
+  if (align & 15) return GPS_ERR_UNSUPPORTED;
+  const unsigned int thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  const dim3 grid(grid_rows(n_rows)), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+#define GPS_BE_FWD(IT)                                                                                                     \
+  hipLaunchKernelGGL((fwd_kernel<IT>), grid, block, 0, s, n_rows, d, (const int64_t *)ids, (const int64_t *)pos, word,   \
+                     pos_table, type_row, gamma, beta, eps, p_drop, thr, seed, (const unsigned long long *)seed_dev, y, \
+                     (uint16_t *)y_bf16, mean, rstd, rows_dev)
+  switch (d >> 8) {
+    case 1: GPS_BE_FWD(1); break;
+    case 2: GPS_BE_FWD(2); break;
+    case 3: GPS_BE_FWD(3); break;
+    case 4: GPS_BE_FWD(4); break;
+    default: return GPS_ERR_UNSUPPORTED;
+  }
+#undef GPS_BE_FWD
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_bert_embed_backward(int n_rows, int d, const float *dy, const void *dy_bf16, const long long *ids, const long long *pos,
+                            const float *word, const float *pos_table, const float *type_row, const float *gamma,
+                            const float *mean, const float *rstd, float p_drop, unsigned long long seed, const void *seed_dev,
+                            float *dz, float *dgamma_part, float *dbeta_part, const int *rows_dev, gps_stream_t stream) {
+  using namespace gps_bert_embed;
+  if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
+  if ((d & 255) || d > 1024) return GPS_ERR_UNSUPPORTED;
+  if (n_rows == 0) return GPS_OK;
+  if (!dy || !ids || !pos || !word || !pos_table || !type_row || !gamma || !mean || !rstd || !dz || !dgamma_part || !dbeta_part)
+    return GPS_ERR_INVALID_ARGUMENT;
+  const uintptr_t align = (uintptr_t)word | (uintptr_t)pos_table | (uintptr_t)type_row | (uintptr_t)gamma | (uintptr_t)dy |
+                          (uintptr_t)dy_bf16 | (uintptr_t)dz;
+  if (align & 15) return GPS_ERR_UNSUPPORTED;
+  const unsigned int thr = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  const dim3 grid(grid_rows(n_rows)), block(kBlock);
+  const size_t lds = sizeof(float) * kWaves * d;
+  hipStream_t s = (hipStream_t)stream;
+#define GPS_BE_BWD(IT)                                                                                                       \
+  hipLaunchKernelGGL((bwd_kernel<IT>), grid, block, lds, s, n_rows, d, dy, (const uint16_t *)dy_bf16, (const int64_t *)ids, \
+                     (const int64_t *)pos, word, pos_table, type_row, gamma, mean, rstd, p_drop, thr, seed,                \
+                     (const unsigned long long *)seed_dev, dz, dgamma_part, dbeta_part, rows_dev)
+  switch (d >> 8) {
+    case 1: GPS_BE_BWD(1); break;
+    case 2: GPS_BE_BWD(2); break;
+    case 3: GPS_BE_BWD(3); break;
+    case 4: GPS_BE_BWD(4); break;
+    default: return GPS_ERR_UNSUPPORTED;
+  }
+#undef GPS_BE_BWD
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

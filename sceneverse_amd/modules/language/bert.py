@@ -106,6 +106,7 @@ class BERTLanguageEncoder(nn.Module):
         from ..layers import gemm
         from ..layers.fused_attention import fused_varlen_self_attention
         from ..layers.fused_norm import add_dropout_layer_norm
+        from . import fused_embedding
         from .fused_embedding import _WordLookup
         m, H = self.model, self.bert_config.num_attention_heads
         emb = m.embeddings
@@ -121,14 +122,19 @@ class BERTLanguageEncoder(nn.Module):
         cu[1:] = torch.cumsum(lens, 0)
         order = torch.argsort(lens, descending=True).to(torch.int32)               # longest sequences dispatched first
         # embedding block on the compacted tokens (HF BertEmbeddings with token type 0): rows past n_valid hold pad ids
-        pad = emb.word_embeddings.padding_idx
-        x = _WordLookup.apply(ids_all.index_select(0, perm), emb.word_embeddings.weight, -1 if pad is None else int(pad))
-        x = x + emb.token_type_embeddings.weight[0]
-        x = x + emb.position_embeddings.weight.index_select(0, pos.index_select(0, perm))
-        x = emb.dropout(emb.LayerNorm(x))
-        x = _ZeroDeadRows.apply(x, n_valid)
-        x16 = x
         training = self.training
+        if fused_embedding.rows_supported(emb):
+            # one launch: lookups + LayerNorm + dropout, fp32 and bf16 outputs, live rows only (gps_bert_embed_forward)
+            x, x16 = fused_embedding.bert_embeddings_rows(emb, ids_all.index_select(0, perm), pos.index_select(0, perm),
+                                                          rows_dev=n_valid, training=training)
+        else:
+            pad = emb.word_embeddings.padding_idx
+            x = _WordLookup.apply(ids_all.index_select(0, perm), emb.word_embeddings.weight, -1 if pad is None else int(pad))
+            x = x + emb.token_type_embeddings.weight[0]
+            x = x + emb.position_embeddings.weight.index_select(0, pos.index_select(0, perm))
+            x = emb.dropout(emb.LayerNorm(x))
+            x = _ZeroDeadRows.apply(x, n_valid)
+            x16 = x
         for layer in m.encoder.layer:
             sa, so = layer.attention.self, layer.attention.output
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):

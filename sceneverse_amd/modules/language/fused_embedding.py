@@ -92,3 +92,92 @@ def bert_embeddings_multi(emb, texts) -> list:
         x = x + emb.position_embeddings.weight[:L]
         outs.append(emb.dropout(emb.LayerNorm(x)))
     return outs
+
+
+class _BertEmbedRows(torch.autograd.Function):
+    """y, y16 = dropout(LayerNorm(word[ids] + type[0] + pos_table[pos])) for a flat list of token rows, one launch per
+    direction (gps_bert_embed_forward / backward); rows past *rows_dev are neither computed nor written."""
+
+    @staticmethod
+    def forward(ctx, ids, pos, word_w, pos_w, type_w, gamma, beta, eps: float, p_drop: float, seed_dev, rows_dev,
+                padding_idx: int):
+        n, d = ids.numel(), word_w.shape[1]
+        dev = word_w.device
+        ids = ids.reshape(-1).to(torch.int64).contiguous()
+        pos = pos.reshape(-1).to(torch.int64).contiguous()
+        type0 = type_w[0].contiguous()
+        y = torch.empty((n, d), dtype=torch.float32, device=dev)
+        y16 = torch.empty((n, d), dtype=torch.bfloat16, device=dev)
+        mean = torch.empty(n, dtype=torch.float32, device=dev)
+        rstd = torch.empty(n, dtype=torch.float32, device=dev)
+        from ...pointnet2._ext import _timed
+        from ..layers.fused_norm import _ptr, _row_fraction
+        with torch.cuda.device(dev), _timed(f"bert_embed_forward(rows={n},d={d})", n * (d * (4 + 4 + 2) + 16),
+                                            work_fraction=_row_fraction(rows_dev, n)):
+            st = _native.load().gps_bert_embed_forward(
+                n, d, ids.data_ptr(), pos.data_ptr(), word_w.data_ptr(), pos_w.data_ptr(), type0.data_ptr(),
+                gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_drop), 0, _ptr(seed_dev), y.data_ptr(),
+                y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(rows_dev), torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(st, "bert_embed_forward")
+        ctx.save_for_backward(ids, pos, word_w, pos_w, type0, gamma, mean, rstd, seed_dev, rows_dev)
+        ctx.meta = (float(p_drop), int(padding_idx), type_w.shape[0])
+        return y, y16
+
+    @staticmethod
+    def backward(ctx, dy, dy16):
+        ids, pos, word_w, pos_w, type0, gamma, mean, rstd, seed_dev, rows_dev = ctx.saved_tensors
+        p_drop, padding_idx, n_types = ctx.meta
+        n, d = ids.numel(), word_w.shape[1]
+        dev = word_w.device
+        if dy is None:
+            dy = torch.zeros((n, d), dtype=torch.float32, device=dev)
+        dy = dy.reshape(n, d).float().contiguous()
+        dy16 = dy16.reshape(n, d).to(torch.bfloat16).contiguous() if dy16 is not None else None
+        lib = _native.load()
+        parts = int(lib.gps_bert_embed_partial_rows(n))
+        part = torch.empty((2, parts, d), dtype=torch.float32, device=dev)
+        dz = torch.empty((n, d), dtype=torch.float32, device=dev)
+        from ...pointnet2._ext import _timed
+        from ..layers.fused_norm import _ptr, _reduce_scratch, _row_fraction
+        with torch.cuda.device(dev), _timed(f"bert_embed_backward(rows={n},d={d})", n * (d * (4 + 2 + 4 + 4) + 24),
+                                            work_fraction=_row_fraction(rows_dev, n)):
+            st = lib.gps_bert_embed_backward(
+                n, d, dy.data_ptr(), _ptr(dy16), ids.data_ptr(), pos.data_ptr(), word_w.data_ptr(), pos_w.data_ptr(),
+                type0.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, 0, _ptr(seed_dev),
+                dz.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), _ptr(rows_dev), torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(st, "bert_embed_backward")
+        sums = torch.empty((2, d), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), sums.data_ptr(), _reduce_scratch(dev, d).data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(st, "ln_reduce_partials")
+        d_word = embedding_grad(ids, dz, word_w.shape[0], padding_idx)
+        d_pos = embedding_grad(pos, dz, pos_w.shape[0], -1)
+        d_type = torch.zeros((n_types, d), dtype=torch.float32, device=dev)
+        d_type[0] = d_pos.sum(0)                 # every row has exactly one position: sum of all rows' dz
+        return None, None, d_word, d_pos, d_type, sums[0], sums[1], None, None, None, None, None
+
+
+def rows_supported(emb) -> bool:
+    w, ln = emb.word_embeddings.weight, emb.LayerNorm
+    d = w.shape[1]
+    return (w.is_cuda and w.dtype == torch.float32 and d % 256 == 0 and d <= 1024
+            and emb.position_embeddings.weight.dtype == torch.float32 and emb.token_type_embeddings.weight.dtype == torch.float32
+            and ln.elementwise_affine and ln.bias is not None and ln.weight.dtype == torch.float32
+            and emb.word_embeddings.max_norm is None and not emb.word_embeddings.scale_grad_by_freq
+            and not emb.word_embeddings.sparse)
+
+
+def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=None, training: bool = False):
+    """HF BertEmbeddings for a flat list of (token id, position) rows -> (y fp32 (n, d), y bf16 (n, d)); rows at or past
+    the device-side count `rows_dev` are left unwritten."""
+    p = float(emb.dropout.p) if training else 0.0
+    seed_dev = None
+    if p > 0.0:
+        from ..layers.fused_attention import _next_device_seed
+        seed_dev = _next_device_seed(ids.device)
+    pad = emb.word_embeddings.padding_idx
+    ln = emb.LayerNorm
+    return _BertEmbedRows.apply(ids, pos, emb.word_embeddings.weight, emb.position_embeddings.weight,
+                                emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, p, seed_dev, rows_dev,
+                                -1 if pad is None else int(pad))

@@ -99,6 +99,10 @@ class _PointnetSAModuleBase(nn.Module):
         if self.npoint is None:
             return None
         inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        if xyz.is_cuda and not xyz.requires_grad:
+            # the reference's transpose -> gather_operation -> transpose (pointnet2_modules.py:47-54) is a pure row
+            # gather: same values without the two full-cloud copies
+            return torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
         picked = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds)
         return picked.transpose(1, 2).contiguous()
 
@@ -115,7 +119,7 @@ class _PointnetSAModuleBase(nn.Module):
             grouped = mlp(grouped)                             # (B, mlp[-1], npoint, nsample)
             # max over nsample (max_pool2d like ref :68-71, so tie routing in backward matches)
             pooled.append(F.max_pool2d(grouped, kernel_size=[1, grouped.size(3)]).squeeze(-1))
-        return new_xyz, torch.cat(pooled, dim=1)
+        return new_xyz, (pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=1))     # cat of one tensor copies it
 
 
     # ---- frozen encoder: one native launch per level -------------------------------------------

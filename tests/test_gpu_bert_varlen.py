@@ -73,6 +73,12 @@ def test_varlen_bert_matches_the_padded_fast_path_and_huggingface():
     assert set(g_v) == set(g_p)
     for n in g_p:
         assert torch.isfinite(g_v[n]).all(), n
+        if n.endswith("attention.self.key.bias"):
+            # the exact gradient of a key bias is ZERO (a shift of all keys of a row leaves its softmax unchanged): what
+            # both paths hold is rounding noise, to be small against the query bias of the same layer, not equal
+            q = g_p[n.replace("key.bias", "query.bias")].float().norm().item()
+            assert g_v[n].float().norm().item() <= 0.05 * q and g_p[n].float().norm().item() <= 0.05 * q, n
+            continue
         rel = ((g_v[n].float() - g_p[n].float()).norm() / (g_p[n].float().norm() + 1e-12)).item()
         assert rel <= 2e-2, (n, rel)
     # HuggingFace's own forward (fp32) on the padded batch

@@ -121,3 +121,86 @@ def test_argument_errors():
         FE.embedding_grad(ids, torch.randn(4, 6, device=DEV), 10)          # d not a multiple of 4
     out = FE.embedding_grad(ids[:0], torch.randn(0, 8, device=DEV), 10)    # no tokens: all-zero table
     assert out.shape == (10, 8) and torch.all(out == 0)
+
+
+class _Emb(torch.nn.Module):
+    """The parameters of HF BertEmbeddings (bert-base sizes) without the HF class."""
+
+    def __init__(self, vocab=30522, d=768, n_pos=512, p=0.1, seed=3):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.word_embeddings = torch.nn.Embedding(vocab, d, padding_idx=0)
+        self.position_embeddings = torch.nn.Embedding(n_pos, d)
+        self.token_type_embeddings = torch.nn.Embedding(2, d)
+        self.LayerNorm = torch.nn.LayerNorm(d, eps=1e-12)
+        self.dropout = torch.nn.Dropout(p)
+        with torch.no_grad():
+            for prm in self.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.3 if prm.dim() == 2 else 1.0))
+            self.LayerNorm.weight.add_(1.0)
+
+
+@pytest.mark.parametrize("live", [None, 1500, 0, 2048])
+def test_bert_embed_rows_forward_and_backward_match_the_torch_chain(live):
+    """gps_bert_embed_forward / backward (lookups + LayerNorm, no dropout) against word + type + pos -> layer_norm in
+    fp64: outputs (fp32 and the bf16 copy), and the gradients of all five parameters, with and without a device-side
+    row count (rows past it: not written forward, no contribution backward)."""
+    n, d = 2048, 768
+    emb = _Emb().to(DEV)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(1, 30522, (n,), generator=g)
+    ids[::7] = 101                                             # duplicates
+    ids[5::31] = 0                                             # the padding row: no gradient
+    pos = torch.randint(0, 300, (n,), generator=g)
+    ids, pos = ids.to(DEV), pos.to(DEV)
+    rows_dev = None if live is None else torch.tensor([live], dtype=torch.int32, device=DEV)
+    m = n if live is None else live
+    y, y16 = FE.bert_embeddings_rows(emb, ids, pos, rows_dev=rows_dev, training=False)
+    # fp64 reference on the live rows
+    prm64 = {k: v.detach().double().requires_grad_(True) for k, v in emb.named_parameters()}
+    e = prm64["word_embeddings.weight"][ids[:m]] + prm64["token_type_embeddings.weight"][0] + prm64["position_embeddings.weight"][pos[:m]]
+    ref = F.layer_norm(e, (d,), prm64["LayerNorm.weight"], prm64["LayerNorm.bias"], 1e-12)
+    if m:
+        assert (y[:m].double() - ref).abs().max().item() <= 2e-5
+        assert (y16[:m].double() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
+    wy = torch.randn(n, d, generator=g).to(DEV)
+    wy16 = (torch.randn(n, d, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    if live is not None:                                        # dead rows carry garbage gradients in the real step
+        wy[m:] = float("nan")
+        wy16[m:] = float("nan")
+    for prm in emb.parameters():
+        prm.grad = None
+    torch.autograd.backward([y, y16], [wy, wy16])
+    (ref * (wy[:m].double() + wy16[:m].double())).sum().backward()
+    for name, prm in emb.named_parameters():
+        got, want = prm.grad.double(), prm64[name].grad.clone()
+        if name == "word_embeddings.weight":
+            want[0] = 0                                          # nn.Embedding(padding_idx=0): that row gets no gradient
+        assert torch.isfinite(got).all(), name
+        scale = max(1.0, want.abs().max().item())
+        assert (got - want).abs().max().item() <= 3e-5 * scale, (name, (got - want).abs().max().item(), scale)
+    assert torch.all(emb.word_embeddings.weight.grad[0] == 0)     # padding row
+    assert torch.all(emb.token_type_embeddings.weight.grad[1] == 0)
+
+
+def test_bert_embed_rows_dropout_mask_is_the_same_in_both_directions():
+    n, d, p = 1024, 768, 0.1
+    emb = _Emb(p=p).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(1, 30522, (n,), generator=g).to(DEV)
+    pos = torch.randint(0, 300, (n,), generator=g).to(DEV)
+    torch.manual_seed(0)
+    y, y16 = FE.bert_embeddings_rows(emb, ids, pos, training=True)
+    y0, _ = FE.bert_embeddings_rows(emb, ids, pos, training=False)
+    dropped = y == 0
+    frac = dropped.float().mean().item()
+    assert abs(frac - p) < 0.01, frac
+    keep = ~dropped
+    assert torch.allclose(y[keep], y0[keep] / (1 - p), rtol=1e-6, atol=1e-6)
+    assert torch.equal(y16, y.to(torch.bfloat16))
+    # backward: a cotangent that only touches DROPPED elements produces exactly zero gradients everywhere
+    for prm in emb.parameters():
+        prm.grad = None
+    torch.autograd.backward([y, y16], [dropped.float(), torch.zeros_like(y16)])
+    for name, prm in emb.named_parameters():
+        assert torch.all(prm.grad == 0), name

@@ -211,3 +211,9 @@ if [[ $WHAT == *attrib* ]]; then
   ts attrib
   timeout 600 python tools/step_attrib.py --steps 2 --out $OUT/step_attrib.txt > $OUT/step_attrib.log 2>&1; echo "attrib exit $?"; tail -5 $OUT/step_attrib.log
 fi
+if [[ $WHAT == *embcheck* ]]; then
+  ts embcheck
+  timeout 1200 python -m pytest ${EMB_TESTS:-tests/test_gpu_embedding.py tests/test_gpu_bert_varlen.py tests/test_gpu_model.py tests/test_gpu_point_ops.py tests/test_gpu_sa_fused.py} -m gpu -q -x > $OUT/pytest_emb.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_emb.log
+  grep -E "^(FAILED|ERROR)|passed|failed|exit|Error|assert " $OUT/pytest_emb.log | head -20 | cut -c1-400
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; head -c 330 $OUT/bench.json; echo; tail -2 $OUT/bench.err
+fi
