@@ -370,6 +370,12 @@ GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, c
  * (gps_bert_embed_partial_rows(n_rows), d) fp32 per-workgroup partial sums for gps_ln_reduce_partials.
  * d a multiple of 256, <= 1024; all fp32 / bf16 pointers 16-byte aligned. */
 GPS_API int gps_bert_embed_partial_rows(int n_rows);
+/* position-table gradient when the rows are n_seq whole sequences laid end to end (sequence s = rows cu_rows[s] ..
+ * cu_rows[s + 1] - 1, cu_rows (n_seq + 1) device int32) and a row's position is its offset inside its sequence (HF's
+ * default position_ids): out (n_pos, d) fp32, out[p] = sum over the sequences longer than p of dz[cu_rows[s] + p], in
+ * sequence order (deterministic); positions no sequence reaches get zeros. */
+GPS_API int gps_bert_position_grad(int n_seq, int n_pos, int d, const int *cu_rows, const float *dz, float *out,
+                                   gps_stream_t stream);
 GPS_API int gps_bert_embed_forward(int n_rows, int d, const long long *ids, const long long *pos, const float *word,
                                    const float *pos_table, const float *type_row, const float *gamma, const float *beta,
                                    float eps, float p_drop, unsigned long long seed, const void *seed_dev, float *y,

@@ -33,6 +33,15 @@ def set_fast_bert(flag: bool) -> None:
     _FAST = bool(flag)
 
 
+_CLS_TAIL = True
+
+
+def set_cls_tail(flag: bool) -> None:
+    """Last-layer tail on the rows that reach an output only (texts read at [CLS]); off = every live row (A/B, tests)."""
+    global _CLS_TAIL
+    _CLS_TAIL = bool(flag)
+
+
 def set_varlen(flag: bool) -> None:
     """False: the fast path keeps the padded (B, L) row batch (A/B runs, parity tests against the padded form)."""
     global _VARLEN
@@ -126,7 +135,7 @@ class BERTLanguageEncoder(nn.Module):
         if fused_embedding.rows_supported(emb):
             # one launch: lookups + LayerNorm + dropout, fp32 and bf16 outputs, live rows only (gps_bert_embed_forward)
             x, x16 = fused_embedding.bert_embeddings_rows(emb, ids_all.index_select(0, perm), pos.index_select(0, perm),
-                                                          rows_dev=n_valid, training=training)
+                                                          rows_dev=n_valid, training=training, cu_rows=cu)
         else:
             pad = emb.word_embeddings.padding_idx
             x = _WordLookup.apply(ids_all.index_select(0, perm), emb.word_embeddings.weight, -1 if pad is None else int(pad))
@@ -135,19 +144,41 @@ class BERTLanguageEncoder(nn.Module):
             x = emb.dropout(emb.LayerNorm(x))
             x = _ZeroDeadRows.apply(x, n_valid)
             x16 = x
-        for layer in m.encoder.layer:
+        # Texts that are only read at [CLS] (`cls_only`, listed after the fully-read ones): in the LAST layer, everything
+        # behind the attention core is row-wise, and of those texts only the first row of each sequence reaches an output
+        # -- the other rows' results are never read and their gradients are exactly zero in the reference as well.  The
+        # tail of the last layer (output projection, LayerNorm, FFN, LayerNorm) therefore runs on the rows
+        #     [ first row of every [CLS]-only sequence | the live rows of the fully-read texts ]
+        # (the compact buffer holds the fully-read texts' live rows first, so the second part is a prefix of it).
+        n_full = sum(1 for ti in range(len(texts)) if ti not in cls_only)
+        cls_tail = (_CLS_TAIL and 0 < n_full < len(texts) and all(ti >= n_full for ti in cls_only)
+                    and len(m.encoder.layer) > 0)
+        if cls_tail:
+            T_full = sum(texts[ti][0].numel() for ti in range(n_full))
+            S_full = sum(texts[ti][0].shape[0] for ti in range(n_full))
+            n_live_full = valid[:T_full].sum(dtype=torch.int32).reshape(1)
+            sel = torch.cat([cu[S_full:S].long(), torch.arange(T_full, device=dev)])
+            rows_tail = n_live_full + (S - S_full)
+        last = len(m.encoder.layer) - 1
+        for li, layer in enumerate(m.encoder.layer):
             sa, so = layer.attention.self, layer.attention.output
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 packed = gemm.packed_linear(x16, [sa.query, sa.key, sa.value], rows_dev=n_valid)
                 ctx = fused_varlen_self_attention(packed, cu, S, cap, H, dropout_p=sa.dropout.p, training=training,
                                                   order=order)
-                attn_out = gemm.linear(ctx, so.dense.weight, so.dense.bias, rows_dev=n_valid)
+                rows = n_valid
+                if cls_tail and li == last:
+                    # rows past `rows_tail` of the tail batch are never written by the extent-aware kernels, forward or
+                    # backward: their (undefined) gradients must not be scattered back into the full row batch
+                    ctx = _ZeroDeadRows.apply(ctx.index_select(0, sel), rows_tail)
+                    x, rows = _ZeroDeadRows.apply(x.index_select(0, sel), rows_tail), rows_tail
+                attn_out = gemm.linear(ctx, so.dense.weight, so.dense.bias, rows_dev=rows)
                 x, x16 = add_dropout_layer_norm(x, attn_out, so.LayerNorm, so.dropout.p, training, want_bf16=True,
-                                                rows_dev=n_valid)
+                                                rows_dev=rows)
                 ffn_out = gemm.ffn(x16, layer.intermediate.dense, layer.output.dense, "gelu", 0.0, training,
-                                   rows_dev=n_valid)
+                                   rows_dev=rows)
                 x, x16 = add_dropout_layer_norm(x, ffn_out, layer.output.LayerNorm, layer.output.dropout.p, training,
-                                                want_bf16=True, rows_dev=n_valid)
+                                                want_bf16=True, rows_dev=rows)
         # back to the callers' layouts
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(T, device=dev)
@@ -155,10 +186,16 @@ class BERTLanguageEncoder(nn.Module):
         for ti, (ids, masks) in enumerate(texts):
             B, L = ids.shape
             if ti in cls_only:
-                first = cu[s0:s0 + B].long()                                 # compact row of every sequence's first token
-                outs.append(x.index_select(0, first).view(B, 1, -1))
+                if cls_tail:                                                 # rows [0, S - S_full) of the tail batch
+                    outs.append(x[s0 - S_full:s0 - S_full + B].view(B, 1, -1))
+                else:
+                    first = cu[s0:s0 + B].long()                             # compact row of every sequence's first token
+                    outs.append(x.index_select(0, first).view(B, 1, -1))
             else:
-                rows = x.index_select(0, inv[r0:r0 + B * L])
+                src = inv[r0:r0 + B * L]
+                if cls_tail:      # tail batch: compact row c of a fully-read text sits at (S - S_full) + c; padded tokens
+                    src = (src + (S - S_full)).clamp(max=x.shape[0] - 1)      # (masked below) may point past the batch
+                rows = x.index_select(0, src)
                 live = valid[r0:r0 + B * L, None]
                 outs.append(torch.where(live, rows, torch.zeros((), dtype=rows.dtype, device=dev)).view(B, L, -1))
             r0 += B * L

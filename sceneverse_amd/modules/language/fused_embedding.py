@@ -100,7 +100,7 @@ class _BertEmbedRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, pos, word_w, pos_w, type_w, gamma, beta, eps: float, p_drop: float, seed_dev, rows_dev,
-                padding_idx: int):
+                padding_idx: int, cu_rows=None):
         n, d = ids.numel(), word_w.shape[1]
         dev = word_w.device
         ids = ids.reshape(-1).to(torch.int64).contiguous()
@@ -119,13 +119,13 @@ class _BertEmbedRows(torch.autograd.Function):
                 gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_drop), 0, _ptr(seed_dev), y.data_ptr(),
                 y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(rows_dev), torch.cuda.current_stream(dev).cuda_stream)
         _native.check(st, "bert_embed_forward")
-        ctx.save_for_backward(ids, pos, word_w, pos_w, type0, gamma, mean, rstd, seed_dev, rows_dev)
+        ctx.save_for_backward(ids, pos, word_w, pos_w, type0, gamma, mean, rstd, seed_dev, rows_dev, cu_rows)
         ctx.meta = (float(p_drop), int(padding_idx), type_w.shape[0])
         return y, y16
 
     @staticmethod
     def backward(ctx, dy, dy16):
-        ids, pos, word_w, pos_w, type0, gamma, mean, rstd, seed_dev, rows_dev = ctx.saved_tensors
+        ids, pos, word_w, pos_w, type0, gamma, mean, rstd, seed_dev, rows_dev, cu_rows = ctx.saved_tensors
         p_drop, padding_idx, n_types = ctx.meta
         n, d = ids.numel(), word_w.shape[1]
         dev = word_w.device
@@ -152,10 +152,18 @@ class _BertEmbedRows(torch.autograd.Function):
                                             torch.cuda.current_stream(dev).cuda_stream)
         _native.check(st, "ln_reduce_partials")
         d_word = embedding_grad(ids, dz, word_w.shape[0], padding_idx)
-        d_pos = embedding_grad(pos, dz, pos_w.shape[0], -1)
+        if cu_rows is not None:      # whole sequences end to end, position = offset inside the sequence
+            d_pos = torch.empty((pos_w.shape[0], d), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev), _timed(f"bert_position_grad(seqs={cu_rows.numel() - 1},d={d})", n * d * 4,
+                                                work_fraction=_row_fraction(rows_dev, n)):
+                st = lib.gps_bert_position_grad(cu_rows.numel() - 1, pos_w.shape[0], d, cu_rows.data_ptr(), dz.data_ptr(),
+                                                d_pos.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            _native.check(st, "bert_position_grad")
+        else:
+            d_pos = embedding_grad(pos, dz, pos_w.shape[0], -1)
         d_type = torch.zeros((n_types, d), dtype=torch.float32, device=dev)
         d_type[0] = d_pos.sum(0)                 # every row has exactly one position: sum of all rows' dz
-        return None, None, d_word, d_pos, d_type, sums[0], sums[1], None, None, None, None, None
+        return None, None, d_word, d_pos, d_type, sums[0], sums[1], None, None, None, None, None, None
 
 
 def rows_supported(emb) -> bool:
@@ -168,9 +176,11 @@ def rows_supported(emb) -> bool:
             and not emb.word_embeddings.sparse)
 
 
-def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=None, training: bool = False):
+def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=None, training: bool = False, cu_rows=None):
     """HF BertEmbeddings for a flat list of (token id, position) rows -> (y fp32 (n, d), y bf16 (n, d)); rows at or past
-    the device-side count `rows_dev` are left unwritten."""
+    the device-side count `rows_dev` are left unwritten.  cu_rows (int32, n_seq + 1): promise that the live rows are whole
+    sequences laid end to end (sequence s = rows cu_rows[s] .. cu_rows[s + 1] - 1) with pos = offset inside the sequence
+    -- the position-table gradient then takes the per-position form (gps_bert_position_grad)."""
     p = float(emb.dropout.p) if training else 0.0
     seed_dev = None
     if p > 0.0:
@@ -180,4 +190,4 @@ def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=Non
     ln = emb.LayerNorm
     return _BertEmbedRows.apply(ids, pos, emb.word_embeddings.weight, emb.position_embeddings.weight,
                                 emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, p, seed_dev, rows_dev,
-                                -1 if pad is None else int(pad))
+                                -1 if pad is None else int(pad), cu_rows)

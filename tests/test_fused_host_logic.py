@@ -231,77 +231,21 @@ def test_graph_step_rejects_batches_that_do_not_match_the_capture():
 
 
 def test_weight_gradient_split_rule_fills_one_resident_round():
-    """gps_gemm_pick_splits: largest split count with tiles * splits <= 512 resident workgroups and >= 8 stages per
-    split (profiles/r2/split_sweep.json)."""
+    """gps_gemm_pick_splits.  128 x 128 tiles (two workgroups per CU): largest split count with tiles * splits <= 512
+    resident workgroups and >= 8 stages per split (profiles/r2/split_sweep.json).  Wide weight gradients over a long
+    token reduction (>= 18 tiles of 256 x 256, >= 24 stages per split): the two-group 256 x 256 kernel, one workgroup per
+    CU, 160 .. 256 workgroups (profiles/r3/gemm_8p_shapes.log)."""
     from sceneverse_amd import _native
     lib = _native.load()
     pick = lambda M, N, K: lib.gps_gemm_pick_splits(_native.GEMM_TN, M, N, K)  # noqa: E731
-    assert pick(768, 768, 19200) == 14 and pick(768, 2048, 8320) == 5 and pick(768, 2304, 19200) == 4
-    assert pick(768, 3072, 19200) == 3 and pick(768, 768, 3200) == 6 and pick(30528, 768, 3200) == 1
-    for M, N, K in ((768, 768, 19200), (2376, 768, 5120), (768, 3072, 22400)):
+    assert pick(768, 768, 19200) == 14 and pick(768, 2048, 8320) == 5 and pick(768, 768, 3200) == 6
+    assert pick(30528, 768, 3200) == 1
+    for M, N, K in ((768, 768, 19200), (2376, 768, 5120), (768, 2304, 8320)):          # the 128 x 128 rule
         s = pick(M, N, K)
         tiles = -(-M // 128) * -(-N // 128)
         assert tiles * s <= 512 and (K + 63) // 64 // s >= 8
-
-
-def test_lazy_lm_logits_and_head_switch_on_cpu():
-    """The masked-LM head only hands out LazyLMLogits inside the engine's context, in training mode, on the GPU;
-    on the CPU (and in eval mode) it stays the reference's dense tensor.  materialize() is that tensor."""
-    from sceneverse_amd.modules.heads import pretrain_head as PH
-    from sceneverse_amd.optim.loss.fused_lm_loss import LazyLMLogits
-    torch.manual_seed(0)
-    head = PH.BertLMPredictionHead(32, 50)
-    h = torch.randn(2, 5, 32)
-    dense = head(h)
-    assert torch.is_tensor(dense) and dense.shape == (2, 5, 50)
-    with PH.fused_lm_loss(True):
-        assert torch.is_tensor(head(h))                      # CPU tensors: never lazy
-        assert PH._FUSED_LM_LOSS is True
-    assert PH._FUSED_LM_LOSS is False
-    lazy = LazyLMLogits(head.transform(h), head.decoder.weight, head.bias)
-    assert lazy.shape == (2, 5, 50)
-    torch.testing.assert_close(lazy.materialize(), dense)
-
-
-def test_padded_shadow_rows_and_optimizer_targets():
-    """shadow_of(pad_rows=8): zero rows behind the data, a padded fp32 bias copy, and optimizer targets that cover
-    exactly the parameter's own rows (the clip + AdamW kernel writes them with the masters)."""
-    import gc
-
-    from sceneverse_amd.modules.layers import gemm as G
-    G.clear_shadows()
-    lin = torch.nn.Linear(16, 13)
-    w16, b32 = G.shadow_of([lin.weight], [lin.bias], pad_rows=8)
-    assert w16.shape == (16, 16) and b32.shape == (16,)
-    assert torch.equal(w16[:13], lin.weight.to(torch.bfloat16)) and w16[13:].abs().sum() == 0 and b32[13:].abs().sum() == 0
-    tg = G.shadow_targets()
-    assert tg[id(lin.weight)][0].shape == (13, 16) and tg[id(lin.bias)][1].shape == (13,)
-    assert tg[id(lin.weight)][0].data_ptr() == w16.data_ptr() and tg[id(lin.bias)][1].data_ptr() == b32.data_ptr()
-    with torch.no_grad():
-        lin.weight.add_(1.0)                                # in-place update bumps the version: refreshed at next use
-    w16b, _ = G.shadow_of([lin.weight], [lin.bias], pad_rows=8)
-    assert w16b.data_ptr() == w16.data_ptr() and torch.equal(w16b[:13], lin.weight.to(torch.bfloat16))
-    del lin
-    gc.collect()
-    G.clear_shadows()
-
-
-def test_bench_final_line_is_bounded():
-    """The driver keeps only the last ~8 KB of stdout: the ONE JSON line bench.py prints must stay far below that
-    (round 2's 28 KB line could not be parsed); everything bulky goes to the detail file."""
-    import json
-
-    import bench
-    small = {"metric": "GPS pre-train pairs/sec (fwd+bwd)", "value": 1.0, "unit": "pairs/s", "roofline": {"frac": 0.2},
-             "headline": {}, "cpu_baseline": {"value": 1.9, "cores": 64, "kind": "port", "sample": "x" * 200}}
-    line = bench.final_line(small)
-    assert json.loads(line)["value"] == 1.0 and len(line) < bench.MAX_LINE_BYTES <= 4000
-    big = dict(small, kernels=[{"kernel": f"gemm_nt(M={i})", "avg_us": 1.0} for i in range(400)])
-    with pytest.raises(RuntimeError):
-        bench.final_line(big)
-    # the line of this round's own GPU run (profiles/r3/bench_h.json) respects the bound
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3", "bench_h.json")
-    if os.path.exists(path):
-        last = open(path).read().strip().splitlines()[-1]
-        assert len(last) < bench.MAX_LINE_BYTES and "roofline" in json.loads(last)
+    assert pick(768, 2304, 19200) == 9 and pick(768, 3072, 19200) == 7 and pick(3072, 768, 22400) == 7
+    for M, N, K in ((768, 2304, 19200), (768, 3072, 22400), (2048, 768, 19200)):       # the 256 x 256 rule
+        s = pick(M, N, K)
+        tiles = -(-M // 256) * -(-N // 256)
+        assert 160 <= tiles * s <= 256 and (K + 63) // 64 // s >= 24

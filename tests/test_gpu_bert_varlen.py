@@ -89,6 +89,37 @@ def test_varlen_bert_matches_the_padded_fast_path_and_huggingface():
     assert (c_v - hf_c).abs().max().item() <= 0.06
 
 
+def test_cls_only_tail_of_the_last_layer_changes_nothing_observable():
+    """The caption is read at [CLS] only: running the last layer's row-wise tail on [CLS rows | sentence rows] instead of
+    every live row must give the same sentence states, the same [CLS] states and the same gradients (the skipped rows'
+    gradients are exactly zero in the full form)."""
+    from sceneverse_amd.modules.language import bert as B
+    enc = _encoder(seed=4)
+    texts = _texts(seed=7)
+    g = torch.Generator().manual_seed(6)
+    valid_a = texts[0][1].bool()
+    probe_w = (torch.randn(8, 50, 768, generator=g).to(DEV) * valid_a[..., None], torch.randn(8, 768, generator=g).to(DEV))
+    junk = torch.full((64, 1024, 1024), float("nan"), device=DEV)     # poison: dead rows must never be read as data
+    del junk
+    a_t, c_t, g_t = _run(enc, texts, True, probe_w)
+    B.set_cls_tail(False)
+    try:
+        a_f, c_f, g_f = _run(enc, texts, True, probe_w)
+    finally:
+        B.set_cls_tail(True)
+    assert torch.isfinite(a_t).all() and torch.isfinite(c_t).all()
+    assert a_t[~valid_a].abs().max().item() == 0.0
+    # identical arithmetic per row (same kernels, same operands): only the weight-gradient sums see a different row set
+    assert torch.equal(a_t, a_f) and torch.equal(c_t, c_f)
+    assert set(g_t) == set(g_f)
+    for n in g_f:
+        assert torch.isfinite(g_t[n]).all(), n
+        if n.endswith("attention.self.key.bias"):
+            continue                                               # exact value zero: rounding noise in both
+        rel = ((g_t[n].float() - g_f[n].float()).norm() / (g_f[n].float().norm() + 1e-12)).item()
+        assert rel <= 5e-3, (n, rel)
+
+
 def test_varlen_bert_with_dropout_runs_and_is_finite():
     enc = _encoder(seed=2)
     for m in enc.modules():

@@ -204,3 +204,33 @@ def test_bert_embed_rows_dropout_mask_is_the_same_in_both_directions():
     torch.autograd.backward([y, y16], [dropped.float(), torch.zeros_like(y16)])
     for name, prm in emb.named_parameters():
         assert torch.all(prm.grad == 0), name
+
+
+def test_position_gradient_per_position_form_equals_the_scatter_form():
+    """Rows = whole sequences end to end, pos = offset inside the sequence: gps_bert_position_grad (cu_rows given) and
+    gps_embedding_grad on the position ids must give the same table gradient (fp32 summation order aside), with a
+    device-side row count that leaves a dead tail."""
+    d = 768
+    emb = _Emb().to(DEV)
+    g = torch.Generator().manual_seed(21)
+    lens = torch.randint(1, 301, (128,), generator=g)
+    lens[3] = 300
+    n_live = int(lens.sum())
+    n = n_live + 777                                             # dead tail (capacity rows)
+    cu = torch.zeros(129, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    pos = torch.cat([torch.arange(int(L)) for L in lens] + [torch.zeros(777, dtype=torch.long)]).to(DEV)
+    ids = torch.randint(1, 30522, (n,), generator=g).to(DEV)
+    rows_dev = torch.tensor([n_live], dtype=torch.int32, device=DEV)
+    wy = torch.randn(n, d, generator=g).to(DEV)
+    grads = []
+    for cu_rows in (None, cu.to(DEV)):
+        for prm in emb.parameters():
+            prm.grad = None
+        y, y16 = FE.bert_embeddings_rows(emb, ids, pos, rows_dev=rows_dev, training=False, cu_rows=cu_rows)
+        torch.autograd.backward([y[:n_live]], [wy[:n_live]])
+        grads.append({k: v.grad.clone() for k, v in emb.named_parameters()})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item()), k
+    assert torch.all(grads[1]["position_embeddings.weight"][300:] == 0)
