@@ -386,6 +386,21 @@ GPS_API int gps_bert_embed_backward(int n_rows, int d, const float *dy, const vo
                                     unsigned long long seed, const void *seed_dev, float *dz, float *dgamma_part,
                                     float *dbeta_part, const int *rows_dev, gps_stream_t stream);
 
+/* ---- box-location embedding  y = LayerNorm(x W^T + b)  (tiny reduction length) ---------------------------------
+ * Replaces `loc_layers = nn.Sequential(nn.Linear(dim_loc, hidden), nn.LayerNorm(hidden))` of the object encoder and the
+ * unified encoder (modules/vision/pcd_openvocab_encoder.py:64-66, :177; modules/grounding/unified_encoder.py:28-30, :158).
+ * x (n_rows, k_in) fp32 contiguous (k_in in {3, 6, 8}), w (d, k_in) fp32 contiguous, bias (d) or NULL, gamma / beta (d),
+ * y (n_rows, d) fp32, mean / rstd (n_rows) saved for the backward pass; d == 768.
+ * backward (no input gradient: the boxes are data): sums (k_in + 3, d) fp32 = [dW^T rows k = 0 .. k_in - 1 | db | dgamma |
+ * dbeta]; partials: (gps_loc_embed_partial_rows(n_rows), k_in + 3, d) fp32 scratch.  Deterministic. */
+GPS_API int gps_loc_embed_partial_rows(int n_rows);
+GPS_API int gps_loc_embed_forward(int n_rows, int k_in, int d, const float *x, const float *w, const float *bias,
+                                  const float *gamma, const float *beta, float eps, float *y, float *mean, float *rstd,
+                                  gps_stream_t stream);
+GPS_API int gps_loc_embed_backward(int n_rows, int k_in, int d, const float *dy, const float *x, const float *w,
+                                   const float *bias, const float *gamma, const float *mean, const float *rstd,
+                                   float *partials, float *sums, gps_stream_t stream);
+
 /* ---- bf16 MFMA GEMMs of the transformer projections / FFNs -------------------------------------------
  * Replaces the nn.Linear contractions of the GPS transformer layers -- w_qs / w_ks / w_vs / fc / lang_cond_fc
  * (modules/layers/transformers.py:173-186, 193-197), nn.MultiheadAttention's in/out projections (:120-121, 141)

@@ -76,6 +76,9 @@ SIGNATURES = {
     "gps_obj_processing_post": [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp],
     "gps_embedding_grad": [_i, _i, _i, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],
+    "gps_loc_embed_partial_rows": [_i],
+    "gps_loc_embed_forward": [_i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
+    "gps_loc_embed_backward": [_i, _i, _i] + [_vp] * 10,
     "gps_bert_embed_partial_rows": [_i],
     "gps_bert_position_grad": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_bert_embed_forward": [_i, _i] + [_vp] * 7 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 7,

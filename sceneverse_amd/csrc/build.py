@@ -23,6 +23,7 @@ SOURCES = [
     ("gps_reduce.hip", []),
     ("gps_embedding.hip", []),
     ("gps_bert_embed.hip", []),
+    ("gps_loc_embed.hip", []),
     ("gps_gemm.hip", []),
     ("gps_optim.hip", []),
 ]

@@ -17,6 +17,7 @@ from ..layers.transformers import (TransformerDecoderLayer, TransformerEncoderLa
                                    TransformerSpatialDecoderLayer)
 from ..utils import calc_pairwise_locs, layer_repeat
 from ..weights import _init_weights_bert
+from ..layers.fused_loc import loc_embed
 
 
 def _loc_layer(dim_loc, hidden_size):
@@ -45,7 +46,7 @@ class EntitySpatialCrossEncoder(nn.Module):
         obj_pad, txt_pad = obj_masks.logical_not(), txt_masks.logical_not()
         out = obj_embeds
         for layer in self.layers:
-            out = out + self.loc_layers[0](obj_locs)
+            out = out + loc_embed(self.loc_layers[0], obj_locs)
             out, _, _ = layer(out, txt_embeds, pairwise_locs, tgt_key_padding_mask=obj_pad,
                               memory_key_padding_mask=txt_pad)
         return txt_embeds, out
@@ -74,7 +75,7 @@ class UnifiedSpatialCrossEncoderV1(nn.Module):
                                            pairwise_rel_type=self.pairwise_rel_type)
         obj_pad, txt_pad = obj_masks.logical_not(), txt_masks.logical_not()
         for pc_layer, lang_layer in zip(self.pc_encoder, self.lang_encoder):
-            obj_embeds = obj_embeds + self.loc_layers[0](obj_locs)
+            obj_embeds = obj_embeds + loc_embed(self.loc_layers[0], obj_locs)
             # both streams read the PRE-update state of the other (ref :100-115)
             obj_next, _, _ = pc_layer(obj_embeds, txt_embeds, pairwise_locs,
                                       tgt_key_padding_mask=obj_pad, memory_key_padding_mask=txt_pad)
@@ -103,7 +104,7 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         # the same deterministic embeddings are re-added to both streams every layer (ref :154-164) and the
         # streams are concatenated right after: build the joint (B, T, D) addend once and keep the sequence joint
         # across layers -- the same elementwise sums, one add per layer instead of two adds + cat + split
-        obj_extra = self.loc_layers[0](obj_locs) + self.token_type_embeddings.weight[1]
+        obj_extra = loc_embed(self.loc_layers[0], obj_locs) + self.token_type_embeddings.weight[1]
         extra = torch.cat((type_txt.to(obj_extra.dtype).expand(txt_embeds.shape[0], txt_len, -1), obj_extra), dim=1)
         joint = torch.cat((txt_embeds, obj_embeds), dim=1)
         for layer in self.unified_encoder:

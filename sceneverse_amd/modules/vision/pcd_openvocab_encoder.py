@@ -21,6 +21,7 @@ from ..layers.pointnet import PointNetPP
 from ..layers.transformers import TransformerSpatialEncoderLayer
 from ..utils import calc_pairwise_locs, layer_repeat
 from ..weights import _init_weights_bert
+from ..layers.fused_loc import loc_embed
 
 
 @VISION_REGISTRY.register()
@@ -115,7 +116,7 @@ class PointOpenVocabEncoder(nn.Module):
                 obj_locs[:, :, :3], obj_locs[:, :, 3:], pairwise_rel_type=self.pairwise_rel_type,
                 spatial_dist_norm=True, spatial_dim=self.spatial_dim)
             pad = obj_masks.logical_not()
-            loc_embeds = self.loc_layers[0](obj_locs)      # re-added every layer (ref :176-178); evaluated once
+            loc_embeds = loc_embed(self.loc_layers[0], obj_locs)      # re-added every layer (ref :176-178); evaluated once
             for layer in self.spatial_encoder:
                 obj_embeds = obj_embeds + loc_embeds
                 obj_embeds, _ = layer(obj_embeds, pairwise_locs, tgt_key_padding_mask=pad)
