@@ -163,6 +163,14 @@ GPS_API int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int
                                       int c3, const float *xyz, const float *new_xyz, const float *features,
                                       const int32_t *idx, const float *wpack, float *out,
                                       gps_stream_t stream);
+/* the same launch with the features given POINT-major: features_pm[(obj * n + p) * ld_feat + c], c < c_feat -- e.g. the
+ * colour columns of the interleaved (B, N, 3 + C) cloud the reference hands to break_up_pc
+ * (modules/layers/pointnet.py:10-17; pointer at column 3, ld_feat = 3 + C): no transposed copy of the cloud in HBM.
+ * First level only (c_feat == 3, 64-64-128). */
+GPS_API int gps_sa_mlp_forward_bf16x3_pm(int b, int n, int npoint, int nsample, int c_feat, int c1, int c2, int c3,
+                                         const float *xyz, const float *new_xyz, const float *features_pm,
+                                         long long ld_feat, const int32_t *idx, const float *wpack, float *out,
+                                         gps_stream_t stream);
 
 /* ---- fused self-attention core (object-level spatial transformer, joint text+object transformer) --
  * One launch for what the reference runs between the QKV projections and the output projection:

@@ -73,6 +73,7 @@ SIGNATURES = {
     "gps_sa_mlp_forward": [_i] * 8 + [_vp] * 7,
     "gps_sa_mlp_pack_layer_bf16x3": [_i, _i, _vp, _vp, _vp, _vp],
     "gps_sa_mlp_forward_bf16x3": [_i] * 8 + [_vp] * 7,
+    "gps_sa_mlp_forward_bf16x3_pm": [_i] * 8 + [_vp] * 3 + [ctypes.c_longlong] + [_vp] * 4,
     "gps_obj_processing_post": [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp],
     "gps_embedding_grad": [_i, _i, _i, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],

@@ -441,11 +441,14 @@ __device__ __forceinline__ f32x16 mfma_tile16(const float *__restrict__ tile, co
 // the 32-row weight tiles stream through a double buffer (one barrier per tile).  More waves per
 // workgroup = more columns per streamed weight byte (the LDS-DMA weight stream, not the matrix pipe,
 // bounds the streaming form: profiles/r1).
-template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT>
+// PM: the features arrive point-major -- feats[(obj * n + p) * ld_feat + c], e.g. the rgb columns of an interleaved
+// (B, N, 3 + C) cloud (pointer at column 3, ld_feat = 6) -- and are transposed into the channel-major LDS image while
+// they are staged, instead of by a separate full-cloud transpose copy in HBM (63 us per step at SA1).
+template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM = false>
 __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
     int b, int n, int npoint, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ feats, const int32_t *__restrict__ idx,
-    const float *__restrict__ wpack, float *__restrict__ out) {
+    const float *__restrict__ wpack, float *__restrict__ out, int ld_feat = 0) {
   constexpr int BLOCK = WAVES * 64;
   constexpr int CIN = 3 + CF;
   constexpr int S1 = steps16(CIN), S2 = C1 / 16, S3 = C2 / 16;
@@ -469,16 +472,24 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
   {
-    const float *gf = feats + (size_t)obj * CF * n;
     const float *gx = xyz + (size_t)obj * n * 3;
     const float *gc = new_xyz + (size_t)obj * npoint * 3;
     const int32_t *gi = idx + (size_t)obj * npoint * kNS;
-    if (((CF * n) & 3) == 0) {
-      const float4 *g4 = reinterpret_cast<const float4 *>(gf);
-      float4 *l4 = reinterpret_cast<float4 *>(s_feat);
-      for (int e = tid; e < (CF * n) >> 2; e += BLOCK) l4[e] = g4[e];
+    if (PM) {
+      const float *gf = feats + (size_t)obj * n * ld_feat;
+      for (int e = tid; e < CF * n; e += BLOCK) {
+        const int p = e / CF, c = e - p * CF;
+        s_feat[c * n + p] = gf[(size_t)p * ld_feat + c];
+      }
     } else {
-      for (int e = tid; e < CF * n; e += BLOCK) s_feat[e] = gf[e];
+      const float *gf = feats + (size_t)obj * CF * n;
+      if (((CF * n) & 3) == 0) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(gf);
+        float4 *l4 = reinterpret_cast<float4 *>(s_feat);
+        for (int e = tid; e < (CF * n) >> 2; e += BLOCK) l4[e] = g4[e];
+      } else {
+        for (int e = tid; e < CF * n; e += BLOCK) s_feat[e] = gf[e];
+      }
     }
     for (int e = tid; e < n * 3; e += BLOCK) s_xyz[e] = gx[e];
     for (int e = tid; e < npoint * 3; e += BLOCK) s_ctr[e] = gc[e];
@@ -604,9 +615,9 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
   }
 }
 
-template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT>
+template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM = false>
 int launch_sa_x3(int b, int n, int npoint, const float *xyz, const float *new_xyz, const float *feats,
-                 const int32_t *idx, const float *wpack, float *out, hipStream_t s) {
+                 const int32_t *idx, const float *wpack, float *out, hipStream_t s, int ld_feat = 0) {
   constexpr int CIN = 3 + CF;
   constexpr int T1 = tile_floats16(CIN), T2 = tile_floats16(C1), T3 = tile_floats16(C2);
   constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
@@ -617,13 +628,13 @@ int launch_sa_x3(int b, int n, int npoint, const float *xyz, const float *new_xy
   if (lds > 160 * 1024) return GPS_ERR_UNSUPPORTED;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT, PM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GPS_ERR_LAUNCH;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT>), dim3(b), dim3(WAVES * 64), lds, s, b, n,
-                     npoint, xyz, new_xyz, feats, idx, wpack, out);
+  hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT, PM>), dim3(b), dim3(WAVES * 64), lds, s, b, n,
+                     npoint, xyz, new_xyz, feats, idx, wpack, out, ld_feat);
   return GPS_OK;
 }
 
@@ -683,6 +694,23 @@ int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int c_feat,
   else if (c_feat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
     st = gps_sa::x3::launch_sa_x3<128, 128, 128, 256, GPS_SA2_WAVES, false>(b, n, npoint, xyz, new_xyz, features,
                                                                             idx, wpack, out, s);
+  if (st != GPS_OK) return st;
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_sa_mlp_forward_bf16x3_pm(int b, int n, int npoint, int nsample, int c_feat, int c1, int c2, int c3,
+                                 const float *xyz, const float *new_xyz, const float *features_pm, long long ld_feat,
+                                 const int32_t *idx, const float *wpack, float *out, gps_stream_t stream) {
+  if (b < 0 || n < 1 || npoint < 1 || nsample < 1 || c_feat < 1 || ld_feat < c_feat || ld_feat > 0x7FFFFFFF)
+    return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0) return GPS_OK;
+  if (!xyz || !new_xyz || !idx || !wpack || !out || !features_pm) return GPS_ERR_INVALID_ARGUMENT;
+  if (nsample != gps_sa::kNS) return GPS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  int st = GPS_ERR_UNSUPPORTED;
+  if (c_feat == 3 && c1 == 64 && c2 == 64 && c3 == 128)
+    st = gps_sa::x3::launch_sa_x3<3, 64, 64, 128, GPS_SA1_WAVES, true, true>(b, n, npoint, xyz, new_xyz, features_pm, idx,
+                                                                            wpack, out, s, (int)ld_feat);
   if (st != GPS_OK) return st;
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }

@@ -1,5 +1,6 @@
 """PointNet++ object encoder (reference modules/layers/pointnet.py:6-63): three set-abstraction
 levels over each object's (P, 3 + C) cloud, then `fc`.  State-dict names `encoder.{i}.*`, `fc.*`."""
+import torch
 import torch.nn as nn
 
 from ...pointnet2.pointnet2_modules import PointnetSAModule
@@ -28,7 +29,16 @@ class PointNetPP(nn.Module):
 
     def forward(self, features):
         """features: (B * N_objects, N_points, 3 + C) -> (B * N_objects, sa_mlps[-1][-1])."""
-        xyz, features = break_up_pc(features)
-        for sa in self.encoder:
+        pc = features
+        first = self.encoder[0]
+        out = None
+        if pc.size(-1) > 3 and pc.is_cuda and pc.dtype == torch.float32 and hasattr(first, "forward_point_major"):
+            # frozen first level: the colour columns are read in place from the interleaved cloud (no (B, C, P) copy)
+            out = first.forward_point_major(pc[..., 0:3].contiguous(), pc[..., 3:])
+        if out is None:
+            xyz, features = break_up_pc(pc)
+            out = first(xyz, features)
+        xyz, features = out
+        for sa in list(self.encoder)[1:]:
             xyz, features = sa(xyz, features)
         return self.fc(features.view(features.size(0), -1))

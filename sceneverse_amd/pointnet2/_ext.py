@@ -263,15 +263,43 @@ def sa_mlp_pack(weights, shifts, precision: str = "fp32") -> torch.Tensor:
     return buf
 
 
+def sa_mlp_point_major_supported(c_feat: int, channels, nsample: int, precision: str) -> bool:
+    return precision == "bf16x3" and c_feat == 3 and list(channels) == [64, 64, 128] and nsample == 32
+
+
 def sa_mlp_forward(xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor,
-                   idx: torch.Tensor, wpack: torch.Tensor, channels, precision: str = "fp32") -> torch.Tensor:
+                   idx: torch.Tensor, wpack: torch.Tensor, channels, precision: str = "fp32",
+                   point_major: bool = False) -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N), idx (B,npoint,32) i32, packed folded
-    MLP C+3 -> channels  ->  (B, channels[-1], npoint) pooled features (one launch)."""
+    MLP C+3 -> channels  ->  (B, channels[-1], npoint) pooled features (one launch).
+    point_major: features is a (B,N,C) view with unit channel stride and row pitch features.stride(1) -- e.g.
+    cloud[..., 3:] of the interleaved (B,N,3+C) cloud -- read in place (gps_sa_mlp_forward_bf16x3_pm)."""
     _chk(xyz, "xyz", torch.float32)
     _chk(new_xyz, "new_xyz", torch.float32)
-    _chk(features, "features", torch.float32)
     _chk(idx, "idx", torch.int32)
     _chk(wpack, "wpack", torch.float32)
+    if point_major:
+        b, n, _ = xyz.shape
+        if not (features.is_cuda and features.dtype == torch.float32 and features.dim() == 3 and features.stride(2) == 1
+                and features.shape[:2] == (b, n) and features.stride(0) == n * features.stride(1)):
+            raise ValueError("point-major features: (B, N, C) float32 view with unit channel stride and dense rows")
+        c_feat, ld_feat = features.shape[2], features.stride(1)
+        _, npoint, nsample = idx.shape
+        c1, c2, c3 = (int(c) for c in channels)
+        if not sa_mlp_point_major_supported(c_feat, [c1, c2, c3], nsample, precision):
+            raise ValueError("point-major features: first level (3 -> 64-64-128, nsample 32, bf16x3) only")
+        _same_device(xyz, new_xyz, features, idx, wpack)
+        out = torch.empty((b, c3, npoint), dtype=torch.float32, device=xyz.device)
+        algo = 4 * (b * 3 * n + b * 3 * npoint + b * c_feat * n + b * npoint * nsample + b * c3 * npoint)
+        flops = 2 * b * npoint * nsample * ((3 + c_feat) * c1 + c1 * c2 + c2 * c3)
+        with torch.cuda.device(xyz.device), _timed(f"sa_mlp_forward(c={c_feat},n={n},np={npoint},mlp={c1}-{c2}-{c3},{precision})",
+                                                    algo, 3 * flops, "bf16"):
+            st = _native.load().gps_sa_mlp_forward_bf16x3_pm(b, n, npoint, nsample, c_feat, c1, c2, c3, xyz.data_ptr(),
+                                                             new_xyz.data_ptr(), features.data_ptr(), ld_feat, idx.data_ptr(),
+                                                             wpack.data_ptr(), out.data_ptr(), _stream())
+        _native.check(st, "sa_mlp_forward_pm")
+        return out
+    _chk(features, "features", torch.float32)
     _same_device(xyz, new_xyz, features, idx, wpack)
     b, n, _ = xyz.shape
     c_feat = features.shape[1]

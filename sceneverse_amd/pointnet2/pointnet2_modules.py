@@ -106,6 +106,31 @@ class _PointnetSAModuleBase(nn.Module):
         picked = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds)
         return picked.transpose(1, 2).contiguous()
 
+    def forward_point_major(self, xyz: torch.Tensor, features_pm: torch.Tensor):
+        """The frozen single-scale level on POINT-major features -- features_pm (B,N,C), e.g. the view cloud[..., 3:] of
+        an interleaved (B,N,3+C) cloud -- without materialising the (B,C,N) transpose; None when that form does not
+        apply (the caller then transposes and calls forward)."""
+        ext = pointnet2_utils._ext
+        if not (_FUSED_SA and xyz.is_cuda and len(self.groupers) == 1 and self.npoint is not None
+                and hasattr(ext, "sa_mlp_point_major_supported") and not xyz.requires_grad and not features_pm.requires_grad):
+            return None
+        grouper, mlp = self.groupers[0], self.mlps[0]
+        if not (isinstance(grouper, pointnet2_utils.QueryAndGroup) and _is_frozen(mlp) and grouper.use_xyz
+                and not (grouper.sample_uniformly or grouper.normalize_xyz or grouper.ret_grouped_xyz or grouper.ret_unique_cnt)):
+            return None
+        chans = [l.conv.out_channels for l in mlp.children() if hasattr(l, "conv")]
+        if not ext.sa_mlp_point_major_supported(features_pm.shape[2], chans, grouper.nsample, _SA_PRECISION):
+            return None
+        folded = self._folded(mlp, pack=True)
+        if folded is None:
+            return None
+        new_xyz = self._sample_centres(xyz)
+        with torch.no_grad():
+            idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            pooled = ext.sa_mlp_forward(xyz, new_xyz.float().contiguous(), features_pm, idx, folded[2], chans,
+                                        _SA_PRECISION, point_major=True)
+        return new_xyz, pooled
+
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum mlp[-1],npoint)."""
         new_xyz = self._sample_centres(xyz)

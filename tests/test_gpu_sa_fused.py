@@ -141,3 +141,18 @@ def test_full_bench_batch_fused_equals_unfused_on_a_sample():
         perm = torch.randperm(5120, generator=torch.Generator().manual_seed(2)).to(DEV)
         assert torch.equal(net(pcs[perm]), full[perm])
     assert torch.isfinite(full).all()
+
+
+def test_point_major_first_level_is_bit_identical_to_the_transposed_form():
+    """gps_sa_mlp_forward_bf16x3_pm reads the colour columns in place from the interleaved (B, P, 6) cloud; the LDS image
+    and everything after it are those of the channel-major launch, so the pooled features must be the same bits."""
+    if M._SA_PRECISION != "bf16x3":
+        pytest.skip("the point-major form exists for the default (bf16x3) precision")
+    net, pcs = _encoder(seed=2), _clouds().to(DEV)
+    sa = net.encoder[0]
+    xyz = pcs[..., :3].contiguous()
+    with torch.no_grad():
+        got = sa.forward_point_major(xyz, pcs[..., 3:])
+        assert got is not None
+        want = sa(xyz, pcs[..., 3:].transpose(1, 2).contiguous())
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
