@@ -273,6 +273,16 @@ GPS_API int gps_masked_ce_backward(int n_rows, int vocab, int logits_bf16, const
                                    const float *grad_rows, void *dlogits, long long ldd,
                                    gps_stream_t stream);
 
+/* ---- y = x / max(||x||_2, eps) per row and its backward ------------------------------------------------------------
+ * Replaces F.normalize(x, dim=-1, p=2) in the contrastive losses (optim/loss/contra_loss.py:38-39, 60, 82-83): torch runs
+ * norm, clamp, expand, div forward and seven elementwise / reduction kernels backward.  x, y, dy, dx (n_rows, d) fp32
+ * contiguous, inv_norm (n_rows) fp32 = 1 / max(norm, eps) saved by the forward pass; d a multiple of 4, <= 2048;
+ * backward: dx = inv (dy - y (y . dy)); rows whose norm was clamped get dx = inv dy (torch's clamp_min semantics). */
+GPS_API int gps_l2_normalize_forward(int n_rows, int d, const float *x, float eps, float *y, float *inv_norm,
+                                     gps_stream_t stream);
+GPS_API int gps_l2_normalize_backward(int n_rows, int d, const float *dy, const float *y, const float *inv_norm, float eps,
+                                      float *dx, gps_stream_t stream);
+
 /* ---- fused residual + dropout + LayerNorm (post-norm transformer layers) ---------------------------
  * y = LayerNorm(x + dropout(h)) * gamma + beta, the pattern of modules/layers/transformers.py:143-153
  * and :311-315 (`self.norm1(tgt + self.dropout1(tgt2))`), one launch instead of dropout, add,

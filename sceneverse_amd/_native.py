@@ -91,6 +91,8 @@ SIGNATURES = {
     "gps_masked_ce_backward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp],
     "gps_ln_reduce_partials": [_i, _i, _vp, _vp, _vp, _vp],
+    "gps_l2_normalize_forward": [_i, _i, _vp, _f, _vp, _vp, _vp],
+    "gps_l2_normalize_backward": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp],
     "gps_add_dropout_layernorm_forward": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_add_dropout_layernorm_backward": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_add_dropout_layernorm_forward_rows": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 7,

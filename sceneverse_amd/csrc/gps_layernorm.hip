@@ -279,6 +279,60 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int 
   out[c] = sum;
 }
 
+// ---- y = x / max(||x||_2, eps) per row (F.normalize(x, p=2, dim=-1)) and its backward ---------------------------------
+// One wave per row; the row is read once (d <= 2048: kept in registers), forward also stores 1 / max(norm, eps).
+// backward: dx = inv * (dy - y (y . dy)), or inv * dy where the norm was clamped (torch treats the clamp as a constant).
+__global__ __launch_bounds__(kBlock) void l2norm_fwd_kernel(int n_rows, int d, const float *__restrict__ x, float eps,
+                                                            float *__restrict__ y, float *__restrict__ inv_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
+    const size_t base = (size_t)row * d;
+    float4 v[kMaxIter];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      v[i] = c0 < d ? load4(x, base + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float inv = 1.f / fmaxf(sqrtf(wave_sum(ss)), eps);
+    if (lane == 0) inv_out[row] = inv;
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      if (c0 < d) store4(y, base + c0, make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv));
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void l2norm_bwd_kernel(int n_rows, int d, const float *__restrict__ dy,
+                                                            const float *__restrict__ y, const float *__restrict__ inv_in,
+                                                            float eps, float *__restrict__ dx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_cap = 1.f / eps;
+  for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
+    const size_t base = (size_t)row * d;
+    float4 g[kMaxIter], yv[kMaxIter];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      g[i] = c0 < d ? load4(dy, base + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[i] = c0 < d ? load4(y, base + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dot += (g[i].x * yv[i].x + g[i].y * yv[i].y) + (g[i].z * yv[i].z + g[i].w * yv[i].w);
+    }
+    const float inv = inv_in[row];
+    const float tot = wave_sum(dot);
+    dot = inv >= inv_cap ? 0.f : tot;                    // clamped norm: a constant divisor
+#pragma unroll
+    for (int i = 0; i < kMaxIter; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      if (c0 < d)
+        store4(dx, base + c0, make_float4(inv * (g[i].x - yv[i].x * dot), inv * (g[i].y - yv[i].y * dot),
+                                          inv * (g[i].z - yv[i].z * dot), inv * (g[i].w - yv[i].w * dot)));
+    }
+  }
+}
+
 inline int grid_rows(int n_rows) {
   int g = (n_rows + kWaves - 1) / kWaves;
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
@@ -304,6 +358,27 @@ int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, void
   unsigned int *tickets = scratch ? reinterpret_cast<unsigned int *>(part2 + (size_t)gps_ln::kRedSlices * 2 * d) : nullptr;
   hipLaunchKernelGGL(gps_ln::reduce_partials_kernel, dim3(groups, slices), dim3(gps_ln::kBlock), 0,
                      (hipStream_t)stream, parts, d, part, out, part2, tickets);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_l2_normalize_forward(int n_rows, int d, const float *x, float eps, float *y, float *inv_norm, gps_stream_t stream) {
+  if (n_rows < 0 || d < 1 || !(eps > 0.f)) return GPS_ERR_INVALID_ARGUMENT;
+  if ((d & 3) || d > 256 * gps_ln::kMaxIter) return GPS_ERR_UNSUPPORTED;
+  if (n_rows == 0) return GPS_OK;
+  if (!x || !y || !inv_norm || (((uintptr_t)x | (uintptr_t)y) & 15)) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps_ln::l2norm_fwd_kernel, dim3(gps_ln::grid_rows(n_rows)), dim3(gps_ln::kBlock), 0, (hipStream_t)stream,
+                     n_rows, d, x, eps, y, inv_norm);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_l2_normalize_backward(int n_rows, int d, const float *dy, const float *y, const float *inv_norm, float eps, float *dx,
+                              gps_stream_t stream) {
+  if (n_rows < 0 || d < 1 || !(eps > 0.f)) return GPS_ERR_INVALID_ARGUMENT;
+  if ((d & 3) || d > 256 * gps_ln::kMaxIter) return GPS_ERR_UNSUPPORTED;
+  if (n_rows == 0) return GPS_OK;
+  if (!dy || !y || !inv_norm || !dx || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15)) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps_ln::l2norm_bwd_kernel, dim3(gps_ln::grid_rows(n_rows)), dim3(gps_ln::kBlock), 0, (hipStream_t)stream,
+                     n_rows, d, dy, y, inv_norm, eps, dx);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...common.dist_utils import all_gather
+from ...modules.layers.fused_norm import l2_normalize
 from .loss import LOSS_REGISTRY
 
 
@@ -35,8 +36,8 @@ class TextObjWithinBatch(nn.Module):
             rep = int(obj_feats.shape[0] / masks.shape[0])
             masks = masks.unsqueeze(1).repeat(1, rep, 1).view(-1, masks.shape[1])
             labels = labels.view(-1, 1)
-        obj_feats = F.normalize(obj_feats, dim=-1, p=2)
-        text_feats = F.normalize(text_feats, dim=-1, p=2)
+        obj_feats = l2_normalize(obj_feats)
+        text_feats = l2_normalize(text_feats)
         logits = torch.einsum('bod,bd->bo', obj_feats, text_feats)
         labels = labels.squeeze(-1)
         if self.bce:
@@ -61,7 +62,7 @@ class TextObjBetweenBatch(nn.Module):
         if obj_feats.shape[0] != labels.shape[0]:
             labels = labels.view(-1, 1)
         tgt = obj_feats[torch.arange(labels.size(0)), labels[:, 0], :]
-        return [F.normalize(tgt, dim=-1, p=2), F.normalize(data_dict["inter_text_embed"], dim=-1, p=2)]
+        return [l2_normalize(tgt), l2_normalize(data_dict["inter_text_embed"])]
 
     def forward(self, data_dict):
         logit_scale = torch.clamp(self.logit_scale, max=100)
@@ -85,8 +86,8 @@ class TextSceneBetweenBatch(nn.Module):
     _gathered = None
 
     def gather_inputs(self, data_dict):
-        return [F.normalize(data_dict["scene_embed"], dim=-1, p=2),
-                F.normalize(data_dict["scene_text_embed"], dim=-1, p=2)]
+        return [l2_normalize(data_dict["scene_embed"]),
+                l2_normalize(data_dict["scene_text_embed"])]
 
     def forward(self, data_dict):
         logit_scale = torch.clamp(self.logit_scale, max=100)

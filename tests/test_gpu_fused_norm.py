@@ -126,3 +126,37 @@ def test_partial_row_reduction_is_exact_order_independent_and_reusable(parts, d)
     plain = torch.empty((2, d), device=DEV)
     _native.check(lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), plain.data_ptr(), None, stream), "reduce")
     assert (plain.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(64, 80, 768), (64, 768), (3, 1, 100), (5, 2048)])
+def test_l2_normalize_matches_torch(shape):
+    from sceneverse_amd.modules.layers.fused_norm import l2_normalize
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to("cuda")
+    x[0] = 0                                                    # zero rows: clamped norm (y = 0, dx = dy / eps)
+    x.requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    y = l2_normalize(x)
+    ref = F.normalize(x2, dim=-1, p=2)
+    assert (y - ref).abs().max().item() <= 1e-6
+    w = torch.randn(*shape, generator=g).to("cuda")
+    w[0] = 0                                                    # (dy / 1e-12 would overflow the comparison's scale)
+    y.backward(w)
+    ref.backward(w)
+    assert (x.grad - x2.grad).abs().max().item() <= 2e-6 * max(1.0, x2.grad.abs().max().item())
+
+
+def test_add_row_gradient_is_the_column_sum():
+    from sceneverse_amd.modules.layers.fused_norm import add_row, column_sum
+    g = torch.Generator().manual_seed(3)
+    for rows in ((64, 50), (5120,), (7,), (1,)):
+        x = torch.randn(*rows, 768, generator=g).to("cuda").requires_grad_(True)
+        r = torch.randn(768, generator=g).to("cuda").requires_grad_(True)
+        w = torch.randn(*rows, 768, generator=g).to("cuda")
+        y = add_row(x, r)
+        assert torch.equal(y, x + r)
+        y.backward(w)
+        assert torch.equal(x.grad, w)
+        ref = w.double().reshape(-1, 768).sum(0)
+        assert (r.grad.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+        assert torch.equal(column_sum(w), column_sum(w))        # deterministic
