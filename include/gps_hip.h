@@ -253,6 +253,11 @@ typedef struct gps_attn_args {
   /* with cu_rows: optional (B) int32 permutation of the sequences (device); workgroups are dispatched in block order,
    * so listing the longest sequences first balances the tail of the launch.  NULL = natural order. */
   const int *seq_order;
+  /* with cu_rows: optional (B) int32 (device): only the first min(length_b, q_limit[b]) QUERY rows of sequence b are
+   * computed -- forward leaves the other out / lse rows unwritten, backward takes their dout as zero (dq rows zero-filled,
+   * no contribution to dk / dv).  For consumers that read a sequence at a few leading rows only (a caption read at
+   * [CLS] in its last layer).  NULL = every row. */
+  const int *q_limit;
 } gps_attn_args;
 GPS_API int gps_attn_forward_ex(const gps_attn_args *args, gps_stream_t stream);
 GPS_API int gps_attn_backward_ex(const gps_attn_args *args, gps_stream_t stream);

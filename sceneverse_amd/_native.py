@@ -45,7 +45,7 @@ class AttnArgs(ctypes.Structure):
                 ("p_drop", _f), ("seed", ctypes.c_ulonglong), ("seed_dev", _vp),
                 ("out", _vp), ("ld_o", _i), ("lse", _vp),
                 ("dout", _vp), ("dq", _vp), ("ld_dq", _i), ("dk", _vp), ("dv", _vp), ("ld_dkv", _i), ("dsw", _vp),
-                ("cu_rows", _vp), ("seq_order", _vp)]
+                ("cu_rows", _vp), ("seq_order", _vp), ("q_limit", _vp)]
 
 
 ATTN_BF16, ATTN_F32 = 0, 1

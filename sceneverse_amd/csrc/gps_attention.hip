@@ -66,6 +66,7 @@ struct Params {
   const int *seq_order;                 // optional (B) permutation: workgroups visit the sequences in this order
                                         // (longest first: the dispatcher hands out workgroups in block order, so the
                                         // long ones start early and the short ones fill the tail)
+  const int *q_limit;                   // optional (B), with cu_rows: number of leading QUERY rows of a sequence that are computed
   const int *cu_rows;                   // optional (B + 1) row offsets of VARIABLE-LENGTH sequences packed back to back
                                         // (self-attention, streaming kernels): sequence b = rows [cu[b], cu[b + 1]),
                                         // L / Lq are then the CAPACITY (longest sequence; LDS sizing, lse pitch)
@@ -831,6 +832,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const Params P) {
     row0 = row0q = (size_t)P.cu_rows[b];
     L = Lq = P.cu_rows[b + 1] - P.cu_rows[b];
     if (L <= 0) return;                                     // workgroup-uniform: an empty sequence has no rows at all
+    if (P.q_limit) Lq = min(Lq, max(P.q_limit[b], 0));      // only the leading queries are wanted
   }
   const int nt = (L + 15) / 16, nc = (nt + 1) / 2, rows = nc * 32;       // keys
   const int ntq = (Lq + 15) / 16;                                         // queries
@@ -964,6 +966,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
     row0 = row0q = (size_t)P.cu_rows[b];
     L = Lq = P.cu_rows[b + 1] - P.cu_rows[b];
     if (L <= 0) return;
+    if (P.q_limit) Lq = min(Lq, max(P.q_limit[b], 0));       // the other queries' dout counts as zero
   }
   const int nt = (L + 15) / 16, nc = (nt + 1) / 2, rows = nc * 32;               // keys
   const int ntq = (Lq + 15) / 16, ncq = (ntq + 1) / 2, rows_q = ncq * 32;         // queries
@@ -1119,6 +1122,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(const Params P) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) op[16 * n] = f2bf(o[n][r] * 0.125f);
       }
+    }
+  }
+  if (P.q_limit && Lq < L) {               // queries that were not computed: their dQ rows are zero
+    for (int e = threadIdx.x; e < (L - Lq) * 8; e += blockDim.x) {
+      const int qr = Lq + (e >> 3), c8 = e & 7;
+      *reinterpret_cast<u32x4 *>(P.dq + (row0q + qr) * P.ld_dq + h * DH + 8 * c8) = zero4();
     }
   }
   __syncthreads();   // K / V tiles no longer needed: the same storage now takes Q and dO (row-major as well)
@@ -1395,6 +1404,7 @@ int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
   P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
   P.cu_rows = a->cu_rows;
   P.seq_order = a->cu_rows ? a->seq_order : nullptr;
+  P.q_limit = a->cu_rows ? a->q_limit : nullptr;
   if (backward) {
     P.dout = (const uint16_t *)a->dout; P.dq = (uint16_t *)a->dq; P.dk = (uint16_t *)a->dk; P.dv = (uint16_t *)a->dv;
     P.ld_dq = a->ld_dq; P.ld_dkv = a->ld_dkv; P.dsw = a->dsw;

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(kBlock, 1) void bwd_kernel(int n, int d, const floa
       }
   }
   float *dst = part + (size_t)blockIdx.x * (K + 3) * d;
-  for (int q = 0; q < K + 3; ++q) {      // cross-wave reduction, one set at a time through the same LDS rows
+#pragma unroll
+  for (int q = 0; q < K + 3; ++q) {      // cross-wave reduction, one set at a time through the same LDS rows (unrolled: acc stays in registers)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kIters; ++i)
@@ -182,8 +183,17 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int parts, int sets, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane, set = blockIdx.y;
   float acc = 0.f;
-  if (c < d)
-    for (int g = wave; g < parts; g += kWaves) acc += part[((size_t)g * sets + set) * d + c];
+  if (c < d) {
+    int g = wave;
+    for (; g + 7 * kWaves < parts; g += 8 * kWaves) {       // 8 independent loads in flight, added in workgroup order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(g + u * kWaves) * sets + set) * d + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; g < parts; g += kWaves) acc += part[((size_t)g * sets + set) * d + c];
+  }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c < d) out[(size_t)set * d + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
@@ -208,7 +218,7 @@ int gps_loc_embed_forward(int n_rows, int k_in, int d, const float *x, const flo
   if (n_rows == 0) return GPS_OK;
   if (!x || !w || !gamma || !beta || !y || !mean || !rstd) return GPS_ERR_INVALID_ARGUMENT;
   if (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) return GPS_ERR_UNSUPPORTED;
-  const dim3 grid((n_rows + kWaves - 1) / kWaves > 2048 ? 2048 : (n_rows + kWaves - 1) / kWaves), block(kBlock);
+  const dim3 grid(grid_rows(n_rows) * 2 < (n_rows + kWaves - 1) / kWaves ? grid_rows(n_rows) * 2 : (n_rows + kWaves - 1) / kWaves), block(kBlock);   // <= 512: a wave keeps its weight slice for several rows
   hipStream_t s = (hipStream_t)stream;
   switch (k_in) {
     case 3: hipLaunchKernelGGL((fwd_kernel<3>), grid, block, 0, s, n_rows, d, x, w, bias, gamma, beta, eps, y, mean, rstd); break;

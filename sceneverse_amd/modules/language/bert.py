@@ -159,13 +159,15 @@ class BERTLanguageEncoder(nn.Module):
             n_live_full = valid[:T_full].sum(dtype=torch.int32).reshape(1)
             sel = torch.cat([cu[S_full:S].long(), torch.arange(T_full, device=dev)])
             rows_tail = n_live_full + (S - S_full)
+            # last-layer attention: every query of the fully-read sequences, the first one of the [CLS]-only ones
+            q_limit = torch.cat([lens[:S_full], torch.ones(S - S_full, dtype=torch.int32, device=dev)])
         last = len(m.encoder.layer) - 1
         for li, layer in enumerate(m.encoder.layer):
             sa, so = layer.attention.self, layer.attention.output
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 packed = gemm.packed_linear(x16, [sa.query, sa.key, sa.value], rows_dev=n_valid)
                 ctx = fused_varlen_self_attention(packed, cu, S, cap, H, dropout_p=sa.dropout.p, training=training,
-                                                  order=order)
+                                                  order=order, q_limit=q_limit if (cls_tail and li == last) else None)
                 rows = n_valid
                 if cls_tail and li == last:
                     # rows past `rows_tail` of the tail batch are never written by the extent-aware kernels, forward or

@@ -209,7 +209,8 @@ class _FusedVarlenSelfAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, packed: torch.Tensor, cu_rows: torch.Tensor, n_seq: int, cap: int, n_head: int, p_drop: float,
-                seed_dev: Optional[torch.Tensor], order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                seed_dev: Optional[torch.Tensor], order: Optional[torch.Tensor] = None,
+                q_limit: Optional[torch.Tensor] = None) -> torch.Tensor:
         T, W = packed.shape
         D = n_head * HEAD_DIM
         assert W == 3 * D and packed.is_cuda and packed.dtype == torch.bfloat16 and packed.is_contiguous()
@@ -224,14 +225,14 @@ class _FusedVarlenSelfAttention(torch.autograd.Function):
                   B=n_seq, H=n_head, Lq=cap, Lk=cap, head_dim=HEAD_DIM, dtype=_native.ATTN_BF16,
                   compute=_native.ATTN_COMPUTE_NATIVE, q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W,
                   p_drop=float(p_drop), seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, cu_rows=cu_rows,
-                  seq_order=_ptr(order))
-        ctx.save_for_backward(packed, cu_rows, lse, seed_dev, out, order)
+                  seq_order=_ptr(order), q_limit=_ptr(q_limit))
+        ctx.save_for_backward(packed, cu_rows, lse, seed_dev, out, order, q_limit)
         ctx.meta = (n_seq, cap, n_head, float(p_drop))
         return out
 
     @staticmethod
     def backward(ctx, dout: torch.Tensor):
-        packed, cu_rows, lse, seed_dev, out, order = ctx.saved_tensors
+        packed, cu_rows, lse, seed_dev, out, order, q_limit = ctx.saved_tensors
         n_seq, cap, n_head, p_drop = ctx.meta
         T, W = packed.shape
         D = n_head * HEAD_DIM
@@ -246,8 +247,8 @@ class _FusedVarlenSelfAttention(torch.autograd.Function):
                   compute=_native.ATTN_COMPUTE_NATIVE, q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W,
                   p_drop=p_drop, seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
                   dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz, ld_dkv=W, cu_rows=cu_rows,
-                  seq_order=_ptr(order))
-        return dpacked, None, None, None, None, None, None, None
+                  seq_order=_ptr(order), q_limit=_ptr(q_limit))
+        return dpacked, None, None, None, None, None, None, None, None
 
 
 def _varlen_fraction(cu_rows: torch.Tensor, n_seq: int, cap: int):
@@ -265,12 +266,15 @@ def _varlen_fraction(cu_rows: torch.Tensor, n_seq: int, cap: int):
 
 def fused_varlen_self_attention(packed: torch.Tensor, cu_rows: torch.Tensor, n_seq: int, cap: int, n_head: int,
                                 dropout_p: float = 0.0, training: bool = False,
-                                order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                                order: Optional[torch.Tensor] = None,
+                                q_limit: Optional[torch.Tensor] = None) -> torch.Tensor:
     """order: optional (n_seq) int32 permutation, longest sequences first (launch balance only; results do not
-    depend on it)."""
+    depend on it).  q_limit: optional (n_seq) int32: only the first q_limit[b] query rows of sequence b are computed (the
+    other output rows are left unwritten and take no gradient)."""
     p = float(dropout_p) if training else 0.0
     seed_dev = _next_device_seed(packed.device) if p > 0.0 else None
-    return _FusedVarlenSelfAttention.apply(packed.contiguous(), cu_rows, int(n_seq), int(cap), n_head, p, seed_dev, order)
+    return _FusedVarlenSelfAttention.apply(packed.contiguous(), cu_rows, int(n_seq), int(cap), n_head, p, seed_dev, order,
+                                           q_limit)
 
 
 def fused_self_attention(packed: torch.Tensor, n_head: int, pairwise_locs: Optional[torch.Tensor] = None,

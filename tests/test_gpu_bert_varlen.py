@@ -157,3 +157,33 @@ def test_gemm_weight_gradient_ignores_rows_past_the_device_extent(T, N, K):
         assert torch.isfinite(dw).all() and torch.isfinite(db).all(), ext
         assert (dw - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), ext
         assert (db - refb).abs().max().item() <= 1e-4 * max(1.0, refb.abs().max().item()), ext
+
+
+def test_varlen_attention_query_limit_equals_zeroed_cotangents():
+    """q_limit: sequence b computes its first q_limit[b] query rows only.  Those rows must equal the full launch's, and
+    the gradient must equal the full launch's with the cotangent of the skipped rows set to zero (dq of skipped rows 0)."""
+    from sceneverse_amd.modules.layers.fused_attention import fused_varlen_self_attention
+    g = torch.Generator().manual_seed(17)
+    H, D = 12, 768
+    lens = torch.tensor([50, 7, 300, 1, 130, 64, 17, 299], dtype=torch.int32)
+    lim = torch.tensor([50, 3, 1, 1, 16, 0, 400, 33], dtype=torch.int32)
+    cu = torch.zeros(9, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    T = int(cu[-1]) + 40                                        # dead tail
+    packed = (torch.randn(T, 3 * D, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    wy = torch.randn(T, D, generator=g).to(torch.bfloat16).to(DEV)
+    keep = torch.zeros(T, dtype=torch.bool)
+    for b in range(8):
+        keep[int(cu[b]):int(cu[b]) + min(int(lens[b]), int(lim[b]))] = True
+    keep = keep.to(DEV)
+    cu_d, lim_d = cu.to(DEV), lim.to(DEV)
+    p_full = packed.clone().requires_grad_(True)
+    o_full = fused_varlen_self_attention(p_full, cu_d, 8, 300, H)
+    o_full.backward(torch.where(keep[:, None], wy, torch.zeros_like(wy)))
+    p_lim = packed.clone().requires_grad_(True)
+    o_lim = fused_varlen_self_attention(p_lim, cu_d, 8, 300, H, q_limit=lim_d)
+    o_lim.backward(wy * 0 + torch.where(keep[:, None], wy, torch.full_like(wy, float("nan"))).nan_to_num(0.0))
+    assert torch.equal(o_lim[keep], o_full[keep])
+    live = torch.arange(T, device=DEV) < int(cu[-1])
+    assert torch.equal(p_lim.grad[live], p_full.grad[live])
+    assert torch.all(p_lim.grad[live & ~keep][:, :D] == 0)
