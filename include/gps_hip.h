@@ -335,6 +335,22 @@ GPS_API int gps_add_dropout_layernorm_backward_rows(int n_rows, int d, int x_bf1
                                                     float p_drop, unsigned long long seed, const void *seed_dev,
                                                     void *dx, void *dh, float *dgamma_part, float *dbeta_part,
                                                     const int *rows_dev, gps_stream_t stream);
+/* the same pair with an addend behind the normalisation: y = LayerNorm(x + dropout(h)) * gamma + beta + post, post (n_rows, d)
+ * fp32 (x fp32) -- the per-layer `obj_embeds + loc_embeds` / `joint + extra` of the object and unified encoders
+ * (modules/vision/pcd_openvocab_encoder.py:176-178, modules/grounding/unified_encoder.py:154-164) folded into the previous
+ * layer's last LayerNorm, so that the layer input and its bf16 copy leave one launch.  backward: dpost (n_rows, d) fp32, if not
+ * NULL, receives the gradient of y (dy + dy_bf16) = the gradient of the addend; everything else as in the _rows forms. */
+GPS_API int gps_add_dropout_layernorm_forward_post(int n_rows, int d, int x_bf16, int h_bf16, const void *x, const void *h,
+                                                   const float *gamma, const float *beta, float eps, float p_drop,
+                                                   unsigned long long seed, const void *seed_dev, void *y, void *y_bf16,
+                                                   float *mean, float *rstd, const int *rows_dev, const float *post,
+                                                   gps_stream_t stream);
+GPS_API int gps_add_dropout_layernorm_backward_post(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                                    const void *dy_bf16, const void *x, const void *h, const float *gamma,
+                                                    const float *mean, const float *rstd, float p_drop,
+                                                    unsigned long long seed, const void *seed_dev, void *dx, void *dh,
+                                                    float *dgamma_part, float *dbeta_part, const int *rows_dev,
+                                                    float *dpost, gps_stream_t stream);
 
 /* ---- per-object input processing of the data loader ------------------------------------------------
  * Replaces ScanBase._obj_processing_post (data/datasets/base.py:697-740: optional rotation, centre/size

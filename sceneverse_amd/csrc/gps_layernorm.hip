@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
     int n_rows, int d, const TX *__restrict__ x, const TH *__restrict__ h, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, float p_drop, unsigned int thr, unsigned long long seed,
     const unsigned long long *__restrict__ seed_dev, TX *__restrict__ y, uint16_t *__restrict__ y16,
-    float *__restrict__ mean_out, float *__restrict__ rstd_out, const int *__restrict__ rows_dev) {
+    float *__restrict__ mean_out, float *__restrict__ rstd_out, const int *__restrict__ rows_dev,
+    const float *__restrict__ post) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rows_dev) n_rows = min(n_rows, *rows_dev);        // device-side count of leading rows that carry work
   constexpr int iters = ITERS;
@@ -126,6 +127,10 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
         o.y = (z[i].y - mean) * rstd * g.y + bt.y;
         o.z = (z[i].z - mean) * rstd * g.z + bt.z;
         o.w = (z[i].w - mean) * rstd * g.w + bt.w;
+        if (post) {      // y = LayerNorm(...) + post: the addend the NEXT layer would add to its input (same shape as y)
+          const float4 e = *reinterpret_cast<const float4 *>(post + base + c0);
+          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
         store4(y, base + c0, o);
         if (y16) store4(y16, base + c0, o);
       }
@@ -140,7 +145,8 @@ __global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd
     const TH *__restrict__ h, const float *__restrict__ gamma, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, float p_drop, unsigned int thr, unsigned long long seed,
     const unsigned long long *__restrict__ seed_dev, TX *__restrict__ dx, TH *__restrict__ dh,
-    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, const int *__restrict__ rows_dev) {
+    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, const int *__restrict__ rows_dev,
+    float *__restrict__ g_out) {
   extern __shared__ float red[];      // [kWaves][d] reused for dgamma then dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rows_dev) n_rows = min(n_rows, *rows_dev);        // rows past it contribute nothing to dgamma / dbeta either
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd
           const float4 g2 = load4(dy16, e0);
           g = make_float4(g.x + g2.x, g.y + g2.y, g.z + g2.z, g.w + g2.w);
         }
+        if (g_out) *reinterpret_cast<float4 *>(g_out + e0) = g;      // gradient of the output = gradient of a post-addend
         zh[i] = make_float4((xv.x + hv.x - mean) * rstd, (xv.y + hv.y - mean) * rstd,
                             (xv.z + hv.z - mean) * rstd, (xv.w + hv.w - mean) * rstd);
         a[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
@@ -394,6 +401,16 @@ int gps_add_dropout_layernorm_forward_rows(int n_rows, int d, int x_bf16, int h_
                                            const float *gamma, const float *beta, float eps, float p_drop,
                                            unsigned long long seed, const void *seed_dev, void *y, void *y_bf16,
                                            float *mean, float *rstd, const int *rows_dev, gps_stream_t stream) {
+  return gps_add_dropout_layernorm_forward_post(n_rows, d, x_bf16, h_bf16, x, h, gamma, beta, eps, p_drop, seed, seed_dev, y,
+                                                y_bf16, mean, rstd, rows_dev, nullptr, stream);
+}
+
+int gps_add_dropout_layernorm_forward_post(int n_rows, int d, int x_bf16, int h_bf16, const void *x, const void *h,
+                                           const float *gamma, const float *beta, float eps, float p_drop,
+                                           unsigned long long seed, const void *seed_dev, void *y, void *y_bf16,
+                                           float *mean, float *rstd, const int *rows_dev, const float *post,
+                                           gps_stream_t stream) {
+  if (post && (x_bf16 || ((uintptr_t)post & 15))) return GPS_ERR_UNSUPPORTED;      // fp32 rows only
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
   if ((d & 255) || d > 256 * gps_ln::kMaxIter || ((d >> 8) > 4 && (d >> 8) != 8)) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
@@ -404,7 +421,7 @@ int gps_add_dropout_layernorm_forward_rows(int n_rows, int d, int x_bf16, int h_
   const unsigned long long *sd = (const unsigned long long *)seed_dev;
 #define GPS_LN_FWD_I(TX, TH, IT)                                                                                  \
   hipLaunchKernelGGL((gps_ln::add_dropout_ln_fwd_kernel<TX, TH, IT>), grid, block, 0, s, n_rows, d, (const TX *)x, \
-                     (const TH *)h, gamma, beta, eps, p_drop, thr, seed, sd, (TX *)y, (uint16_t *)y_bf16, mean, rstd, rows_dev)
+                     (const TH *)h, gamma, beta, eps, p_drop, thr, seed, sd, (TX *)y, (uint16_t *)y_bf16, mean, rstd, rows_dev, post)
 #define GPS_LN_FWD(TX, TH)                          \
   do { switch (d >> 8) {                            \
     case 1: GPS_LN_FWD_I(TX, TH, 1); break;         \
@@ -438,6 +455,17 @@ int gps_add_dropout_layernorm_backward_rows(int n_rows, int d, int x_bf16, int h
                                             unsigned long long seed, const void *seed_dev, void *dx, void *dh,
                                             float *dgamma_part, float *dbeta_part, const int *rows_dev,
                                             gps_stream_t stream) {
+  return gps_add_dropout_layernorm_backward_post(n_rows, d, x_bf16, h_bf16, dy, dy_bf16, x, h, gamma, mean, rstd, p_drop, seed,
+                                                 seed_dev, dx, dh, dgamma_part, dbeta_part, rows_dev, nullptr, stream);
+}
+
+int gps_add_dropout_layernorm_backward_post(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                            const void *dy_bf16, const void *x, const void *h, const float *gamma,
+                                            const float *mean, const float *rstd, float p_drop,
+                                            unsigned long long seed, const void *seed_dev, void *dx, void *dh,
+                                            float *dgamma_part, float *dbeta_part, const int *rows_dev, float *dpost,
+                                            gps_stream_t stream) {
+  if (dpost && (x_bf16 || ((uintptr_t)dpost & 15))) return GPS_ERR_UNSUPPORTED;
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
   if ((d & 255) || d > 256 * gps_ln::kMaxIter || ((d >> 8) > 4 && (d >> 8) != 8)) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
@@ -451,7 +479,7 @@ int gps_add_dropout_layernorm_backward_rows(int n_rows, int d, int x_bf16, int h
 #define GPS_LN_BWD_I(TX, TH, IT)                                                                                    \
   hipLaunchKernelGGL((gps_ln::add_dropout_ln_bwd_kernel<TX, TH, IT>), grid, block, lds, s, n_rows, d, (const TX *)dy, \
                      (const uint16_t *)dy_bf16, (const TX *)x, (const TH *)h, gamma, mean, rstd, p_drop, thr,       \
-                     seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part, rows_dev)
+                     seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part, rows_dev, dpost)
 #define GPS_LN_BWD(TX, TH)                          \
   do { switch (d >> 8) {                            \
     case 1: GPS_LN_BWD_I(TX, TH, 1); break;         \

@@ -111,8 +111,11 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         txt_extra = add_row(obj_extra.new_zeros((txt_embeds.shape[0], txt_len, obj_extra.shape[-1])), type_txt.to(obj_extra.dtype))
         extra = torch.cat((txt_extra, obj_extra), dim=1)
         joint = torch.cat((txt_embeds, obj_embeds), dim=1)
-        for layer in self.unified_encoder:
-            joint = joint + extra
-            joint, _ = layer(joint, tgt_key_padding_mask=joint_pad)
+        # layer l reads joint_l + extra: the first sum is explicit, every later one leaves the previous layer's last
+        # LayerNorm launch together with its bf16 copy (post_add)
+        joint = joint + extra
+        n_layers = len(self.unified_encoder)
+        for li, layer in enumerate(self.unified_encoder):
+            joint, _ = layer(joint, tgt_key_padding_mask=joint_pad, post_add=extra if li + 1 < n_layers else None)
         txt_embeds, obj_embeds = torch.split(joint, [txt_len, obj_len], dim=1)
         return txt_embeds, obj_embeds

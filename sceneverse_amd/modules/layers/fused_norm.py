@@ -49,11 +49,12 @@ def _row_fraction(rows_dev: Optional[torch.Tensor], n: int):
 
 class _AddDropoutLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev, want_bf16: bool, rows_dev=None):
+    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev, want_bf16: bool, rows_dev=None, post=None):
         d = x.shape[-1]
         x2 = x.reshape(-1, d).contiguous()
         h2 = h.reshape(-1, d).contiguous()
         n = x2.shape[0]
+        post2 = post.reshape(-1, d).float().contiguous() if post is not None else None
         g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
         y = torch.empty_like(x2)
         y16 = torch.empty((n, d), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
@@ -63,14 +64,15 @@ class _AddDropoutLN(torch.autograd.Function):
         nbytes = n * d * (2 * x2.element_size() + h2.element_size())
         with torch.cuda.device(x.device), _timed(f"add_dropout_layernorm_forward(rows={n},d={d})", nbytes,
                                                  work_fraction=_row_fraction(rows_dev, n)):
-            st = _native.load().gps_add_dropout_layernorm_forward_rows(
+            st = _native.load().gps_add_dropout_layernorm_forward_post(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), x2.data_ptr(),
                 h2.data_ptr(), g32.data_ptr(), b32.data_ptr(), float(eps), float(p_drop), 0, _ptr(seed_dev),
-                y.data_ptr(), _ptr(y16), mean.data_ptr(), rstd.data_ptr(), _ptr(rows_dev),
+                y.data_ptr(), _ptr(y16), mean.data_ptr(), rstd.data_ptr(), _ptr(rows_dev), _ptr(post2),
                 torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_forward")
         ctx.save_for_backward(x2, h2, g32, mean, rstd, seed_dev, rows_dev)
         ctx.meta = (float(p_drop), x.shape, h.shape, gamma.dtype, beta.dtype)
+        ctx.post = (post.shape, post.dtype) if post is not None else None
         if want_bf16:
             return y.view(x.shape), y16.view(x.shape)
         return y.view(x.shape)
@@ -86,6 +88,10 @@ class _AddDropoutLN(torch.autograd.Function):
         dy16_2 = dy16.reshape(n, d).to(torch.bfloat16).contiguous() if dy16 is not None else None
         dx = torch.empty_like(x2)
         dh = torch.empty_like(h2)
+        want_dpost = ctx.post is not None and ctx.needs_input_grad[9]
+        dpost = torch.empty((n, d), dtype=torch.float32, device=x2.device) if want_dpost else None
+        if dpost is not None and rows_dev is not None:
+            dpost.zero_()                                      # rows past the device count are not written
         lib = _native.load()
         parts = int(lib.gps_ln_partial_rows(n))
         part = torch.empty((2, parts, d), dtype=torch.float32, device=x2.device)
@@ -93,11 +99,11 @@ class _AddDropoutLN(torch.autograd.Function):
         nbytes = n * d * (3 * x2.element_size() + 2 * h2.element_size())
         with torch.cuda.device(x2.device), _timed(f"add_dropout_layernorm_backward(rows={n},d={d})", nbytes,
                                                   work_fraction=_row_fraction(rows_dev, n)):
-            st = lib.gps_add_dropout_layernorm_backward_rows(
+            st = lib.gps_add_dropout_layernorm_backward_post(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), dy2.data_ptr(),
                 _ptr(dy16_2), x2.data_ptr(), h2.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, 0,
                 _ptr(seed_dev), dx.data_ptr(), dh.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), _ptr(rows_dev),
-                torch.cuda.current_stream().cuda_stream)
+                _ptr(dpost), torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_backward")
         sums = torch.empty((2, d), dtype=torch.float32, device=x2.device)
         with torch.cuda.device(x2.device):
@@ -105,8 +111,10 @@ class _AddDropoutLN(torch.autograd.Function):
                                             _reduce_scratch(x2.device, d).data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
         _native.check(st, "ln_reduce_partials")
+        if dpost is not None:
+            dpost = dpost.view(ctx.post[0]).to(ctx.post[1])
         return (dx.view(x_shape), dh.view(h_shape), sums[0].to(g_dtype), sums[1].to(b_dtype),
-                None, None, None, None, None)
+                None, None, None, None, None, dpost)
 
 
 def supported(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm) -> bool:
@@ -118,23 +126,30 @@ def supported(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm) -> bool:
 
 
 def add_dropout_layer_norm(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm, p_drop: float = 0.0,
-                           training: bool = False, want_bf16: bool = False, rows_dev: Optional[torch.Tensor] = None):
+                           training: bool = False, want_bf16: bool = False, rows_dev: Optional[torch.Tensor] = None,
+                           post: Optional[torch.Tensor] = None):
     """norm(x + dropout(h, p_drop, training)); y has x's dtype on the fused path.
     want_bf16: also return a bf16 copy of y written by the same launch (what the next GEMM reads
     under autocast; its gradient is added inside the fused backward) -> (y, y_bf16).
+    post: optional addend of x's shape applied BEHIND the normalisation, y = norm(...) + post (and y_bf16 = bf16 of that
+    sum): the per-layer `x + loc_embeds` / `joint + extra` of the NEXT encoder layer folded into this launch.
     rows_dev: int32 device word = number of leading rows (of the flattened (rows, d) view) that carry work; the other
     rows are neither read nor written (their content is undefined) and do not enter the dgamma / dbeta sums."""
     p = float(p_drop) if training else 0.0
+    if post is not None and not (post.shape == x.shape and x.dtype == torch.float32 and post.is_cuda == x.is_cuda):
+        raise ValueError("add_dropout_layer_norm: `post` must have the shape of x (fp32 rows)")
     if not supported(x, h, norm):
         if rows_dev is not None:
             raise RuntimeError("add_dropout_layer_norm: a device-side row count needs the fused kernel")
         y = norm(x + F.dropout(h, p, training=p > 0.0))
+        if post is not None:
+            y = y + post
         return (y, y) if want_bf16 else y
     seed_dev = None
     if p > 0.0:
         from .fused_attention import _next_device_seed
         seed_dev = _next_device_seed(x.device)
-    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev, bool(want_bf16), rows_dev)
+    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev, bool(want_bf16), rows_dev, post)
 
 
 class _L2Normalize(torch.autograd.Function):

@@ -117,7 +117,9 @@ class PointOpenVocabEncoder(nn.Module):
                 spatial_dist_norm=True, spatial_dim=self.spatial_dim)
             pad = obj_masks.logical_not()
             loc_embeds = loc_embed(self.loc_layers[0], obj_locs)      # re-added every layer (ref :176-178); evaluated once
-            for layer in self.spatial_encoder:
-                obj_embeds = obj_embeds + loc_embeds
-                obj_embeds, _ = layer(obj_embeds, pairwise_locs, tgt_key_padding_mask=pad)
+            obj_embeds = obj_embeds + loc_embeds
+            n_layers = len(self.spatial_encoder)
+            for li, layer in enumerate(self.spatial_encoder):     # later re-adds ride on the previous layer's last LayerNorm
+                obj_embeds, _ = layer(obj_embeds, pairwise_locs, tgt_key_padding_mask=pad,
+                                      post_add=loc_embeds if li + 1 < n_layers else None)
         return obj_embeds, obj_embeds_pre, obj_sem_cls

@@ -160,3 +160,43 @@ def test_add_row_gradient_is_the_column_sum():
         ref = w.double().reshape(-1, 768).sum(0)
         assert (r.grad.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
         assert torch.equal(column_sum(w), column_sum(w))        # deterministic
+
+
+@pytest.mark.parametrize("want_bf16,p", [(True, 0.0), (False, 0.0), (True, 0.1)])
+def test_post_addend_rides_on_the_layernorm_launch(want_bf16, p):
+    """y = LayerNorm(x + dropout(h)) + post in one launch: values and every gradient (x, h, gamma, beta, post) against the
+    torch chain; the bf16 copy is the rounded SUM; its cotangent reaches post as well."""
+    g = torch.Generator().manual_seed(31)
+    n, d = 520, 768
+    norm = nn.LayerNorm(d).to("cuda")
+    with torch.no_grad():
+        norm.weight.add_(torch.randn(d, generator=g).to("cuda") * 0.1)
+        norm.bias.add_(torch.randn(d, generator=g).to("cuda") * 0.1)
+    x = torch.randn(n, d, generator=g).to("cuda").requires_grad_(True)
+    h = torch.randn(n, d, generator=g).to("cuda").to(torch.bfloat16).requires_grad_(True)
+    post = torch.randn(n, d, generator=g).to("cuda").requires_grad_(True)
+    out = add_dropout_layer_norm(x, h, norm, p, training=p > 0, want_bf16=want_bf16, post=post)
+    y, y16 = out if want_bf16 else (out, None)
+    base = add_dropout_layer_norm(x.detach(), h.detach(), norm, 0.0, False)
+    if p == 0.0:
+        assert torch.equal(y, base + post.detach()) or (y - (base + post.detach())).abs().max().item() <= 1e-6
+    if y16 is not None:
+        assert torch.equal(y16, y.to(torch.bfloat16))
+    wy = torch.randn(n, d, generator=g).to("cuda")
+    wy16 = torch.randn(n, d, generator=g).to("cuda").to(torch.bfloat16)
+    if y16 is not None:
+        torch.autograd.backward([y, y16], [wy, wy16])
+        want_post = wy + wy16.float()
+    else:
+        y.backward(wy)
+        want_post = wy
+    assert (post.grad - want_post).abs().max().item() <= 1e-6
+    if p == 0.0:
+        got = (x.grad.clone(), h.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone())
+        for t in (x, h, norm.weight, norm.bias):
+            t.grad = None
+        ref = norm(x + h.float())
+        ref.backward(want_post)
+        for a, b in zip(got, (x.grad, h.grad, norm.weight.grad, norm.bias.grad)):
+            scale = max(1.0, b.float().abs().max().item())
+            assert (a.float() - b.float()).abs().max().item() <= 2e-2 * scale      # h's gradient is bf16

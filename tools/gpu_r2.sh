@@ -217,3 +217,26 @@ if [[ $WHAT == *embcheck* ]]; then
   grep -E "^(FAILED|ERROR)|passed|failed|exit|Error|assert " $OUT/pytest_emb.log | head -20 | cut -c1-400
   timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; head -c 330 $OUT/bench.json; echo; tail -2 $OUT/bench.err
 fi
+if [[ $WHAT == *dbgdp* ]]; then
+  ts dbgdp
+  for v in "" "GPS_NO_BF16_ATTR=1" "GPS_NO_POST=1"; do
+    echo "== $v"; env $v timeout 300 python -m pytest tests/test_gpu_model.py -m gpu -q -x -k "hip_graph_step_matches" 2>&1 | grep -E "passed|failed|AssertionError: \(" | cut -c1-300
+  done
+fi
+if [[ $WHAT == *stagedprobe* ]]; then
+  ts stagedprobe; timeout 300 python tools/probes/${PROBE:-staged_backward_probe.py} 2>&1 | grep -v "amdgpu.ids" | tail -40
+fi
+if [[ $WHAT == *dbgbench* ]]; then
+  ts dbgbench
+  for v in "X=1" "GPS_NO_BF16_ATTR=1" "GPS_NO_POST=1"; do
+    for extra in "--no-extras" ""; do
+      echo "== $v $extra"; env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $extra > $OUT/b.json 2> $OUT/b.err; echo "exit $?"; head -c 200 $OUT/b.json; echo; grep -v "amdgpu.ids\|UserWarning\|_warn_once" $OUT/b.err | tail -3
+    done
+  done
+fi
+if [[ $WHAT == *poisonprobe* ]]; then
+  ts poisonprobe
+  for v in "POISON=40" "POISON=40 GPS_POST_TORCH_DPOST=1" "POISON=40 GPS_NO_POST=1"; do
+    echo "== $v"; env $v timeout 300 python tools/probes/dp_graph_nan_probe.py 2>&1 | grep -E "^step|NONFINITE|nonfinite params|flat grad" | head -24
+  done
+fi
