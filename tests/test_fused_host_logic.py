@@ -249,3 +249,44 @@ def test_weight_gradient_split_rule_fills_one_resident_round():
         s = pick(M, N, K)
         tiles = -(-M // 256) * -(-N // 256)
         assert 160 <= tiles * s <= 256 and (K + 63) // 64 // s >= 24
+
+
+def test_round3_fused_helpers_fall_back_to_torch_on_cpu():
+    """l2_normalize / add_row / column_sum / loc_embed / post-addend LayerNorm: CPU tensors take the torch formulation (the
+    native kernels are GPU-only and the product path never routes GPU work through these fallbacks)."""
+    import torch.nn.functional as F
+    from torch import nn
+    from sceneverse_amd.modules.layers.fused_loc import loc_embed, supported as loc_supported
+    from sceneverse_amd.modules.layers.fused_norm import add_dropout_layer_norm, add_row, column_sum, l2_normalize
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 768, generator=g)
+    assert torch.equal(l2_normalize(x), F.normalize(x, dim=-1, p=2))
+    row = torch.randn(768, generator=g, requires_grad=True)
+    y = add_row(x, row)
+    assert torch.equal(y, x + row)
+    y.sum().backward()
+    assert torch.allclose(row.grad, torch.full((768,), 15.0))
+    assert torch.allclose(column_sum(x), x.reshape(-1, 768).sum(0))
+    seq = nn.Sequential(nn.Linear(6, 768), nn.LayerNorm(768))
+    locs = torch.randn(2, 4, 6, generator=g)
+    assert not loc_supported(seq, locs)
+    assert torch.equal(loc_embed(seq, locs), seq(locs))
+    norm = nn.LayerNorm(768)
+    h, post = torch.randn(3, 5, 768, generator=g), torch.randn(3, 5, 768, generator=g)
+    assert torch.equal(add_dropout_layer_norm(x, h, norm, post=post), norm(x + h) + post)
+    with pytest.raises(ValueError):
+        add_dropout_layer_norm(x, h, norm, post=post[:, :2])
+
+
+def test_encoder_layers_accept_a_post_addend():
+    """`post_add` of the encoder layers = the addend the NEXT layer would apply to its input: same values as adding it
+    outside (the object / unified encoders pass their re-added embeddings this way)."""
+    from sceneverse_amd.modules.layers.transformers import TransformerEncoderLayer, TransformerSpatialEncoderLayer
+    torch.manual_seed(0)
+    x, e = torch.randn(2, 7, 64), torch.randn(2, 7, 64)
+    layer = TransformerEncoderLayer(64, 4, dim_feedforward=128, dropout=0.0).eval()
+    assert torch.allclose(layer(x, post_add=e)[0], layer(x)[0] + e)
+    sp = TransformerSpatialEncoderLayer(64, 4, dim_feedforward=128, dropout=0.0, spatial_multihead=True, spatial_dim=5,
+                                        spatial_attn_fusion='cond').eval()
+    pl = torch.randn(2, 7, 7, 5)
+    assert torch.allclose(sp(x, pl, post_add=e)[0], sp(x, pl)[0] + e)

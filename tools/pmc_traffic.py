@@ -29,6 +29,8 @@ NAMES = [
     (r"add_dropout_ln_fwd_kernel", "add_dropout_layernorm_forward"),
     (r"attn_bwd_stream_kernel", "attn_backward(L<=300,varlen,seqs=128)"),
     (r"attn_fwd_stream_kernel", "attn_forward(L<=300,varlen,seqs=128)"),
+    (r"gemm8p_kernel<false, true, 0>", "gemm_nn(M=22400,N=768,K=3072,epi=0)"),          # two-group 256 x 256 form [r3]
+    (r"gemm8p_kernel<true, true, 5>", "gemm_tn(M=3072,N=768,K=22400,epi=5)"),
     (r"gemm_kernel<128, 128, 4, 2, false, false, 1,", "gemm_nt(M=22400,N=3072,K=768,epi=1)"),
     (r"gemm_kernel<128, 128, 4, 2, false, true, 0,", "gemm_nn(M=22400,N=768,K=3072,epi=0)"),
     (r"gemm_kernel<128, 128, 4, 2, true, true, 5,", "gemm_tn(M=3072,N=768,K=22400,epi=5)"),
