@@ -48,6 +48,38 @@ if os.path.exists(_TUNED.replace(".csv", "0.csv")) and not os.environ.get("GPS_N
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
     os.environ["PYTORCH_TUNABLEOP_FILENAME"] = _TUNED
+    # every rank reads the SAME table: torch looks for <name><device ordinal>.csv, the committed file is ordinal 0's
+    _lr = os.environ.get("LOCAL_RANK", "0")
+    if _lr.isdigit() and int(_lr) > 0 and not os.path.exists(_TUNED.replace(".csv", f"{int(_lr)}.csv")):
+        try:
+            import shutil
+            import tempfile
+            _d = os.path.join(tempfile.gettempdir(), "gps_tunableop")
+            os.makedirs(_d, exist_ok=True)
+            shutil.copyfile(_TUNED.replace(".csv", "0.csv"), os.path.join(_d, f"tunableop_gfx950{int(_lr)}.csv"))
+            os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(_d, "tunableop_gfx950.csv")
+        except OSError:
+            pass
+
+
+def _pin_rank_to_its_cores() -> None:
+    """One process per GPU: give local rank r the r-th slice of the host's cores (the launch thread, the autograd thread
+    and RCCL's proxy threads of a rank then stay on one set of cores instead of migrating over all 256)."""
+    try:
+        world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if world <= 1 or not hasattr(os, "sched_setaffinity"):
+            return
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per >= 2:
+            os.sched_setaffinity(0, cores[local * per:(local + 1) * per])
+            os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(per, 16))))
+    except (OSError, ValueError):
+        pass
+
+
+_pin_rank_to_its_cores()
 
 import torch  # noqa: E402
 

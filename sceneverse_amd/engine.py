@@ -48,6 +48,8 @@ import torch
 import torch.nn as nn
 
 from .common import dist_utils
+
+_CAPTURE_MODE = "thread_local"     # split-graph data-parallel captures (see _graph_dp_step)
 from .model.build import build_model
 from .optim.build import build_optim
 
@@ -308,7 +310,9 @@ class GPSTrainStep:
                 off += p.numel()
             torch.cuda.synchronize(self.device)
             g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
-            with torch.cuda.graph(g1):
+            # thread-local capture mode: RCCL's watchdog thread polls its events (hipEventQuery) while we capture; in the
+            # default global mode any such call from another thread invalidates the capture
+            with torch.cuda.graph(g1, capture_error_mode=_CAPTURE_MODE):
                 self._begin_step()
                 with self._autocast():
                     out = self.net(static_dict)
@@ -316,7 +320,7 @@ class GPSTrainStep:
             boundary = list(getattr(self.model, "_stage_boundary", None) or [])
             segmented = bool(boundary) and bool(top) and bool(bottom) and not self.wgrad_overlap
             torch.cuda.synchronize(self.device)
-            with torch.cuda.graph(g2a, pool=g1.pool()):
+            with torch.cuda.graph(g2a, pool=g1.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._flat_grad.zero_()
                 with self._autocast():
                     total, losses = self.loss(out)
@@ -327,13 +331,13 @@ class GPSTrainStep:
                     self._backward(total)             # accumulates into the flat views
             torch.cuda.synchronize(self.device)
             if segmented:
-                with torch.cuda.graph(g2b, pool=g1.pool()):
+                with torch.cuda.graph(g2b, pool=g1.pool(), capture_error_mode=_CAPTURE_MODE):
                     live = [t for t in boundary if t.grad is not None]
                     torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bottom)
                 torch.cuda.synchronize(self.device)
             else:
                 g2b = None
-            with torch.cuda.graph(g3):
+            with torch.cuda.graph(g3, capture_error_mode=_CAPTURE_MODE):
                 self._clip_and_step()
             self._graph, self._graph_out = (g1, g2a, g2b, g3), (out, total, losses)
         else:

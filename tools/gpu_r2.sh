@@ -240,3 +240,9 @@ if [[ $WHAT == *poisonprobe* ]]; then
     echo "== $v"; env $v timeout 300 python tools/probes/dp_graph_nan_probe.py 2>&1 | grep -E "^step|NONFINITE|nonfinite params|flat grad" | head -24
   done
 fi
+if [[ $WHAT == *modes* ]]; then
+  ts modes
+  for extra in "--no-graph" "--graph-dp"; do
+    echo "== $extra"; timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $extra > $OUT/m.json 2> $OUT/m.err; echo "exit $?"; head -c 230 $OUT/m.json; echo; grep -v "amdgpu.ids\|UserWarning\|_warn_once" $OUT/m.err | tail -2
+  done
+fi
