@@ -355,15 +355,18 @@ def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout, want_b
 
 
 # Folding the next layer's `x + embedding` into this layer's last LayerNorm launch (fused_norm `post`): +0.7 % on the
-# pre-train step as one HIP graph, but the SEGMENTED data-parallel graph step (engine._graph_dp_step) then diverged from
-# the eager step after its first replay, by amounts that depended on what the freed memory held;
-# the cause was not found within the round's GPU budget, so the encoders keep the explicit add unless this is switched on.
+# pre-train step as one HIP graph, but in the SEGMENTED data-parallel graph step (engine._graph_dp_step) the bottom
+# graph then produces wrong gradients for the TEXT encoder (last layer zero, the others off) as soon as the OBJECT
+# encoder's layers use it -- the unified encoder's layers alone are fine; eager staged backward is exact
+# (tools/probes/staged_backward_probe.py, dp_graph_grad_diff_probe.py).  The cause was not found
+# within the round's GPU budget, so the encoders keep the explicit add unless this is switched on.
 _FUSE_POST_ADD = False
+_FUSE_POST_ONLY = None          # probes: "spatial" = object encoder layers only, "plain" = unified encoder layers only
 
 
-def set_fuse_post_add(flag: bool) -> None:
-    global _FUSE_POST_ADD
-    _FUSE_POST_ADD = bool(flag)
+def set_fuse_post_add(flag: bool, only=None) -> None:
+    global _FUSE_POST_ADD, _FUSE_POST_ONLY
+    _FUSE_POST_ADD, _FUSE_POST_ONLY = bool(flag), only
 
 
 def _gemm_input(x: Tensor) -> Tensor:
@@ -379,7 +382,8 @@ def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add):
     copy leave the same launch; the copy travels as an attribute of the fp32 result for the next layer's `_gemm_input`."""
     if post_add is None:
         return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2)
-    if _FUSE_POST_ADD and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
+    fuse = _FUSE_POST_ADD and (_FUSE_POST_ONLY is None or (_FUSE_POST_ONLY == "spatial") == hasattr(layer.self_attn, "lang_cond_fc"))
+    if fuse and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
         y, y16 = _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2, want_bf16=True, post=post_add)
         if y16 is not y:
             y._gps_bf16 = y16

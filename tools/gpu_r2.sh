@@ -246,3 +246,18 @@ if [[ $WHAT == *modes* ]]; then
     echo "== $extra"; timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $extra > $OUT/m.json 2> $OUT/m.err; echo "exit $?"; head -c 230 $OUT/m.json; echo; grep -v "amdgpu.ids\|UserWarning\|_warn_once" $OUT/m.err | tail -2
   done
 fi
+if [[ $WHAT == *smoke* ]]; then
+  ts smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -5 $OUT/smoke.log | cut -c1-300
+fi
+if [[ $WHAT == *postsplit* ]]; then
+  ts postsplit
+  for v in "POISON=40 FUSE_POST=1 GPS_POST_ONLY=spatial" "POISON=40 FUSE_POST=1 GPS_POST_ONLY=plain" "POISON=40"; do
+    echo "== $v"; env $v timeout 300 python tools/probes/dp_graph_nan_probe.py 2>&1 | grep -E "^step" | head -8
+  done
+fi
+if [[ $WHAT == *graddiff* ]]; then
+  ts graddiff
+  env X=1 timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_plain.pt 2>&1 | grep -E "^loss"
+  env FUSE_POST=1 GPS_POST_ONLY=spatial timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_post.pt 2>&1 | grep -E "^loss"
+  timeout 300 python tools/probes/dp_graph_grad_diff_probe.py diff /tmp/g_plain.pt /tmp/g_post.pt 2>&1 | tail -40
+fi

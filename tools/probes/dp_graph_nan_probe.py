@@ -7,6 +7,9 @@ from sceneverse_amd.data.synthetic import synth_batch
 from sceneverse_amd.engine import GPSTrainStep
 
 DEV = "cuda"
+if os.environ.get("FUSE_POST"):
+    from sceneverse_amd.modules.layers.transformers import set_fuse_post_add
+    set_fuse_post_add(True, os.environ.get("GPS_POST_ONLY"))
 if os.environ.get("POISON"):
     junk = [torch.full((256, 1024, 1024), float("nan"), device=DEV) for _ in range(int(os.environ["POISON"]))]
     del junk
