@@ -258,6 +258,6 @@ fi
 if [[ $WHAT == *graddiff* ]]; then
   ts graddiff
   env X=1 timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_plain.pt 2>&1 | grep -E "^loss"
-  env FUSE_POST=1 GPS_POST_ONLY=spatial timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_post.pt 2>&1 | grep -E "^loss"
-  timeout 300 python tools/probes/dp_graph_grad_diff_probe.py diff /tmp/g_plain.pt /tmp/g_post.pt 2>&1 | tail -40
+  env GPS_POST_TORCH_FWD=1 FUSE_POST=1 GPS_POST_ONLY=spatial timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_post.pt 2>&1 | grep -E "^loss"
+  timeout 300 python tools/probes/dp_graph_grad_diff_probe.py diff /tmp/g_plain.pt /tmp/g_post.pt 2>&1 | tail -6
 fi

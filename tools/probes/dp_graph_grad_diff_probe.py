@@ -24,6 +24,9 @@ from sceneverse_amd.modules.layers.transformers import MultiheadSelfAttention, s
 DEV = "cuda"
 if os.environ.get("FUSE_POST"):
     set_fuse_post_add(True, os.environ.get("GPS_POST_ONLY"))
+if os.environ.get("NO_CLS_TAIL"):
+    from sceneverse_amd.modules.language import bert as _B
+    _B.set_cls_tail(False)
 junk = [torch.full((256, 1024, 1024), float("nan"), device=DEV) for _ in range(40)]
 del junk
 cfg = gps_pretrain_cfg(_lang_dir())
