@@ -469,7 +469,9 @@ GPS_API int gps_loc_embed_backward(int n_rows, int k_in, int d, const float *dy,
  *   of GPS_GEMM_EPI_DGELU is recomputed from the same (seed, index), nothing is stored.  p_drop = 0: none.
  * splits (TN only): K is cut into `splits` ranges whose fp32 partial tiles go to `workspace`
  *   (gps_gemm_workspace_floats() floats) and are summed in split order by a second launch (deterministic);
- *   gps_gemm_pick_splits() gives the default.  variant: tile configuration 0..10 (8, 9, 10: persistent workgroups), or -1 = chosen from the shape.
+ *   gps_gemm_pick_splits() gives the default.  variant: tile configuration 0..12 (8, 9, 10: persistent workgroups;
+ *   11: four-wave 256 x 256 with register-staged operands; 12: eight-wave two-group 256 x 256, the default for long
+ *   reductions and wide weight gradients), or -1 = chosen from the shape.
  * Requirements (else GPS_ERR_UNSUPPORTED): lda, ldb multiples of 8, K too unless form TN; N, ldc, ldaux multiples of 4; for
  *   reduction-major operands their column count (N, and M in form TN) a multiple of 8; A, B, C, bias 16-byte aligned. */
 #define GPS_GEMM_NT 0
