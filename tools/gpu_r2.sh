@@ -257,7 +257,13 @@ if [[ $WHAT == *postsplit* ]]; then
 fi
 if [[ $WHAT == *graddiff* ]]; then
   ts graddiff
-  env X=1 timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_plain.pt 2>&1 | grep -E "^loss"
-  env GPS_POST_TORCH_FWD=1 FUSE_POST=1 GPS_POST_ONLY=spatial timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_post.pt 2>&1 | grep -E "^loss"
-  timeout 300 python tools/probes/dp_graph_grad_diff_probe.py diff /tmp/g_plain.pt /tmp/g_post.pt 2>&1 | tail -6
+  env ${GD_ENV:-X=1} PROBE_B=${GD_B:-64} PROBE_OBJ=${GD_OBJ:-80} timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_one.pt one 2>&1 | grep -E "^loss"
+  env ${GD_ENV:-X=1} PROBE_B=${GD_B:-64} PROBE_OBJ=${GD_OBJ:-80} timeout 300 python tools/probes/dp_graph_grad_diff_probe.py run /tmp/g_dp.pt dp 2>&1 | grep -v "amdgpu.ids" | tail -12
+  timeout 300 python tools/probes/dp_graph_grad_diff_probe.py diff /tmp/g_one.pt /tmp/g_dp.pt 2>&1 | tail -8
+fi
+if [[ $WHAT == *strictalloc* ]]; then
+  ts strictalloc
+  for v in "X=1" "FUSE_POST=1"; do
+    echo "== $v"; env $v PYTORCH_NO_CUDA_MEMORY_CACHING=1 HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3 timeout 400 python tools/probes/strict_alloc_probe.py 2>&1 | grep -v "amdgpu.ids" | tail -14 | cut -c1-300
+  done
 fi

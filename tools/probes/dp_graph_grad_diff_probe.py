@@ -30,7 +30,7 @@ if os.environ.get("NO_CLS_TAIL"):
 junk = [torch.full((256, 1024, 1024), float("nan"), device=DEV) for _ in range(40)]
 del junk
 cfg = gps_pretrain_cfg(_lang_dir())
-st = GPSTrainStep(cfg, device=DEV, ddp=False, graph=sys.argv[3] if len(sys.argv) > 3 else "dp", graph_warmup=2, seed=7)
+st = GPSTrainStep(cfg, device=DEV, ddp=False, graph=("dp" if len(sys.argv) <= 3 or sys.argv[3] == "dp" else True), graph_warmup=2, seed=7)
 for m in st.model.modules():
     if isinstance(m, torch.nn.Dropout):
         m.p = 0.0
@@ -38,7 +38,9 @@ for m in st.model.modules():
         m.dropout = 0.0
     if hasattr(m, "attention_probs_dropout_prob"):
         m.attention_probs_dropout_prob = 0.0
-batches = [synth_batch(4, n_obj=16, seed=20 + i, min_real=5, device=DEV) for i in range(3)]
+BS = int(os.environ.get("PROBE_B", "4"))
+NO = int(os.environ.get("PROBE_OBJ", "16"))
+batches = [synth_batch(BS, n_obj=NO, seed=20 + i, min_real=5, device=DEV) for i in range(3)]
 for b in batches:
     total, _ = st.step(dict(b))
 torch.cuda.synchronize()
