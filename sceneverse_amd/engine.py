@@ -428,6 +428,12 @@ class GPSTrainStep:
         total, losses = self._graph_out
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
 
+    def static_inputs(self):
+        """The batch buffers the captured graph reads ({key: tensor}), or None before capture.  A loader that writes a
+        batch straight into them (gps_obj_processing_post takes an output pointer) and passes them to `step` saves the
+        per-step copy of the batch (126 MB of object points at B = 64): `_fill_static` skips identical storage."""
+        return None if self._graph is None else dict(self._static)
+
     def _fill_static(self, tensors) -> None:
         """Copy a batch into the buffers the captured graph reads.  The graph was captured for ONE set of keys,
         shapes and dtypes: anything else (a smaller last batch, a missing or extra tensor) would replay stale or
