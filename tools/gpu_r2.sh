@@ -267,3 +267,6 @@ if [[ $WHAT == *strictalloc* ]]; then
     echo "== $v"; env $v PYTORCH_NO_CUDA_MEMORY_CACHING=1 HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3 timeout 400 python tools/probes/strict_alloc_probe.py 2>&1 | grep -v "amdgpu.ids" | tail -14 | cut -c1-300
   done
 fi
+if [[ $WHAT == *gemmtable* ]]; then
+  ts gemmtable; timeout 700 python tools/gemm_bench.py --rounds 6 --json $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "gemm bench exit $?"; grep -c "^{" $OUT/gemm_bench.log
+fi
