@@ -326,3 +326,32 @@ def test_deferred_weight_gradients_equal_the_autograd_ones():
         for a, b in zip(got, want):
             assert torch.isfinite(a).all()
             assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-7, (preset, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("variant", [7, 12])
+@pytest.mark.parametrize("form", ["nt", "nn"])
+def test_device_side_row_extent_forward_and_input_gradient(form, variant):
+    """NT / NN with extent_dev: rows below the device-side count equal the full product, rows of LIVE tiles past it may
+    hold anything, tiles that lie entirely past it are never written (a NaN prefill survives there), and operand rows
+    past it may be NaN.  Variant 12 = the two-group 256 x 256 kernel (256-row tiles), 7 = the 128-row default."""
+    M, N, K = 5000, 768, 1536
+    tile = 256 if variant == 12 else 128
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    for ext in (0, 1, 255, 256, 3000, 4999, 5000):
+        rows = torch.tensor([ext], dtype=torch.int32, device=DEV)
+        xin = x.clone()
+        xin[ext:] = float("nan")
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        if form == "nt":
+            w = _rand16(N, K, scale=0.05, seed=42)
+            G.gemm(_native.GEMM_NT, _native.EPI_BIAS, M, N, K, xin, K, w, K, y, N, variant=variant, extent_dev=rows)
+            ref = x.float() @ w.float().t()
+        else:
+            w = _rand16(K, N, scale=0.05, seed=43)
+            G.gemm(_native.GEMM_NN, _native.EPI_BIAS, M, N, K, xin, K, w, N, y, N, variant=variant, extent_dev=rows)
+            ref = x.float() @ w.float()
+        if ext:
+            _close16(y[:ext], ref[:ext], f"{form} v{variant} extent {ext}")
+        first_dead = -(-ext // tile) * tile
+        assert torch.isnan(y[first_dead:].float()).all(), (form, variant, ext)

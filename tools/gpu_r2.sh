@@ -270,3 +270,6 @@ fi
 if [[ $WHAT == *gemmtable* ]]; then
   ts gemmtable; timeout 700 python tools/gemm_bench.py --rounds 6 --json $OUT/gemm_bench.json > $OUT/gemm_bench.log 2>&1; echo "gemm bench exit $?"; grep -c "^{" $OUT/gemm_bench.log
 fi
+if [[ $WHAT == *extenttest* ]]; then
+  ts extenttest; timeout 600 python -m pytest tests/test_gpu_gemm.py -m gpu -q -x -k "device_side_row_extent" 2>&1 | tail -6 | cut -c1-300
+fi
