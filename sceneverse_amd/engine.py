@@ -128,6 +128,8 @@ class GPSTrainStep:
         self.wgrad_overlap = bool(wgrad_overlap) and bool(native_gemm) and self.device.type == "cuda"
         self.frozen_unused: list = []
         self.global_step = 0
+        # diagnostics only (tools/probes): called with a stage name at the capture / replay points of the split-graph step
+        self.stage_hook = None
         if self.graph_dp and dist_utils.is_dist():
             with torch.no_grad():                      # what DDP does at construction
                 for t in list(self.model.parameters()) + list(self.model.buffers()):
@@ -183,6 +185,10 @@ class GPSTrainStep:
         buffers = [(b, b.detach().clone()) for b in self.model.buffers()]
         rng_cpu = torch.get_rng_state()
         rng_dev = torch.cuda.get_rng_state(self.device) if self.device.type == "cuda" else None
+        seed_state = None
+        if self.device.type == "cuda":                     # the device-side dropout seed block of the native kernels
+            from .modules.layers import fused_attention
+            seed_state = fused_attention.snapshot_seed_state(self.device)
         with self._autocast():
             out = self.model(dict(data_dict))
             total, _ = self.loss(out)
@@ -202,10 +208,14 @@ class GPSTrainStep:
         torch.set_rng_state(rng_cpu)                       # the probe must not shift the training RNG streams
         if rng_dev is not None:
             torch.cuda.set_rng_state(rng_dev, self.device)
+        if seed_state is not None:
+            fused_attention.restore_seed_state(self.device, seed_state)
         if self.frozen_unused and dist_utils.get_rank() == 0:
             import logging
-            logging.getLogger("sceneverse_amd").info("DDP: %d trainable tensors receive no gradient on any rank and were "
-                                                     "frozen: %s", len(self.frozen_unused), ", ".join(self.frozen_unused))
+            logging.getLogger("sceneverse_amd").warning(
+                "DDP: %d trainable tensors receive no gradient on any rank in the probe step and were FROZEN "
+                "(requires_grad=False stays on the model; pass find_unused_parameters=True for the reference's "
+                "setting): %s", len(self.frozen_unused), ", ".join(self.frozen_unused))
 
     # ---- split-graph data parallelism ------------------------------------------------------------
     def _dist_losses(self):
@@ -316,6 +326,7 @@ class GPSTrainStep:
                 self._begin_step()
                 with self._autocast():
                     out = self.net(static_dict)
+            self._stage("captured_g1", out=out)
             self._gather_features(out)
             boundary = list(getattr(self.model, "_stage_boundary", None) or [])
             segmented = bool(boundary) and bool(top) and bool(bottom) and not self.wgrad_overlap
@@ -330,11 +341,13 @@ class GPSTrainStep:
                 else:
                     self._backward(total)             # accumulates into the flat views
             torch.cuda.synchronize(self.device)
+            self._stage("captured_g2a", out=out, total=total)
             if segmented:
                 with torch.cuda.graph(g2b, pool=g1.pool(), capture_error_mode=_CAPTURE_MODE):
                     live = [t for t in boundary if t.grad is not None]
                     torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bottom)
                 torch.cuda.synchronize(self.device)
+                self._stage("captured_g2b")
             else:
                 g2b = None
             with torch.cuda.graph(g3, capture_error_mode=_CAPTURE_MODE):
@@ -345,17 +358,25 @@ class GPSTrainStep:
         g1, g2a, g2b, g3 = self._graph
         out, total, losses = self._graph_out
         g1.replay()
+        self._stage("replayed_g1")
         self._gather_features(out)
+        self._stage("replayed_gather")
         g2a.replay()
+        self._stage("replayed_g2a")
         if g2b is not None:
             h_top = self._allreduce_async(0, self._n_top)              # overlaps the bottom segment's backward
             g2b.replay()
+            self._stage("replayed_g2b")
             h_bot = self._allreduce_async(self._n_top, self._flat_grad.numel())
             self._wait_allreduce(h_top, h_bot)
         else:
             self._allreduce_grads()
         g3.replay()
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
+
+    def _stage(self, name: str, **kw) -> None:
+        if self.stage_hook is not None:
+            self.stage_hook(name, self, **kw)
 
     def _autocast(self):
         """Context of every model / loss evaluation of the step: bf16 autocast, and (train mode, native GEMMs) the

@@ -26,6 +26,7 @@ _FAST_EMB = True
 # observable changes; at the bench workload 45 % of the text rows are padding (sentence 6..50 of 50, caption 30..300
 # of 300 tokens).  Shapes stay static (the counts live on the device): the step remains one replayable HIP graph.
 _VARLEN = True
+_PREFIX_CHECKS = 4      # eager forwards per encoder whose masks are verified to be non-empty prefixes (see below)
 
 
 def set_fast_bert(flag: bool) -> None:
@@ -86,6 +87,11 @@ class BERTLanguageEncoder(nn.Module):
             from transformers import BertTokenizer
             self.tokenizer = BertTokenizer.from_pretrained(weights, do_lower_case=True)
             self.model = BertModel.from_pretrained(weights, config=self.bert_config)
+        # which formulation the most recent forward took: "varlen" | "padded" (both on libgps_hip.so) | "hf" (the
+        # HuggingFace module itself); bench.py refuses to report a number measured on a silent fallback
+        self.last_path = None
+        self._varlen_masks_ok = True
+        self._prefix_checks_left = _PREFIX_CHECKS
 
     def _fast_ok(self, txt_ids) -> bool:
         from ..layers.transformers import _bf16_mode
@@ -107,6 +113,26 @@ class BERTLanguageEncoder(nn.Module):
         return (gemm.enabled() and gemm.usable(probe, D, D) and self.bert_config.intermediate_size % 8 == 0
                 and _FAST_EMB and all(ids.dim() == 2 and ids.shape[1] <= MAX_LEN
                                       and fused_embedding.supported(self.model.embeddings, ids) for ids, _ in texts))
+
+    def _masks_are_prefixes(self, texts) -> bool:
+        """The variable-length form promises `gps_bert_position_grad` that every text's valid tokens are a non-empty
+        PREFIX of its row (position = offset inside the compacted sequence; the [CLS] row exists).  Right-padded
+        tokenizer output (the reference: BertTokenizer(..., padding='max_length')) always is.  The property is data,
+        so it is checked on the host -- one sync -- in the first `_PREFIX_CHECKS` eager forwards of an encoder (the
+        warm-up steps that precede any graph capture; never inside a capture); a batch with holes, left padding or an
+        empty text switches this encoder to the padded row batch for good, which handles any mask like HF does."""
+        if not self._varlen_masks_ok:
+            return False
+        if self._prefix_checks_left > 0 and not torch.cuda.is_current_stream_capturing():
+            self._prefix_checks_left -= 1
+            ok = torch.stack([((m[:, 1:] != 0) <= (m[:, :-1] != 0)).all() & (m[:, 0] != 0).all() for _, m in texts]).all()
+            if not bool(ok.item()):
+                import logging
+                logging.getLogger("sceneverse_amd").warning(
+                    "BERT: attention masks are not non-empty prefixes (holes / left padding / empty text): the "
+                    "variable-length path is disabled for this encoder, the padded row batch is used instead")
+                self._varlen_masks_ok = False
+        return self._varlen_masks_ok
 
     def _fast_forward_varlen(self, texts, cls_only=()):
         """The encoder stack over the VALID tokens only (see _VARLEN above).  texts = [(ids (B_i, L_i), masks), ...];
@@ -217,8 +243,10 @@ class BERTLanguageEncoder(nn.Module):
         from ..layers.fused_norm import add_dropout_layer_norm
         from . import fused_embedding
         m, H = self.model, self.bert_config.num_attention_heads
-        if _VARLEN and self._varlen_ok(texts):
+        if _VARLEN and self._varlen_ok(texts) and self._masks_are_prefixes(texts):
+            self.last_path = "varlen"
             return self._fast_forward_varlen(texts, cls_only)
+        self.last_path = "padded"
         xs, shapes, pads = [], [], []
         fused_emb = _FAST_EMB and all(fused_embedding.supported(m.embeddings, ids) for ids, _ in texts)
         embs = fused_embedding.bert_embeddings_multi(m.embeddings, [ids for ids, _ in texts]) if fused_emb else None
@@ -282,9 +310,11 @@ class BERTLanguageEncoder(nn.Module):
             # the variable-length form hands back just those rows, as a (B, 1, D) tensor
             a, b = self._fast_forward_multi([(ids_a, masks_a), (ids_b, masks_b)], cls_only=(1,) if cls_second else ())
             return a, b
+        self.last_path = "hf"
         return self.forward(ids_a, masks_a), self.forward(ids_b, masks_b)
 
     def forward(self, txt_ids, txt_masks, **kwargs):
         if self._fast_ok(txt_ids):
             return self._fast_forward(txt_ids, txt_masks)
+        self.last_path = "hf"
         return self.model(txt_ids, txt_masks).last_hidden_state

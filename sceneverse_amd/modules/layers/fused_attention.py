@@ -357,5 +357,28 @@ def begin_step(device) -> None:
     _stream_for(device).begin_step()
 
 
+def snapshot_seed_state(device):
+    """(block values, position) of the device's dropout seed stream, or None before its first use."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = _SEED_STATE.get(device)
+    return None if st is None else (st.block.clone(), st.pos)
+
+
+def restore_seed_state(device, state) -> None:
+    """Put the stream back where `snapshot_seed_state` saw it (a probe step must leave no trace in the training
+    streams).  A stream that did not exist at the snapshot is dropped, so that its first real use re-creates it."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if state is None:
+        _SEED_STATE.pop(device, None)
+        return
+    st = _stream_for(device)
+    st.block = state[0].clone()
+    st.pos = state[1]
+
+
 def _next_device_seed(device: torch.device) -> torch.Tensor:
     return _stream_for(device).next()

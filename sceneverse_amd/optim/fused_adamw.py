@@ -87,14 +87,15 @@ class GpsAdamW(torch.optim.Optimizer):
         return self._scalars[1]
 
     def load_state_dict(self, state_dict):
+        # checked BEFORE anything is touched: a failed load must not leave a half-loaded optimizer behind
+        if self._keep:
+            raise RuntimeError("GpsAdamW.load_state_dict after a HIP-graph capture: the captured tables point at the old "
+                               "learning-rate / state words -- load the checkpoint before the first captured step")
         super().load_state_dict(state_dict)
         for p, st in self.state.items():
             if "step" in st:
                 self._steps[self._slot[id(p)]] = float(st["step"])
                 st["step"] = self._steps[self._slot[id(p)]]
-        if self._keep:
-            raise RuntimeError("GpsAdamW.load_state_dict after a HIP-graph capture: the captured tables point at the old "
-                               "learning-rate / state words -- load the checkpoint before the first captured step")
         for g in self.param_groups:
             # a checkpoint loaded with map_location='cpu' carries lr as a CPU tensor: the kernel dereferences the
             # word on the device, so it must live there (fp32, 0-dim)

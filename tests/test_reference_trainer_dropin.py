@@ -11,7 +11,8 @@ DataLoader construction) is the reference's.  A synthetic dataset is registered 
 Checked: the reference trainer runs its steps on our model classes, and the total loss it logs at every step equals
 what `sceneverse_amd.engine.GPSTrainStep` computes from the same initial weights on the same batches (dropout
 probabilities zeroed on both sides so that the comparison is deterministic).  CPU variant: point ops on the CPU oracle
-(tests only); `-m gpu` variant: libgps_hip.so.  Skipped where /root/reference does not exist (the GPU box).
+(tests only); `-m gpu` variant: libgps_hip.so.  Where /root/reference does not exist (the GPU box) the same files are imported
+from oracle/_ref/ref_python.zip (oracle/stage_ref_python.py; git-ignored, travels like oracle/_ref/*.so).
 """
 import builtins
 import copy
@@ -25,11 +26,18 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-REF = "/root/reference"
 STUBS = os.path.join(HERE, "golden", "ref_stubs")
+# the reference's packages: the tree itself in the build container; on the GPU box (no /root/reference) the archive
+# oracle/stage_ref_python.py packed from it -- the same files, byte for byte, imported through zipimport
+_REF_DIR = "/root/reference"
+_REF_ZIP = os.path.join(ROOT, "oracle", "_ref", "ref_python.zip")
+if os.path.isdir(os.path.join(_REF_DIR, "trainer")) and os.environ.get("GPS_REF_FROM_ZIP") != "1":
+    REF = _REF_DIR
+else:
+    REF = _REF_ZIP
 
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "trainer")),
-                                reason="/root/reference is only present in the build container")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF),
+                                reason="neither /root/reference nor oracle/_ref/ref_python.zip (python oracle/stage_ref_python.py) exists")
 
 N_SCENES, BATCH, N_OBJ = 4, 2, 6
 
@@ -50,7 +58,8 @@ def _shadow_and_import():
         au.DistributedType.TPU = au.DistributedType.XLA
     import trainer.build as tb                           # the reference's files, unmodified
     import trainer.default_trainer as dt
-    assert os.path.realpath(dt.__file__).startswith(REF) and os.path.realpath(tb.__file__).startswith(REF)
+    assert os.path.realpath(dt.__file__).startswith(os.path.realpath(REF)), dt.__file__
+    assert os.path.realpath(tb.__file__).startswith(os.path.realpath(REF)), tb.__file__
     import data.build as db
     import evaluator  # noqa: F401  registers PretrainEval
     return tb, dt, db
