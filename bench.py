@@ -416,6 +416,12 @@ def main() -> None:
     ap.add_argument("--detail", default=None, help="where the per-kernel detail JSON goes (default gpurun_out/bench_detail.json)")
     ap.add_argument("--fp8", action="store_true",
                     help="attention-core products (QK^T, PV) on the OCP e4m3 MFMA path (BASELINE configs[4]: --config stress --fp8)")
+    ap.add_argument("--no-wgrad-group", action="store_true",
+                    help="weight gradients one split-K GEMM at a time instead of one grouped launch per backward segment "
+                         "(A/B of modules/layers/gemm.grouped_wgrads)")
+    ap.add_argument("--eager-ddp", action="store_true",
+                    help="N > 1: torch DDP in eager mode (bucketed all-reduce from autograd hooks) instead of the "
+                         "split-graph data-parallel step")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the reporting-only passes after the timed region (profiler, unfused point-op timing)")
     args = ap.parse_args()
@@ -446,6 +452,9 @@ def main() -> None:
     if args.no_varlen:
         from sceneverse_amd.modules.language import bert as _bert
         _bert.set_varlen(False)
+    # a shape the fused attention core stops supporting must FAIL the run, not fall back to torch ops silently
+    from sceneverse_amd.modules.layers import transformers as _tf
+    _tf.set_attention_backend("hip")
     if args.fp8:
         # BASELINE configs[4]: Q K^T and P V of every bf16 attention call on the OCP e4m3 MFMA (forward)
         from sceneverse_amd.modules.layers import fused_attention as _fa
@@ -462,14 +471,14 @@ def main() -> None:
     torch.cuda.set_device(dev)
 
     cfg = gps_pretrain_cfg(_lang_dir(), num_gpu=world, workload=args.config)
-    # One GPU: the whole step as one HIP graph (19.3 ms).  N > 1: torch DDP in eager mode (20.6 ms on one GPU):
-    # DDP overlaps the gradient all-reduce (246 MB as bf16) with backward, which the split-graph form
-    # (--graph-dp: 3 graphs around eager RCCL collectives, 20.1 ms + an exposed 491 MB fp32 all-reduce) cannot.
-    use_graph = (world == 1 and not args.no_graph) or args.graph_dp
+    # One GPU: the whole step as one HIP graph.  N > 1 [r4]: the split-graph data-parallel step (forward | losses + top
+    # backward | bottom backward | clip + AdamW as HIP graphs around the eager RCCL all-gather and the two all-reduces);
+    # --eager-ddp keeps torch DDP in eager mode (~1 200 launches per step from Python) for A/B.
+    use_graph = not args.no_graph and not (world > 1 and args.eager_ddp)
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
                         graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm,
                         grad_compress=("bf16_fp32acc" if (world > 1 and not share and args.bf16_grads) else None),
-                        wgrad_overlap=args.wgrad_overlap)
+                        wgrad_overlap=args.wgrad_overlap, wgrad_group=not args.no_wgrad_group)
     use_graph = step.graph or step.graph_dp
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank,
                         device=dev)
@@ -491,6 +500,8 @@ def main() -> None:
         graph_note = ("whole step replayed as one HIP graph" if step.graph else
                       "4 HIP graphs per step (forward | losses + top backward | bottom backward | clip+AdamW) around "
                       "the eager RCCL all-gather and two all-reduces")
+        if step.wgrad_group:
+            graph_note += "; weight gradients of a backward segment in one grouped launch"
     if use_graph and step.static_inputs() is not None:
         # the batch lives in the graph's own input buffers from here on (what a loader writing into them would hand
         # over): no per-step copy of the 126 MB of object points into the static buffers
@@ -498,6 +509,11 @@ def main() -> None:
         for k, v in static.items():
             v.copy_(batch[k])
         batch = {**batch, **static}
+    lang = getattr(step.model, "lang_encoder", None)
+    want_path = "padded" if args.no_varlen else "varlen"
+    if lang is not None and hasattr(lang, "last_path") and not args.fp32 and lang.last_path != want_path:
+        raise SystemExit(f"bench: the text encoder ran its '{lang.last_path}' formulation, expected '{want_path}' "
+                         f"(libgps_hip.so fast path): refusing to report a number measured on a fallback")
     for _ in range(args.warmup):
         step.step(dict(batch))
     barrier()
@@ -506,6 +522,30 @@ def main() -> None:
         loss, _ = step.step(dict(batch))
     barrier()
     dt = time.perf_counter() - t0
+    # The same step with EVERY sentence at 50 and every caption at 300 tokens (no padded text rows at all): what the
+    # variable-length text path gains depends on the caption-length distribution of the synthetic batch (U{30..300}),
+    # so the fully-populated figure is measured beside `value`, same process, same graphs (the row counts live on the
+    # device), W warm-up + K timed steps.
+    dt_full = None
+    if preset["scene_cap"] and not args.no_extras:
+        full = dict(batch)
+        g = torch.Generator(device="cpu").manual_seed(4242 + rank)
+        for ids_k, mask_k in (("txt_ids", "txt_masks"), ("scene_txt_ids", "scene_txt_masks")):
+            ids = batch[ids_k].clone()
+            mk = batch[mask_k]
+            fill = torch.randint(1000, 30522, ids.shape, generator=g).to(ids.device)
+            ids = torch.where(mk != 0, ids, fill)                # padding positions become ordinary tokens
+            ids[:, -1] = 102                                     # [SEP]
+            full[ids_k], full[mask_k] = ids, torch.ones_like(mk)
+        for _ in range(max(1, args.warmup)):
+            step.step(dict(full))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step.step(dict(full))
+        barrier()
+        dt_full = time.perf_counter() - t1
+        step.step(dict(batch))              # back on the measured batch (static buffers refilled)
     # Per-launch durations (HIP events around every native call) are taken from three EXTRA eager steps of the same
     # workload right after the timed region, on every rank (the steps contain the data-parallel collectives): a
     # replayed graph cannot host event pairs, and in the eager modes the ~1 200 event records per step would sit on
@@ -522,10 +562,11 @@ def main() -> None:
     kern = hip_ext.profile_stop()
     for k in kern.values():
         k["launches"] = k["launches"] * args.steps / 3.0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt, dt_full or 0.0], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = float(t[0].item())
+    dt_full = float(t[1].item()) if dt_full is not None else None
     final_loss = float(loss)
     step_kernels, bqg, eval_metrics = [], None, None
     if args.config == "finetune":
@@ -712,6 +753,8 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
+            **({"value_full_length_text": round(args.batch * world * args.steps / dt_full, 2),
+                "ms_per_step_full_length_text": round(1e3 * dt_full / args.steps, 3)} if dt_full else {}),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -727,6 +770,9 @@ def main() -> None:
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
                        "text_rows": "padded (B, L) batch" if args.no_varlen else "valid tokens only (variable-length BERT path)",
+                       **({"sentence_len": f"U{{6..{preset['txt_len']}}}", "caption_len": "U{30..300}" if preset["scene_cap"] else None,
+                           "text_live_row_fraction": round(float(sum(batch[k].float().sum().item() for k in batch if k.endswith("txt_masks")))
+                                                           / max(1.0, float(sum(batch[k].numel() for k in batch if k.endswith("txt_masks")))), 4)}),
                        "launch": (graph_note or "eager") + ("; weight-gradient GEMMs on a second stream" if step.wgrad_overlap else ""),
                        **({"grad_exchange": "fp32 all-reduce of the top / bottom segment of one flat buffer, the first beside "
                                             "the bottom backward graph" if step.graph_dp
@@ -738,6 +784,9 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "pretrain":
             result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.n_obj, args.n_pts)
+            # the CPU leg runs HF BERT on every row of the padded (B, L) batch: its like-for-like GPU figure is
+            # value_full_length_text (no padded rows to skip), not `value`
+            result["cpu_baseline"]["text_rows"] = "padded (B, L) batch; compare with value_full_length_text"
         detail = dict(result)
         detail["config"] = dict(result["config"],
                                 point_ops="fp32-accurate split-bf16 MFMA (libgps_hip.so)",

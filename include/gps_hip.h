@@ -513,6 +513,28 @@ typedef struct gps_gemm_args {
 } gps_gemm_args;
 GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
 GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
+/* Grouped weight gradients: for every problem p,  C_p (M,N) fp32 [+]= A_p (K,M)^T . B_p (K,N)  and, when colsum_p is not
+ * NULL, colsum_p (M) [+]= column sums of A_p over K -- the weight and bias gradient of one nn.Linear (A = dY, B = X, bf16,
+ * both reduction-major as in form GPS_GEMM_TN) -- for ALL problems in one persistent launch, each 256 x 256 output tile
+ * walked over its whole reduction by one workgroup: no split over K, no partial tiles, no reduce launch.  Meant for the
+ * weight gradients of a whole backward pass, deferred by the host and issued together (their reductions over 5 000 -
+ * 22 000 token rows cannot fill the chip one GEMM at a time without splitting).  accumulate != 0: read-modify-write
+ * (the destination already holds a gradient); every output element has one writer, results are deterministic.
+ * extent_dev: as in gps_gemm_args (the reduction stops after the first *extent_dev rows).  Requirements as form TN:
+ * M, N, lda, ldb multiples of 8, ldc of 4, 16-byte aligned A, B, C, K * ld* * 2 < 2^31.  The problem array is host
+ * memory and is consumed before the call returns (capturable: the table travels as kernel arguments). */
+typedef struct gps_wgrad_problem {
+  int M, N, K, accumulate;
+  const void *A;
+  long long lda;
+  const void *B;
+  long long ldb;
+  float *C;
+  long long ldc;
+  float *colsum;
+  const int *extent_dev;
+} gps_wgrad_problem;
+GPS_API int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gps_stream_t stream);
 /* First operand of a split-bf16 MLP chain over a group-all point level (reference: GroupAll in
  * modules/third_party/pointnet2/pointnet2_utils.py -- cat of the grouped xyz and features): row (b, j) =
  * [xyz (b, n, 3)[b][j] | feats (b, c, n)[b][:, j]] as bf16 [hi | lo | hi], each third k_pad >= 3 + c columns wide

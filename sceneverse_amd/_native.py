@@ -36,6 +36,13 @@ class GemmArgs(ctypes.Structure):
                 ("p_drop", _f), ("reserved2", _i), ("extent_dev", _vp)]
 
 
+class WgradProblem(ctypes.Structure):
+    """struct gps_wgrad_problem of include/gps_hip.h, field for field."""
+    _fields_ = [("M", _i), ("N", _i), ("K", _i), ("accumulate", _i),
+                ("A", _vp), ("lda", ctypes.c_longlong), ("B", _vp), ("ldb", ctypes.c_longlong),
+                ("C", _vp), ("ldc", ctypes.c_longlong), ("colsum", _vp), ("extent_dev", _vp)]
+
+
 class AttnArgs(ctypes.Structure):
     """struct gps_attn_args of include/gps_hip.h, field for field."""
     _fields_ = [("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("head_dim", _i), ("dtype", _i), ("compute", _i),
@@ -59,6 +66,7 @@ SIGNATURES = {
     "gps_adamw_step": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "gps_gemm_pick_splits": [_i, _i, _i, _i],
     "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
+    "gps_gemm_wgrad_grouped": [ctypes.POINTER(WgradProblem), _i, _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -74,6 +74,7 @@ struct Params {
   unsigned long long seed;
   const unsigned long long *seed_dev;
   const int *extent_dev;   // optional device count of leading token rows that carry work (rows of M for NT / NN, of K for TN)
+  int accumulate;          // EPI_F32, splits == 1: C += acc, colsum += column sums (grouped weight gradients into live .grad buffers)
 };
 
 __device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even (finite inputs)
@@ -375,15 +376,22 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   if (EPI == EPI_F32) {
     float *out = (P.splits > 1) ? P.partial + (size_t)split * P.M * P.N : reinterpret_cast<float *>(P.C);
     const long long ldo = (P.splits > 1) ? (long long)P.N : P.ldc;
+    const bool accum = P.accumulate && P.splits == 1;           // partial tiles are always plain stores
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int m = m0 + wm0 + 16 * a + i;
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int n = n0 + wn0 + 16 * b + 4 * g;
-        if (m < P.M && n < P.N) *reinterpret_cast<f32x4 *>(out + (size_t)m * ldo + n) = acc[a][b];
+        if (m < P.M && n < P.N) {
+          f32x4 *dst = reinterpret_cast<f32x4 *>(out + (size_t)m * ldo + n);
+          *dst = accum ? *dst + acc[a][b] : acc[a][b];
+        }
       }
-      if (do_colsum && g == 0 && m < P.M) P.colsum[(size_t)split * P.M + m] = csum[a][0];
+      if (do_colsum && g == 0 && m < P.M) {
+        float *cs = P.colsum + (size_t)split * P.M + m;
+        *cs = accum ? *cs + csum[a][0] : csum[a][0];
+      }
     }
     return;
   }
@@ -829,16 +837,18 @@ int launch_256(Params &P, hipStream_t s) {
 // second one (for group 0: after group 1's wait as well, because group 1's first barrier of a phase IS group 0's second).
 // Forms NT / NN; K a multiple of 64; no split-K.
 // ---------------------------------------------------------------------------------------------------------
+// one 256 x 256 output tile at (m0, n0): K tiles kt0 .. kt0 + nst - 1 of the reduction (k_eff = reduction indices that
+// carry work), partial index `split`; tile_n == 0 computes the column sums of the TN form
+template <bool ATR, bool BTR, int EPI>
+__device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem, int lane, int wave, int m0, int n0,
+                                            int tile_n, int split, int kt0, int nst, int k_eff);
+
 template <bool ATR, bool BTR, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Params P) {
-  constexpr int HALF = 128 * BK * 2, BUF = 4 * HALF;
-  constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
-  constexpr bool COLSUM = EPI == EPI_F32 && ATR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * BUF = 128 KB
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
   const int GM = P.gm;
   int ntm = P.ntm;
   if (!ATR && P.extent_dev) ntm = min(P.ntm, max(0, (*P.extent_dev + 255) / 256));   // live tile rows only (see gemm_kernel)
@@ -864,6 +874,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Params P) {
     kt0 = split * per;
     nst = max(0, min(nkt_eff, kt0 + per) - kt0);
   }
+  gemm8p_tile<ATR, BTR, EPI>(P, smem, lane, wave, m0, n0, tile_n, split, kt0, nst, k_eff);
+}
+
+template <bool ATR, bool BTR, int EPI>
+__device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem, int lane, int wave, int m0, int n0,
+                                            int tile_n, int split, int kt0, int nst, int k_eff) {
+  constexpr int HALF = 128 * BK * 2, BUF = 4 * HALF;
+  constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+  constexpr bool COLSUM = EPI == EPI_F32 && ATR;
+  const int wr = wave >> 2, wc = wave & 3;
   const int k_span = k_eff - kt0 * BK;                      // reduction indices from this workgroup's first K tile on
 
   Stager<128, ATR, 8> sa0, sa1;
@@ -1026,7 +1046,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Params P) {
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         const int m = m0 + 128 * (a >> 2) + 64 * wr + 16 * (a & 3) + (lane & 15);
-        if (lane < 16 && m < P.M) P.colsum[(size_t)split * P.M + m] = v;
+        if (lane < 16 && m < P.M) {
+          float *cs = P.colsum + (size_t)split * P.M + m;
+          *cs = (P.accumulate && P.splits == 1) ? *cs + v : v;
+        }
       }
     }
   }
@@ -1053,6 +1076,81 @@ int launch_8p(Params &P, hipStream_t s) {
   if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS, s, P);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: MANY dW_p (M_p x N_p) [+]= dY_p^T X_p in ONE launch, no split over K.
+//
+// A single weight gradient of this model has a few dozen output tiles and a reduction over 5 000 - 22 000 token rows:
+// to fill 256 CUs it must be split over K, and every split dumps its fp32 accumulators (one 256 x 256 or two 128 x 128
+// tiles per CU = 33 MB per GEMM, written and read again by splitk_reduce_kernel) -- for the 768 x 768 ... 768 x 2 376
+// gradients of the object / joint layers that round trip costs as much as their MFMAs.  The gradients of a backward pass
+// are independent of each other and of the input-gradient chain, so the host defers them (modules/layers/gemm.py
+// grouped_wgrads) and issues them together: ~1 100 tiles of 256 x 256 at the bench workload, each walked over its WHOLE
+// reduction by one workgroup with gemm8p_tile -- the long-K regime where that schedule runs at library speed -- and
+// written once, straight into the parameter's .grad (plain store, or read-modify-write when the buffer already holds
+// a gradient: the flat buffer of the data-parallel step).  Deterministic: every output element has exactly one writer
+// and one summation order.
+//
+// Tiles are enumerated problem by problem in the order given (the host sorts by decreasing reduction length) and dealt
+// round-robin to min(tiles, CUs) persistent workgroups, alternate rounds in reverse (longest-first + snake = every
+// workgroup gets one tile of each cost class); inside a round the workgroups of an XCD take consecutive tiles (tiles of
+// one output row share their dY panel in that XCD's L2).  The problem table lives in device memory (written by
+// wgrad_table_write_kernel from kernel arguments, 32 records per launch: capturable, no host buffer to keep alive).
+// ---------------------------------------------------------------------------------------------------------
+struct WgradRec {          // 64 bytes
+  const uint16_t *A, *B;
+  float *C, *colsum;
+  const int *extent;
+  int lda, ldb, ldc, M, N, K;
+  int tile0;               // id of this problem's first tile
+  int flags;               // bit 0: accumulate
+};
+constexpr int kWgradMaxProblems = 256, kWgradSlots = 4, kWgradChunk = 32;
+__device__ WgradRec g_wgrad_table[kWgradSlots][kWgradMaxProblems];
+struct WgradChunkArgs { WgradRec r[kWgradChunk]; };
+
+__global__ __launch_bounds__(64) void wgrad_table_write_kernel(const WgradChunkArgs c, int slot, int offset, int count) {
+  if ((int)threadIdx.x < count) g_wgrad_table[slot][offset + threadIdx.x] = c.r[threadIdx.x];
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_problems, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 128 KB (gemm8p_tile)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const WgradRec *tab = g_wgrad_table[slot];
+  const int G = (int)gridDim.x;
+  const int vw = xcd_virtual_id(blockIdx.x, G);
+  int p = 0;
+  for (int r = 0;; ++r) {
+    const int t = r * G + ((r & 1) ? G - 1 - vw : vw);
+    if (t >= total_tiles) break;                            // (the rounds after a partial one are empty for everybody)
+    if (r & 1) p = 0;                                       // tile ids are not monotonic across a reversed round
+    while (p + 1 < n_problems && tab[p + 1].tile0 <= t) ++p;
+    const WgradRec rec = tab[p];
+    Params P = {};
+    P.M = rec.M; P.N = rec.N; P.K = rec.K;
+    P.A = rec.A; P.lda = rec.lda;
+    P.B = rec.B; P.ldb = rec.ldb;
+    P.C = rec.C; P.ldc = rec.ldc;
+    P.colsum = rec.colsum;
+    P.splits = 1;
+    P.accumulate = rec.flags & 1;
+    int k_eff = rec.K;
+    if (rec.extent) k_eff = min(rec.K, max(*rec.extent, 0));
+    const int ntn = (rec.N + 255) >> 8;
+    const int lt = t - rec.tile0;
+    // (integer division runs on the vector ALU: back to scalar registers, the tile code branches on these)
+    const int tile_m = __builtin_amdgcn_readfirstlane(lt / ntn);
+    const int tile_n = lt - tile_m * ntn;
+    k_eff = __builtin_amdgcn_readfirstlane(k_eff);
+    const int nst = (k_eff + BK - 1) / BK;
+    // every scalar load of the record has landed before the tile starts: the tile's counted lgkmcnt waits must only
+    // ever see its own LDS traffic
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gemm8p_tile<true, true, EPI_F32>(P, smem, lane, wave, tile_m * 256, tile_n * 256, tile_n, 0, 0, nst, k_eff);
+    __syncthreads();                                        // the next tile's first copies overwrite the stage buffers
+  }
 }
 
 // out[e] = sum over splits of partial[s][e] in split order (deterministic); the same for the column sums
@@ -1272,6 +1370,79 @@ int gps_split3_points(int b, int n, int c, const float *xyz, const float *feats,
   hipLaunchKernelGGL(gps_gemm::split3_points_kernel, dim3(b), dim3(256), lds, (hipStream_t)stream, n, c, xyz, feats, k_pad,
                      (uint16_t *)out);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gps_stream_t stream) {
+  using namespace gps_gemm;
+  if (n_problems < 0 || (n_problems > 0 && !problems)) return GPS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int LDS = 2 * 4 * 128 * BK * 2;
+  static bool attr_done = false;
+  static int n_cu = 0;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return GPS_ERR_LAUNCH;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GPS_ERR_LAUNCH;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    attr_done = true;
+  }
+  // validate everything before the first launch (requirements of the TN form of gps_gemm_bf16)
+  int live = 0;
+  for (int i = 0; i < n_problems; ++i) {
+    const gps_wgrad_problem &q = problems[i];
+    if (q.M < 0 || q.N < 0 || q.K < 0) return GPS_ERR_INVALID_ARGUMENT;
+    if (q.M == 0 || q.N == 0) continue;
+    if (!q.A || !q.B || !q.C) return GPS_ERR_INVALID_ARGUMENT;
+    if ((q.lda & 7) || (q.ldb & 7) || (q.ldc & 3) || (q.M & 7) || (q.N & 7)) return GPS_ERR_UNSUPPORTED;
+    if (((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15) || ((uintptr_t)q.C & 15)) return GPS_ERR_UNSUPPORTED;
+    if ((long long)q.K * q.lda * 2 >= 0x7FFFFFFFLL || (long long)q.K * q.ldb * 2 >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+    if (q.lda >= 0x7FFFFFFFLL || q.ldb >= 0x7FFFFFFFLL || q.ldc >= 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+    ++live;
+  }
+  if (live == 0) return GPS_OK;
+  // longest reductions first (stable): with the snake deal of wgrad_grouped_kernel every workgroup gets one tile of each cost class
+  int order[kWgradMaxProblems];
+  static unsigned int slot_counter = 0;
+  for (int base = 0; base < n_problems;) {
+    int cnt = 0, end = base;
+    while (end < n_problems && cnt < kWgradMaxProblems) {
+      if (problems[end].M > 0 && problems[end].N > 0) order[cnt++] = end;
+      ++end;
+    }
+    base = end;
+    if (cnt == 0) break;
+    for (int i = 1; i < cnt; ++i) {                           // insertion sort by K descending (cnt <= 256)
+      const int v = order[i];
+      int j = i - 1;
+      while (j >= 0 && problems[order[j]].K < problems[v].K) { order[j + 1] = order[j]; --j; }
+      order[j + 1] = v;
+    }
+    const int slot = (int)(slot_counter++ % kWgradSlots);
+    long long tile0 = 0;
+    for (int c0 = 0; c0 < cnt; c0 += kWgradChunk) {
+      WgradChunkArgs args = {};
+      const int n = cnt - c0 < kWgradChunk ? cnt - c0 : kWgradChunk;
+      for (int i = 0; i < n; ++i) {
+        const gps_wgrad_problem &q = problems[order[c0 + i]];
+        WgradRec &r = args.r[i];
+        r.A = (const uint16_t *)q.A; r.B = (const uint16_t *)q.B; r.C = q.C; r.colsum = q.colsum; r.extent = q.extent_dev;
+        r.lda = (int)q.lda; r.ldb = (int)q.ldb; r.ldc = (int)q.ldc; r.M = q.M; r.N = q.N; r.K = q.K;
+        r.tile0 = (int)tile0;
+        r.flags = q.accumulate ? 1 : 0;
+        tile0 += (long long)((q.M + 255) / 256) * ((q.N + 255) / 256);
+        if (tile0 > 0x3FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+      }
+      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, args, slot, c0, n);
+      if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
+    }
+    const int total = (int)tile0;
+    const int grid = total < n_cu ? total : n_cu;
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)grid), dim3(512), LDS, s, slot, cnt, total);
+    if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
+  }
+  return GPS_OK;
 }
 
 int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {

@@ -21,6 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "gps_hip.h"
 
@@ -285,7 +288,27 @@ __global__ __launch_bounds__(kBlock) void gather_points_grad_kernel(
 // soon as nsample hits are found, so the output equals the reference's serial scan.
 // ------------------------------------------------------------------------------------------
 constexpr int kCentresPerLoad = 21;   // 63 lanes = 21 centres x 3 coordinates
-template <int R>  // R > 0: register-resident cloud of <= 64*R points; R == 0: streamed
+// compile-time loop (the block schedule below indexes registers with its counter)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// Block schedule of the register-resident scan (R % 8 == 0): the chunks of a cloud are tested in blocks, the scan of a
+// centre ends at the first block boundary where nsample hits exist.  A block costs ~10 vector instructions per chunk
+// whether or not its hits are needed, so short first blocks pay when many scans end early (padding objects: every
+// point is a hit; dense clouds: 32 hits inside the first 100 - 300 points) and long ones when the whole cloud is
+// walked (one scalar decision per block).  S = (A, B, C, REST): blocks of A, B, C chunks (0 = absent), then blocks of
+// REST chunks to the end of the cloud.  All even (registers hold PAIRS of chunks) and <= 8 (overshoot area of a row).
+template <int A_, int B_, int C_, int REST_>
+struct BqSched {
+  static constexpr int A = A_, B = B_, C = C_, REST = REST_;
+  static_assert(A % 2 == 0 && B % 2 == 0 && C % 2 == 0 && REST % 2 == 0 && REST >= 2, "blocks are whole chunk pairs");
+  static_assert(A <= 8 && B <= 8 && C <= 8 && REST <= 8, "a block may overshoot nsample by < 512 slots");
+};
+template <int R, typename S = BqSched<8, 0, 0, 8>>  // R > 0: register-resident cloud of <= 64*R points; R == 0: streamed
 __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m, float radius,
                                                              int nsample,
                                                              const float *__restrict__ new_xyz,
@@ -355,20 +378,21 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
       const float c2 = __int_as_float(__builtin_amdgcn_readlane(cv, 3 * jj + 2));
       const f2 cx = {c0, c0}, cy = {c1, c1}, cz = {c2, c2};
       int cnt = 0;                                                          // wave-uniform (SGPR)
-      if (R % 8 == 0) {
+      if constexpr (R >= 8 && R % 8 == 0) {
         // [r3] blocks of 8 chunks (512 points): ALL eight radius tests first (pure VALU throughput: 4 packed
         // distance evaluations + 8 compares, their 64-bit masks land in SGPR pairs), then ONE scalar prefix over the
         // eight popcounts, then the compaction of the chunks that have hits and still start below nsample.  The
         // scalar unit is consulted once per block instead of once per chunk pair: the compare -> popcount -> add ->
         // branch chain that bounded the previous form (57 us, VALU active 40 %) is off the critical path.
+        // one block of NB chunks starting at chunk C0 (both compile-time: they index the register file)
+        auto scan = [&](auto c0_, auto nb_) {
+          constexpr int C0 = decltype(c0_)::value, NB = decltype(nb_)::value;
+          if (cnt < nsample && C0 < nchunks) {
+            unsigned long long mk[NB];
+            bool hit[NB];                                                   // a lane's own bit of mk[i]: the same SGPR pair
 #pragma unroll
-        for (int blk = 0; blk < R / 8; ++blk) {
-          if (cnt < nsample && 8 * blk < nchunks) {
-            unsigned long long mk[8];
-            bool hit[8];                                                    // a lane's own bit of mk[i]: the same SGPR pair
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const f2 dx = cx - px[4 * blk + i], dy = cy - py[4 * blk + i], dz = cz - pz[4 * blk + i];
+            for (int i = 0; i < NB / 2; ++i) {
+              const f2 dx = cx - px[C0 / 2 + i], dy = cy - py[C0 / 2 + i], dz = cz - pz[C0 / 2 + i];
               const f2 d2 = (dx * dx + dy * dy) + dz * dz;
               hit[2 * i] = d2.x < radius2;
               hit[2 * i + 1] = d2.y < radius2;
@@ -382,20 +406,30 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
             // store address is SELECTED by the lane's hit bit (hit -> row[slot], miss -> a private dummy word), no
             // exec masking, no branch; the scalar unit only keeps the running count (popcount + add per chunk) and
             // takes one decision per block.  Slots past nsample land in the overshoot area of the row and are ignored.
-            int base[9];
+            int base[NB + 1];
             base[0] = cnt;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) base[i + 1] = base[i] + __popcll(mk[i]);
+            for (int i = 0; i < NB; ++i) base[i + 1] = base[i] + __popcll(mk[i]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NB; ++i) {
+              // (a hand-written v_mbcnt / v_lshl_add / v_cndmask / ds_write sequence -- 4 vector + 3 scalar instructions
+              // per chunk instead of the compiler's exec-masked 5 + 4 -- measured no faster: 56.9 vs 56.6 us, r4h)
               const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[i] >> 32),
                                                               __builtin_amdgcn_mbcnt_lo((unsigned)mk[i], (unsigned)base[i]));
               const int at = hit[i] ? slot : dummy_at;                      // v_cndmask on the compare's own SGPR pair
-              wrow[at] = (8 * blk + i) * kWave + L;
+              wrow[at] = (C0 + i) * kWave + L;
             }
-            cnt = base[8];
+            cnt = base[NB];
           }
-        }
+        };
+        constexpr int HEAD = S::A + S::B + S::C;
+        static_assert(HEAD <= R && (R - HEAD) % S::REST == 0, "the schedule must tile the R chunks");
+        if constexpr (S::A > 0) scan(std::integral_constant<int, 0>{}, std::integral_constant<int, S::A>{});
+        if constexpr (S::B > 0) scan(std::integral_constant<int, S::A>{}, std::integral_constant<int, S::B>{});
+        if constexpr (S::C > 0) scan(std::integral_constant<int, S::A + S::B>{}, std::integral_constant<int, S::C>{});
+        static_for<0, (R - HEAD) / S::REST>([&](auto k) {
+          scan(std::integral_constant<int, HEAD + decltype(k)::value * S::REST>{}, std::integral_constant<int, S::REST>{});
+        });
       } else {
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
@@ -921,6 +955,8 @@ int gps_gather_points_grad(int b, int c, int n, int npoints, const float *grad_o
   return finish_launch();
 }
 
+constexpr int kBqDefaultSched = 2;   // index into the GPS_BQ_SCHEDS table below: blocks of 2, 6, 8 chunks (53.1 vs 56.6 us, r4f)
+
 int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                    const float *xyz, int32_t *idx, gps_stream_t stream) {
   if (b < 0 || n < 0 || m < 0 || nsample < 0) return GPS_ERR_INVALID_ARGUMENT;
@@ -935,16 +971,37 @@ int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *
 #define GPS_BQ_CASE(R_)                                                                         \
   hipLaunchKernelGGL(gps::ball_query_kernel<R_>, grid, block, lds, s, b, n, m, radius, nsample, \
                      new_xyz, xyz, idx)
+  // block schedule of the register-resident scan for 1024 / 2048-point clouds (gps::BqSched); GPS_BQ_SCHED selects one
+  // of the compiled alternatives for tuning runs (tools/kernel_bench.py), the default is the measured best
+#define GPS_BQ_SCHED_CASE(R_, A_, B_, C_, REST_)                                                                          \
+  hipLaunchKernelGGL((gps::ball_query_kernel<R_, gps::BqSched<A_, B_, C_, REST_>>), grid, block, lds, s, b, n, m, radius, \
+                     nsample, new_xyz, xyz, idx)
+#define GPS_BQ_SCHEDS(R_)                                        \
+  switch (sched) {                                               \
+    case 1: GPS_BQ_SCHED_CASE(R_, 4, 4, 0, 8); break;            \
+    case 2: GPS_BQ_SCHED_CASE(R_, 2, 6, 0, 8); break;            \
+    case 3: GPS_BQ_SCHED_CASE(R_, 4, 4, 0, 4); break;            \
+    case 4: GPS_BQ_SCHED_CASE(R_, 2, 2, 4, 8); break;            \
+    case 5: GPS_BQ_SCHED_CASE(R_, 2, 2, 4, 4); break;            \
+    case 6: GPS_BQ_SCHED_CASE(R_, 2, 6, 0, 4); break;            \
+    default: GPS_BQ_SCHED_CASE(R_, 8, 0, 0, 8); break;           \
+  }
+  static const int sched = [] {
+    const char *e = getenv("GPS_BQ_SCHED");
+    return e ? atoi(e) : kBqDefaultSched;
+  }();
   if (need <= 1) {
     hipLaunchKernelGGL(gps::ball_query_small_kernel, dim3((b + gps::kWavesPerBlock - 1) / gps::kWavesPerBlock), block, 0, s, b, n,
                        m, radius, nsample, new_xyz, xyz, idx);
   } else if (need <= 2) GPS_BQ_CASE(2);
   else if (need <= 4) GPS_BQ_CASE(4);
   else if (need <= 8) GPS_BQ_CASE(8);
-  else if (need <= 16) GPS_BQ_CASE(16);
-  else if (need <= 32) GPS_BQ_CASE(32);
+  else if (need <= 16) { GPS_BQ_SCHEDS(16) }
+  else if (need <= 32) { GPS_BQ_SCHEDS(32) }
   else GPS_BQ_CASE(0);
 #undef GPS_BQ_CASE
+#undef GPS_BQ_SCHED_CASE
+#undef GPS_BQ_SCHEDS
   return finish_launch();
 }
 

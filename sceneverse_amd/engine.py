@@ -59,7 +59,8 @@ class GPSTrainStep:
                  amp_dtype: Optional[torch.dtype] = torch.bfloat16, ddp: Optional[bool] = None,
                  bucket_cap_mb: int = 64, seed: int = 42, graph: bool = False, graph_warmup: int = 3,
                  native_gemm: bool = True, grad_compress: Optional[str] = None, native_optimizer: bool = True,
-                 fused_lm_loss: bool = True, find_unused_parameters: bool = False, wgrad_overlap: bool = False):
+                 fused_lm_loss: bool = True, find_unused_parameters: bool = False, wgrad_overlap: bool = False,
+                 wgrad_group: bool = True):
         self.cfg = cfg
         self.device = torch.device(device)
         # projections / FFNs of the transformer stacks on libgps_hip.so's MFMA GEMMs (modules/layers/gemm.py);
@@ -126,6 +127,10 @@ class GPSTrainStep:
         # forms already occupy every CU's LDS with two workgroups, so a second stream's workgroups queue behind them
         # instead of filling idle matrix-pipe time, and the two kernels evict each other's L2 panels
         self.wgrad_overlap = bool(wgrad_overlap) and bool(native_gemm) and self.device.type == "cuda"
+        # [r4] weight / bias gradients of the native Linears deferred to ONE grouped launch per backward segment
+        # (modules/layers/gemm.grouped_wgrads -> gps_gemm_wgrad_grouped: no split over K, no partial tiles, results
+        # written straight into param.grad / the flat gradient buffer).  Never under torch DDP (reducer hooks).
+        self.wgrad_group = bool(wgrad_group) and bool(native_gemm) and self.device.type == "cuda" and not self.wgrad_overlap
         self.frozen_unused: list = []
         self.global_step = 0
         # diagnostics only (tools/probes): called with a stage name at the capture / replay points of the split-graph step
@@ -311,13 +316,16 @@ class GPSTrainStep:
             top = [p for p in used if id(p) not in bottom_ids]
             bottom = [p for p in used if id(p) in bottom_ids]
             used = top + bottom
-            self._flat_grad = torch.zeros(sum(p.numel() for p in used), dtype=torch.float32, device=self.device)
-            self._n_top = sum(p.numel() for p in top)
+            # every view starts on a 16-byte boundary (kernels store gradients as 4-float vectors): sizes are rounded up
+            # to 4 elements, the padding stays zero and travels with the all-reduce
+            pad4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
+            self._flat_grad = torch.zeros(sum(pad4(p.numel()) for p in used), dtype=torch.float32, device=self.device)
+            self._n_top = sum(pad4(p.numel()) for p in top)
             off = 0
             self.optimizer.zero_grad(set_to_none=True)
             for p in used:
                 p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
-                off += p.numel()
+                off += pad4(p.numel())
             torch.cuda.synchronize(self.device)
             g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
             # thread-local capture mode: RCCL's watchdog thread polls its events (hipEventQuery) while we capture; in the
@@ -335,18 +343,45 @@ class GPSTrainStep:
                 self._flat_grad.zero_()
                 with self._autocast():
                     total, losses = self.loss(out)
+                if segmented and not _cut_is_valid(total, boundary, bottom):
+                    # a gradient path from the loss into a bottom-segment parameter that does not cross a boundary
+                    # tensor (a head reading an encoder-internal tensor, a tied weight ...): the staged backward would
+                    # silently drop it -- keep the backward pass in one piece instead
+                    import logging
+                    logging.getLogger("sceneverse_amd").warning(
+                        "split-graph step: the stage boundary does not separate the text / object encoders from the "
+                        "loss; the backward pass stays ONE graph (no overlap of the gradient exchange)")
+                    segmented = False
                 if segmented:
                     # gradients of the top parameters (into their flat views) and of the boundary tensors
-                    torch.autograd.backward(total, inputs=top + boundary, retain_graph=True)
+                    with self._wgrad_ctx():
+                        torch.autograd.backward(total, inputs=top + boundary, retain_graph=True)
                 else:
                     self._backward(total)             # accumulates into the flat views
             torch.cuda.synchronize(self.device)
             self._stage("captured_g2a", out=out, total=total)
             if segmented:
-                with torch.cuda.graph(g2b, pool=g1.pool(), capture_error_mode=_CAPTURE_MODE):
-                    live = [t for t in boundary if t.grad is not None]
-                    torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bottom)
-                torch.cuda.synchronize(self.device)
+                live = [t for t in boundary if t.grad is not None]
+                groups = [live]
+                if getattr(self, "_debug_split_bottom", False):
+                    # diagnostics (tools/probes): the independent sub-graphs below the boundary as separate HIP graphs,
+                    # last-created first (the order the autograd engine runs them in inside one backward call)
+                    groups = [[t for t in live if t is boundary[-1]], [t for t in live if t is not boundary[-1]]]
+                    groups = [g for g in groups if g]
+                g2b = []
+                dbg_inputs = getattr(self, "_debug_bottom_inputs", None)        # probes: restrict the bottom backward
+                bot_in = bottom if dbg_inputs is None else \
+                    [p for p in bottom if any(p is q for q in getattr(self.model, dbg_inputs).parameters())]
+                if getattr(self, "_debug_eager_g2b", False):
+                    self._eager_g2b = (live, bot_in)                            # probes: run it uncaptured at every step
+                    groups = []
+                for gi, grp in enumerate(groups):
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg, pool=g1.pool(), capture_error_mode=_CAPTURE_MODE), self._wgrad_ctx():
+                        roots = [t.grad.clone() for t in grp] if getattr(self, "_debug_clone_roots", False) else [t.grad for t in grp]
+                        torch.autograd.backward(grp, grad_tensors=roots, inputs=bot_in)
+                    torch.cuda.synchronize(self.device)
+                    g2b.append(gg)
                 self._stage("captured_g2b")
             else:
                 g2b = None
@@ -365,8 +400,14 @@ class GPSTrainStep:
         self._stage("replayed_g2a")
         if g2b is not None:
             h_top = self._allreduce_async(0, self._n_top)              # overlaps the bottom segment's backward
-            g2b.replay()
-            self._stage("replayed_g2b")
+            for gi, gg in enumerate(g2b):
+                gg.replay()
+                self._stage("replayed_g2b" if gi + 1 == len(g2b) else f"replayed_g2b_part{gi}")
+            if getattr(self, "_eager_g2b", None) is not None:                   # probes only
+                live, bot_in = self._eager_g2b
+                with self._wgrad_ctx():
+                    torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bot_in, retain_graph=True)
+                self._stage("replayed_g2b")
             h_bot = self._allreduce_async(self._n_top, self._flat_grad.numel())
             self._wait_allreduce(h_top, h_bot)
         else:
@@ -399,7 +440,14 @@ class GPSTrainStep:
             with deferred_wgrads():
                 total.backward()
         else:
-            total.backward()
+            with self._wgrad_ctx():
+                total.backward()
+
+    def _wgrad_ctx(self):
+        """Grouped weight gradients around a backward call (a no-op context under torch DDP or when switched off)."""
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from .modules.layers.gemm import grouped_wgrads
+        return grouped_wgrads(self.wgrad_group and not isinstance(self.net, DDP) and not self._want_ddp)
 
     def _begin_step(self):
         # one tiny launch that advances the device-side dropout seed block; it sits inside every captured
@@ -502,6 +550,31 @@ class GPSTrainStep:
         self.net.eval()
         out, total, losses = self.forward_loss(data_dict)
         return out, total, losses
+
+
+def _cut_is_valid(total: torch.Tensor, boundary, bottom) -> bool:
+    """True iff every autograd path from `total` to a parameter of `bottom` passes through one of the `boundary`
+    tensors, i.e. backward(total, inputs=top + boundary) followed by backward(boundary, inputs=bottom) computes the
+    same gradients as one backward pass.  Walks the graph above the boundary once (at capture time)."""
+    bottom_ids = {id(p) for p in bottom}
+    blocked = {(t.grad_fn, t.output_nr) for t in boundary if t.grad_fn is not None}
+    keep = [fn for fn, _ in blocked]              # node wrappers stay alive: their identity is what `blocked` compares
+    if total.grad_fn is None:
+        return True
+    seen, stack = set(), [total.grad_fn]
+    while stack:
+        fn = stack.pop()
+        if id(fn) in seen:
+            continue
+        seen.add(id(fn))
+        keep.append(fn)
+        var = getattr(fn, "variable", None)       # AccumulateGrad: a leaf
+        if var is not None and id(var) in bottom_ids:
+            return False
+        for nxt, idx in fn.next_functions:
+            if nxt is not None and (nxt, idx) not in blocked:
+                stack.append(nxt)
+    return True
 
 
 def scanrefer_accuracy(og3d_logits: torch.Tensor, iou25_onehot: torch.Tensor,

@@ -58,6 +58,9 @@ class _GPSBase(BaseModel):
         return groups
 
 
+_OBJ_FIRST = False
+
+
 @MODEL_REGISTRY.register()
 class OpenVocab(_GPSBase):
     def __init__(self, cfg):
@@ -72,6 +75,7 @@ class OpenVocab(_GPSBase):
             data_dict['total_steps'] = 1
 
         scene_txt = None
+        pre = self._encode_objects(data_dict) if _OBJ_FIRST else None      # probes only: encoder order in autograd's eyes
         if self.use_scene_cap and hasattr(self.lang_encoder, "forward_pair"):
             # the sentence and the scene caption go through the text encoder's layers as one row batch
             txt, scene_txt = self.lang_encoder.forward_pair(data_dict['txt_ids'], data_dict['txt_masks'],
@@ -84,7 +88,7 @@ class OpenVocab(_GPSBase):
                 scene_txt = self.lang_encoder(data_dict['scene_txt_ids'], data_dict['scene_txt_masks'])
                 data_dict['scene_text_embed'] = scene_txt[:, 0]
 
-        obj, obj_pre, obj_cls_raw = self._encode_objects(data_dict)
+        obj, obj_pre, obj_cls_raw = pre if pre is not None else self._encode_objects(data_dict)
         if self.use_scene_cap:
             data_dict["scene_embed"] = self.object_pool(obj)
         # outputs of the two bottom encoders (text, objects): where sceneverse_amd.engine cuts the backward pass of the

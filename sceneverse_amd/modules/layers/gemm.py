@@ -210,15 +210,119 @@ def join_wgrads() -> None:
     _DEFER["keep"].clear()
 
 
+# ---- grouped weight gradients ---------------------------------------------------------------------------------------
+# The weight / bias gradients of a backward pass are independent of its input-gradient chain.  One at a time each of
+# them is a small output (768 x 768 ... 3072 x 768) with a reduction over 5 000 - 22 000 token rows: split over K to
+# fill the chip, every split dumping fp32 partial tiles that a second launch sums.  `grouped_wgrads()` DEFERS them --
+# the backward functions below hand (dY, X, parameters) to `_GROUP` instead of launching -- and issues all of them in
+# one persistent launch when the block is left (gps_gemm_wgrad_grouped: every 256 x 256 tile of every gradient walks its
+# whole reduction in one workgroup, no partial tiles, results written straight into `param.grad`, or added to it when it
+# already exists: the flat gradient buffer of the split-graph data-parallel step).  Deterministic.  Not used under torch
+# DDP, whose reducer hooks live on autograd's accumulation nodes (sceneverse_amd/engine.py decides).
+_GROUP = {"on": False, "items": [], "seen": set()}
+
+
+class grouped_wgrads:
+    """with grouped_wgrads(): loss.backward()   -- weight / bias gradients of the native Linears are collected and
+    computed by ONE grouped launch into `param.grad` when the block is left."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _GROUP["on"]
+        _GROUP["on"] = self.enabled
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        _GROUP["on"] = self.prev
+        if exc_type is None:
+            flush_grouped_wgrads()
+        else:
+            _GROUP["items"].clear()
+            _GROUP["seen"].clear()
+        return False
+
+
+def _grad_buffer(p: torch.nn.Parameter, force_existing: bool):
+    """-> (fp32 gradient buffer of p, accumulate flag).  A parameter without a gradient gets a fresh buffer (plain
+    store); an existing one is added to in place when the kernel can address it (contiguous fp32, 16-byte aligned)."""
+    g = p.grad
+    if g is None:
+        if force_existing:
+            g = p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            return g, 1
+        g = p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+        return g, 0
+    if g.dtype != torch.float32 or not g.is_contiguous() or (g.data_ptr() & 15):
+        return None, 0
+    return g, 1
+
+
+def flush_grouped_wgrads() -> None:
+    """Issue every deferred weight gradient (one gps_gemm_wgrad_grouped call) and forget the operands."""
+    items, _GROUP["items"] = _GROUP["items"], []
+    _GROUP["seen"].clear()
+    if not items:
+        return
+    from ..._native import WgradProblem
+    probs, keep, fallback = [], [], []
+    for dy16, x16, weights, biases, rows, rows_dev in items:
+        T, K_in = x16.shape
+        r = 0
+        for w, b, n in zip(weights, biases, rows):
+            gw, acc = _grad_buffer(w, force_existing=b is not None and b.grad is not None)
+            gb = None
+            if gw is not None and b is not None:
+                gb, acc_b = _grad_buffer(b, force_existing=bool(acc))
+                if gb is None or bool(acc_b) != bool(acc):
+                    gw = None
+            if gw is None or (n & 7):                     # a gradient buffer the kernel cannot address: classic path
+                fallback.append((dy16, x16, w, b, r, n, rows_dev))
+            else:
+                q = WgradProblem()
+                q.M, q.N, q.K, q.accumulate = n, K_in, T, int(acc)
+                q.A, q.lda = dy16.data_ptr() + 2 * r, dy16.stride(0)
+                q.B, q.ldb = x16.data_ptr(), x16.stride(0)
+                q.C, q.ldc = gw.data_ptr(), K_in
+                q.colsum = gb.data_ptr() if gb is not None else None
+                q.extent_dev = _ptr(rows_dev)
+                probs.append(q)
+            r += n
+        keep.append((dy16, x16, rows_dev))
+    dev = items[0][0].device
+    if probs:
+        arr = (WgradProblem * len(probs))(*probs)
+        from ...pointnet2._ext import _timed
+        flops = sum(2 * q.M * q.N * q.K for q in probs)
+        nbytes = sum(2 * q.K * (q.M + q.N) + 4 * q.M * q.N for q in probs)
+        with torch.cuda.device(dev), _timed(f"wgrad_grouped(problems={len(probs)})", nbytes, flops, "bf16"):
+            st = _native.load().gps_gemm_wgrad_grouped(arr, len(probs), _stream())
+        _native.check(st, f"gemm_wgrad_grouped({len(probs)} problems)")
+    for dy16, x16, w, b, r, n, rows_dev in fallback:
+        dw, db = linear_wgrad(dy16[:, r:r + n], x16, want_bias=b is not None, rows_dev=rows_dev)
+        w.grad = dw if w.grad is None else w.grad.add_(dw)
+        if b is not None:
+            b.grad = db if b.grad is None else b.grad.add_(db)
+    del keep
+
+
 def _wgrad_to_params(dy16: torch.Tensor, x16: torch.Tensor, weights, biases, rows, rows_dev=None) -> bool:
-    """Side-stream form of `linear_wgrad` for a (packed) Linear whose parameters are leaf tensors: dW / db land in
-    (or are added to) `param.grad`.  Returns False when the deferred form does not apply (the caller then returns
-    ordinary gradients to autograd)."""
-    if not _DEFER["on"]:
+    """Deferred forms of `linear_wgrad` for a (packed) Linear whose parameters are leaf tensors: dW / db land in
+    (or are added to) `param.grad` -- collected for one grouped launch (`grouped_wgrads`) or computed on a side stream
+    (`deferred_wgrads`).  Returns False when neither applies (the caller then returns ordinary gradients to autograd)."""
+    if not (_DEFER["on"] or _GROUP["on"]):
         return False
     params = [w for w in weights] + [b for b in biases if b is not None]
     if not all(isinstance(t, torch.nn.Parameter) and t.is_leaf and t.requires_grad and t.dtype == torch.float32 for t in params):
         return False
+    if _GROUP["on"]:
+        ids = {id(t) for t in params}
+        if ids & _GROUP["seen"]:          # a parameter used twice in one pass: its two gradients must not share a launch
+            flush_grouped_wgrads()
+        _GROUP["seen"] |= ids
+        _GROUP["items"].append((dy16, x16, tuple(weights), tuple(biases), tuple(rows), rows_dev))
+        return True
     dev = dy16.device
     cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
     want_bias = any(b is not None for b in biases)
@@ -480,6 +584,12 @@ class _LinearFn(torch.autograd.Function):
         x16, w16 = ctx.saved_tensors
         x_shape, x_dtype, n, rows, has_b = ctx.meta
         dy16 = _as_rows16(dy)
+        from ... import _debug
+        if _debug.ENABLED:
+            tag = f"lin{w16.shape[0]}x{w16.shape[1]}r{x16.shape[0]}"
+            _debug.tap(tag + ".dy16", dy16)
+            _debug.tap(tag + ".x16", x16)
+            _debug.tap(tag + ".rows", ctx.rows_dev)
         need_w = any(ctx.needs_input_grad[2:2 + n])
         need_b = any(ctx.needs_input_grad[2 + n:])
         dws, dbs = [None] * n, [None] * n

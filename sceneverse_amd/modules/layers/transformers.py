@@ -384,8 +384,12 @@ def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add):
         return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2)
     fuse = _FUSE_POST_ADD and (_FUSE_POST_ONLY is None or (_FUSE_POST_ONLY == "spatial") == hasattr(layer.self_attn, "lang_cond_fc"))
     if fuse and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
+        import os
+        variant = os.environ.get("GPS_POST_VARIANT", "")        # probes only (tools/probes/post_addend_corruption_probe.py)
+        if variant == "nobf16":
+            return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2, want_bf16=False, post=post_add)
         y, y16 = _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2, want_bf16=True, post=post_add)
-        if y16 is not y:
+        if y16 is not y and variant != "noattr":
             y._gps_bf16 = y16
         return y
     return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2) + post_add

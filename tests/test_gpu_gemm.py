@@ -355,3 +355,97 @@ def test_device_side_row_extent_forward_and_input_gradient(form, variant):
             _close16(y[:ext], ref[:ext], f"{form} v{variant} extent {ext}")
         first_dead = -(-ext // tile) * tile
         assert torch.isnan(y[first_dead:].float()).all(), (form, variant, ext)
+
+
+def _grouped(probs):
+    """probs: list of dicts(dy (T, M) bf16, x (T, N) bf16, C fp32 (M, N), colsum or None, accumulate, extent or None)."""
+    import ctypes
+    arr = (_native.WgradProblem * len(probs))()
+    for q, p in zip(arr, probs):
+        q.M, q.N, q.K, q.accumulate = p["dy"].shape[1], p["x"].shape[1], p["dy"].shape[0], int(p.get("accumulate", 0))
+        q.A, q.lda = p["dy"].data_ptr(), p["dy"].stride(0)
+        q.B, q.ldb = p["x"].data_ptr(), p["x"].stride(0)
+        q.C, q.ldc = p["C"].data_ptr(), p["C"].stride(0)
+        q.colsum = p["colsum"].data_ptr() if p.get("colsum") is not None else None
+        q.extent_dev = p["extent"].data_ptr() if p.get("extent") is not None else None
+    st = _native.load().gps_gemm_wgrad_grouped(arr, len(probs), torch.cuda.current_stream().cuda_stream)
+    _native.check(st, "gemm_wgrad_grouped")
+
+
+def test_grouped_weight_gradients_against_fp32():
+    """gps_gemm_wgrad_grouped: many dW = dY^T X (+ column sums of dY) in one persistent launch, no split over K: ragged
+    M / N / K, a 72-row problem, strided operands (column slices of a packed dY), a device-side row extent with NaN rows
+    behind it, plain stores and read-modify-write into buffers that already hold a gradient, more tiles than CUs."""
+    torch.manual_seed(5)
+    shapes = [(5120, 768, 768), (3000, 72, 768), (1400, 2304, 768), (777, 264, 136), (64, 8, 8), (2500, 3072, 768),
+              (8320, 768, 2048), (130, 520, 264), (4096, 768, 3072)]
+    probs, refs = [], []
+    for i, (T, M, N) in enumerate(shapes):
+        dyb = _rand16(T, M + 16, scale=0.5, seed=10 + i)           # dY as a column slice of a wider (packed) buffer
+        dy = dyb[:, 8:8 + M]
+        x = _rand16(T, N, seed=40 + i)
+        ext, live = None, T
+        if i % 3 == 1:
+            live = T - 37
+            ext = torch.tensor([live], dtype=torch.int32, device=DEV)
+            dyb[live:] = float("nan")                              # rows past the extent must never reach the sums
+            x[live:] = float("nan")
+        acc = i % 2
+        C = torch.full((M, N), 0.5, device=DEV) if acc else torch.full((M, N), float("nan"), device=DEV)
+        cs = torch.full((M,), -2.0, device=DEV) if acc else torch.full((M,), float("nan"), device=DEV)
+        ref = dy[:live].float().t() @ x[:live].float() + (0.5 if acc else 0.0)
+        ref_cs = dy[:live].float().sum(0) + (-2.0 if acc else 0.0)
+        probs.append(dict(dy=dy, x=x, C=C, colsum=cs if i != 4 else None, accumulate=acc, extent=ext))
+        refs.append((ref, ref_cs))
+    _grouped(probs)
+    torch.cuda.synchronize()
+    for p, (ref, ref_cs), shp in zip(probs, refs, shapes):
+        err = (p["C"] - ref).abs().max().item()
+        assert err <= 1e-4 * ref.abs().max().item() + 1e-5, (shp, err)
+        if p["colsum"] is not None:
+            err = (p["colsum"] - ref_cs).abs().max().item()
+            assert err <= 1e-4 * ref_cs.abs().max().item() + 1e-4, (shp, "colsum", err)
+    # deterministic: a second run into fresh buffers gives the same bits
+    again = [dict(p, C=torch.full_like(p["C"], 0.5 if p["accumulate"] else 0.0),
+                  colsum=None if p["colsum"] is None else torch.full_like(p["colsum"], -2.0 if p["accumulate"] else 0.0))
+             for p in probs]
+    _grouped(again)
+    torch.cuda.synchronize()
+    for a, p in zip(again, probs):
+        assert torch.equal(a["C"], p["C"])
+
+
+def test_grouped_weight_gradients_equal_the_autograd_ones():
+    """modules/layers/gemm.grouped_wgrads: the deferred, grouped form must give the gradients autograd accumulates --
+    single Linears, a packed group (column slices of one dY), an FFN, a weight used twice in one backward (two launches),
+    with and without pre-existing .grad tensors (the flat-buffer views of the split-graph step)."""
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(768, 768).to(DEV)
+    pack = [torch.nn.Linear(768, n).to(DEV) for n in (768, 768, 72)]
+    l1, l2 = torch.nn.Linear(768, 2048).to(DEV), torch.nn.Linear(2048, 768).to(DEV)
+    mods = [lin, l1, l2] + pack
+    x = torch.randn(16, 80, 768, device=DEV)
+
+    def loss_fn():
+        a = G.linear(x.to(torch.bfloat16), lin.weight, lin.bias)
+        a = G.linear(a, lin.weight, lin.bias)                      # second use of the same weight
+        b = G.packed_linear(a, pack)
+        c = G.ffn(a, l1, l2, "gelu", 0.0, False)
+        return b.float().square().mean() + c.float().square().mean()
+
+    def grads(grouped, preset):
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+            if preset:
+                for p in m.parameters():
+                    p.grad = torch.full_like(p, 0.25)
+        with G.grouped_wgrads(grouped):
+            loss_fn().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for m in mods for p in m.parameters()]
+
+    for preset in (False, True):
+        want, got = grads(False, preset), grads(True, preset)
+        for a, b in zip(got, want):
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-7, (preset, (a - b).abs().max().item())

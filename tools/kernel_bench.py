@@ -79,7 +79,9 @@ def main():
     ops = [
         ("fps SA1 (n=1024,m=32)", lambda m: m.furthest_point_sampling(xyz, 32), b * (1024 * 12 + 32 * 4)),
         ("fps SA2 (n=32,m=16)", lambda m: m.furthest_point_sampling(new_xyz, 16), b * (32 * 12 + 16 * 4)),
-        ("gather SA1 (c=3)", lambda m: m.gather_points(xyz_t, fps), b * (3 * 1024 * 4 + 32 * 4 + 3 * 32 * 4)),
+        # a gather reads the m gathered columns of each channel + the m indices and writes (c, m): 896 B per
+        # object -- NOT the whole (c, n) source row block (charging that gave frac > 1 in profiles/r3/kernel_bench_f.log)
+        ("gather SA1 (c=3)", lambda m: m.gather_points(xyz_t, fps), b * (3 * 32 * 4 + 32 * 4 + 3 * 32 * 4)),
         ("ball_query SA1", lambda m: m.ball_query(new_xyz, xyz, 0.2, 32), b * ((1024 + 32) * 12 + 32 * 32 * 4)),
         ("ball_query SA2", lambda m: m.ball_query(nx2, new_xyz, 0.4, 32), b * ((32 + 16) * 12 + 16 * 32 * 4)),
         ("group SA1 xyz (c=3,n=1024)", lambda m: m.group_points(xyz_t, idx), b * (3 * 1024 * 4 + 1024 * 4 + 3 * 1024 * 4)),

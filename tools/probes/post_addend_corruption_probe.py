@@ -30,6 +30,24 @@ ap.add_argument("--graph", default="dp")
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--n-obj", type=int, default=16)
 ap.add_argument("--save-grads", default=None)
+ap.add_argument("--split-bottom", action="store_true", help="object-encoder and text-encoder backward as separate graphs")
+ap.add_argument("--no-varlen", action="store_true")
+ap.add_argument("--bottom-inputs", default=None, choices=["lang_encoder", "point_encoder"])
+ap.add_argument("--eager-g2b", action="store_true")
+ap.add_argument("--clone-roots", action="store_true")
+ap.add_argument("--capture-mode", default=None, choices=["global", "thread_local", "relaxed"])
+ap.add_argument("--no-wgrad-group", action="store_true", help="classic weight gradients: one split-K GEMM + reduce per Linear")
+ap.add_argument("--ws-mode", default="cached", choices=["cached", "fresh", "prealloc"],
+                help="split-K workspace: the product's cached growing buffer | a fresh buffer per call | one 256 MB buffer "
+                     "made before any capture")
+ap.add_argument("--no-split", action="store_true", help="weight gradients without split-K (splits = 1)")
+ap.add_argument("--taps", default=None, help="save the debug taps (sceneverse_amd/_debug.py) of the last step here")
+ap.add_argument("--obj-first", action="store_true", help="run the object encoder BEFORE the text encoder in forward")
+ap.add_argument("--no-cls-tail", action="store_true")
+ap.add_argument("--fill-nan", action="store_true",
+                help="every torch.empty is filled with NaN (torch.utils.deterministic.fill_uninitialized_memory; the fills "
+                     "are captured into the graphs too): a kernel that reads memory nobody wrote shows up as NaN whatever "
+                     "the allocator handed out")
 args = ap.parse_args()
 
 from bench import gps_pretrain_cfg, _lang_dir
@@ -38,6 +56,9 @@ from sceneverse_amd.engine import GPSTrainStep
 from sceneverse_amd.modules.layers import transformers as T
 
 DEV = "cuda"
+if args.fill_nan:
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
 if args.post != "off" and hasattr(T, "set_fuse_post_add"):
     T.set_fuse_post_add(True, None if args.post == "all" else args.post)
 try:
@@ -63,6 +84,9 @@ snaps = {}            # stage -> [np.ndarray per region]
 report = {"post": args.post, "graph": args.graph, "changed": [], "history": HISTORY}
 
 
+KEEP = []     # python wrappers of the visited nodes stay alive during the walk: a recycled id() would truncate it
+
+
 def walk(owner: str, t: torch.Tensor, seen_nodes: set, seen_ptr: set):
     stack = [t.grad_fn] if t.grad_fn is not None else []
     while stack:
@@ -70,6 +94,7 @@ def walk(owner: str, t: torch.Tensor, seen_nodes: set, seen_ptr: set):
         if fn is None or id(fn) in seen_nodes:
             continue
         seen_nodes.add(id(fn))
+        KEEP.append(fn)
         saved = []
         try:
             if hasattr(fn, "saved_tensors"):
@@ -119,17 +144,55 @@ def hook(stage, step, **kw):
         # parameters and the static batch are not activations
         skip = {p.data_ptr() for p in step.model.parameters()} | {b.data_ptr() for b in step.model.buffers()}
         regions[:] = [r for r in regions if r["ptr"] not in skip]
+        KEEP.clear()
         print(f"[probe] {len(regions)} saved regions below the boundary, {sum(r['nbytes'] for r in regions) / 1e6:.1f} MB")
     elif stage.startswith("replayed_") and not first_replay["done"]:
         torch.cuda.synchronize()
+        print("[probe] stage ok:", stage, flush=True)
         snaps[stage] = [dtoh(r["ptr"], r["nbytes"]) for r in regions]
         if stage == "replayed_g2b":
             first_replay["done"] = True
 
 
+if args.taps:
+    from sceneverse_amd import _debug
+    _debug.ENABLED = True
+if args.obj_first:
+    import sceneverse_amd.model.openvocab as OV
+    OV._OBJ_FIRST = True
+from sceneverse_amd.modules.layers import gemm as _G
+if args.ws_mode == "fresh":
+    _G._workspace = lambda device, floats: torch.empty(max(floats, 1), dtype=torch.float32, device=device)
+elif args.ws_mode == "prealloc":
+    _BIG = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    _G._workspace = lambda device, floats: _BIG
+if args.no_split:
+    _lib = _G._native.load()
+    _orig_pick = _lib.gps_gemm_pick_splits
+
+    class _NoSplitLib:
+        def __getattr__(self, name):
+            if name == "gps_gemm_pick_splits":
+                return lambda *a: 1
+            return getattr(_lib, name)
+    _G._native.load = lambda *a, **k: _NoSplitLib()
 cfg = gps_pretrain_cfg(_lang_dir())
-st = GPSTrainStep(cfg, device=DEV, ddp=False, graph=("dp" if args.graph == "dp" else True), graph_warmup=2, seed=7)
+st = GPSTrainStep(cfg, device=DEV, ddp=False, graph={"dp": "dp", "one": True, "off": False}[args.graph], graph_warmup=2, seed=7,
+                  wgrad_group=not args.no_wgrad_group)
 st.stage_hook = hook
+st._debug_split_bottom = bool(args.split_bottom)
+st._debug_bottom_inputs = args.bottom_inputs
+st._debug_eager_g2b = bool(args.eager_g2b)
+st._debug_clone_roots = bool(args.clone_roots)
+if args.capture_mode:
+    import sceneverse_amd.engine as _E
+    _E._CAPTURE_MODE = args.capture_mode
+if args.no_varlen or args.no_cls_tail:
+    from sceneverse_amd.modules.language import bert as _B
+    if args.no_varlen:
+        _B.set_varlen(False)
+    if args.no_cls_tail:
+        _B.set_cls_tail(False)
 for m in st.model.modules():
     if isinstance(m, torch.nn.Dropout):
         m.p = 0.0
@@ -141,29 +204,41 @@ junk = [torch.full((256, 1024, 1024), float("nan"), device=DEV) for _ in range(2
 del junk
 batches = [synth_batch(args.batch, n_obj=args.n_obj, seed=20 + i, min_real=5, device=DEV) for i in range(3)]
 for b in batches:
+    if args.taps:
+        _debug.reset()
     total, _ = st.step(dict(b))
 torch.cuda.synchronize()
 print("loss", total.item(), "graph", st._graph is not None)
+nan_names = [n for n, p in st.model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+print(f"[probe] parameters with a non-finite gradient: {len(nan_names)}", nan_names[:6], "..." if len(nan_names) > 6 else "")
+report["nan_grads"] = nan_names
+if args.taps:
+    from sceneverse_amd import _debug
+    torch.save({k: v.detach().float().cpu() for k, v in _debug.TAPS.items()}, args.taps)
+    print("[probe] taps:", len(_debug.TAPS))
 if args.save_grads:
     torch.save({n: p.grad.detach().to(torch.bfloat16).cpu() for n, p in st.model.named_parameters() if p.grad is not None},
                args.save_grads)
 
 # ---- which saved regions changed before graph 2b read them? ------------------------------------------------
-order = [s for s in ("replayed_g1", "replayed_gather", "replayed_g2a") if s in snaps]
+order = [s for s in ("replayed_g1", "replayed_gather", "replayed_g2a", "replayed_g2b_part0") if s in snaps]
 changed = []
-for i, r in enumerate(regions):
+for i, r in enumerate(regions if order else []):
     base = snaps[order[0]][i]
     for later in order[1:]:
         cur = snaps[later][i]
         if not np.array_equal(base, cur):
             d = np.nonzero(base != cur)[0]
+            w = slice(int(d[0]) // 4 * 4, int(d[0]) // 4 * 4 + 32)
             changed.append(dict(r, stage=later, first=int(d[0]), last=int(d[-1]), n_diff=int(d.size),
+                                before_i32=base[w].view(np.int32).tolist(), after_i32=cur[w].view(np.int32).tolist(),
+                                before_f32=base[w].view(np.float32).tolist(), after_f32=cur[w].view(np.float32).tolist(),
                                 crc_before=zlib.crc32(base.tobytes()), crc_after=zlib.crc32(cur.tobytes())))
             break
 print(f"[probe] {len(changed)} of {len(regions)} saved regions CHANGED between graph 1 and graph 2b")
 for c in changed[:40]:
     print(f"  {c['owner']:9s} {c['node']:28s} {c['slot']:14s} {c['shape']} {c['dtype']} ptr {c['ptr']:#x} +[{c['first']}, {c['last']}] "
-          f"({c['n_diff']} bytes differ) after {c['stage']}")
+          f"({c['n_diff']} bytes differ) after {c['stage']}\n      i32 {c['before_i32']} -> {c['after_i32']}\n      f32 {c['before_f32']} -> {c['after_f32']}")
 report["regions"] = len(regions)
 report["changed"] = changed
 
