@@ -629,6 +629,9 @@ def main() -> None:
             mm = _re.match(r"(attn_\w+)\(L=\d+,spatial=(\d)\)(\[\w+\])?", name)
             if mm:
                 return f"{mm.group(1)}(spatial={mm.group(2)}){mm.group(3) or ''}"
+            mm = _re.match(r"(gemm_tn_grouped)\(", name)
+            if mm:
+                return mm.group(1)
             mm = _re.match(r"(add_dropout_layernorm_\w+)\(", name)
             if mm:
                 return mm.group(1)
@@ -693,7 +696,9 @@ def main() -> None:
                         "dtype": dom["mfma_dtype"], "traffic": traffic, "ms_per_step": round(dom["ms_per_step"], 4),
                         "launches_per_step": dom["launches_per_step"], "avg_us": dom["avg_us"], "shapes": dom["shapes"],
                         **({"mfma_utilisation": dom["mfma_utilisation"]} if "mfma_utilisation" in dom else {}),
-                        **({"note": "weight+bias gradient GEMMs; avg_us per gps_gemm_bf16 call = split-K kernel + its "
+                        **({"note": "all weight+bias gradients of a backward segment in one launch (wgrad_grouped_kernel "
+                                    "+ its table-write launches in rocprofv3)"} if dom["kernel"].startswith("gemm_tn_grouped") else
+                           {"note": "weight+bias gradient GEMMs; avg_us per gps_gemm_bf16 call = split-K kernel + its "
                                     "splitk_reduce_kernel launch (two rocprofv3 rows)"} if dom["kernel"].startswith("gemm_tn") else {})}
         else:
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"],

@@ -79,9 +79,13 @@ class GPSTrainStep:
         self.world = world
         self.graph = want_graph and not use_ddp and not self.graph_dp
         if self.graph or self.graph_dp:
-            # eager steps after a capture (bench's per-kernel timing pass) meet AccumulateGrad nodes
-            # created on the capture stream; the cross-stream sync torch inserts is what we want
-            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            # [r4] torch warns when a parameter's AccumulateGrad node runs on another stream than the node that produced
+            # its gradient ("... break CUDA graph capture ...").  Round 3 silenced that warning; it was the root cause of
+            # the corrupted split-graph steps (see _work_stream below).  It is an ERROR here: a captured backward must be
+            # a linear chain of nodes.
+            import warnings
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
+            warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
         self.graph_warmup = max(1, int(graph_warmup))
         self._graph = None
         self._static = None
@@ -133,6 +137,15 @@ class GPSTrainStep:
         self.wgrad_group = bool(wgrad_group) and bool(native_gemm) and self.device.type == "cuda" and not self.wgrad_overlap
         self.frozen_unused: list = []
         self.global_step = 0
+        # [r4] ONE stream for everything the graph modes run outside a replay: the eager warm-up steps, every capture, the
+        # eager steps after a capture.  A parameter's AccumulateGrad node remembers the stream that was current when it
+        # was created and outlives a step whenever anything still references that step's autograd graph; its
+        # `grad += dW` is then issued on THAT stream.  Inside a capture this forks the graph (the accumulations become
+        # parallel branches of the compute chain), and ROCm 7's multi-queue graph executor does not keep such graphs in
+        # order: the text encoder's saved activations were overwritten by later kernels of the same graph (wrong
+        # gradients, memory-aperture violations; root-caused with tools/probes/post_addend_corruption_probe.py, DESIGN.md
+        # section 9).  With one stream every capture is a linear chain of nodes.
+        self._work_stream = None
         # diagnostics only (tools/probes): called with a stage name at the capture / replay points of the split-graph step
         self.stage_hook = None
         if self.graph_dp and dist_utils.is_dist():
@@ -275,7 +288,7 @@ class GPSTrainStep:
         cur = torch.cuda.current_stream(self.device)
         if self._graph is None and self.global_step < self.graph_warmup:
             # eager warm-up with the same exchange points (lazy inits, hipBLASLt heuristics, ...)
-            side = torch.cuda.Stream(device=self.device)
+            side = self._stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._begin_step()
@@ -330,7 +343,8 @@ class GPSTrainStep:
             g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
             # thread-local capture mode: RCCL's watchdog thread polls its events (hipEventQuery) while we capture; in the
             # default global mode any such call from another thread invalidates the capture
-            with torch.cuda.graph(g1, capture_error_mode=_CAPTURE_MODE):
+            ws = self._stream()
+            with torch.cuda.graph(g1, stream=ws, capture_error_mode=_CAPTURE_MODE):
                 self._begin_step()
                 with self._autocast():
                     out = self.net(static_dict)
@@ -339,7 +353,7 @@ class GPSTrainStep:
             boundary = list(getattr(self.model, "_stage_boundary", None) or [])
             segmented = bool(boundary) and bool(top) and bool(bottom) and not self.wgrad_overlap
             torch.cuda.synchronize(self.device)
-            with torch.cuda.graph(g2a, pool=g1.pool(), capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(g2a, pool=g1.pool(), stream=ws, capture_error_mode=_CAPTURE_MODE):
                 self._flat_grad.zero_()
                 with self._autocast():
                     total, losses = self.loss(out)
@@ -377,17 +391,25 @@ class GPSTrainStep:
                     groups = []
                 for gi, grp in enumerate(groups):
                     gg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gg, pool=g1.pool(), capture_error_mode=_CAPTURE_MODE), self._wgrad_ctx():
+                    if getattr(self, "_debug_dump_graphs", None):
+                        gg.enable_debug_mode()
+                    with torch.cuda.graph(gg, pool=g1.pool(), stream=ws, capture_error_mode=_CAPTURE_MODE), self._wgrad_ctx():
                         roots = [t.grad.clone() for t in grp] if getattr(self, "_debug_clone_roots", False) else [t.grad for t in grp]
                         torch.autograd.backward(grp, grad_tensors=roots, inputs=bot_in)
                     torch.cuda.synchronize(self.device)
+                    if getattr(self, "_debug_dump_graphs", None):
+                        gg.debug_dump(f"{self._debug_dump_graphs}/g2b_{gi}.dot")
                     g2b.append(gg)
                 self._stage("captured_g2b")
             else:
                 g2b = None
-            with torch.cuda.graph(g3, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(g3, stream=ws, capture_error_mode=_CAPTURE_MODE):
                 self._clip_and_step()
-            self._graph, self._graph_out = (g1, g2a, g2b, g3), (out, total, losses)
+            self._drop_previous_graph()
+            # only the VALUES of the outputs are read after a replay: no reference to the captured autograd graph is kept
+            self._graph, self._graph_out = (g1, g2a, g2b, g3), (
+                {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}, total.detach(),
+                {k: v.detach() for k, v in losses.items()})
         else:
             self._fill_static(tensors)
         g1, g2a, g2b, g3 = self._graph
@@ -414,6 +436,17 @@ class GPSTrainStep:
             self._allreduce_grads()
         g3.replay()
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
+
+    def _stream(self):
+        if self._work_stream is None:
+            self._work_stream = torch.cuda.Stream(device=self.device)
+        return self._work_stream
+
+    def _drop_previous_graph(self) -> None:
+        """Nothing of the previous step's autograd graph may survive into this step's forward (see _work_stream): the
+        stage boundary the model publishes is the one reference this package keeps."""
+        if getattr(self.model, "_stage_boundary", None) is not None:
+            self.model._stage_boundary = None
 
     def _stage(self, name: str, **kw) -> None:
         if self.stage_hook is not None:
@@ -475,7 +508,7 @@ class GPSTrainStep:
         captured once; afterwards: copy the batch into the static buffers, replay."""
         tensors = {k: v for k, v in data_dict.items() if torch.is_tensor(v)}
         if self._graph is None and self.global_step < self.graph_warmup:
-            side = torch.cuda.Stream(device=self.device)
+            side = self._stream()
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 total, losses = self._eager_body(data_dict)
@@ -488,9 +521,10 @@ class GPSTrainStep:
             self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=self._stream()):
                 total, losses = self._eager_body(static_dict)
-            self._graph, self._graph_out = g, (total, losses)
+            self._drop_previous_graph()
+            self._graph, self._graph_out = g, (total.detach(), {k: v.detach() for k, v in losses.items()})
         else:
             self._fill_static(tensors)
         self._graph.replay()
@@ -521,6 +555,7 @@ class GPSTrainStep:
     def step(self, data_dict):
         """One optimisation step; returns (total_loss tensor, dict of loss tensors).  No host sync."""
         self.net.train()
+        self._drop_previous_graph()
         if self.graph or self.graph_dp:
             data_dict['cur_step'] = 0
             data_dict['total_steps'] = 1 << 30
@@ -537,10 +572,19 @@ class GPSTrainStep:
             # touching their Python-side version counters, so the bf16 shadows must be rebuilt from them
             from .modules.layers import gemm as _gemm
             _gemm.invalidate_shadows()
-        out, total, losses = self.forward_loss(data_dict)
-        self.optimizer.zero_grad(set_to_none=True)
-        self._backward(total)
-        self._clip_and_step()
+        # an eager step of an engine that has captured graphs runs on the stream the captures used (see _work_stream)
+        ctx, cur = contextlib.nullcontext(), None
+        if self._graph is not None and self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            self._stream().wait_stream(cur)
+            ctx = torch.cuda.stream(self._stream())
+        with ctx:
+            out, total, losses = self.forward_loss(data_dict)
+            self.optimizer.zero_grad(set_to_none=True)
+            self._backward(total)
+            self._clip_and_step()
+        if cur is not None:
+            cur.wait_stream(self._stream())
         self.scheduler.step()
         self.global_step += 1
         return total.detach(), {k: v.detach() for k, v in losses.items()}

@@ -266,7 +266,7 @@ def flush_grouped_wgrads() -> None:
     if not items:
         return
     from ..._native import WgradProblem
-    probs, keep, fallback = [], [], []
+    probs, prob_rows, keep, fallback = [], [], [], []
     for dy16, x16, weights, biases, rows, rows_dev in items:
         T, K_in = x16.shape
         r = 0
@@ -288,15 +288,31 @@ def flush_grouped_wgrads() -> None:
                 q.colsum = gb.data_ptr() if gb is not None else None
                 q.extent_dev = _ptr(rows_dev)
                 probs.append(q)
+                prob_rows.append((dy16, x16, rows_dev))
             r += n
         keep.append((dy16, x16, rows_dev))
     dev = items[0][0].device
     if probs:
         arr = (WgradProblem * len(probs))(*probs)
-        from ...pointnet2._ext import _timed
+        from ...pointnet2._ext import _timed, profiling
         flops = sum(2 * q.M * q.N * q.K for q in probs)
         nbytes = sum(2 * q.K * (q.M + q.N) + 4 * q.M * q.N for q in probs)
-        with torch.cuda.device(dev), _timed(f"wgrad_grouped(problems={len(probs)})", nbytes, flops, "bf16"):
+        work_fraction = None
+        if profiling():
+            # bench accounting: a problem with a device-side row extent does extent / K of its static work; snapshots of
+            # the extent words now, read back at profile_stop (the words may be rewritten by the next step)
+            shapes = [(q.M, q.N, q.K) for q in probs]
+            exts = [(i, rd.detach().clone()) for i, (_, _, rd) in enumerate(prob_rows) if rd is not None]
+
+            def live():
+                k = [kk for _, _, kk in shapes]
+                for i, snap in exts:
+                    k[i] = min(k[i], max(0, int(snap.item())))
+                return k
+
+            work_fraction = lambda: sum(2 * m * n * kk for (m, n, _), kk in zip(shapes, live())) / max(1, flops)  # noqa: E731
+            nbytes = lambda f: sum(2 * kk * (m + n) + 4 * m * n for (m, n, _), kk in zip(shapes, live()))       # noqa: E731
+        with torch.cuda.device(dev), _timed(f"gemm_tn_grouped(problems={len(probs)})", nbytes, flops, "bf16", work_fraction):
             st = _native.load().gps_gemm_wgrad_grouped(arr, len(probs), _stream())
         _native.check(st, f"gemm_wgrad_grouped({len(probs)} problems)")
     for dy16, x16, w, b, r, n, rows_dev in fallback:

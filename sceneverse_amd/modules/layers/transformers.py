@@ -354,13 +354,14 @@ def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout, want_b
     return add_dropout_layer_norm(x, h, norm, drop.p, drop.training, want_bf16=want_bf16, post=post)
 
 
-# Folding the next layer's `x + embedding` into this layer's last LayerNorm launch (fused_norm `post`): +0.7 % on the
-# pre-train step as one HIP graph, but in the SEGMENTED data-parallel graph step (engine._graph_dp_step) the bottom
-# graph then produces wrong gradients for the TEXT encoder (last layer zero, the others off) as soon as the OBJECT
-# encoder's layers use it -- the unified encoder's layers alone are fine; eager staged backward is exact
-# (tools/probes/staged_backward_probe.py, dp_graph_grad_diff_probe.py).  The cause was not found
-# within the round's GPU budget, so the encoders keep the explicit add unless this is switched on.
-_FUSE_POST_ADD = False
+# Folding the next layer's `x + embedding` into this layer's last LayerNorm launch (fused_norm `post`): the sum and its
+# bf16 copy leave the LayerNorm launch, the explicit add, the cast in front of the next projection GEMM and the gradient
+# accumulation of the addend's four uses go away.  [r3] measured +0.7 % on the one-graph step but kept off: with it the
+# split-graph data-parallel step returned wrong text-encoder gradients.  [r4] root-caused -- not this code: stale
+# AccumulateGrad nodes forked the captured bottom-backward graph and ROCm ran its nodes out of order; ANY change of the
+# allocation pattern moved the damage (sceneverse_amd/engine.py `_work_stream`, tests/test_gpu_graph_chain.py,
+# DESIGN.md section 9).  On by default since.
+_FUSE_POST_ADD = True
 _FUSE_POST_ONLY = None          # probes: "spatial" = object encoder layers only, "plain" = unified encoder layers only
 
 
@@ -384,12 +385,8 @@ def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add):
         return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2)
     fuse = _FUSE_POST_ADD and (_FUSE_POST_ONLY is None or (_FUSE_POST_ONLY == "spatial") == hasattr(layer.self_attn, "lang_cond_fc"))
     if fuse and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
-        import os
-        variant = os.environ.get("GPS_POST_VARIANT", "")        # probes only (tools/probes/post_addend_corruption_probe.py)
-        if variant == "nobf16":
-            return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2, want_bf16=False, post=post_add)
         y, y16 = _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2, want_bf16=True, post=post_add)
-        if y16 is not y and variant != "noattr":
+        if y16 is not y:
             y._gps_bf16 = y16
         return y
     return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2) + post_add

@@ -35,6 +35,15 @@ ap.add_argument("--no-varlen", action="store_true")
 ap.add_argument("--bottom-inputs", default=None, choices=["lang_encoder", "point_encoder"])
 ap.add_argument("--eager-g2b", action="store_true")
 ap.add_argument("--clone-roots", action="store_true")
+ap.add_argument("--dump-graphs", default=None, help="directory for hipGraphDebugDotPrint dumps of the bottom-backward graphs")
+ap.add_argument("--alias-scan", action="store_true",
+                help="allocator history: for every saved region of the text encoder, list the allocations that overlap it "
+                     "between its own allocation and its own free (= the allocator handed out live memory)")
+ap.add_argument("--watch", action="store_true",
+                help="snapshot one victim (the bf16 input the last text layer's QKV projection saved) after EVERY backward "
+                     "node of the bottom segment: the first snapshot that differs names the node whose kernels wrote it")
+ap.add_argument("--single-thread-backward", action="store_true",
+                help="torch.autograd.set_multithreading_enabled(False): every backward node runs on the calling thread")
 ap.add_argument("--capture-mode", default=None, choices=["global", "thread_local", "relaxed"])
 ap.add_argument("--no-wgrad-group", action="store_true", help="classic weight gradients: one split-K GEMM + reduce per Linear")
 ap.add_argument("--ws-mode", default="cached", choices=["cached", "fresh", "prealloc"],
@@ -133,6 +142,44 @@ def walk(owner: str, t: torch.Tensor, seen_nodes: set, seen_ptr: set):
 
 
 first_replay = {"done": False}
+WATCH = {"victim": None, "snaps": [], "nodes": []}
+
+
+def install_watch(step):
+    """Post-hooks on every node below the boundary; each clones the victim (a captured copy kernel)."""
+    seen, stack = set(), [t.grad_fn for t in (getattr(step.model, "_stage_boundary", []) or []) if t.grad_fn is not None]
+    nodes = []
+    while stack:
+        fn = stack.pop()
+        if fn is None or id(fn) in seen:
+            continue
+        seen.add(id(fn))
+        nodes.append(fn)
+        for nxt, _ in fn.next_functions:
+            stack.append(nxt)
+    WATCH["nodes"] = nodes                      # keep the wrappers (and their hooks) alive
+    cand = []
+    for fn in nodes:
+        if type(fn).__name__ == "_LinearFnBackward":
+            try:
+                sv = fn.saved_tensors
+            except Exception:  # noqa: BLE001
+                continue
+            if len(sv) >= 2 and tuple(sv[1].shape) == (2304, 768) and sv[0].shape[0] > 1000:
+                cand.append((fn._sequence_nr() if hasattr(fn, "_sequence_nr") else 0, sv[0]))
+    cand.sort(key=lambda c: -c[0])
+    WATCH["victim"] = cand[0][1]
+    print(f"[probe] watch: {len(nodes)} nodes, victim {tuple(WATCH['victim'].shape)} at {WATCH['victim'].data_ptr():#x}", flush=True)
+
+    def mk(name):
+        def hook(grad_inputs, grad_outputs):
+            WATCH["snaps"].append((name, WATCH["victim"].detach().clone()))
+        return hook
+    for fn in nodes:
+        try:
+            fn.register_hook(mk(type(fn).__name__))
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def hook(stage, step, **kw):
@@ -145,6 +192,10 @@ def hook(stage, step, **kw):
         skip = {p.data_ptr() for p in step.model.parameters()} | {b.data_ptr() for b in step.model.buffers()}
         regions[:] = [r for r in regions if r["ptr"] not in skip]
         KEEP.clear()
+        if args.alias_scan and HISTORY:
+            report["walk_events"] = len(torch.cuda.memory._snapshot().get("device_traces", [[]])[0])
+        if args.watch:
+            install_watch(step)
         print(f"[probe] {len(regions)} saved regions below the boundary, {sum(r['nbytes'] for r in regions) / 1e6:.1f} MB")
     elif stage.startswith("replayed_") and not first_replay["done"]:
         torch.cuda.synchronize()
@@ -184,6 +235,7 @@ st._debug_split_bottom = bool(args.split_bottom)
 st._debug_bottom_inputs = args.bottom_inputs
 st._debug_eager_g2b = bool(args.eager_g2b)
 st._debug_clone_roots = bool(args.clone_roots)
+st._debug_dump_graphs = args.dump_graphs
 if args.capture_mode:
     import sceneverse_amd.engine as _E
     _E._CAPTURE_MODE = args.capture_mode
@@ -203,19 +255,62 @@ for m in st.model.modules():
 junk = [torch.full((256, 1024, 1024), float("nan"), device=DEV) for _ in range(20)]
 del junk
 batches = [synth_batch(args.batch, n_obj=args.n_obj, seed=20 + i, min_real=5, device=DEV) for i in range(3)]
+if args.single_thread_backward:
+    torch.autograd.set_multithreading_enabled(False)
 for b in batches:
     if args.taps:
         _debug.reset()
     total, _ = st.step(dict(b))
 torch.cuda.synchronize()
 print("loss", total.item(), "graph", st._graph is not None)
+if args.watch and WATCH["snaps"]:
+    ref = WATCH["snaps"][0][1].float()
+    nv = 1035 if ref.shape[0] == 1400 else ref.shape[0]
+    prev = None
+    print(f"[probe] watch: {len(WATCH['snaps'])} snapshots")
+    for i, (name, snap) in enumerate(WATCH["snaps"]):
+        x = snap.float()[:nv]
+        sig = (float(x.norm().item()), int((~torch.isfinite(x)).sum().item()))
+        if sig != prev:
+            print(f"   #{i:4d} after {name:34s} victim norm {sig[0]:.6e} nonfinite {sig[1]}")
+        prev = sig
 nan_names = [n for n, p in st.model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
 print(f"[probe] parameters with a non-finite gradient: {len(nan_names)}", nan_names[:6], "..." if len(nan_names) > 6 else "")
 report["nan_grads"] = nan_names
 if args.taps:
+    # per-tap statistics over the rows that carry work (dead rows of the variable-length text path hold garbage by design)
     from sceneverse_amd import _debug
-    torch.save({k: v.detach().float().cpu() for k, v in _debug.TAPS.items()}, args.taps)
-    print("[probe] taps:", len(_debug.TAPS))
+    T = _debug.TAPS
+    stats = []
+    n_valid_txt = None
+    for k, v in T.items():
+        if k.startswith("vattn.cu#"):
+            n_valid_txt = int(v[-1].item())
+    for k, v in T.items():
+        x = v.detach().float()
+        rows = None
+        if k.startswith("lin") and not k.endswith(tuple(f".rows#{i}" for i in range(8))):
+            tag, idx = k.split(".")[0], k.split("#")[1]
+            r = T.get(f"{tag}.rows#{idx}")
+            if r is not None:
+                rows = int(r.item())
+        elif k.startswith("vattn.") and x.dim() == 2 and n_valid_txt is not None and x.shape[0] >= n_valid_txt:
+            rows = n_valid_txt
+        if rows is not None and x.dim() >= 1:
+            x = x[:rows]
+        bad = (~torch.isfinite(x)).reshape(x.shape[0], -1) if x.dim() >= 2 else (~torch.isfinite(x)).reshape(-1, 1)
+        where = None
+        if bad.any():
+            rr = bad.any(1).nonzero().flatten()
+            cc = bad.any(0).nonzero().flatten()
+            where = dict(rows=[int(rr[0]), int(rr[-1]), int(rr.numel())], cols=[int(cc[0]), int(cc[-1]), int(cc.numel())],
+                         ptr=hex(v.data_ptr()))
+        stats.append(dict(name=k, shape=list(v.shape), rows=rows, norm=float(x.norm().item()) if x.numel() else 0.0,
+                          sum=float(x.sum().item()) if x.numel() else 0.0, nonfinite=int((~torch.isfinite(x)).sum().item()),
+                          where=where))
+    with open(args.taps, "w") as f:
+        json.dump(stats, f, indent=0)
+    print("[probe] taps:", len(T))
 if args.save_grads:
     torch.save({n: p.grad.detach().to(torch.bfloat16).cpu() for n, p in st.model.named_parameters() if p.grad is not None},
                args.save_grads)
@@ -274,6 +369,63 @@ if HISTORY and changed:
                 print("        ", fr)
         detail.append(dict(region={k: c[k] for k in ("owner", "node", "slot", "shape", "dtype", "ptr", "first", "last")}, events=evs[-40:]))
     report["events"] = detail
+if args.alias_scan and HISTORY:
+    snap = torch.cuda.memory._snapshot()
+    traces = snap.get("device_traces", [[]])[0]
+    print(f"[probe] alias scan over {len(traces)} allocator events, {len(regions)} regions")
+
+    def frames_of(ev, n=6):
+        out = []
+        for f in ev.get("frames", []):
+            fn = f.get("filename", "")
+            if "sceneverse_amd" in fn or "tools/" in fn or "bench.py" in fn:
+                out.append(f"{os.path.basename(fn)}:{f.get('line')} {f.get('name')}")
+            if len(out) >= n:
+                break
+        return out
+    allocs = [(k, ev) for k, ev in enumerate(traces) if ev.get("action") in ("alloc", "free_requested", "free_completed", "segment_alloc", "segment_free")]
+    n_alias = 0
+    for r in regions:
+        if r["owner"] == "obj":
+            continue
+        lo, hi = r["ptr"], r["ptr"] + r["nbytes"]
+        # the block that holds this region: the LAST alloc event before the walk whose range covers lo
+        own = None
+        for k, ev in allocs:
+            if k >= report.get("walk_events", 1 << 60):
+                break
+            if ev["action"] == "alloc" and ev["addr"] <= lo < ev["addr"] + ev["size"]:
+                own = (k, ev)
+        if own is None:
+            continue
+        k0, ev0 = own
+        freed_at = None
+        for k, ev in allocs:
+            if k > k0 and ev["action"] == "free_requested" and ev["addr"] == ev0["addr"]:
+                freed_at = k
+                break
+        for k, ev in allocs:
+            if k <= k0 or (freed_at is not None and k >= freed_at):
+                continue
+            if ev["action"] == "alloc" and ev["addr"] < hi and ev["addr"] + ev["size"] > lo:
+                n_alias += 1
+                print(f"  ALIAS: {r['owner']} {r['node']} {r['slot']} {r['shape']} block [{ev0['addr']:#x}, +{ev0['size']}) alloc #{k0} "
+                      f"free #{freed_at}; overlapped by alloc #{k} [{ev['addr']:#x}, +{ev['size']}) {frames_of(ev)}")
+        if r["node"] in ("_LinearFnBackward", "_FusedVarlenSelfAttentionBackward") and r["shape"][0] >= 1000:
+            print(f"  region {r['owner']} {r['node']} {r['slot']} {r['shape']} [{lo:#x}, {hi:#x}) block alloc #{k0} by {frames_of(ev0, 3)} free #{freed_at}")
+    print(f"[probe] alias scan: {n_alias} overlapping allocations of live text-encoder regions")
+    # who lives right below / above the first victim (the bf16 input the last text layer's QKV projection saved) while
+    # the bottom backward is captured?  An overrun of a neighbour is the other way to reach it.
+    vic = [r for r in regions if r["owner"] != "obj" and r["node"] == "_LinearFnBackward" and r["slot"] == "saved[0]" and r["shape"][0] >= 1000]
+    if vic:
+        lo, hi = vic[0]["ptr"], vic[0]["ptr"] + vic[0]["nbytes"]
+        print(f"[probe] neighbours of the victim [{lo:#x}, {hi:#x}) after the walk (event {report.get('walk_events')}):")
+        for k, ev in allocs:
+            if k < report.get("walk_events", 0) or ev["action"] != "alloc":
+                continue
+            end = ev["addr"] + ev["size"]
+            if (lo - (8 << 20) <= end <= lo) or (hi <= ev["addr"] <= hi + (1 << 20)):
+                print(f"    #{k} [{ev['addr']:#x}, {end:#x}) size {ev['size']} gap-to-victim {lo - end if end <= lo else ev['addr'] - hi} {frames_of(ev, 3)}")
 with open(args.out, "w") as f:
     json.dump(report, f, indent=1, default=str)
 print("[probe] wrote", args.out)

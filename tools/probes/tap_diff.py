@@ -1,17 +1,13 @@
-"""Compare two tap files of post_addend_corruption_probe.py --taps."""
+"""Compare two tap-statistics files of post_addend_corruption_probe.py --taps (execution order)."""
+import json
 import sys
-import torch
-a, b = torch.load(sys.argv[1]), torch.load(sys.argv[2])
-for k in a:
-    if k not in b:
-        print("missing in b:", k)
+a, b = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+bm = {r["name"]: r for r in b}
+for r in a:
+    q = bm.get(r["name"])
+    if q is None:
+        print("missing in b:", r["name"])
         continue
-    x, y = a[k].float(), b[k].float()
-    if x.shape != y.shape:
-        print(f"{k}: shape {tuple(x.shape)} vs {tuple(y.shape)}")
-        continue
-    fin = torch.isfinite(x) & torch.isfinite(y)
-    nbad = int((~torch.isfinite(y)).sum()) - int((~torch.isfinite(x)).sum())
-    rel = ((x - y)[fin].norm() / (x[fin].norm() + 1e-20)).item() if fin.any() else float("nan")
-    flag = "  <<<<" if (rel > 2e-2 or nbad != 0) else ""
-    print(f"{k:34s} {str(tuple(x.shape)):18s} rel {rel:.3e} |a| {x[fin].norm().item():.3e} |b| {y[fin].norm().item():.3e} extra-nonfinite {nbad}{flag}")
+    rel = abs(r["norm"] - q["norm"]) / (abs(r["norm"]) + 1e-30)
+    flag = "  <<<<" if (rel > 1e-2 or r["nonfinite"] != q["nonfinite"] or r["norm"] != r["norm"] or q["norm"] != q["norm"]) else ""
+    print(f"{r['name']:30s} {str(r['shape']):16s} rows {str(r['rows']):6s} norm {r['norm']:.5e} vs {q['norm']:.5e}  nonfinite {r['nonfinite']} vs {q['nonfinite']}{flag}")
