@@ -503,7 +503,8 @@ typedef struct gps_gemm_args {
   const void *seed_dev; /* optional device uint64 added to `seed` (HIP-graph replays advance it on the device) */
   unsigned long long seed;
   float p_drop;
-  int reserved2;
+  int reserved2; /* forms NT / NN: index of this call's first row in the (larger) product whose dropout stream it continues
+                  * (the mask of row m, column n is drawn at index (reserved2 + m) * N + n); 0 for a whole product */
   /* optional device int32: the number of LEADING token rows that carry work.  Forms NT / NN: output rows at or
    * past it are not computed (their tiles exit at once; rows of the last started tile may be written).  Form TN:
    * the reduction stops at the end of the 64-row stage that contains row *extent_dev - 1 (operand rows between

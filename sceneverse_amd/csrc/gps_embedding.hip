@@ -6,8 +6,8 @@
 // BERT passes, profiles/r1/bench_z_kernel_stats.csv).  Here:
 //   memset   out = 0, first[] = +big, count[] = 0
 //   mark     one thread per token: atomicMin(first[id], t), atomicAdd(count[id], 1)  (order-independent)
-//   sum      one wave per token; only the FIRST occurrence of an id works: it adds the rows of all
-//            tokens with that id in ASCENDING token order (ids scanned 64 at a time with a ballot, stop
+//   sum      one wave per (token, 256-column chunk); only the FIRST occurrence of an id works: it adds the rows of
+//            all tokens with that id in ASCENDING token order (ids scanned 64 at a time with a ballot, stop
 //            after count[id] matches) and writes the table row once.  No floating-point atomics: the
 //            result does not depend on scheduling.
 // HBM-bound: n rows of d floats read once, the touched table rows written once, plus the table memset.
@@ -32,29 +32,30 @@ __global__ __launch_bounds__(kBlock) void mark_kernel(int n, int num_rows, const
   atomicAdd(count + id, 1);
 }
 
+// [r4] one wave per (token, 256-column chunk): a wave keeps ONE float4 accumulator per lane and fetches the rows of up to
+// 16 duplicates per trip (16 independent loads in flight).  The first version gave a token's whole row (3 chunks at
+// d = 768) to one wave with 4 rows in flight: the wave of [MASK] (~270 duplicates at the bench workload) and of [CLS] /
+// [SEP] (128 each) walked 30 - 70 dependent memory round trips while every other wave had long finished -- 157 - 208 us
+// for a 19 us memory job.  The order of the additions is unchanged (first occurrence, then ascending token order).
 __global__ __launch_bounds__(kBlock) void sum_kernel(int n, int d, int num_rows, const int64_t *__restrict__ ids,
                                                      const float *__restrict__ dy, long long ld,
                                                      long long padding_idx, const int32_t *__restrict__ first,
                                                      const int32_t *__restrict__ count, float *__restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);          // one wave per token
+  const int t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);          // token
+  const int col = blockIdx.y * 256 + lane * 4;                            // this wave's 256-column chunk
   if (t >= n) return;
   const long long id = ids[t];
   if (id < 0 || id >= num_rows || id == padding_idx) return;
   if (first[id] != t) return;                                             // a later duplicate: its first occurrence sums it
   const int want = count[id];
-  float4 acc[kMaxChunks];
-  const int chunks = (d + 255) / 256;
-#pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) {
-    const int col = c * 256 + lane * 4;
-    acc[c] = (c < chunks && col < d) ? *reinterpret_cast<const float4 *>(dy + (size_t)t * ld + col)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  const bool live = col < d;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = live ? *reinterpret_cast<const float4 *>(dy + (size_t)t * ld + col) : zero;
   int found = 1;
   // ids are scanned kAhead x 64 at a time: the loads of one trip are independent, so an id that occurs
   // across the whole batch ([CLS], [SEP]) costs n / (64 * kAhead) memory round trips, not n / 64
-  constexpr int kAhead = 16;
+  constexpr int kAhead = 16, kRows = 16;
   for (int base = t + 1; base < n && found < want; base += 64 * kAhead) {
     unsigned long long masks[kAhead];
 #pragma unroll
@@ -63,47 +64,41 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(int n, int d, int num_rows,
       const bool match = tt < n && ids[tt] == id;
       masks[u] = __ballot(match);
     }
+    // the matching rows of this trip in ascending token order, kRows at a time
+    int u = 0;
+    unsigned long long mask = masks[0];
+    for (;;) {
+      int rows[kRows];
+      int nr = 0;
 #pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-      unsigned long long mask = masks[u];
-      while (mask) {                                                      // ascending token order, four rows per trip:
-        int rows[4];                                                      // their loads are issued together, the adds
-        int nr = 0;                                                       // stay in token order
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          rows[q] = -1;
-          if (mask) {
-            rows[q] = base + u * 64 + (__ffsll((long long)mask) - 1);
-            mask &= mask - 1ull;
-            ++nr;
-          }
+      for (int q = 0; q < kRows; ++q) {
+        rows[q] = -1;
+        while (!mask && u + 1 < kAhead) {            // (wave-uniform: masks are ballots)
+          ++u;
+          mask = u == 1 ? masks[1] : u == 2 ? masks[2] : u == 3 ? masks[3] : u == 4 ? masks[4] : u == 5 ? masks[5] : u == 6 ? masks[6]
+               : u == 7 ? masks[7] : u == 8 ? masks[8] : u == 9 ? masks[9] : u == 10 ? masks[10] : u == 11 ? masks[11]
+               : u == 12 ? masks[12] : u == 13 ? masks[13] : u == 14 ? masks[14] : masks[15];
         }
-        float4 v[4][kMaxChunks];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int c = 0; c < kMaxChunks; ++c) {
-            const int col = c * 256 + lane * 4;
-            v[q][c] = (rows[q] >= 0 && c < chunks && col < d) ? *reinterpret_cast<const float4 *>(dy + (size_t)rows[q] * ld + col)
-                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (rows[q] < 0) continue;
-#pragma unroll
-          for (int c = 0; c < kMaxChunks; ++c) {
-            acc[c].x += v[q][c].x; acc[c].y += v[q][c].y; acc[c].z += v[q][c].z; acc[c].w += v[q][c].w;
-          }
+        if (mask) {
+          rows[q] = base + u * 64 + (__ffsll((long long)mask) - 1);
+          mask &= mask - 1ull;
+          ++nr;
         }
-        found += nr;
       }
+      if (nr == 0) break;
+      float4 v[kRows];
+#pragma unroll
+      for (int q = 0; q < kRows; ++q)
+        v[q] = (rows[q] >= 0 && live) ? *reinterpret_cast<const float4 *>(dy + (size_t)rows[q] * ld + col) : zero;
+#pragma unroll
+      for (int q = 0; q < kRows; ++q) {
+        if (rows[q] < 0) continue;
+        acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w;
+      }
+      found += nr;
     }
   }
-#pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) {
-    const int col = c * 256 + lane * 4;
-    if (c < chunks && col < d) *reinterpret_cast<float4 *>(out + (size_t)id * d + col) = acc[c];
-  }
+  if (live) *reinterpret_cast<float4 *>(out + (size_t)id * d + col) = acc;
 }
 
 }  // namespace gps_emb
@@ -124,7 +119,7 @@ extern "C" int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids
   hipLaunchKernelGGL(gps_emb::mark_kernel, dim3((n + gps_emb::kBlock - 1) / gps_emb::kBlock), dim3(gps_emb::kBlock), 0, s,
                      n, num_rows, ids, padding_idx, first, count);
   const int waves_per_block = gps_emb::kBlock / 64;
-  hipLaunchKernelGGL(gps_emb::sum_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(gps_emb::kBlock), 0, s,
-                     n, d, num_rows, ids, dy, ld, padding_idx, first, count, out);
+  hipLaunchKernelGGL(gps_emb::sum_kernel, dim3((n + waves_per_block - 1) / waves_per_block, (d + 255) / 256), dim3(gps_emb::kBlock),
+                     0, s, n, d, num_rows, ids, dy, ld, padding_idx, first, count, out);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }

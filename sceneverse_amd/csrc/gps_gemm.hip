@@ -25,6 +25,7 @@
 //            x GELU'(pre) x dropout-mask | x ReLU'(h) | fp32 (partial) sums + column sums.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gps_gemm_layout.h"
 #include "gps_hip.h"
@@ -74,6 +75,7 @@ struct Params {
   unsigned long long seed;
   const unsigned long long *seed_dev;
   const int *extent_dev;   // optional device count of leading token rows that carry work (rows of M for NT / NN, of K for TN)
+  int row0;                // NT / NN: this launch covers rows row0 .. row0 + M - 1 of a larger product (dropout stream index only)
   int accumulate;          // EPI_F32, splits == 1: C += acc, colsum += column sums (grouped weight gradients into live .grad buffers)
 };
 
@@ -427,7 +429,7 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   // pre-activation / low halves through `pre` for the GELU and split forms); aux4 = this group's 4 saved values
   auto finish = [&](f32x4 v, int m, int n, const f32x4 &bias, const u32x2 &aux4, u32x2 &pre) -> u32x2 {
     v = v + bias;
-    const unsigned long long idx = (unsigned long long)m * (unsigned long long)P.N + (unsigned long long)n;
+    const unsigned long long idx = (unsigned long long)(m + P.row0) * (unsigned long long)P.N + (unsigned long long)n;
     if (EPI == EPI_BIAS_GELU) {
       pre = pack4(v);
       v[0] = gelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
@@ -1092,10 +1094,10 @@ int launch_8p(Params &P, hipStream_t s) {
 // a gradient: the flat buffer of the data-parallel step).  Deterministic: every output element has exactly one writer
 // and one summation order.
 //
-// Tiles are enumerated problem by problem in the order given (the host sorts by decreasing reduction length) and dealt
-// round-robin to min(tiles, CUs) persistent workgroups, alternate rounds in reverse (longest-first + snake = every
-// workgroup gets one tile of each cost class); inside a round the workgroups of an XCD take consecutive tiles (tiles of
-// one output row share their dY panel in that XCD's L2).  The problem table lives in device memory (written by
+// Tiles are enumerated problem by problem in the order given (the host sorts by decreasing reduction length).  The
+// min(tiles, CUs) persistent workgroups take their first tile statically (the workgroups of an XCD take consecutive
+// tiles: tiles of one output row share their dY panel in that XCD's L2) and every later one from an atomic counter --
+// longest first, whoever is free takes the next: the greedy schedule keeps the makespan within one short tile of the mean.  The problem table lives in device memory (written by
 // wgrad_table_write_kernel from kernel arguments, 32 records per launch: capturable, no host buffer to keep alive).
 // ---------------------------------------------------------------------------------------------------------
 struct WgradRec {          // 64 bytes
@@ -1108,24 +1110,30 @@ struct WgradRec {          // 64 bytes
 };
 constexpr int kWgradMaxProblems = 256, kWgradSlots = 4, kWgradChunk = 32;
 __device__ WgradRec g_wgrad_table[kWgradSlots][kWgradMaxProblems];
+__device__ unsigned int g_wgrad_next[kWgradSlots];       // next tile id to hand out (dynamic part of the schedule)
 struct WgradChunkArgs { WgradRec r[kWgradChunk]; };
 
-__global__ __launch_bounds__(64) void wgrad_table_write_kernel(const WgradChunkArgs c, int slot, int offset, int count) {
+__global__ __launch_bounds__(64) void wgrad_table_write_kernel(const WgradChunkArgs c, int slot, int offset, int count,
+                                                               int first_dynamic_tile) {
   if ((int)threadIdx.x < count) g_wgrad_table[slot][offset + threadIdx.x] = c.r[threadIdx.x];
+  if (offset == 0 && threadIdx.x == 0) g_wgrad_next[slot] = (unsigned int)first_dynamic_tile;
 }
 
 __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_problems, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 128 KB (gemm8p_tile)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ int s_next;
   const WgradRec *tab = g_wgrad_table[slot];
   const int G = (int)gridDim.x;
-  const int vw = xcd_virtual_id(blockIdx.x, G);
+  // First tile: static, the workgroups of an XCD take consecutive tiles (tiles of one output row share their dY panel
+  // in that XCD's L2 while everybody still walks K in step).  Every later tile: the next one of the longest-first list,
+  // handed out by an atomic counter -- whoever finishes first takes it (greedy longest-processing-time schedule; every
+  // tile is still computed by exactly one workgroup, so results do not depend on who that is).
+  int t = xcd_virtual_id(blockIdx.x, G);
   int p = 0;
-  for (int r = 0;; ++r) {
-    const int t = r * G + ((r & 1) ? G - 1 - vw : vw);
-    if (t >= total_tiles) break;                            // (the rounds after a partial one are empty for everybody)
-    if (r & 1) p = 0;                                       // tile ids are not monotonic across a reversed round
+  for (;;) {
+    if (t >= total_tiles) break;
     while (p + 1 < n_problems && tab[p + 1].tile0 <= t) ++p;
     const WgradRec rec = tab[p];
     Params P = {};
@@ -1149,7 +1157,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_p
     // ever see its own LDS traffic
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     gemm8p_tile<true, true, EPI_F32>(P, smem, lane, wave, tile_m * 256, tile_n * 256, tile_n, 0, 0, nst, k_eff);
-    __syncthreads();                                        // the next tile's first copies overwrite the stage buffers
+    if (threadIdx.x == 0) s_next = (int)atomicAdd(&g_wgrad_next[slot], 1u);
+    __syncthreads();                                        // s_next visible; the next tile's first copies overwrite the stage buffers
+    t = __builtin_amdgcn_readfirstlane(s_next);
+    __syncthreads();                                        // (s_next is rewritten at the end of the next tile)
   }
 }
 
@@ -1420,6 +1431,10 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
       order[j + 1] = v;
     }
     const int slot = (int)(slot_counter++ % kWgradSlots);
+    long long all_tiles = 0;
+    for (int i = 0; i < cnt; ++i) all_tiles += (long long)((problems[order[i]].M + 255) / 256) * ((problems[order[i]].N + 255) / 256);
+    if (all_tiles > 0x3FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+    const int grid = all_tiles < n_cu ? (int)all_tiles : n_cu;
     long long tile0 = 0;
     for (int c0 = 0; c0 < cnt; c0 += kWgradChunk) {
       WgradChunkArgs args = {};
@@ -1432,13 +1447,11 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
         r.tile0 = (int)tile0;
         r.flags = q.accumulate ? 1 : 0;
         tile0 += (long long)((q.M + 255) / 256) * ((q.N + 255) / 256);
-        if (tile0 > 0x3FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
       }
-      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, args, slot, c0, n);
+      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, args, slot, c0, n, grid);
       if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
     }
     const int total = (int)tile0;
-    const int grid = total < n_cu ? total : n_cu;
     hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)grid), dim3(512), LDS, s, slot, cnt, total);
     if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
   }
@@ -1505,6 +1518,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
   P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
   P.extent_dev = a->extent_dev;
+  P.row0 = a->form != GPS_GEMM_TN ? a->reserved2 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (a->K == 0) P.nkt = 0;
 
@@ -1513,6 +1527,10 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
 
   int st;
+  // ([r4] negative result: cutting the rows of a product whose 128 x 128 tiles leave a nearly empty last round -- 8 320 x
+  // 2 048: 1 040 tiles = 2.03 rounds of 512 -- into whole rounds + a tail launch of 128 x 64 tiles was built, verified
+  // bit-equal and measured: 13.79 / 13.88 ms per step against 13.69 / 13.54 without it on one box.  A nearly empty
+  // round is short -- its few tiles have their CUs to themselves -- so the tail launch only adds its own ramp.)
   if (a->form == GPS_GEMM_NT) {
     switch (a->epilogue) {
       case GPS_GEMM_EPI_BIAS: st = launch_variant<false, false, EPI_BIAS>(P, variant, s); break;

@@ -95,11 +95,18 @@ class GPSTrainStep:
         if self.graph or self.graph_dp:
             # capturable optimizer state: step counters and learning rates live on the device
             cfg.solver.optim.args["capturable"] = True
-            for g in param_groups:
+            # the live learning rates are 0-dim views of ONE device vector: the scheduler's update is one host-to-device
+            # copy per step (torch's LambdaLR.step fills every group's tensor separately: 16 launches per step on the
+            # stream the graph replays on)
+            self._lr_dev = torch.tensor([float(g["lr"]) for g in param_groups], dtype=torch.float32, device=self.device)
+            # pinned staging ring: an asynchronous copy reads its source when the GPU gets to it, possibly several steps
+            # after the host queued it -- every step writes its own slot (the host never runs 256 steps ahead)
+            self._lr_host = torch.empty((256, len(param_groups)), dtype=torch.float32).pin_memory()
+            for gi, g in enumerate(param_groups):
                 # float `initial_lr` keeps LambdaLR's arithmetic on the host (a tensor base lr would
                 # cost one .item() sync per group and step); the live `lr` is filled in place
                 g["initial_lr"] = float(g["lr"])
-                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
+                g["lr"] = self._lr_dev[gi]
         self.loss, self.optimizer, self.scheduler = build_optim(cfg, param_groups, total_steps)
         self.loss = self.loss.to(self.device)
         self.grad_norm = cfg.solver.get("grad_norm", None)
@@ -137,6 +144,8 @@ class GPSTrainStep:
         self.wgrad_group = bool(wgrad_group) and bool(native_gemm) and self.device.type == "cuda" and not self.wgrad_overlap
         self.frozen_unused: list = []
         self.global_step = 0
+        if not hasattr(self, "_lr_dev"):
+            self._lr_dev = self._lr_host = None
         # [r4] ONE stream for everything the graph modes run outside a replay: the eager warm-up steps, every capture, the
         # eager steps after a capture.  A parameter's AccumulateGrad node remembers the stream that was current when it
         # was created and outlives a step whenever anything still references that step's autograd graph; its
@@ -442,6 +451,23 @@ class GPSTrainStep:
             self._work_stream = torch.cuda.Stream(device=self.device)
         return self._work_stream
 
+    def _sched_step(self) -> None:
+        """`scheduler.step()`; with device-resident learning rates (graph modes) and a LambdaLR: the same bookkeeping and
+        values, written to the device with one copy."""
+        from torch.optim.lr_scheduler import LambdaLR
+        sch = self.scheduler
+        if self._lr_dev is None or type(sch) is not LambdaLR or len(sch.base_lrs) != self._lr_dev.numel():
+            sch.step()
+            return
+        sch._step_count += 1
+        sch.last_epoch += 1
+        vals = [float(base) * float(fn(sch.last_epoch)) for fn, base in zip(sch.lr_lambdas, sch.base_lrs)]
+        slot = self._lr_host[sch._step_count % self._lr_host.shape[0]]
+        for i, v in enumerate(vals):
+            slot[i] = v
+        self._lr_dev.copy_(slot, non_blocking=True)
+        sch._last_lr = vals
+
     def _drop_previous_graph(self) -> None:
         """Nothing of the previous step's autograd graph may survive into this step's forward (see _work_stream): the
         stage boundary the model publishes is the one reference this package keeps."""
@@ -560,7 +586,7 @@ class GPSTrainStep:
             data_dict['cur_step'] = 0
             data_dict['total_steps'] = 1 << 30
             total, losses = self._graph_dp_step(data_dict) if self.graph_dp else self._graph_step(data_dict)
-            self.scheduler.step()
+            self._sched_step()
             self.global_step += 1
             return total, losses
         data_dict['cur_step'] = self.global_step
@@ -585,7 +611,7 @@ class GPSTrainStep:
             self._clip_and_step()
         if cur is not None:
             cur.wait_stream(self._stream())
-        self.scheduler.step()
+        self._sched_step()
         self.global_step += 1
         return total.detach(), {k: v.detach() for k, v in losses.items()}
 
