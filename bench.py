@@ -498,8 +498,9 @@ def main() -> None:
             step.step(dict(batch))
         torch.cuda.synchronize()
         graph_note = ("whole step replayed as one HIP graph" if step.graph else
-                      "4 HIP graphs per step (forward | losses + top backward | bottom backward | clip+AdamW) around "
-                      "the eager RCCL all-gather and two all-reduces")
+                      "5 HIP graphs per step (forward | losses + top backward | text-encoder backward | object-encoder "
+                      "backward | clip+AdamW) around the eager RCCL all-gather and three all-reduces (two of them beside "
+                      "the next backward graph)")
         if step.wgrad_group:
             graph_note += "; weight gradients of a backward segment in one grouped launch"
     if use_graph and step.static_inputs() is not None:
@@ -783,8 +784,8 @@ def main() -> None:
                            "text_live_row_fraction": round(float(sum(batch[k].float().sum().item() for k in batch if k.endswith("txt_masks")))
                                                            / max(1.0, float(sum(batch[k].numel() for k in batch if k.endswith("txt_masks")))), 4)}),
                        "launch": (graph_note or "eager") + ("; weight-gradient GEMMs on a second stream" if step.wgrad_overlap else ""),
-                       **({"grad_exchange": "fp32 all-reduce of the top / bottom segment of one flat buffer, the first beside "
-                                            "the bottom backward graph" if step.graph_dp
+                       **({"grad_exchange": "fp32 all-reduce of the top / text / object range of one flat buffer, the first two "
+                                            "beside the next backward graph" if step.graph_dp
                            else "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
                            if (args.bf16_grads and not share) else "fp32 all-reduce (DDP buckets)"} if world > 1 else {}),
                        "final_loss": round(final_loss, 4)},

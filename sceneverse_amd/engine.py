@@ -29,8 +29,10 @@ box, so the step is split at its two exchange points instead and the collectives
     eager    all-gather of the contrastive features (C2)          RCCL, into static buffers
     graph 2a losses + backward of the TOP segment (joint encoder, heads) into the flat fp32 gradient buffer
     eager    all-reduce of the top range of the buffer (C1, part 1)  RCCL, asynchronous: runs beside graph 2b
-    graph 2b backward of the BOTTOM segment (text + object encoders) from the boundary gradients
-    eager    all-reduce of the bottom range (C1, part 2), wait for both, / world
+    graph 2b backward of the TEXT encoder from its boundary gradients
+    eager    all-reduce of the text range (C1, part 2), asynchronous: runs beside graph 2c
+    graph 2c backward of the OBJECT encoder
+    eager    all-reduce of the object range (C1, part 3), wait for all, / world
     graph 3  gradient clipping + AdamW                             (replay)
 
 [r3] The backward pass is cut at the outputs of the text and object encoders (model._stage_boundary;
@@ -330,19 +332,27 @@ class GPSTrainStep:
             # [r3] two backward segments: "top" = joint encoder, heads, loss parameters; "bottom" = the text and the
             # object encoder.  Their gradients sit in two contiguous ranges of the flat buffer, so the all-reduce of
             # the top range travels over xGMI while the bottom segment's backward graph replays.
-            bottom_ids = set()
-            for name in ("lang_encoder", "point_encoder"):
+            # [r4] the bottom segment itself is two independent autograd sub-graphs (text encoder, object encoder): each
+            # gets its own backward graph and its own range, so the exchange is top | text | objects with only the LAST
+            # (smallest) range exposed: the text range (BERT incl. its 94 MB word table) travels beside the object
+            # encoder's backward.
+            seg_of = {}
+            for si, name in enumerate(("lang_encoder", "point_encoder")):
                 sub = getattr(self.model, name, None)
                 if sub is not None:
-                    bottom_ids.update(id(p) for p in sub.parameters())
-            top = [p for p in used if id(p) not in bottom_ids]
-            bottom = [p for p in used if id(p) in bottom_ids]
+                    seg_of.update({id(p): si for p in sub.parameters()})
+            top = [p for p in used if id(p) not in seg_of]
+            bottom_segs = [[p for p in used if seg_of.get(id(p)) == si] for si in range(2)]
+            bottom = bottom_segs[0] + bottom_segs[1]
             used = top + bottom
             # every view starts on a 16-byte boundary (kernels store gradients as 4-float vectors): sizes are rounded up
             # to 4 elements, the padding stays zero and travels with the all-reduce
             pad4 = lambda n: (n + 3) // 4 * 4  # noqa: E731
             self._flat_grad = torch.zeros(sum(pad4(p.numel()) for p in used), dtype=torch.float32, device=self.device)
             self._n_top = sum(pad4(p.numel()) for p in top)
+            self._seg_ends = [self._n_top]                          # end offsets of the ranges: top, text, objects
+            for seg in bottom_segs:
+                self._seg_ends.append(self._seg_ends[-1] + sum(pad4(p.numel()) for p in seg))
             off = 0
             self.optimizer.zero_grad(set_to_none=True)
             for p in used:
@@ -385,12 +395,13 @@ class GPSTrainStep:
             self._stage("captured_g2a", out=out, total=total)
             if segmented:
                 live = [t for t in boundary if t.grad is not None]
-                groups = [live]
-                if getattr(self, "_debug_split_bottom", False):
-                    # diagnostics (tools/probes): the independent sub-graphs below the boundary as separate HIP graphs,
-                    # last-created first (the order the autograd engine runs them in inside one backward call)
-                    groups = [[t for t in live if t is boundary[-1]], [t for t in live if t is not boundary[-1]]]
-                    groups = [g for g in groups if g]
+                # boundary tensors by the encoder that produced them (OpenVocab lists the text outputs first, the object
+                # encoder's output last): one backward graph per encoder, text first (see the ranges above).
+                # `_debug_joint_bottom` (probes): both in ONE backward call, as round 3 did.
+                groups = [[t for t in live if t is not boundary[-1]], [t for t in live if t is boundary[-1]]]
+                if getattr(self, "_debug_joint_bottom", False) or not all(groups) or not all(bottom_segs):
+                    groups = [live]
+                self._bottom_graphs_per_range = len(groups) == 2
                 g2b = []
                 dbg_inputs = getattr(self, "_debug_bottom_inputs", None)        # probes: restrict the bottom backward
                 bot_in = bottom if dbg_inputs is None else \
@@ -430,17 +441,20 @@ class GPSTrainStep:
         g2a.replay()
         self._stage("replayed_g2a")
         if g2b is not None:
-            h_top = self._allreduce_async(0, self._n_top)              # overlaps the bottom segment's backward
+            handles = [self._allreduce_async(0, self._n_top)]          # overlaps the bottom segments' backward graphs
             for gi, gg in enumerate(g2b):
                 gg.replay()
                 self._stage("replayed_g2b" if gi + 1 == len(g2b) else f"replayed_g2b_part{gi}")
+                if getattr(self, "_bottom_graphs_per_range", False) and gi + 1 < len(g2b):
+                    handles.append(self._allreduce_async(self._seg_ends[gi], self._seg_ends[gi + 1]))
             if getattr(self, "_eager_g2b", None) is not None:                   # probes only
                 live, bot_in = self._eager_g2b
                 with self._wgrad_ctx():
                     torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bot_in, retain_graph=True)
                 self._stage("replayed_g2b")
-            h_bot = self._allreduce_async(self._n_top, self._flat_grad.numel())
-            self._wait_allreduce(h_top, h_bot)
+            done = self._seg_ends[len(handles) - 1]                    # ranges already on their way
+            handles.append(self._allreduce_async(done, self._flat_grad.numel()))
+            self._wait_allreduce(*handles)
         else:
             self._allreduce_grads()
         g3.replay()

@@ -143,6 +143,11 @@ def _worker(rank, world, port, tmp):
         h_bot = eng._allreduce_async(4, 10)
         eng._wait_allreduce(h_top, h_bot)
         result["graph_dp_segments_ok"] = bool(torch.allclose(eng._flat_grad, torch.arange(10.0) * (world + 1) / 2.0))
+        # [r4] three ranges in flight (top | text | objects), waited for together
+        eng._flat_grad = torch.arange(12.0) * (rank + 1)
+        hs = [eng._allreduce_async(0, 5), eng._allreduce_async(5, 9), eng._allreduce_async(9, 12)]
+        eng._wait_allreduce(*hs)
+        result["graph_dp_three_ranges_ok"] = bool(torch.allclose(eng._flat_grad, torch.arange(12.0) * (world + 1) / 2.0))
         # staged backward = one backward: gradients of the top parameters and of the boundary tensors first, then the
         # bottom parameters from the boundary gradients (what graphs 2a / 2b capture)
         stage = GPSTrainStep(_small_cfg(lp, world, between_batch=False), device="cpu", ddp=False, seed=5)
@@ -167,6 +172,25 @@ def _worker(rank, world, port, tmp):
                     for n, p in stage.model.named_parameters() if n in want_g)
         result["staged_backward_rel_err"] = worst
         result["staged_counts"] = (len(top), len(bottom), len(boundary))
+        # [r4] the N > 1 default: the bottom segment as TWO backward calls, text encoder first, then the object encoder
+        # (one HIP graph and one all-reduce range each in engine._graph_dp_step); still the gradients of one backward
+        stage.model.zero_grad(set_to_none=True)
+        _, total_s, _ = stage.forward_loss(dict(batch))
+        boundary = list(stage.model._stage_boundary)
+        torch.autograd.backward(total_s, inputs=top + boundary, retain_graph=True)
+        live = [t for t in boundary if t.grad is not None]
+        groups = [[t for t in live if t is not boundary[-1]], [t for t in live if t is boundary[-1]]]
+        assert all(groups)
+        lang_ids = {id(p) for p in stage.model.lang_encoder.parameters()}
+        for gi, grp in enumerate(groups):
+            torch.autograd.backward(grp, grad_tensors=[t.grad for t in grp], inputs=bottom)
+            if gi == 0:      # after the text graph only the text encoder's parameters have gradients: its range can leave
+                assert all((p.grad is not None) == (id(p) in lang_ids) for p in bottom)
+        result["three_stage_backward_rel_err"] = max(
+            (p.grad - want_g[n]).abs().max().item() / (want_g[n].abs().max().item() + 1e-12)
+            for n, p in stage.model.named_parameters() if n in want_g)
+        stage._drop_previous_graph()
+        result["boundary_dropped"] = stage.model._stage_boundary is None
 
         # -- the probe's "received a gradient" mask is agreed across ranks: on rank 0 the probe batch leaves the
         #    masked-LM branch unused (its loss term is dropped there, a stand-in for a data-dependent branch); rank 1
@@ -235,6 +259,7 @@ def test_ddp_world_size_2_gloo():
         assert r["n_frozen_unused"] >= 13 and r["n_unused"] == 0, r     # found by the probe step, frozen before the wrap
         assert r["graph_dp_gather_ok"] and r["graph_dp_allreduce_ok"] and r["graph_dp_segments_ok"], r
         assert r["staged_backward_rel_err"] <= 1e-6 and min(r["staged_counts"]) > 0, r
+        assert r["graph_dp_three_ranges_ok"] and r["three_stage_backward_rel_err"] <= 1e-6 and r["boundary_dropped"], r
         assert r["frozen_sets_equal"] and r["lm_head_kept"] and r["n_frozen_agreed"] >= 13, r
         assert r["probe_keeps_rng"] and r["probe_keeps_buffers"], r
         assert r["hook_vs_fp32_sum"] <= 2.0 ** -8 and r["hook_vs_exact"] <= 2.0 ** -7, r

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+OUT=$PWD/gpurun_out/r4_5; mkdir -p $OUT
+export TMPDIR=/tmp
+echo "== tests"; timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_graph_chain.py -q -x > $OUT/pytest.log 2>&1; grep -E "passed|failed|Error|assert" $OUT/pytest.log | tail -8
+for i in 1 2; do
+echo "== one graph"; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+echo "== graph-dp"; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --graph-dp 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['launch'])"
+done
+echo "== N=2 on one GPU (gloo, shared)"; GPS_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-extras --batch 16 2>&1 | tail -1 | cut -c1-700

@@ -25,6 +25,7 @@ for sec in (cfg.model.language, cfg.model.vision, cfg.model.grounding):
     if "num_layers" in sec.args:
         sec.args.num_layers = 1
 st = GPSTrainStep(cfg, device="cuda", ddp=False, graph="dp", graph_warmup=2, seed=7, wgrad_group=not classic)
+st._debug_joint_bottom = legacy                                          # round 3: both encoders in one backward call
 if legacy:
     import warnings
     warnings.filterwarnings("ignore", message=".*AccumulateGrad node's stream does not match.*")

@@ -231,7 +231,7 @@ cfg = gps_pretrain_cfg(_lang_dir())
 st = GPSTrainStep(cfg, device=DEV, ddp=False, graph={"dp": "dp", "one": True, "off": False}[args.graph], graph_warmup=2, seed=7,
                   wgrad_group=not args.no_wgrad_group)
 st.stage_hook = hook
-st._debug_split_bottom = bool(args.split_bottom)
+st._debug_joint_bottom = not bool(args.split_bottom)
 st._debug_bottom_inputs = args.bottom_inputs
 st._debug_eager_g2b = bool(args.eager_g2b)
 st._debug_clone_roots = bool(args.clone_roots)
