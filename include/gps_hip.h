@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 5
+#define GPS_HIP_ABI_VERSION 6
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -308,6 +308,21 @@ GPS_API int gps_ln_partial_rows(int n_rows);
  * first use and left zero by every call (second-level partial rows + arrival counters of the row slices; one
  * stream at a time); NULL = one workgroup per 64 columns walks all rows (slow above a few dozen rows). */
 GPS_API long long gps_ln_reduce_scratch_bytes(int d);
+/* The same reduction for many LayerNorms in one launch: problem i sums part_i[2][parts_i][d] into out_gamma_i (d) and
+ * out_beta_i (d) (accumulate != 0: added to what is there), same summation order as gps_ln_reduce_partials.  Meant for
+ * the dgamma / dbeta of every fused residual-LayerNorm backward of a step, deferred by the host (they are only needed by
+ * the optimizer).  scratch: gps_ln_reduce_grouped_scratch_bytes(d) bytes, ZERO before its first use, left zero by every
+ * call; one stream at a time.  The problem array is host memory, consumed before the call returns. */
+typedef struct gps_ln_reduce_problem {
+  const float *part;
+  float *out_gamma;
+  float *out_beta;
+  int parts;
+  int accumulate;
+} gps_ln_reduce_problem;
+GPS_API long long gps_ln_reduce_grouped_scratch_bytes(int d);
+GPS_API int gps_ln_reduce_partials_grouped(const gps_ln_reduce_problem *problems, int n_problems, int d, void *scratch,
+                                           gps_stream_t stream);
 GPS_API int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, void *scratch,
                                    gps_stream_t stream);
 /* dy (x's dtype) [+ dy_bf16: gradient that arrived through the bf16 copy, may be NULL] -> dx (x's

@@ -43,6 +43,11 @@ class WgradProblem(ctypes.Structure):
                 ("C", _vp), ("ldc", ctypes.c_longlong), ("colsum", _vp), ("extent_dev", _vp)]
 
 
+class LnReduceProblem(ctypes.Structure):
+    """struct gps_ln_reduce_problem of include/gps_hip.h, field for field."""
+    _fields_ = [("part", _vp), ("out_gamma", _vp), ("out_beta", _vp), ("parts", _i), ("accumulate", _i)]
+
+
 class AttnArgs(ctypes.Structure):
     """struct gps_attn_args of include/gps_hip.h, field for field."""
     _fields_ = [("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("head_dim", _i), ("dtype", _i), ("compute", _i),
@@ -99,6 +104,7 @@ SIGNATURES = {
     "gps_masked_ce_backward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp],
     "gps_ln_reduce_partials": [_i, _i, _vp, _vp, _vp, _vp],
+    "gps_ln_reduce_partials_grouped": [ctypes.POINTER(LnReduceProblem), _i, _i, _vp, _vp],
     "gps_l2_normalize_forward": [_i, _i, _vp, _f, _vp, _vp, _vp],
     "gps_l2_normalize_backward": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp],
     "gps_add_dropout_layernorm_forward": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 6,
@@ -159,6 +165,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_ln_partial_rows.argtypes = [_i]
     lib.gps_ln_reduce_scratch_bytes.restype = ctypes.c_longlong
     lib.gps_ln_reduce_scratch_bytes.argtypes = [_i]
+    lib.gps_ln_reduce_grouped_scratch_bytes.restype = ctypes.c_longlong
+    lib.gps_ln_reduce_grouped_scratch_bytes.argtypes = [_i]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -286,6 +286,79 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(int parts, int 
   out[c] = sum;
 }
 
+// [r4] The same reduction for MANY LayerNorms in one launch (blockIdx.z = problem): the 24 + fused residual-LayerNorm
+// backward passes of a step each ended in their own 7 us reduce launch (0.19 ms per step); their parameter gradients are
+// only needed by the optimizer, so the host defers them (modules/layers/fused_norm.py) and sums them together.  Results
+// go straight into gamma.grad / beta.grad (plain store, or added to what is there).  Same two-level scheme and the same
+// fixed summation order per problem as reduce_partials_kernel.
+struct LnRedProblem {          // 40 bytes
+  const float *part;           // [2][parts][d]
+  float *out_g, *out_b;        // (d) each
+  int parts, accumulate;
+};
+constexpr int kLnRedMax = 64;
+struct LnRedArgs { LnRedProblem p[kLnRedMax]; };
+
+__global__ __launch_bounds__(kBlock) void reduce_partials_grouped_kernel(const LnRedArgs args, int d, float *__restrict__ part2_all,
+                                                                          unsigned int *__restrict__ tickets_all) {
+  __shared__ float red[kWaves][64];
+  __shared__ int last;
+  const LnRedProblem P = args.p[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;           // column in [0, 2 d)
+  const int groups = gridDim.x;
+  const int parts = P.parts;
+  int slices = (parts + 63) / 64;
+  slices = slices > (int)gridDim.y ? (int)gridDim.y : slices;       // this problem's slices (<= kRedSlices)
+  if ((int)blockIdx.y >= slices) return;
+  float *part2 = part2_all + (size_t)blockIdx.z * kRedSlices * 2 * d;
+  unsigned int *tickets = tickets_all + (size_t)blockIdx.z * groups;
+  const int per = (parts + slices - 1) / slices;
+  const int r_begin = blockIdx.y * per, r_end = min(parts, r_begin + per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < 2 * d) {
+    const int which = c / d, col = c - which * d;
+    const float *p = P.part + (size_t)which * parts * d + col;
+    int r = r_begin + wave;
+    for (; r + 7 * kWaves < r_end; r += 8 * kWaves) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += p[(size_t)(r + u * kWaves) * d];
+    }
+    for (; r < r_end; r += kWaves) acc[0] += p[(size_t)r * d];
+  }
+  red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  auto emit = [&](float v) {
+    float *dst = c < d ? P.out_g + c : P.out_b + (c - d);
+    *dst = P.accumulate ? *dst + v : v;
+  };
+  if (slices == 1) {
+    if (wave == 0 && c < 2 * d) emit((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    return;
+  }
+  if (wave == 0) {
+    if (c < 2 * d)
+      __hip_atomic_store(part2 + (size_t)blockIdx.y * 2 * d + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const unsigned int t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t == (unsigned int)slices - 1u);
+      if (last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!last || wave != 0 || c >= 2 * d) return;
+  float v[kRedSlices];
+#pragma unroll
+  for (int s2 = 0; s2 < kRedSlices; ++s2)
+    v[s2] = (s2 < slices) ? __hip_atomic_load(part2 + (size_t)s2 * 2 * d + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  float sum = v[0];
+#pragma unroll
+  for (int s2 = 1; s2 < kRedSlices; ++s2) sum += v[s2];
+  emit(sum);
+}
+
 // ---- y = x / max(||x||_2, eps) per row (F.normalize(x, p=2, dim=-1)) and its backward ---------------------------------
 // One wave per row; the row is read once (d <= 2048: kept in registers), forward also stores 1 / max(norm, eps).
 // backward: dx = inv * (dy - y (y . dy)), or inv * dy where the norm was clamped (torch treats the clamp as a constant).
@@ -366,6 +439,40 @@ int gps_ln_reduce_partials(int parts, int d, const float *part, float *out, void
   hipLaunchKernelGGL(gps_ln::reduce_partials_kernel, dim3(groups, slices), dim3(gps_ln::kBlock), 0,
                      (hipStream_t)stream, parts, d, part, out, part2, tickets);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_ln_reduce_partials_grouped(const gps_ln_reduce_problem *problems, int n_problems, int d, void *scratch,
+                                   gps_stream_t stream) {
+  using namespace gps_ln;
+  if (n_problems < 0 || d < 1 || (n_problems > 0 && (!problems || !scratch))) return GPS_ERR_INVALID_ARGUMENT;
+  const int groups = (2 * d + 63) / 64;
+  for (int base = 0; base < n_problems; base += kLnRedMax) {
+    const int n = n_problems - base < kLnRedMax ? n_problems - base : kLnRedMax;
+    LnRedArgs args = {};
+    int max_slices = 1;
+    for (int i = 0; i < n; ++i) {
+      const gps_ln_reduce_problem &q = problems[base + i];
+      if (q.parts < 1 || !q.part || !q.out_gamma || !q.out_beta) return GPS_ERR_INVALID_ARGUMENT;
+      args.p[i].part = q.part;
+      args.p[i].out_g = q.out_gamma;
+      args.p[i].out_b = q.out_beta;
+      args.p[i].parts = q.parts;
+      args.p[i].accumulate = q.accumulate ? 1 : 0;
+      int sl = (q.parts + 63) / 64;
+      sl = sl > kRedSlices ? kRedSlices : sl;
+      max_slices = sl > max_slices ? sl : max_slices;
+    }
+    float *part2 = reinterpret_cast<float *>(scratch);
+    unsigned int *tickets = reinterpret_cast<unsigned int *>(part2 + (size_t)kLnRedMax * kRedSlices * 2 * d);
+    hipLaunchKernelGGL(reduce_partials_grouped_kernel, dim3(groups, max_slices, n), dim3(kBlock), 0, (hipStream_t)stream, args, d,
+                       part2, tickets);
+    if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
+  }
+  return GPS_OK;
+}
+
+long long gps_ln_reduce_grouped_scratch_bytes(int d) {
+  return (long long)gps_ln::kLnRedMax * (gps_ln::kRedSlices * 2 * d * 4 + ((2 * d + 63) / 64) * 4);
 }
 
 int gps_l2_normalize_forward(int n_rows, int d, const float *x, float eps, float *y, float *inv_norm, gps_stream_t stream) {

@@ -69,6 +69,7 @@ class GPSTrainStep:
         # False = hipBLASLt through F.linear, kept for A/B runs
         from .modules.layers import gemm as _gemm
         _gemm.set_gemm_backend(bool(native_gemm))
+        _gemm.reset_grouped_bookkeeping()
         torch.manual_seed(seed)
         self.model = build_model(cfg).to(self.device)
         world = dist_utils.get_world_size()
@@ -326,6 +327,10 @@ class GPSTrainStep:
             self._static = {k: v.clone() for k, v in tensors.items()}
             static_dict = dict(data_dict)
             static_dict.update(self._static)
+            # parameters whose gradient the grouped weight-gradient launch writes (learnt in the warm-up steps): their
+            # part of the flat buffer is never zero-filled, the launch stores instead of adding (gemm.mark_stale_grads)
+            from .modules.layers import gemm as _gemm
+            direct_ids = _gemm.grouped_written_ids() if self.wgrad_group else set()
             # gradients live as views of ONE flat fp32 buffer (only for parameters that do receive a
             # gradient: the never-used ones keep grad None, as under DDP / eager AdamW)
             used = [p for p in self.model.parameters() if p.grad is not None]
@@ -341,8 +346,9 @@ class GPSTrainStep:
                 sub = getattr(self.model, name, None)
                 if sub is not None:
                     seg_of.update({id(p): si for p in sub.parameters()})
-            top = [p for p in used if id(p) not in seg_of]
-            bottom_segs = [[p for p in used if seg_of.get(id(p)) == si] for si in range(2)]
+            by_kind = lambda ps: [p for p in ps if id(p) not in direct_ids] + [p for p in ps if id(p) in direct_ids]  # noqa: E731
+            top = by_kind([p for p in used if id(p) not in seg_of])
+            bottom_segs = [by_kind([p for p in used if seg_of.get(id(p)) == si]) for si in range(2)]
             bottom = bottom_segs[0] + bottom_segs[1]
             used = top + bottom
             # every view starts on a 16-byte boundary (kernels store gradients as 4-float vectors): sizes are rounded up
@@ -353,6 +359,14 @@ class GPSTrainStep:
             self._seg_ends = [self._n_top]                          # end offsets of the ranges: top, text, objects
             for seg in bottom_segs:
                 self._seg_ends.append(self._seg_ends[-1] + sum(pad4(p.numel()) for p in seg))
+            # inside every range: [accumulated by autograd: zero-filled each step | written by the grouped launch]
+            zero_ranges, lo = [], 0
+            for seg in (top, bottom_segs[0], bottom_segs[1]):
+                n_acc = sum(pad4(p.numel()) for p in seg if id(p) not in direct_ids)
+                if n_acc:
+                    zero_ranges.append((lo, lo + n_acc))
+                lo += sum(pad4(p.numel()) for p in seg)
+            direct_params = [p for p in used if id(p) in direct_ids]
             off = 0
             self.optimizer.zero_grad(set_to_none=True)
             for p in used:
@@ -373,7 +387,9 @@ class GPSTrainStep:
             segmented = bool(boundary) and bool(top) and bool(bottom) and not self.wgrad_overlap
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g2a, pool=g1.pool(), stream=ws, capture_error_mode=_CAPTURE_MODE):
-                self._flat_grad.zero_()
+                for lo, hi in zero_ranges:
+                    self._flat_grad[lo:hi].zero_()
+                _gemm.mark_stale_grads(direct_params)
                 with self._autocast():
                     total, losses = self.loss(out)
                 if segmented and not _cut_is_valid(total, boundary, bottom):
@@ -387,7 +403,7 @@ class GPSTrainStep:
                     segmented = False
                 if segmented:
                     # gradients of the top parameters (into their flat views) and of the boundary tensors
-                    with self._wgrad_ctx():
+                    with self._wgrad_ctx(only=top):
                         torch.autograd.backward(total, inputs=top + boundary, retain_graph=True)
                 else:
                     self._backward(total)             # accumulates into the flat views
@@ -413,7 +429,7 @@ class GPSTrainStep:
                     gg = torch.cuda.CUDAGraph()
                     if getattr(self, "_debug_dump_graphs", None):
                         gg.enable_debug_mode()
-                    with torch.cuda.graph(gg, pool=g1.pool(), stream=ws, capture_error_mode=_CAPTURE_MODE), self._wgrad_ctx():
+                    with torch.cuda.graph(gg, pool=g1.pool(), stream=ws, capture_error_mode=_CAPTURE_MODE), self._wgrad_ctx(only=bot_in):
                         roots = [t.grad.clone() for t in grp] if getattr(self, "_debug_clone_roots", False) else [t.grad for t in grp]
                         torch.autograd.backward(grp, grad_tensors=roots, inputs=bot_in)
                     torch.cuda.synchronize(self.device)
@@ -423,6 +439,12 @@ class GPSTrainStep:
                 self._stage("captured_g2b")
             else:
                 g2b = None
+            # a buffer marked "written by the grouped launch" that no launch of this capture wrote would keep last step's
+            # values for ever (cannot happen while warm-up and capture run the same step: fail loudly if it does)
+            left = _gemm.stale_grads_left()
+            if left:
+                raise RuntimeError(f"split-graph step: {len(left)} gradient buffers marked for direct stores were not "
+                                   "written during capture (the warm-up steps and the captured step differ)")
             with torch.cuda.graph(g3, stream=ws, capture_error_mode=_CAPTURE_MODE):
                 self._clip_and_step()
             self._drop_previous_graph()
@@ -449,7 +471,7 @@ class GPSTrainStep:
                     handles.append(self._allreduce_async(self._seg_ends[gi], self._seg_ends[gi + 1]))
             if getattr(self, "_eager_g2b", None) is not None:                   # probes only
                 live, bot_in = self._eager_g2b
-                with self._wgrad_ctx():
+                with self._wgrad_ctx(only=bot_in):
                     torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bot_in, retain_graph=True)
                 self._stage("replayed_g2b")
             done = self._seg_ends[len(handles) - 1]                    # ranges already on their way
@@ -516,11 +538,12 @@ class GPSTrainStep:
             with self._wgrad_ctx():
                 total.backward()
 
-    def _wgrad_ctx(self):
-        """Grouped weight gradients around a backward call (a no-op context under torch DDP or when switched off)."""
+    def _wgrad_ctx(self, only=None):
+        """Grouped weight gradients around a backward call (a no-op context under torch DDP or when switched off).
+        only: the parameters of a backward pass restricted with `inputs=` (the deferred writes must honour it too)."""
         from torch.nn.parallel import DistributedDataParallel as DDP
         from .modules.layers.gemm import grouped_wgrads
-        return grouped_wgrads(self.wgrad_group and not isinstance(self.net, DDP) and not self._want_ddp)
+        return grouped_wgrads(self.wgrad_group and not isinstance(self.net, DDP) and not self._want_ddp, only=only)
 
     def _begin_step(self):
         # one tiny launch that advances the device-side dropout seed block; it sits inside every captured

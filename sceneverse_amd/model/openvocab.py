@@ -89,6 +89,12 @@ class OpenVocab(_GPSBase):
                 data_dict['scene_text_embed'] = scene_txt[:, 0]
 
         obj, obj_pre, obj_cls_raw = pre if pre is not None else self._encode_objects(data_dict)
+        if torch.is_tensor(obj) and obj.requires_grad:
+            # autograd EXECUTES the grad_fn of a non-leaf tensor named in backward(inputs=...) (it is how the gradient is
+            # captured), and executes it again when the staged backward continues from that tensor: everything above reads
+            # a trivial view of the encoder output, so that the node run twice is a ViewBackward and not the object
+            # encoder's last LayerNorm (sceneverse_amd/engine.py cuts the backward pass at this tensor)
+            obj = obj.view_as(obj)
         if self.use_scene_cap:
             data_dict["scene_embed"] = self.object_pool(obj)
         # outputs of the two bottom encoders (text, objects): where sceneverse_amd.engine cuts the backward pass of the

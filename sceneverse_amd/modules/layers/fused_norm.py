@@ -72,6 +72,7 @@ class _AddDropoutLN(torch.autograd.Function):
         _native.check(st, "add_dropout_layernorm_forward")
         ctx.save_for_backward(x2, h2, g32, mean, rstd, seed_dev, rows_dev)
         ctx.meta = (float(p_drop), x.shape, h.shape, gamma.dtype, beta.dtype)
+        ctx.ln_params = (gamma, beta)                       # the parameter OBJECTS (deferred dgamma / dbeta, see backward)
         ctx.post = (post.shape, post.dtype) if post is not None else None
         if want_bf16:
             return y.view(x.shape), y16.view(x.shape)
@@ -105,14 +106,20 @@ class _AddDropoutLN(torch.autograd.Function):
                 _ptr(seed_dev), dx.data_ptr(), dh.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), _ptr(rows_dev),
                 _ptr(dpost), torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_backward")
+        if dpost is not None:
+            dpost = dpost.view(ctx.post[0]).to(ctx.post[1])
+        # dgamma / dbeta = column sums of the per-workgroup partial rows.  Inside gemm.grouped_wgrads() they are not
+        # reduced here: every LayerNorm of the pass hands its partial rows to ONE reduce launch when the block is left
+        # (gps_ln_reduce_partials_grouped writes gamma.grad / beta.grad); otherwise one reduce launch per LayerNorm.
+        from . import gemm
+        if gemm.defer_ln_param_grads(part, parts, d, *ctx.ln_params, needs=(ctx.needs_input_grad[2], ctx.needs_input_grad[3])):
+            return (dx.view(x_shape), dh.view(h_shape), None, None, None, None, None, None, None, dpost)
         sums = torch.empty((2, d), dtype=torch.float32, device=x2.device)
         with torch.cuda.device(x2.device):
             st = lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), sums.data_ptr(),
                                             _reduce_scratch(x2.device, d).data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
         _native.check(st, "ln_reduce_partials")
-        if dpost is not None:
-            dpost = dpost.view(ctx.post[0]).to(ctx.post[1])
         return (dx.view(x_shape), dh.view(h_shape), sums[0].to(g_dtype), sums[1].to(b_dtype),
                 None, None, None, None, None, dpost)
 

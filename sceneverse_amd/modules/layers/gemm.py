@@ -219,27 +219,55 @@ def join_wgrads() -> None:
 # whole reduction in one workgroup, no partial tiles, results written straight into `param.grad`, or added to it when it
 # already exists: the flat gradient buffer of the split-graph data-parallel step).  Deterministic.  Not used under torch
 # DDP, whose reducer hooks live on autograd's accumulation nodes (sceneverse_amd/engine.py decides).
-_GROUP = {"on": False, "items": [], "seen": set()}
+_GROUP = {"on": False, "only": None, "items": [], "seen": set(), "written": set(), "stale": set(), "ln_items": [], "ln_scratch": {}}
+
+
+def grouped_written_ids() -> set:
+    """ids of the parameters whose gradients the grouped launches have written so far (the engine reads this after its
+    eager warm-up steps to learn which gradient buffers never need zeroing: see `mark_stale_grads`)."""
+    return set(_GROUP["written"])
+
+
+def reset_grouped_bookkeeping() -> None:
+    """Forget which parameters were written (a new engine / model starts from scratch: ids of dead tensors are recycled)."""
+    _GROUP["written"].clear()
+    _GROUP["stale"].clear()
+
+
+def mark_stale_grads(params) -> None:
+    """The `.grad` buffers of these parameters hold LAST step's values: the next grouped write to each of them is a plain
+    store (no zero-fill before, no read-modify-write), a second write in the same pass accumulates as usual."""
+    _GROUP["stale"] = {id(p) for p in params}
+
+
+def stale_grads_left() -> set:
+    """ids marked by `mark_stale_grads` that no write has consumed yet (their buffers still hold last step's values)."""
+    return set(_GROUP["stale"])
 
 
 class grouped_wgrads:
     """with grouped_wgrads(): loss.backward()   -- weight / bias gradients of the native Linears are collected and
     computed by ONE grouped launch into `param.grad` when the block is left."""
 
-    def __init__(self, enabled: bool = True):
+    def __init__(self, enabled: bool = True, only=None):
+        """only: optional iterable of parameters -- gradients of other parameters are NOT written by the deferred
+        launches (they go back to autograd, which keeps or drops them as its `inputs=` say).  A backward pass restricted
+        with `inputs=` must pass the same set here: the deferred writes are side effects autograd does not filter."""
         self.enabled = bool(enabled)
+        self.only = None if only is None else {id(p) for p in only}
 
     def __enter__(self):
-        self.prev = _GROUP["on"]
-        _GROUP["on"] = self.enabled
+        self.prev = (_GROUP["on"], _GROUP.get("only"))
+        _GROUP["on"], _GROUP["only"] = self.enabled, self.only
         return self
 
     def __exit__(self, exc_type, *exc):
-        _GROUP["on"] = self.prev
+        _GROUP["on"], _GROUP["only"] = self.prev
         if exc_type is None:
             flush_grouped_wgrads()
         else:
             _GROUP["items"].clear()
+            _GROUP["ln_items"].clear()
             _GROUP["seen"].clear()
         return False
 
@@ -256,11 +284,76 @@ def _grad_buffer(p: torch.nn.Parameter, force_existing: bool):
         return g, 0
     if g.dtype != torch.float32 or not g.is_contiguous() or (g.data_ptr() & 15):
         return None, 0
+    if id(p) in _GROUP["stale"] and not force_existing:      # last step's values: overwrite
+        _GROUP["stale"].discard(id(p))
+        return g, 0
     return g, 1
+
+
+def defer_ln_param_grads(part: torch.Tensor, parts: int, d: int, gamma, beta, needs=(True, True)) -> bool:
+    """fused_norm's backward hands the (2, parts, d) partial rows of a LayerNorm's dgamma / dbeta over: inside
+    `grouped_wgrads()` they are reduced with all the others of the pass by ONE launch into gamma.grad / beta.grad.
+    Returns False when that does not apply (the caller then reduces them itself and returns them to autograd)."""
+    if not _GROUP["on"] or not all(needs):
+        return False
+    if not all(isinstance(t, torch.nn.Parameter) and t.is_leaf and t.requires_grad and t.dtype == torch.float32 and t.is_contiguous()
+               for t in (gamma, beta)):
+        return False
+    ids = {id(gamma), id(beta)}
+    if _GROUP.get("only") is not None and not ids <= _GROUP["only"]:
+        return False
+    if ids & _GROUP["seen"]:
+        flush_grouped_wgrads()
+    _GROUP["seen"] |= ids
+    _GROUP["ln_items"].append((part, int(parts), int(d), gamma, beta))
+    return True
+
+
+def _flush_ln_param_grads() -> None:
+    items, _GROUP["ln_items"] = _GROUP["ln_items"], []
+    if not items:
+        return
+    from ..._native import LnReduceProblem
+    lib = _native.load()
+    by_d = {}
+    for it in items:
+        by_d.setdefault((it[2], it[0].device), []).append(it)
+    for (d, dev), group in by_d.items():
+        key = (dev, d)
+        scratch = _GROUP["ln_scratch"].get(key)
+        if scratch is None:
+            nbytes = int(lib.gps_ln_reduce_grouped_scratch_bytes(d))
+            scratch = _GROUP["ln_scratch"][key] = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev)
+        probs = []
+        for part, parts, _, gamma, beta in group:
+            gg, acc_g = _grad_buffer(gamma, force_existing=beta.grad is not None and id(beta) not in _GROUP["stale"])
+            gb, acc_b = _grad_buffer(beta, force_existing=bool(acc_g))
+            if gg is None or gb is None or bool(acc_g) != bool(acc_b):      # buffers the kernel cannot address: torch sums
+                sums = part.sum(1)
+                for t, v in ((gamma, sums[0]), (beta, sums[1])):
+                    if t.grad is None:
+                        t.grad = v.clone()
+                    elif id(t) in _GROUP["stale"]:
+                        _GROUP["stale"].discard(id(t))
+                        t.grad.copy_(v)
+                    else:
+                        t.grad.add_(v)
+                continue
+            q = LnReduceProblem()
+            q.part, q.out_gamma, q.out_beta, q.parts, q.accumulate = part.data_ptr(), gg.data_ptr(), gb.data_ptr(), parts, int(acc_g)
+            probs.append(q)
+            _GROUP["written"].update((id(gamma), id(beta)))
+        if probs:
+            arr = (LnReduceProblem * len(probs))(*probs)
+            with torch.cuda.device(dev):
+                st = lib.gps_ln_reduce_partials_grouped(arr, len(probs), d, scratch.data_ptr(), _stream())
+            _native.check(st, f"ln_reduce_partials_grouped({len(probs)} problems)")
+    del items
 
 
 def flush_grouped_wgrads() -> None:
     """Issue every deferred weight gradient (one gps_gemm_wgrad_grouped call) and forget the operands."""
+    _flush_ln_param_grads()
     items, _GROUP["items"] = _GROUP["items"], []
     _GROUP["seen"].clear()
     if not items:
@@ -271,7 +364,8 @@ def flush_grouped_wgrads() -> None:
         T, K_in = x16.shape
         r = 0
         for w, b, n in zip(weights, biases, rows):
-            gw, acc = _grad_buffer(w, force_existing=b is not None and b.grad is not None)
+            stale_pair = id(w) in _GROUP["stale"] and (b is None or id(b) in _GROUP["stale"])
+            gw, acc = _grad_buffer(w, force_existing=b is not None and b.grad is not None and not stale_pair)
             gb = None
             if gw is not None and b is not None:
                 gb, acc_b = _grad_buffer(b, force_existing=bool(acc))
@@ -289,6 +383,9 @@ def flush_grouped_wgrads() -> None:
                 q.extent_dev = _ptr(rows_dev)
                 probs.append(q)
                 prob_rows.append((dy16, x16, rows_dev))
+                _GROUP["written"].add(id(w))
+                if b is not None:
+                    _GROUP["written"].add(id(b))
             r += n
         keep.append((dy16, x16, rows_dev))
     dev = items[0][0].device
@@ -317,9 +414,16 @@ def flush_grouped_wgrads() -> None:
         _native.check(st, f"gemm_wgrad_grouped({len(probs)} problems)")
     for dy16, x16, w, b, r, n, rows_dev in fallback:
         dw, db = linear_wgrad(dy16[:, r:r + n], x16, want_bias=b is not None, rows_dev=rows_dev)
-        w.grad = dw if w.grad is None else w.grad.add_(dw)
-        if b is not None:
-            b.grad = db if b.grad is None else b.grad.add_(db)
+        for t, g in ((w, dw), (b, db)):
+            if t is None:
+                continue
+            if t.grad is None:
+                t.grad = g
+            elif id(t) in _GROUP["stale"]:
+                _GROUP["stale"].discard(id(t))
+                t.grad.copy_(g)
+            else:
+                t.grad.add_(g)
     del keep
 
 
@@ -334,6 +438,8 @@ def _wgrad_to_params(dy16: torch.Tensor, x16: torch.Tensor, weights, biases, row
         return False
     if _GROUP["on"]:
         ids = {id(t) for t in params}
+        if _GROUP.get("only") is not None and not ids <= _GROUP["only"]:
+            return False                      # outside this pass's `inputs=`: autograd decides what happens to them
         if ids & _GROUP["seen"]:          # a parameter used twice in one pass: its two gradients must not share a launch
             flush_grouped_wgrads()
         _GROUP["seen"] |= ids

@@ -200,3 +200,40 @@ def test_post_addend_rides_on_the_layernorm_launch(want_bf16, p):
         for a, b in zip(got, (x.grad, h.grad, norm.weight.grad, norm.bias.grad)):
             scale = max(1.0, b.float().abs().max().item())
             assert (a.float() - b.float()).abs().max().item() <= 2e-2 * scale      # h's gradient is bf16
+
+
+def test_deferred_parameter_gradients_equal_the_autograd_ones():
+    """Inside gemm.grouped_wgrads() the dgamma / dbeta of every fused residual-LayerNorm of a pass are reduced by ONE
+    launch into gamma.grad / beta.grad (gps_ln_reduce_partials_grouped) instead of one reduce launch each: same values
+    (same summation order) as the per-LayerNorm path -- several norms of different row counts (one and many row slices),
+    a norm used twice in the pass, fresh and pre-existing .grad buffers."""
+    from sceneverse_amd.modules.layers import gemm as G
+    torch.manual_seed(11)
+    norms = [nn.LayerNorm(768).to(DEV) for _ in range(4)]
+    rows = [64, 5120, 22400, 8320]
+    xs = [torch.randn(n, 768, device=DEV) for n in rows]
+    hs = [torch.randn(n, 768, device=DEV).to(torch.bfloat16) for n in rows]
+
+    def loss_fn():
+        tot = 0.0
+        for nm, x, h in zip(norms, xs, hs):
+            tot = tot + add_dropout_layer_norm(x, h, nm, 0.0, False).square().mean()
+        y = add_dropout_layer_norm(xs[1], hs[1], norms[0], 0.0, False)          # norms[0] a second time
+        return tot + y.abs().mean()
+
+    def grads(grouped, preset):
+        for nm in norms:
+            nm.zero_grad(set_to_none=True)
+            if preset:
+                for p in nm.parameters():
+                    p.grad = torch.full_like(p, 0.5)
+        with G.grouped_wgrads(grouped):
+            loss_fn().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for nm in norms for p in nm.parameters()]
+
+    for preset in (False, True):
+        want, got = grads(False, preset), grads(True, preset)
+        for a, b in zip(got, want):
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item() + 1e-9, (preset, (a - b).abs().max().item())

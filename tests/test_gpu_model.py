@@ -248,7 +248,7 @@ def _segmented_gradient_parity(gps_pretrain_cfg, _lang_dir, synth_batch, GPSTrai
         for n, g in grads[mode].items():
             assert torch.isfinite(g).all(), (mode, n)
             rel = ((g - ref[n]).norm() / (ref[n].norm() + 1e-20)).item()
-            assert rel <= 5e-3, (mode, n, rel)
+            assert rel <= 5e-3, (mode, n, rel, g.norm().item(), ref[n].norm().item())
 
 
 def test_graph_replays_draw_fresh_dropout_masks():

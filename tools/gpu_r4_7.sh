@@ -1,0 +1,8 @@
+#!/bin/bash
+set -u
+OUT=$PWD/gpurun_out/r4_7; mkdir -p $OUT
+export TMPDIR=/tmp
+echo "== tests"; timeout 900 python -m pytest tests/test_gpu_fused_norm.py tests/test_gpu_model.py tests/test_gpu_bert_varlen.py -q -x > $OUT/pytest.log 2>&1; grep -E "passed|failed|Error|assert" $OUT/pytest.log | tail -8
+for i in 1 2; do
+echo "== one graph"; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done

@@ -22,8 +22,9 @@ NAMES = [
     (r"sa_mlp_kernel<3, 64, 64, 128>", "sa_mlp_forward(c=3,n=1024,np=32,mlp=64-64-128,fp32)"),
     (r"fps_resident_kernel<16>", "furthest_point_sampling(n=1024,m=32)"),
     (r"fps_resident_kernel<1>", "furthest_point_sampling(n=32,m=16)"),
-    (r"ball_query_kernel<16>", "ball_query(n=1024,m=32,ns=32)"),
-    (r"ball_query_kernel<1>", "ball_query(n=32,m=16,ns=32)"),
+    (r"ball_query_kernel<16", "ball_query(n=1024,m=32,ns=32)"),
+    (r"ball_query_kernel<1,", "ball_query(n=32,m=16,ns=32)"),
+    (r"wgrad_grouped_kernel", "gemm_tn_grouped(problems=68)"),
     (r"ball_query_small_kernel", "ball_query(n=32,m=16,ns=32)"),
     (r"add_dropout_ln_bwd_kernel", "add_dropout_layernorm_backward"),
     (r"add_dropout_ln_fwd_kernel", "add_dropout_layernorm_forward"),

@@ -98,6 +98,33 @@ def main():
         GM.linear_dgrad(dyb, w, None, rows_dev=n_valid)
         GM.linear_wgrad(dyb, x, rows_dev=n_valid)
     print("valid text rows", int(n_valid), "of", rows_all, flush=True)
+    # [r4] the grouped weight-gradient launch of the step: the 68 problems of one backward pass (4 text layers over the
+    # live text rows, 4 object layers over 5 120 rows, 4 joint layers over 8 320 rows), written into fresh buffers
+    probs, keep = [], []
+
+    def add(T, parts, K_in, ext=None):
+        dy = (0.1 * torch.randn(T, sum(parts), device=dev)).to(torch.bfloat16)
+        xx = torch.randn(T, K_in, device=dev).to(torch.bfloat16)
+        r = 0
+        for n in parts:
+            q = _native.WgradProblem()
+            C, cs = torch.empty(n, K_in, device=dev), torch.empty(n, device=dev)
+            q.M, q.N, q.K, q.accumulate = n, K_in, T, 0
+            q.A, q.lda, q.B, q.ldb = dy.data_ptr() + 2 * r, dy.stride(0), xx.data_ptr(), K_in
+            q.C, q.ldc, q.colsum = C.data_ptr(), K_in, cs.data_ptr()
+            q.extent_dev = ext.data_ptr() if ext is not None else None
+            probs.append(q)
+            keep.extend((dy, xx, C, cs))
+            r += n
+    for _ in range(4):
+        add(rows_all, [768, 768, 768], 768, n_valid), add(rows_all, [768], 768, n_valid)
+        add(rows_all, [3072], 768, n_valid), add(rows_all, [768], 3072, n_valid)
+        add(5120, [768, 768, 768, 72], 768), add(5120, [768], 768), add(5120, [2048], 768), add(5120, [768], 2048)
+        add(8320, [2304], 768), add(8320, [768], 768), add(8320, [2048], 768), add(8320, [768], 2048)
+    arr = (_native.WgradProblem * len(probs))(*probs)
+    for _ in range(3):
+        _native.check(_native.load().gps_gemm_wgrad_grouped(arr, len(probs), torch.cuda.current_stream().cuda_stream), "wgrad_grouped")
+    print("grouped weight gradients:", len(probs), "problems", flush=True)
     ps = [torch.nn.Parameter(torch.randn(4096, 768, device=dev)) for _ in range(8)]
     from sceneverse_amd.optim.fused_adamw import GpsAdamW
     opt = GpsAdamW(ps, lr=1e-3)
