@@ -551,6 +551,36 @@ def main() -> None:
         for k, v in saved_text.items():     # back on the measured batch
             batch[k].copy_(v)
         step.step(dict(batch))
+    # [r4] The loader-side object sampler in the measured step (data/datasets/base.py:697-740): raw scans
+    # resident in HBM (packed once, untimed), every step draws + normalises the 80 x 1024 points of every scene straight
+    # into the graph's static input buffers (gps_obj_processing_post) and then replays the step.
+    dt_samp = None
+    if args.config == "pretrain" and not args.no_extras and use_graph and step.static_inputs() is not None:
+        import numpy as np
+        from sceneverse_amd.data import gpu_objects as G
+        rng = np.random.default_rng(7 + rank)
+        scans = G.PackedScans(dev)
+        n_real = batch["obj_masks"].sum(1).tolist()                 # as many real objects per scene as the measured batch
+        for si in range(args.batch):
+            n = int(n_real[si])
+            ks = rng.integers(50, 4001, size=n)
+            pts = (rng.normal(size=(int(ks.sum()), 3)) * rng.uniform(0.05, 1.0, size=3)).astype(np.float32)
+            scans.add_scan(f"s{si}", pts, rng.integers(0, 256, size=(int(ks.sum()), 3), dtype=np.uint8),
+                           np.repeat(np.arange(n), ks), list(range(n)))
+        scans.finalize()
+        slots = G.batch_rows(scans, [f"s{i}" for i in range(args.batch)], args.n_obj).to(dev)
+        static = step.static_inputs()
+        outbuf = {k: static[k] for k in ("obj_fts", "obj_locs", "obj_masks")}
+        for i in range(max(1, args.warmup)):
+            G.obj_processing_post(scans, slots, args.n_pts, seed=900 + i, out=outbuf)
+            step.step(dict(batch))
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            G.obj_processing_post(scans, slots, args.n_pts, seed=1000 + i, out=outbuf)
+            step.step(dict(batch))
+        barrier()
+        dt_samp = time.perf_counter() - t2
     # Per-launch durations (HIP events around every native call) are taken from three EXTRA eager steps of the same
     # workload right after the timed region, on every rank (the steps contain the data-parallel collectives): a
     # replayed graph cannot host event pairs, and in the eager modes the ~1 200 event records per step would sit on
@@ -567,11 +597,12 @@ def main() -> None:
     kern = hip_ext.profile_stop()
     for k in kern.values():
         k["launches"] = k["launches"] * args.steps / 3.0
-    t = torch.tensor([dt, dt_full or 0.0], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt, dt_full or 0.0, dt_samp or 0.0], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t[0].item())
     dt_full = float(t[1].item()) if dt_full is not None else None
+    dt_samp = float(t[2].item()) if dt_samp is not None else None
     final_loss = float(loss)
     step_kernels, bqg, eval_metrics = [], None, None
     if args.config == "finetune":
@@ -765,6 +796,7 @@ def main() -> None:
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             **({"value_full_length_text": round(args.batch * world * args.steps / dt_full, 2),
                 "ms_per_step_full_length_text": round(1e3 * dt_full / args.steps, 3)} if dt_full else {}),
+            **({"value_with_device_sampler": round(args.batch * world * args.steps / dt_samp, 2)} if dt_samp else {}),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

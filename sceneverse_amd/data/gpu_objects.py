@@ -113,14 +113,17 @@ def batch_rows(packed: PackedScans, scan_ids: Sequence[str], max_obj_len: int,
 
 def obj_processing_post(packed: PackedScans, row_obj: torch.Tensor, num_points: int = 1024,
                         rot: Optional[torch.Tensor] = None, sample_idx: Optional[torch.Tensor] = None,
-                        seed: int = 0, need_boxes: bool = False) -> dict:
+                        seed: int = 0, need_boxes: bool = False, out: Optional[dict] = None) -> dict:
     """row_obj (B, O) int32 object ids (-1 = padding) -> dict with obj_fts (B,O,num_points,6) f32,
     obj_locs (B,O,6) f32, obj_masks (B,O) bool [, obj_boxes (B,O,6) f32].
 
     rot: per-scene rotations (build_rotate_mat's matrix): a (B,3,3) tensor/array, or a length-B list
     with None for the scenes it left unrotated; None = no rotation at all.
     sample_idx: (B,O,num_points) int32 object-local indices (np.random.choice draws, for bit-compatible
-    replays of the reference loader) or None = drawn on the device from `seed`."""
+    replays of the reference loader) or None = drawn on the device from `seed`.
+    out: optional {"obj_fts", "obj_locs", "obj_masks"} of preallocated contiguous tensors of those shapes (obj_masks bool
+    or uint8) the kernel writes IN PLACE -- the static input buffers of a captured training step
+    (`GPSTrainStep.static_inputs()`), so that no per-step copy of the 126 MB of object points is needed."""
     if packed.xyz is None:
         raise RuntimeError("PackedScans.finalize() has not been called")
     dev = packed.xyz.device
@@ -130,10 +133,18 @@ def obj_processing_post(packed: PackedScans, row_obj: torch.Tensor, num_points: 
     n_rows = B * O
     nbytes = _algorithmic_bytes(packed, row_obj if row_obj.device.type == "cpu" else None, n_rows, num_points)
     row_obj = row_obj.to(device=dev, dtype=torch.int32).contiguous()
-    fts = torch.empty((B, O, num_points, 6), dtype=torch.float32, device=dev)
-    locs = torch.empty((B, O, 6), dtype=torch.float32, device=dev)
+    if out is not None:
+        fts, locs, masks = out["obj_fts"], out["obj_locs"], out["obj_masks"]
+        ok = (fts.shape == (B, O, num_points, 6) and fts.dtype == torch.float32 and locs.shape == (B, O, 6)
+              and locs.dtype == torch.float32 and masks.shape == (B, O) and masks.dtype in (torch.bool, torch.uint8)
+              and all(t.is_contiguous() and t.device == dev for t in (fts, locs, masks)))
+        if not ok:
+            raise ValueError("obj_processing_post: `out` tensors must be contiguous (B,O,P,6) f32 / (B,O,6) f32 / (B,O) bool on the scans' GPU")
+    else:
+        fts = torch.empty((B, O, num_points, 6), dtype=torch.float32, device=dev)
+        locs = torch.empty((B, O, 6), dtype=torch.float32, device=dev)
+        masks = torch.empty((B, O), dtype=torch.uint8, device=dev)
     boxes = torch.empty((B, O, 6), dtype=torch.float32, device=dev) if need_boxes else None
-    masks = torch.empty((B, O), dtype=torch.uint8, device=dev)
     rot_ptr = row_rot_ptr = None
     keep = []
     if rot is not None:
@@ -154,10 +165,10 @@ def obj_processing_post(packed: PackedScans, row_obj: torch.Tensor, num_points: 
             masks.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     _native.check(st, "obj_processing_post")
     del keep
-    out = {"obj_fts": fts, "obj_locs": locs, "obj_masks": masks.bool()}
+    res = {"obj_fts": fts, "obj_locs": locs, "obj_masks": masks if masks.dtype == torch.bool else masks.bool()}
     if need_boxes:
-        out["obj_boxes"] = boxes
-    return out
+        res["obj_boxes"] = boxes
+    return res
 
 
 def rot_rows(rot, B: int, O: int, dev):
