@@ -32,71 +32,76 @@ __global__ __launch_bounds__(kBlock) void mark_kernel(int n, int num_rows, const
   atomicAdd(count + id, 1);
 }
 
-// [r4] one wave per (token, 256-column chunk): a wave keeps ONE float4 accumulator per lane and fetches the rows of up to
-// 16 duplicates per trip (16 independent loads in flight).  The first version gave a token's whole row (3 chunks at
-// d = 768) to one wave with 4 rows in flight: the wave of [MASK] (~270 duplicates at the bench workload) and of [CLS] /
-// [SEP] (128 each) walked 30 - 70 dependent memory round trips while every other wave had long finished -- 157 - 208 us
-// for a 19 us memory job.  The order of the additions is unchanged (first occurrence, then ascending token order).
+// [r4] one wave per (token, 256-column chunk): a wave keeps ONE float4 accumulator per lane.  The first version gave a
+// token's whole row (3 chunks at d = 768) to one wave with 4 rows in flight: the wave of [MASK] (~270 duplicates at the
+// bench workload) and of [CLS] / [SEP] (128 each) walked 30 - 70 dependent memory round trips while every other wave had
+// long finished -- 157 - 208 us for a 19 us memory job.  Now the id scan and the row fetches are decoupled: a scan trip
+// looks at kScan x 64 ids (independent loads, L2 resident) and appends the matching token numbers, in ascending order,
+// to the wave's list in LDS; rows are fetched kRows at a time (independent loads) as soon as kRows are pending, so a
+// token with c duplicates costs n / (64 kScan) + c / kRows round trips instead of one or two per 1024 ids.
+// The order of the additions is unchanged (first occurrence, then ascending token order).
+constexpr int kScan = 32, kRows = 16;
+constexpr int kListCap = kScan * 64 + kRows;
+
 __global__ __launch_bounds__(kBlock) void sum_kernel(int n, int d, int num_rows, const int64_t *__restrict__ ids,
                                                      const float *__restrict__ dy, long long ld,
                                                      long long padding_idx, const int32_t *__restrict__ first,
                                                      const int32_t *__restrict__ count, float *__restrict__ out) {
+  __shared__ int list_s[kBlock / 64][kListCap];
   const int lane = threadIdx.x & 63;
+  int *list = list_s[threadIdx.x >> 6];
   const int t = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);          // token
   const int col = blockIdx.y * 256 + lane * 4;                            // this wave's 256-column chunk
   if (t >= n) return;
   const long long id = ids[t];
   if (id < 0 || id >= num_rows || id == padding_idx) return;
   if (first[id] != t) return;                                             // a later duplicate: its first occurrence sums it
-  const int want = count[id];
+  int missing = count[id] - 1;                                            // duplicates still to be found (wave-uniform)
   const bool live = col < d;
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 acc = live ? *reinterpret_cast<const float4 *>(dy + (size_t)t * ld + col) : zero;
-  int found = 1;
-  // ids are scanned kAhead x 64 at a time: the loads of one trip are independent, so an id that occurs
-  // across the whole batch ([CLS], [SEP]) costs n / (64 * kAhead) memory round trips, not n / 64
-  constexpr int kAhead = 16, kRows = 16;
-  for (int base = t + 1; base < n && found < want; base += 64 * kAhead) {
-    unsigned long long masks[kAhead];
+  const int colc = live ? col : 0;                                        // dead lanes read (and drop) the first columns
+  float4 acc = *reinterpret_cast<const float4 *>(dy + (size_t)t * ld + colc);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int pending = 0;                                                        // list[0 .. pending) wait for their rows
+  for (int base = t + 1; base < n && missing > 0; base += 64 * kScan) {
+    unsigned long long masks[kScan];
 #pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
+    for (int u = 0; u < kScan; ++u) {
       const int tt = base + u * 64 + lane;
-      const bool match = tt < n && ids[tt] == id;
-      masks[u] = __ballot(match);
+      const long long other = ids[min(tt, n - 1)];                        // unconditional: kScan independent loads
+      masks[u] = __ballot(tt < n && other == id);
     }
-    // the matching rows of this trip in ascending token order, kRows at a time
-    int u = 0;
-    unsigned long long mask = masks[0];
-    for (;;) {
-      int rows[kRows];
-      int nr = 0;
 #pragma unroll
-      for (int q = 0; q < kRows; ++q) {
-        rows[q] = -1;
-        while (!mask && u + 1 < kAhead) {            // (wave-uniform: masks are ballots)
-          ++u;
-          mask = u == 1 ? masks[1] : u == 2 ? masks[2] : u == 3 ? masks[3] : u == 4 ? masks[4] : u == 5 ? masks[5] : u == 6 ? masks[6]
-               : u == 7 ? masks[7] : u == 8 ? masks[8] : u == 9 ? masks[9] : u == 10 ? masks[10] : u == 11 ? masks[11]
-               : u == 12 ? masks[12] : u == 13 ? masks[13] : u == 14 ? masks[14] : masks[15];
-        }
-        if (mask) {
-          rows[q] = base + u * 64 + (__ffsll((long long)mask) - 1);
-          mask &= mask - 1ull;
-          ++nr;
-        }
+    for (int u = 0; u < kScan; ++u) {
+      const unsigned long long m = masks[u];
+      if (m) {                                                            // (wave-uniform)
+        if ((m >> lane) & 1ull) list[pending + __popcll(m & below)] = base + u * 64 + lane;
+        const int c = __popcll(m);
+        pending += c;
+        missing -= c;
       }
-      if (nr == 0) break;
+    }
+    const bool last = missing <= 0 || base + 64 * kScan >= n;
+    int head = 0;
+    while (pending - head >= kRows || (last && head < pending)) {
+      const int cnt = min(kRows, pending - head);
       float4 v[kRows];
 #pragma unroll
-      for (int q = 0; q < kRows; ++q)
-        v[q] = (rows[q] >= 0 && live) ? *reinterpret_cast<const float4 *>(dy + (size_t)rows[q] * ld + col) : zero;
-#pragma unroll
       for (int q = 0; q < kRows; ++q) {
-        if (rows[q] < 0) continue;
-        acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w;
+        const int r = list[head + min(q, cnt - 1)];                       // same address in every lane: a broadcast read
+        v[q] = *reinterpret_cast<const float4 *>(dy + (size_t)r * ld + colc);   // unconditional (q >= cnt re-reads the last row)
       }
-      found += nr;
+#pragma unroll
+      for (int q = 0; q < kRows; ++q)
+        if (q < cnt) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }   // (wave-uniform)
+      head += cnt;
     }
+    // fewer than kRows left over: to the front of the list, the next trip appends behind them
+    const int left = pending - head;
+    if (left > 0 && head > 0) {
+      const int keep = lane < left ? list[head + lane] : 0;
+      if (lane < left) list[lane] = keep;
+    }
+    pending = left;
   }
   if (live) *reinterpret_cast<float4 *>(out + (size_t)id * d + col) = acc;
 }

@@ -57,6 +57,19 @@ __device__ __forceinline__ float4 load4(const uint16_t *p, size_t e0) {
   return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u),
                      __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
 }
+// the same 4 elements as they lie in memory (conversion deferred: every load of a row is issued before the first use)
+__device__ __forceinline__ float4 load_raw(const float *p, size_t e0) { return *reinterpret_cast<const float4 *>(p + e0); }
+__device__ __forceinline__ uint2 load_raw(const uint16_t *p, size_t e0) { return *reinterpret_cast<const uint2 *>(p + e0); }
+__device__ __forceinline__ float4 to_f4(float4 v) { return v; }
+__device__ __forceinline__ float4 to_f4(uint2 v) {
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u),
+                     __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+}
+template <typename T> struct Raw4 { using type = float4; };
+template <> struct Raw4<uint16_t> { using type = uint2; };
+// loads above this line are issued before anything below it (the compiler otherwise sinks them next to their first use,
+// i.e. behind the wave-uniform branches of the optional operands: one memory round trip per branch instead of one per row)
+#define GPS_LN_LOADS_ISSUED() asm volatile("" ::: "memory")
 __device__ __forceinline__ void store4(float *p, size_t e0, float4 v) {
   *reinterpret_cast<float4 *>(p + e0) = v;
 }
@@ -81,6 +94,13 @@ __device__ __forceinline__ float4 drop4(float4 h, const Drop &d, unsigned long l
   return h;
 }
 
+// bit j set = element e0 + j is kept (all four when there is no dropout)
+__device__ __forceinline__ unsigned int keep4(const Drop &d, unsigned long long e0) {
+  if (d.thr == 0u) return 15u;
+  return (rng_u32(d.seed, e0 + 0) >= d.thr ? 1u : 0u) | (rng_u32(d.seed, e0 + 1) >= d.thr ? 2u : 0u) |
+         (rng_u32(d.seed, e0 + 2) >= d.thr ? 4u : 0u) | (rng_u32(d.seed, e0 + 3) >= d.thr ? 8u : 0u);
+}
+
 template <typename TX, typename TH, int ITERS>
 __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
     int n_rows, int d, const TX *__restrict__ x, const TH *__restrict__ h, const float *__restrict__ gamma,
@@ -90,50 +110,73 @@ __global__ __launch_bounds__(kBlock) void add_dropout_ln_fwd_kernel(
     const float *__restrict__ post) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rows_dev) n_rows = min(n_rows, *rows_dev);        // device-side count of leading rows that carry work
-  constexpr int iters = ITERS;
   Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
   const float inv_d = 1.f / (float)d;
+  // gamma / beta stay in registers for d <= 1024 (24 VGPRs at d = 768); wider rows fetch them with the row's own loads
+  constexpr bool kHoist = ITERS <= 4;
+  float4 gmh[kHoist ? ITERS : 1], bth[kHoist ? ITERS : 1];
+  if constexpr (kHoist) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      gmh[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
+      bth[i] = *reinterpret_cast<const float4 *>(beta + (i * 64 + lane) * 4);
+    }
+  }
   for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
     const size_t base = (size_t)row * d;
+    // phase 1: every load of the row in flight
+    typename Raw4<TX>::type xr[ITERS];
+    typename Raw4<TH>::type hr[ITERS];
+    float4 pv[ITERS], gml[kHoist ? 1 : ITERS], btl[kHoist ? 1 : ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+      xr[i] = load_raw(x, e0);
+      hr[i] = load_raw(h, e0);
+      if constexpr (!kHoist) {
+        gml[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
+        btl[i] = *reinterpret_cast<const float4 *>(beta + (i * 64 + lane) * 4);
+      }
+    }
+    if (post) {      // y = LayerNorm(...) + post: the addend the NEXT layer would add to its input (same shape as y)
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) pv[i] = *reinterpret_cast<const float4 *>(post + base + (size_t)(i * 64 + lane) * 4);
+    }
+    GPS_LN_LOADS_ISSUED();
+    // phase 2: the row lives in registers
     float4 z[ITERS];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i)
-      if (i < iters) {
-        const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
-        const float4 xv = load4(x, e0);
-        const float4 hv = drop4(load4(h, e0), dr, e0);
-        z[i] = make_float4(xv.x + hv.x, xv.y + hv.y, xv.z + hv.z, xv.w + hv.w);
-        s += (z[i].x + z[i].y) + (z[i].z + z[i].w);
-      }
+    for (int i = 0; i < ITERS; ++i) {
+      const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+      const float4 xv = to_f4(xr[i]);
+      const float4 hv = drop4(to_f4(hr[i]), dr, e0);
+      z[i] = make_float4(xv.x + hv.x, xv.y + hv.y, xv.z + hv.z, xv.w + hv.w);
+      s += (z[i].x + z[i].y) + (z[i].z + z[i].w);
+    }
     const float mean = wave_sum(s) * inv_d;
     float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i)
-      if (i < iters) {
-        const float a = z[i].x - mean, b = z[i].y - mean, c = z[i].z - mean, e = z[i].w - mean;
-        v += (a * a + b * b) + (c * c + e * e);
-      }
+    for (int i = 0; i < ITERS; ++i) {
+      const float a = z[i].x - mean, b = z[i].y - mean, c = z[i].z - mean, e = z[i].w - mean;
+      v += (a * a + b * b) + (c * c + e * e);
+    }
     const float rstd = rsqrtf(wave_sum(v) * inv_d + eps);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i)
-      if (i < iters) {
-        const int c0 = (i * 64 + lane) * 4;
-        const float4 g = *reinterpret_cast<const float4 *>(gamma + c0);
-        const float4 bt = *reinterpret_cast<const float4 *>(beta + c0);
-        float4 o;
-        o.x = (z[i].x - mean) * rstd * g.x + bt.x;
-        o.y = (z[i].y - mean) * rstd * g.y + bt.y;
-        o.z = (z[i].z - mean) * rstd * g.z + bt.z;
-        o.w = (z[i].w - mean) * rstd * g.w + bt.w;
-        if (post) {      // y = LayerNorm(...) + post: the addend the NEXT layer would add to its input (same shape as y)
-          const float4 e = *reinterpret_cast<const float4 *>(post + base + c0);
-          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
-        }
-        store4(y, base + c0, o);
-        if (y16) store4(y16, base + c0, o);
-      }
+    for (int i = 0; i < ITERS; ++i) {
+      const int c0 = (i * 64 + lane) * 4;
+      const float4 g = kHoist ? gmh[kHoist ? i : 0] : gml[kHoist ? 0 : i];
+      const float4 bt = kHoist ? bth[kHoist ? i : 0] : btl[kHoist ? 0 : i];
+      float4 o;
+      o.x = (z[i].x - mean) * rstd * g.x + bt.x;
+      o.y = (z[i].y - mean) * rstd * g.y + bt.y;
+      o.z = (z[i].z - mean) * rstd * g.z + bt.z;
+      o.w = (z[i].w - mean) * rstd * g.w + bt.w;
+      if (post) { o.x += pv[i].x; o.y += pv[i].y; o.z += pv[i].z; o.w += pv[i].w; }
+      store4(y, base + c0, o);
+      if (y16) store4(y16, base + c0, o);
+    }
   }
 }
 
@@ -150,7 +193,6 @@ __global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd
   extern __shared__ float red[];      // [kWaves][d] reused for dgamma then dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rows_dev) n_rows = min(n_rows, *rows_dev);        // rows past it contribute nothing to dgamma / dbeta either
-  constexpr int iters = ITERS;
   Drop dr{thr, thr ? 1.f / (1.f - p_drop) : 1.f, seed + ((thr && seed_dev) ? *seed_dev : 0ull)};
   const float inv_d = 1.f / (float)d;
   float4 gacc[ITERS], bacc[ITERS], gm[ITERS];
@@ -158,62 +200,85 @@ __global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd
   for (int i = 0; i < ITERS; ++i) {
     gacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     bacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < iters) gm[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
+    gm[i] = *reinterpret_cast<const float4 *>(gamma + (i * 64 + lane) * 4);
   }
   for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
     const size_t base = (size_t)row * d;
+    // phase 1: every load of the row in flight
+    typename Raw4<TX>::type xr[ITERS], gr[ITERS];
+    typename Raw4<TH>::type hr[ITERS];
+    uint2 g2r[ITERS];
     const float mean = mean_in[row], rstd = rstd_in[row];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+      gr[i] = load_raw(dy, e0);
+      xr[i] = load_raw(x, e0);
+      hr[i] = load_raw(h, e0);
+    }
+    if (dy16) {             // gradient that arrived through the bf16 copy of y
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) g2r[i] = load_raw(dy16, base + (size_t)(i * 64 + lane) * 4);
+    }
+    GPS_LN_LOADS_ISSUED();
+    // phase 2
     float4 zh[ITERS], a[ITERS];
+    unsigned int keep = 0u;          // 4 bits per step: the dropout decisions, drawn once for dz -> dh below
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i)
-      if (i < iters) {
-        const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
-        const float4 xv = load4(x, e0);
-        const float4 hv = drop4(load4(h, e0), dr, e0);
-        float4 g = load4(dy, e0);
-        if (dy16) {           // gradient that arrived through the bf16 copy of y
-          const float4 g2 = load4(dy16, e0);
-          g = make_float4(g.x + g2.x, g.y + g2.y, g.z + g2.z, g.w + g2.w);
-        }
-        if (g_out) *reinterpret_cast<float4 *>(g_out + e0) = g;      // gradient of the output = gradient of a post-addend
-        zh[i] = make_float4((xv.x + hv.x - mean) * rstd, (xv.y + hv.y - mean) * rstd,
-                            (xv.z + hv.z - mean) * rstd, (xv.w + hv.w - mean) * rstd);
-        a[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
-        s1 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
-        s2 += (a[i].x * zh[i].x + a[i].y * zh[i].y) + (a[i].z * zh[i].z + a[i].w * zh[i].w);
-        gacc[i].x += g.x * zh[i].x; gacc[i].y += g.y * zh[i].y;
-        gacc[i].z += g.z * zh[i].z; gacc[i].w += g.w * zh[i].w;
-        bacc[i].x += g.x; bacc[i].y += g.y; bacc[i].z += g.z; bacc[i].w += g.w;
+    for (int i = 0; i < ITERS; ++i) {
+      const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+      float4 g = to_f4(gr[i]);
+      if (dy16) {
+        const float4 g2 = to_f4(g2r[i]);
+        g = make_float4(g.x + g2.x, g.y + g2.y, g.z + g2.z, g.w + g2.w);
       }
+      if (g_out) *reinterpret_cast<float4 *>(g_out + e0) = g;      // gradient of the output = gradient of a post-addend
+      const float4 xv = to_f4(xr[i]);
+      float4 hv = to_f4(hr[i]);
+      const unsigned int m = keep4(dr, e0);
+      keep |= m << (4 * i);
+      if (dr.thr) {
+        hv.x = (m & 1u) ? hv.x * dr.scale : 0.f;
+        hv.y = (m & 2u) ? hv.y * dr.scale : 0.f;
+        hv.z = (m & 4u) ? hv.z * dr.scale : 0.f;
+        hv.w = (m & 8u) ? hv.w * dr.scale : 0.f;
+      }
+      zh[i] = make_float4((xv.x + hv.x - mean) * rstd, (xv.y + hv.y - mean) * rstd,
+                          (xv.z + hv.z - mean) * rstd, (xv.w + hv.w - mean) * rstd);
+      a[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
+      s1 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+      s2 += (a[i].x * zh[i].x + a[i].y * zh[i].y) + (a[i].z * zh[i].z + a[i].w * zh[i].w);
+      gacc[i].x += g.x * zh[i].x; gacc[i].y += g.y * zh[i].y;
+      gacc[i].z += g.z * zh[i].z; gacc[i].w += g.w * zh[i].w;
+      bacc[i].x += g.x; bacc[i].y += g.y; bacc[i].z += g.z; bacc[i].w += g.w;
+    }
     s1 = wave_sum(s1) * inv_d;
     s2 = wave_sum(s2) * inv_d;
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i)
-      if (i < iters) {
-        const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
-        float4 dz;
-        dz.x = rstd * (a[i].x - s1 - zh[i].x * s2);
-        dz.y = rstd * (a[i].y - s1 - zh[i].y * s2);
-        dz.z = rstd * (a[i].z - s1 - zh[i].z * s2);
-        dz.w = rstd * (a[i].w - s1 - zh[i].w * s2);
-        store4(dx, e0, dz);
-        float4 dhv = dz;
-        if (dr.thr) {
-          const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
-          const float4 k = drop4(one, dr, e0);          // keep * scale per element
-          dhv = make_float4(dz.x * k.x, dz.y * k.y, dz.z * k.z, dz.w * k.w);
-        }
-        store4(dh, e0, dhv);
+    for (int i = 0; i < ITERS; ++i) {
+      const size_t e0 = base + (size_t)(i * 64 + lane) * 4;
+      float4 dz;
+      dz.x = rstd * (a[i].x - s1 - zh[i].x * s2);
+      dz.y = rstd * (a[i].y - s1 - zh[i].y * s2);
+      dz.z = rstd * (a[i].z - s1 - zh[i].z * s2);
+      dz.w = rstd * (a[i].w - s1 - zh[i].w * s2);
+      store4(dx, e0, dz);
+      float4 dhv = dz;
+      if (dr.thr) {
+        const unsigned int m = keep >> (4 * i);
+        dhv = make_float4(dz.x * ((m & 1u) ? dr.scale : 0.f), dz.y * ((m & 2u) ? dr.scale : 0.f),
+                          dz.z * ((m & 4u) ? dr.scale : 0.f), dz.w * ((m & 8u) ? dr.scale : 0.f));
       }
+      store4(dh, e0, dhv);
+    }
   }
   // cross-wave reduction of the column sums, then one partial row per workgroup
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITERS; ++i)
-      if (i < iters)
-        *reinterpret_cast<float4 *>(red + wave * d + (i * 64 + lane) * 4) = pass == 0 ? gacc[i] : bacc[i];
+      *reinterpret_cast<float4 *>(red + wave * d + (i * 64 + lane) * 4) = pass == 0 ? gacc[i] : bacc[i];
     __syncthreads();
     float *dst = (pass == 0 ? dgamma_part : dbeta_part) + (size_t)blockIdx.x * d;
     for (int c = threadIdx.x; c < d; c += kBlock) {
