@@ -652,16 +652,23 @@ def main() -> None:
             row.setdefault("algorithmic_flops", int(algo_flops))
             kernels.append(row)
         # dominant kernel over ALL kernels of the step.  Native launches are grouped the way rocprofv3 groups them --
-        # by kernel symbol = template instantiation: the GEMM by (form, epilogue), attention by direction -- so that
+        # by kernel symbol = template instantiation: the GEMM by (form, epilogue, tile configuration), attention by direction -- so that
         # `roofline` describes the symbol with the largest share of the step and its average launch agrees with the
         # rocprofv3 --stats row of that symbol; the per-shape rows stay in `kernels`.  Compared against every other
         # kernel name the profiler saw (library GEMMs, torch elementwise / reduce kernels).
         import re as _re
 
+        _TILE = {12: "8p256x256", 7: "128x128", 2: "128x128", 6: "128x64"}
+        _FORM = {"nt": 0, "nn": 1, "tn": 2}
+
         def family(name: str) -> str:
-            mm = _re.match(r"gemm_(\w+)\(M=\d+,N=\d+,K=\d+,epi=(\d+)\)", name)
+            mm = _re.match(r"gemm_(\w+)\(M=(\d+),N=(\d+),K=(\d+),epi=(\d+)\)", name)
             if mm:
-                return f"gemm_{mm.group(1)}(epi={mm.group(2)})"
+                # the tile configuration the library picks for the shape = the kernel symbol rocprofv3 lists the launch
+                # under (gemm8p_kernel / gemm_kernel<128,128,..> / gemm_kernel<128,64,..>, each x form x epilogue)
+                from sceneverse_amd import _native as _nat
+                v = _nat.load().gps_gemm_pick_variant(_FORM.get(mm.group(1), -1), int(mm.group(2)), int(mm.group(3)), int(mm.group(4)), 0)
+                return f"gemm_{mm.group(1)}(epi={mm.group(5)},tile={_TILE.get(v, v)})"
             mm = _re.match(r"(attn_\w+)\(L=\d+,spatial=(\d)\)(\[\w+\])?", name)
             if mm:
                 return f"{mm.group(1)}(spatial={mm.group(2)}){mm.group(3) or ''}"

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 6
+#define GPS_HIP_ABI_VERSION 7
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -440,6 +440,31 @@ GPS_API int gps_bert_embed_backward(int n_rows, int d, const float *dy, const vo
                                     unsigned long long seed, const void *seed_dev, float *dz, float *dgamma_part,
                                     float *dbeta_part, const int *rows_dev, gps_stream_t stream);
 
+/* index plan of the variable-length text path (modules/language/bert.py::_fast_forward_varlen; the reference runs the
+ * padded batch, modules/language/bert.py:26-30 -- this is what lets the encoder stack skip padded rows): from the
+ * attention masks of n_texts texts (text i = n_seq x len ids + mask, masks NON-EMPTY PREFIXES of their rows -- the
+ * caller's promise), S = sum n_seq sequences and T = sum n_seq * len token positions, ONE launch writes
+ *   i32_out [4 S + 4]: lens[S] | cu_rows[S + 1] (row offsets of the compacted sequences) | order[S] (sequence indices,
+ *            longest first, ties by index) | q_limit[S] (lens for the first n_seq_full sequences, 1 behind them) |
+ *            n_valid | live rows of the first n_seq_full sequences | that + (S - n_seq_full)
+ *   i64_out [3 T + (S - n_seq_full) + T_full]: ids of the compacted rows (valid tokens in flat order, then the padded
+ *            positions in flat order) | their positions inside their row | inv (compact row of every flat position) |
+ *            sel = cu_rows[n_seq_full .. S) followed by 0 .. T_full - 1 (T_full = token positions of the first
+ *            n_seq_full sequences; written only when 0 < n_seq_full < S, which must be a text boundary)
+ *   valid_out [T] bytes: 1 where the mask is set.
+ * Equal, element for element, to the torch formulation (stable argsort of the valid flag, cumsum, ...) for prefix masks:
+ * tests/test_gpu_bert_varlen.py.  S <= 8192, T < 2^31. */
+#define GPS_VARLEN_MAX_TEXTS 8
+typedef struct gps_varlen_text {
+  const long long *ids;   /* (n_seq, len) int64, contiguous */
+  const void *mask;       /* (n_seq, len), contiguous; element != 0 = valid token */
+  int mask_elem_bytes;    /* 1, 2, 4 or 8 */
+  int mask_is_float;      /* floating-point mask: -0.0 counts as 0 */
+  int n_seq, len;
+} gps_varlen_text;
+GPS_API int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq_full, int *i32_out, long long *i64_out,
+                            unsigned char *valid_out, gps_stream_t stream);
+
 /* ---- box-location embedding  y = LayerNorm(x W^T + b)  (tiny reduction length) ---------------------------------
  * Replaces `loc_layers = nn.Sequential(nn.Linear(dim_loc, hidden), nn.LayerNorm(hidden))` of the object encoder and the
  * unified encoder (modules/vision/pcd_openvocab_encoder.py:64-66, :177; modules/grounding/unified_encoder.py:28-30, :158).
@@ -528,6 +553,10 @@ typedef struct gps_gemm_args {
   const int *extent_dev;
 } gps_gemm_args;
 GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
+/* the tile configuration gps_gemm_bf16 takes for variant = -1 (splits < 1: the default split count): 12 = the two-group
+ * 256 x 256 kernel (gemm8p_kernel), 7 / 2 = 128 x 128 tiles, 6 = 128 x 64 tiles (gemm_kernel instantiations) -- what a
+ * profile reader needs to match a launch with its rocprofv3 row */
+GPS_API int gps_gemm_pick_variant(int form, int M, int N, int K, int splits);
 GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
 /* Grouped weight gradients: for every problem p,  C_p (M,N) fp32 [+]= A_p (K,M)^T . B_p (K,N)  and, when colsum_p is not
  * NULL, colsum_p (M) [+]= column sums of A_p over K -- the weight and bias gradient of one nn.Linear (A = dY, B = X, bf16,

@@ -48,6 +48,11 @@ class LnReduceProblem(ctypes.Structure):
     _fields_ = [("part", _vp), ("out_gamma", _vp), ("out_beta", _vp), ("parts", _i), ("accumulate", _i)]
 
 
+class VarlenText(ctypes.Structure):
+    """struct gps_varlen_text of include/gps_hip.h, field for field."""
+    _fields_ = [("ids", _vp), ("mask", _vp), ("mask_elem_bytes", _i), ("mask_is_float", _i), ("n_seq", _i), ("len", _i)]
+
+
 class AttnArgs(ctypes.Structure):
     """struct gps_attn_args of include/gps_hip.h, field for field."""
     _fields_ = [("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("head_dim", _i), ("dtype", _i), ("compute", _i),
@@ -70,6 +75,7 @@ EPI_RELU_SPLIT, EPI_RELU_MAX16 = 6, 7
 SIGNATURES = {
     "gps_adamw_step": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "gps_gemm_pick_splits": [_i, _i, _i, _i],
+    "gps_gemm_pick_variant": [_i, _i, _i, _i, _i],
     "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
     "gps_gemm_wgrad_grouped": [ctypes.POINTER(WgradProblem), _i, _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
@@ -95,6 +101,7 @@ SIGNATURES = {
     "gps_loc_embed_backward": [_i, _i, _i] + [_vp] * 10,
     "gps_bert_embed_partial_rows": [_i],
     "gps_bert_position_grad": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_varlen_plan": [ctypes.POINTER(VarlenText), _i, _i, _vp, _vp, _vp, _vp],
     "gps_bert_embed_forward": [_i, _i] + [_vp] * 7 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 7,
     "gps_bert_embed_backward": [_i, _i] + [_vp] * 10 + [_f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_colsum_parts": [_i, _i],

@@ -243,6 +243,122 @@ inline int grid_rows(int n_rows) {
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
 }
 
+
+// ---- index plan of the variable-length text path: everything the host derived from the attention masks with ~30 tiny
+// torch launches (cat / sum / stable argsort / cumsum / argsort / index_select / scatter / arange ...), in ONE launch.
+// Masks are non-empty PREFIXES of their rows (the caller checked, see modules/language/bert.py::_masks_are_prefixes), so
+// the stable "valid rows first" permutation has a closed form: token j < len_s of sequence s is compact row cu[s] + j,
+// a padded position with flat index e is compact row n_valid + e - cu[s + 1] (the padded positions in flat order).
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanMaxSeq = 8192;
+
+struct PlanText {
+  const int64_t *ids;
+  const void *mask;
+  int elem_bytes, is_float, n_seq, len;
+  int seq0;           // sequences before this text
+  long long tok0;     // token positions before this text
+};
+struct PlanArgs {
+  PlanText t[GPS_VARLEN_MAX_TEXTS];
+  int n_texts, n_seq, n_seq_full;
+  long long n_tok, n_tok_full;
+};
+
+__device__ __forceinline__ bool mask_set(const void *m, size_t i, int eb, int is_float) {
+  switch (eb) {
+    case 1: return reinterpret_cast<const uint8_t *>(m)[i] != 0;
+    case 2: { const uint16_t v = reinterpret_cast<const uint16_t *>(m)[i]; return (is_float ? (v & 0x7FFFu) : v) != 0; }
+    case 4: { const uint32_t v = reinterpret_cast<const uint32_t *>(m)[i]; return (is_float ? (v & 0x7FFFFFFFu) : v) != 0; }
+    default: { const uint64_t v = reinterpret_cast<const uint64_t *>(m)[i];
+               return (is_float ? (v & 0x7FFFFFFFFFFFFFFFull) : v) != 0; }
+  }
+}
+
+__global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArgs A, int32_t *__restrict__ i32_out,
+                                                                   int64_t *__restrict__ i64_out,
+                                                                   uint8_t *__restrict__ valid_out) {
+  extern __shared__ int plan_lds[];            // lens[S] | cu[S + 1]
+  int *lens = plan_lds, *cu = plan_lds + A.n_seq;
+  const int S = A.n_seq, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kPlanThreads / 64;
+  // (a) sequence lengths: one wave per sequence, 64 mask elements per step
+  for (int ti = 0; ti < A.n_texts; ++ti) {
+    const PlanText &T = A.t[ti];
+    for (int b = wave; b < T.n_seq; b += n_waves) {
+      int cnt = 0;
+      for (int j0 = 0; j0 < T.len; j0 += 64) {
+        const int j = j0 + lane;
+        cnt += __popcll(__ballot(j < T.len && mask_set(T.mask, (size_t)b * T.len + min(j, T.len - 1), T.elem_bytes, T.is_float)));
+      }
+      if (lane == 0) lens[T.seq0 + b] = cnt;
+    }
+  }
+  __syncthreads();
+  // (b) row offsets of the compacted sequences (wave 0, 64 sequences per step)
+  if (wave == 0) {
+    int carry = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const int v = s < S ? lens[s] : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      if (s < S) cu[s] = carry + incl - v;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) cu[S] = carry;
+  }
+  __syncthreads();
+  const int n_valid = cu[S];
+  const int S_full = A.n_seq_full;
+  int32_t *o_lens = i32_out, *o_cu = i32_out + S, *o_order = i32_out + 2 * S + 1, *o_qlim = i32_out + 3 * S + 1,
+          *o_scal = i32_out + 4 * S + 1;
+  // (c) dispatch order: longest sequence first (ties by index), by counting -- S is a few hundred
+  for (int s = tid; s < S; s += kPlanThreads) {
+    const int l = lens[s];
+    int rank = 0;
+    for (int q = 0; q < S; ++q) {
+      const int lq = lens[q];
+      rank += (lq > l || (lq == l && q < s)) ? 1 : 0;
+    }
+    o_order[rank] = s;
+    o_lens[s] = l;
+    o_cu[s] = cu[s];
+    o_qlim[s] = s < S_full ? l : 1;
+  }
+  if (tid == 0) {
+    o_cu[S] = n_valid;
+    o_scal[0] = n_valid;
+    o_scal[1] = cu[S_full];                        // live rows of the fully-read texts
+    o_scal[2] = cu[S_full] + (S - S_full);         // rows of the last layer's tail batch
+  }
+  // (d) the compaction itself
+  int64_t *o_ids = i64_out, *o_pos = i64_out + A.n_tok, *o_inv = i64_out + 2 * A.n_tok, *o_sel = i64_out + 3 * A.n_tok;
+  for (int ti = 0; ti < A.n_texts; ++ti) {
+    const PlanText &T = A.t[ti];
+    const long long n = (long long)T.n_seq * T.len;
+    for (long long i = tid; i < n; i += kPlanThreads) {
+      const int b = (int)(i / T.len), j = (int)(i - (long long)b * T.len), s = T.seq0 + b;
+      const long long e = T.tok0 + i;
+      const bool ok = j < lens[s];
+      const long long c = ok ? (long long)cu[s] + j : (long long)n_valid + e - cu[s + 1];
+      o_ids[c] = T.ids[i];
+      o_pos[c] = j;
+      o_inv[e] = c;
+      valid_out[e] = ok ? 1 : 0;
+    }
+  }
+  // (e) row selection of the last layer's tail batch: first row of every [CLS]-only sequence, then the fully-read rows
+  if (S_full > 0 && S_full < S) {
+    const int n_cls = S - S_full;
+    for (long long i = tid; i < n_cls + A.n_tok_full; i += kPlanThreads)
+      o_sel[i] = i < n_cls ? (long long)cu[S_full + (int)i] : i - n_cls;
+  }
+}
+
 }  // namespace gps_bert_embed
 
 extern "C" {
@@ -328,5 +444,46 @@ int gps_bert_embed_backward(int n_rows, int d, const float *dy, const void *dy_b
 #undef GPS_BE_BWD
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
+
+int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq_full, int *i32_out, long long *i64_out,
+                    unsigned char *valid_out, gps_stream_t stream) {
+  using namespace gps_bert_embed;
+  if (n_texts < 1 || n_texts > GPS_VARLEN_MAX_TEXTS || !texts || !i32_out || !i64_out || !valid_out || n_seq_full < 0)
+    return GPS_ERR_INVALID_ARGUMENT;
+  PlanArgs A = {};
+  int seq = 0;
+  long long tok = 0;
+  A.n_tok_full = 0;
+  for (int i = 0; i < n_texts; ++i) {
+    const gps_varlen_text &q = texts[i];
+    if (q.n_seq < 1 || q.len < 1 || !q.ids || !q.mask) return GPS_ERR_INVALID_ARGUMENT;
+    if (q.mask_elem_bytes != 1 && q.mask_elem_bytes != 2 && q.mask_elem_bytes != 4 && q.mask_elem_bytes != 8)
+      return GPS_ERR_INVALID_ARGUMENT;
+    A.t[i].ids = (const int64_t *)q.ids;
+    A.t[i].mask = q.mask;
+    A.t[i].elem_bytes = q.mask_elem_bytes;
+    A.t[i].is_float = q.mask_is_float ? 1 : 0;
+    A.t[i].n_seq = q.n_seq;
+    A.t[i].len = q.len;
+    A.t[i].seq0 = seq;
+    A.t[i].tok0 = tok;
+    if (seq == n_seq_full) A.n_tok_full = tok;
+    seq += q.n_seq;
+    tok += (long long)q.n_seq * q.len;
+  }
+  if (seq == n_seq_full) A.n_tok_full = tok;
+  if (n_seq_full > seq) return GPS_ERR_INVALID_ARGUMENT;
+  if (n_seq_full > 0 && n_seq_full < seq && A.n_tok_full == 0) return GPS_ERR_INVALID_ARGUMENT;   // not a text boundary
+  if (seq > kPlanMaxSeq || tok > 0x7FFFFFFFll) return GPS_ERR_UNSUPPORTED;
+  A.n_texts = n_texts;
+  A.n_seq = seq;
+  A.n_seq_full = n_seq_full;
+  A.n_tok = tok;
+  const size_t lds = sizeof(int) * (2 * (size_t)seq + 1);
+  hipLaunchKernelGGL(varlen_plan_kernel, dim3(1), dim3(kPlanThreads), lds, (hipStream_t)stream, A, (int32_t *)i32_out,
+                     (int64_t *)i64_out, (uint8_t *)valid_out);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
 
 }  // extern "C"

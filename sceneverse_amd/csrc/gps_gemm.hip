@@ -1366,6 +1366,11 @@ int gps_gemm_pick_splits(int form, int M, int N, int K) {
   return s < 1 ? 1 : (int)s;
 }
 
+int gps_gemm_pick_variant(int form, int M, int N, int K, int splits) {
+  if (form != GPS_GEMM_NT && form != GPS_GEMM_NN && form != GPS_GEMM_TN) return -1;
+  return gps_gemm::pick_variant(form, M, N, K, splits < 1 ? gps_gemm_pick_splits(form, M, N, K) : splits);
+}
+
 long long gps_gemm_workspace_floats(int form, int M, int N, int splits) {
   if (form == GPS_GEMM_NT || splits <= 1) return 0;
   return (long long)splits * ((long long)M * N + M);

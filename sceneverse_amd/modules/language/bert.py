@@ -35,6 +35,9 @@ def set_fast_bert(flag: bool) -> None:
 
 
 _CLS_TAIL = True
+# the index plan of the variable-length path (lens, row offsets, compaction, dispatch order, tail selection) from ONE
+# launch of gps_varlen_plan instead of ~30 torch launches; False = the torch formulation (kept as the test's reference)
+_PLAN_KERNEL = True
 
 
 def set_cls_tail(flag: bool) -> None:
@@ -146,30 +149,7 @@ class BERTLanguageEncoder(nn.Module):
         m, H = self.model, self.bert_config.num_attention_heads
         emb = m.embeddings
         dev = texts[0][0].device
-        ids_all = torch.cat([ids.reshape(-1) for ids, _ in texts])
-        valid = torch.cat([(masks != 0).reshape(-1) for _, masks in texts])
-        lens = torch.cat([(masks != 0).sum(dim=1) for _, masks in texts]).to(torch.int32)
-        pos = torch.cat([torch.arange(ids.shape[1], device=dev).repeat(ids.shape[0]) for ids, _ in texts])
-        T, S, cap = ids_all.numel(), lens.numel(), max(ids.shape[1] for ids, _ in texts)
-        n_valid = valid.sum(dtype=torch.int32).reshape(1)
-        perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)      # compact row r <- flat row perm[r]
-        cu = torch.zeros(S + 1, dtype=torch.int32, device=dev)
-        cu[1:] = torch.cumsum(lens, 0)
-        order = torch.argsort(lens, descending=True).to(torch.int32)               # longest sequences dispatched first
-        # embedding block on the compacted tokens (HF BertEmbeddings with token type 0): rows past n_valid hold pad ids
-        training = self.training
-        if fused_embedding.rows_supported(emb):
-            # one launch: lookups + LayerNorm + dropout, fp32 and bf16 outputs, live rows only (gps_bert_embed_forward)
-            x, x16 = fused_embedding.bert_embeddings_rows(emb, ids_all.index_select(0, perm), pos.index_select(0, perm),
-                                                          rows_dev=n_valid, training=training, cu_rows=cu)
-        else:
-            pad = emb.word_embeddings.padding_idx
-            x = _WordLookup.apply(ids_all.index_select(0, perm), emb.word_embeddings.weight, -1 if pad is None else int(pad))
-            x = x + emb.token_type_embeddings.weight[0]
-            x = x + emb.position_embeddings.weight.index_select(0, pos.index_select(0, perm))
-            x = emb.dropout(emb.LayerNorm(x))
-            x = _ZeroDeadRows.apply(x, n_valid)
-            x16 = x
+        T, S, cap = sum(ids.numel() for ids, _ in texts), sum(ids.shape[0] for ids, _ in texts), max(ids.shape[1] for ids, _ in texts)
         # Texts that are only read at [CLS] (`cls_only`, listed after the fully-read ones): in the LAST layer, everything
         # behind the attention core is row-wise, and of those texts only the first row of each sequence reaches an output
         # -- the other rows' results are never read and their gradients are exactly zero in the reference as well.  The
@@ -179,14 +159,47 @@ class BERTLanguageEncoder(nn.Module):
         n_full = sum(1 for ti in range(len(texts)) if ti not in cls_only)
         cls_tail = (_CLS_TAIL and 0 < n_full < len(texts) and all(ti >= n_full for ti in cls_only)
                     and len(m.encoder.layer) > 0)
-        if cls_tail:
-            T_full = sum(texts[ti][0].numel() for ti in range(n_full))
-            S_full = sum(texts[ti][0].shape[0] for ti in range(n_full))
-            n_live_full = valid[:T_full].sum(dtype=torch.int32).reshape(1)
-            sel = torch.cat([cu[S_full:S].long(), torch.arange(T_full, device=dev)])
-            rows_tail = n_live_full + (S - S_full)
-            # last-layer attention: every query of the fully-read sequences, the first one of the [CLS]-only ones
-            q_limit = torch.cat([lens[:S_full], torch.ones(S - S_full, dtype=torch.int32, device=dev)])
+        T_full = sum(texts[ti][0].numel() for ti in range(n_full)) if cls_tail else 0
+        S_full = sum(texts[ti][0].shape[0] for ti in range(n_full)) if cls_tail else 0
+        plan = None
+        if _PLAN_KERNEL and fused_embedding.varlen_plan_supported(texts):
+            # one launch instead of ~30 (gps_varlen_plan; masks are prefixes -- _masks_are_prefixes -- so the stable
+            # "valid rows first" permutation has a closed form)
+            plan = fused_embedding.varlen_plan(texts, S_full)
+            lens, cu, order, n_valid, valid = plan.lens, plan.cu, plan.order, plan.n_valid, plan.valid
+            ids_c, pos_c = plan.ids, plan.pos
+            if cls_tail:
+                sel, rows_tail, q_limit = plan.sel, plan.rows_tail, plan.q_limit
+        else:
+            ids_all = torch.cat([ids.reshape(-1) for ids, _ in texts])
+            valid = torch.cat([(masks != 0).reshape(-1) for _, masks in texts])
+            lens = torch.cat([(masks != 0).sum(dim=1) for _, masks in texts]).to(torch.int32)
+            pos = torch.cat([torch.arange(ids.shape[1], device=dev).repeat(ids.shape[0]) for ids, _ in texts])
+            n_valid = valid.sum(dtype=torch.int32).reshape(1)
+            perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)      # compact row r <- flat row perm[r]
+            cu = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+            cu[1:] = torch.cumsum(lens, 0)
+            order = torch.argsort(lens, descending=True).to(torch.int32)               # longest sequences dispatched first
+            ids_c, pos_c = ids_all.index_select(0, perm), pos.index_select(0, perm)
+            if cls_tail:
+                n_live_full = valid[:T_full].sum(dtype=torch.int32).reshape(1)
+                sel = torch.cat([cu[S_full:S].long(), torch.arange(T_full, device=dev)])
+                rows_tail = n_live_full + (S - S_full)
+                # last-layer attention: every query of the fully-read sequences, the first one of the [CLS]-only ones
+                q_limit = torch.cat([lens[:S_full], torch.ones(S - S_full, dtype=torch.int32, device=dev)])
+        # embedding block on the compacted tokens (HF BertEmbeddings with token type 0): rows past n_valid hold pad ids
+        training = self.training
+        if fused_embedding.rows_supported(emb):
+            # one launch: lookups + LayerNorm + dropout, fp32 and bf16 outputs, live rows only (gps_bert_embed_forward)
+            x, x16 = fused_embedding.bert_embeddings_rows(emb, ids_c, pos_c, rows_dev=n_valid, training=training, cu_rows=cu)
+        else:
+            pad = emb.word_embeddings.padding_idx
+            x = _WordLookup.apply(ids_c, emb.word_embeddings.weight, -1 if pad is None else int(pad))
+            x = x + emb.token_type_embeddings.weight[0]
+            x = x + emb.position_embeddings.weight.index_select(0, pos_c)
+            x = emb.dropout(emb.LayerNorm(x))
+            x = _ZeroDeadRows.apply(x, n_valid)
+            x16 = x
         last = len(m.encoder.layer) - 1
         for li, layer in enumerate(m.encoder.layer):
             sa, so = layer.attention.self, layer.attention.output
@@ -208,8 +221,11 @@ class BERTLanguageEncoder(nn.Module):
                 x, x16 = add_dropout_layer_norm(x, ffn_out, layer.output.LayerNorm, layer.output.dropout.p, training,
                                                 want_bf16=True, rows_dev=rows)
         # back to the callers' layouts
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(T, device=dev)
+        if plan is not None:
+            inv = plan.inv
+        else:
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(T, device=dev)
         outs, r0, s0 = [], 0, 0
         for ti, (ids, masks) in enumerate(texts):
             B, L = ids.shape

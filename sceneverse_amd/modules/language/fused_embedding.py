@@ -191,3 +191,55 @@ def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=Non
     return _BertEmbedRows.apply(ids, pos, emb.word_embeddings.weight, emb.position_embeddings.weight,
                                 emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, p, seed_dev, rows_dev,
                                 -1 if pad is None else int(pad), cu_rows)
+
+
+class VarlenPlan:
+    """Index tensors of the variable-length text path (gps_varlen_plan, one launch): views into three allocations."""
+    __slots__ = ("lens", "cu", "order", "q_limit", "n_valid", "n_live_full", "rows_tail", "ids", "pos", "inv", "sel",
+                 "valid")
+
+
+def varlen_plan_supported(texts) -> bool:
+    return (0 < len(texts) <= 8 and sum(ids.shape[0] for ids, _ in texts) <= 8192
+            and all(ids.dtype == torch.int64 and ids.dim() == 2 and m.shape == ids.shape and ids.is_cuda and m.is_cuda
+                    and m.element_size() in (1, 2, 4, 8) and not m.is_complex() for ids, m in texts))
+
+
+def varlen_plan(texts, n_seq_full: int = 0) -> VarlenPlan:
+    """texts = [(ids (B_i, L_i) int64, mask (B_i, L_i)), ...] with masks that are non-empty PREFIXES of their rows;
+    n_seq_full = number of leading sequences (whole texts) that are read at every token (0: no [CLS]-only tail).
+    Everything `_fast_forward_varlen` needs from the masks, element for element what the torch formulation gives."""
+    dev = texts[0][0].device
+    S = sum(ids.shape[0] for ids, _ in texts)
+    T = sum(ids.numel() for ids, _ in texts)
+    T_full, seq = 0, 0
+    for ids, _ in texts:
+        if seq == n_seq_full:
+            break
+        seq += ids.shape[0]
+        T_full += ids.numel()
+    tail = 0 < n_seq_full < S
+    n_sel = (S - n_seq_full) + T_full if tail else 0
+    i32 = torch.empty(4 * S + 4, dtype=torch.int32, device=dev)
+    i64 = torch.empty(3 * T + n_sel, dtype=torch.int64, device=dev)
+    valid = torch.empty(T, dtype=torch.bool, device=dev)
+    arr = (_native.VarlenText * len(texts))()
+    keep = []
+    for i, (ids, m) in enumerate(texts):
+        ids_c = ids if ids.is_contiguous() else ids.contiguous()
+        m_c = m if m.is_contiguous() else m.contiguous()
+        keep += [ids_c, m_c]
+        arr[i].ids, arr[i].mask = ids_c.data_ptr(), m_c.data_ptr()
+        arr[i].mask_elem_bytes, arr[i].mask_is_float = m_c.element_size(), int(m_c.is_floating_point())
+        arr[i].n_seq, arr[i].len = ids.shape[0], ids.shape[1]
+    with torch.cuda.device(dev):
+        st = _native.load().gps_varlen_plan(arr, len(texts), int(n_seq_full), i32.data_ptr(), i64.data_ptr(),
+                                            valid.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(st, "varlen_plan")
+    p = VarlenPlan()
+    p.lens, p.cu, p.order, p.q_limit = i32[:S], i32[S:2 * S + 1], i32[2 * S + 1:3 * S + 1], i32[3 * S + 1:4 * S + 1]
+    p.n_valid, p.n_live_full, p.rows_tail = i32[4 * S + 1:4 * S + 2], i32[4 * S + 2:4 * S + 3], i32[4 * S + 3:4 * S + 4]
+    p.ids, p.pos, p.inv = i64[:T], i64[T:2 * T], i64[2 * T:3 * T]
+    p.sel = i64[3 * T:] if tail else None
+    p.valid = valid
+    return p

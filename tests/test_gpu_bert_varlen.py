@@ -187,3 +187,86 @@ def test_varlen_attention_query_limit_equals_zeroed_cotangents():
     live = torch.arange(T, device=DEV) < int(cu[-1])
     assert torch.equal(p_lim.grad[live], p_full.grad[live])
     assert torch.all(p_lim.grad[live & ~keep][:, :D] == 0)
+
+
+def _torch_plan(texts, S_full, T_full):
+    """The torch formulation `_fast_forward_varlen` used before gps_varlen_plan (kept there as the fallback)."""
+    dev = texts[0][0].device
+    ids_all = torch.cat([ids.reshape(-1) for ids, _ in texts])
+    valid = torch.cat([(m != 0).reshape(-1) for _, m in texts])
+    lens = torch.cat([(m != 0).sum(dim=1) for _, m in texts]).to(torch.int32)
+    pos = torch.cat([torch.arange(ids.shape[1], device=dev).repeat(ids.shape[0]) for ids, _ in texts])
+    S, T = lens.numel(), ids_all.numel()
+    perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)
+    cu = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(T, device=dev)
+    out = dict(lens=lens, cu=cu, n_valid=valid.sum(dtype=torch.int32).reshape(1), ids=ids_all[perm], pos=pos[perm],
+               inv=inv, valid=valid)
+    if 0 < S_full < S:
+        out["n_live_full"] = valid[:T_full].sum(dtype=torch.int32).reshape(1)
+        out["sel"] = torch.cat([cu[S_full:S].long(), torch.arange(T_full, device=dev)])
+        out["rows_tail"] = out["n_live_full"] + (S - S_full)
+        out["q_limit"] = torch.cat([lens[:S_full], torch.ones(S - S_full, dtype=torch.int32, device=dev)])
+    return out
+
+
+@pytest.mark.parametrize("mask_dtype", [torch.int64, torch.bool, torch.float32, torch.int32, torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("shapes,n_full", [(((8, 50), (8, 300)), 1), (((8, 50), (8, 300)), 0), (((3, 17),), 0),
+                                           (((5, 64), (7, 65), (130, 33)), 2), (((64, 50), (64, 300)), 1)])
+def test_varlen_plan_kernel_equals_the_torch_formulation(shapes, n_full, mask_dtype):
+    """gps_varlen_plan (one launch) against ~30 torch launches, element for element: lengths, row offsets, the stable
+    valid-first compaction (ids, positions, inverse map), the valid flags, the [CLS]-tail selection; the dispatch order
+    is a permutation with non-increasing lengths (torch's unstable argsort breaks ties differently)."""
+    from sceneverse_amd.modules.language import fused_embedding as FE
+    g = torch.Generator().manual_seed(len(shapes) * 100 + n_full)
+    texts = []
+    for B, L in shapes:
+        lens = torch.randint(1, L + 1, (B,), generator=g)
+        lens[0] = L
+        if B > 1:
+            lens[1] = 1
+        ids = torch.randint(1, 30522, (B, L), generator=g)
+        mask = (torch.arange(L)[None, :] < lens[:, None])
+        m = mask.to(mask_dtype)
+        if mask_dtype == torch.float32:
+            m = torch.where(mask, torch.full_like(m, 0.25), torch.full_like(m, -0.0))     # -0.0 is "not set" (== 0)
+        texts.append((ids.to(DEV), m.to(DEV)))
+    assert FE.varlen_plan_supported(texts)
+    S_full = sum(B for B, _ in shapes[:n_full]) if 0 < n_full < len(shapes) else 0
+    T_full = sum(B * L for B, L in shapes[:n_full]) if S_full else 0
+    plan = FE.varlen_plan(texts, S_full)
+    ref = _torch_plan(texts, S_full, T_full)
+    for k in ("lens", "cu", "n_valid", "ids", "pos", "inv", "valid"):
+        assert torch.equal(getattr(plan, k), ref[k]), k
+    order = plan.order.long()
+    assert torch.equal(torch.sort(order).values, torch.arange(order.numel(), device=DEV))
+    ol = ref["lens"][order]
+    assert bool((ol[1:] <= ol[:-1]).all())
+    if S_full:
+        for k in ("n_live_full", "sel", "rows_tail", "q_limit"):
+            assert torch.equal(getattr(plan, k), ref[k]), k
+    else:
+        assert plan.sel is None
+
+
+def test_varlen_bert_is_the_same_with_and_without_the_plan_kernel():
+    """Outputs and gradients of the variable-length encoder are bit-identical whether the index plan comes from
+    gps_varlen_plan or from the torch formulation (same indices -> same launches)."""
+    from sceneverse_amd.modules.language import bert as B
+    enc = _encoder()
+    texts = _texts()
+    g = torch.Generator().manual_seed(5)
+    probe_w = (torch.randn(8, 50, 768, generator=g).to(DEV), torch.randn(8, 768, generator=g).to(DEV))
+    assert B._PLAN_KERNEL
+    a1, b1, g1 = _run(enc, texts, True, probe_w)
+    B._PLAN_KERNEL = False
+    try:
+        a0, b0, g0 = _run(enc, texts, True, probe_w)
+    finally:
+        B._PLAN_KERNEL = True
+    assert torch.equal(a1, a0) and torch.equal(b1, b0)
+    assert g1.keys() == g0.keys()
+    for k in g1:
+        assert torch.equal(g1[k], g0[k]), k
