@@ -419,6 +419,9 @@ def main() -> None:
     ap.add_argument("--no-wgrad-group", action="store_true",
                     help="weight gradients one split-K GEMM at a time instead of one grouped launch per backward segment "
                          "(A/B of modules/layers/gemm.grouped_wgrads)")
+    ap.add_argument("--wgrad-one-queue", action="store_true",
+                    help="grouped weight gradients: one global longest-first tile queue instead of the XCD-local queues "
+                         "(A/B of gps_gemm_wgrad_grouped_set_xcd_queues)")
     ap.add_argument("--eager-ddp", action="store_true",
                     help="N > 1: torch DDP in eager mode (bucketed all-reduce from autograd hooks) instead of the "
                          "split-graph data-parallel step")
@@ -475,6 +478,9 @@ def main() -> None:
     # backward | bottom backward | clip + AdamW as HIP graphs around the eager RCCL all-gather and the two all-reduces);
     # --eager-ddp keeps torch DDP in eager mode (~1 200 launches per step from Python) for A/B.
     use_graph = not args.no_graph and not (world > 1 and args.eager_ddp)
+    if args.wgrad_one_queue:
+        from sceneverse_amd import _native as _nat
+        _nat.load().gps_gemm_wgrad_grouped_set_xcd_queues(0)
     step = GPSTrainStep(cfg, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16,
                         graph=("dp" if args.graph_dp else use_graph), native_gemm=not args.no_native_gemm,
                         grad_compress=("bf16_fp32acc" if (world > 1 and not share and args.bf16_grads) else None),

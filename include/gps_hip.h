@@ -580,6 +580,11 @@ typedef struct gps_wgrad_problem {
   const int *extent_dev;
 } gps_wgrad_problem;
 GPS_API int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gps_stream_t stream);
+/* tile schedule of gps_gemm_wgrad_grouped: 1 (default) = one queue per XCD -- the tiles of a problem run side by side on
+ * one XCD and share their operand panels in its L2; workgroups take tiles of other XCDs' queues only when their own is
+ * empty -- 0 = one global longest-first queue; < 0 = query.  Returns the previous setting.  Results do not depend on it
+ * (every tile is computed by exactly one workgroup, the same way). */
+GPS_API int gps_gemm_wgrad_grouped_set_xcd_queues(int on);
 /* First operand of a split-bf16 MLP chain over a group-all point level (reference: GroupAll in
  * modules/third_party/pointnet2/pointnet2_utils.py -- cat of the grouped xyz and features): row (b, j) =
  * [xyz (b, n, 3)[b][j] | feats (b, c, n)[b][:, j]] as bf16 [hi | lo | hi], each third k_pad >= 3 + c columns wide

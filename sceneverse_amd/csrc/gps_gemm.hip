@@ -1108,30 +1108,86 @@ struct WgradRec {          // 64 bytes
   int tile0;               // id of this problem's first tile
   int flags;               // bit 0: accumulate
 };
-constexpr int kWgradMaxProblems = 256, kWgradSlots = 4, kWgradChunk = 32;
+constexpr int kWgradMaxProblems = 256, kWgradSlots = 4, kWgradChunk = 32, kWgradQueues = 8;
 __device__ WgradRec g_wgrad_table[kWgradSlots][kWgradMaxProblems];
 __device__ unsigned int g_wgrad_next[kWgradSlots];       // next tile id to hand out (dynamic part of the schedule)
+// [r4] XCD-local queues: the problems are dealt to one queue per XCD (tiles of a problem stay together, every class of
+// reduction length is spread evenly), a workgroup takes tiles from the queue of the XCD it runs on (blockIdx mod 8) and
+// only when that one is empty from the others'.  Tiles of one problem then run side by side on ONE XCD and, having the
+// same reduction length, keep walking K together: their operand panels are fetched once per XCD, not once per tile.
+struct WgradQueueState {
+  int begin[kWgradQueues], end[kWgradQueues], first_problem[kWgradQueues];   // tile ids / first record of every queue
+  unsigned int next[kWgradQueues];
+  int enabled;
+};
+__device__ WgradQueueState g_wgrad_queues[kWgradSlots];
 struct WgradChunkArgs { WgradRec r[kWgradChunk]; };
+struct WgradQueueArgs { int begin[kWgradQueues], end[kWgradQueues], first_problem[kWgradQueues], enabled; };
 
 __global__ __launch_bounds__(64) void wgrad_table_write_kernel(const WgradChunkArgs c, int slot, int offset, int count,
-                                                               int first_dynamic_tile) {
+                                                               int first_dynamic_tile, const WgradQueueArgs q, int grid) {
   if ((int)threadIdx.x < count) g_wgrad_table[slot][offset + threadIdx.x] = c.r[threadIdx.x];
   if (offset == 0 && threadIdx.x == 0) g_wgrad_next[slot] = (unsigned int)first_dynamic_tile;
+  if (offset == 0 && threadIdx.x < kWgradQueues) {
+    const int x = threadIdx.x;
+    WgradQueueState &st = g_wgrad_queues[slot];
+    st.begin[x] = q.begin[x];
+    st.end[x] = q.end[x];
+    st.first_problem[x] = q.first_problem[x];
+    // the workgroups blockIdx = x, x + 8, ... take the queue's first tiles statically
+    const int n_static = grid > x ? (grid - x + kWgradQueues - 1) / kWgradQueues : 0;
+    st.next[x] = (unsigned int)(q.begin[x] + min(n_static, q.end[x] - q.begin[x]));
+    if (x == 0) st.enabled = q.enabled;
+  }
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_problems, int total_tiles) {
+__global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_problems, int total_tiles, int xcd_queues) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 128 KB (gemm8p_tile)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  __shared__ int s_next;
+  __shared__ int s_next, s_queue;
   const WgradRec *tab = g_wgrad_table[slot];
+  WgradQueueState *Q = &g_wgrad_queues[slot];
   const int G = (int)gridDim.x;
-  // First tile: static, the workgroups of an XCD take consecutive tiles (tiles of one output row share their dY panel
-  // in that XCD's L2 while everybody still walks K in step).  Every later tile: the next one of the longest-first list,
-  // handed out by an atomic counter -- whoever finishes first takes it (greedy longest-processing-time schedule; every
-  // tile is still computed by exactly one workgroup, so results do not depend on who that is).
-  int t = xcd_virtual_id(blockIdx.x, G);
-  int p = 0;
+  // One queue (xcd_queues = 0).  First tile: static, the workgroups of an XCD take consecutive tiles.  Every later tile:
+  // the next one of the longest-first list, handed out by an atomic counter -- whoever finishes first takes it (greedy
+  // longest-processing-time schedule; every tile is still computed by exactly one workgroup, so results do not depend on
+  // who that is).  XCD-local queues: see WgradQueueState.
+  const int my_queue = (int)blockIdx.x & (kWgradQueues - 1);
+  unsigned int empty = 0u;                                   // queues this workgroup has seen run dry (thread 0)
+  auto take = [&]() {                                        // thread 0: the next tile (or total_tiles) and its queue
+    if (!xcd_queues) {
+      s_next = (int)atomicAdd(&g_wgrad_next[slot], 1u);
+      s_queue = 0;
+      return;
+    }
+    for (int k = 0; k < kWgradQueues; ++k) {
+      const int y = (my_queue + k) & (kWgradQueues - 1);
+      if ((empty >> y) & 1u) continue;
+      const int t = (int)atomicAdd(&Q->next[y], 1u);
+      if (t < Q->end[y]) { s_next = t; s_queue = y; return; }
+      empty |= 1u << y;
+    }
+    s_next = total_tiles;
+    s_queue = 0;
+  };
+  int t, queue = 0, p = 0;
+  if (!xcd_queues) {
+    t = xcd_virtual_id(blockIdx.x, G);
+  } else {
+    const int i = (int)blockIdx.x / kWgradQueues;
+    if (i < Q->end[my_queue] - Q->begin[my_queue]) {
+      t = Q->begin[my_queue] + i;
+      queue = my_queue;
+    } else {
+      if (threadIdx.x == 0) take();
+      __syncthreads();
+      t = __builtin_amdgcn_readfirstlane(s_next);
+      queue = __builtin_amdgcn_readfirstlane(s_queue);
+      __syncthreads();
+    }
+    p = Q->first_problem[queue];
+  }
   for (;;) {
     if (t >= total_tiles) break;
     while (p + 1 < n_problems && tab[p + 1].tile0 <= t) ++p;
@@ -1157,10 +1213,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_p
     // ever see its own LDS traffic
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     gemm8p_tile<true, true, EPI_F32>(P, smem, lane, wave, tile_m * 256, tile_n * 256, tile_n, 0, 0, nst, k_eff);
-    if (threadIdx.x == 0) s_next = (int)atomicAdd(&g_wgrad_next[slot], 1u);
+    if (threadIdx.x == 0) take();
     __syncthreads();                                        // s_next visible; the next tile's first copies overwrite the stage buffers
     t = __builtin_amdgcn_readfirstlane(s_next);
+    const int nq = __builtin_amdgcn_readfirstlane(s_queue);
     __syncthreads();                                        // (s_next is rewritten at the end of the next tile)
+    if (nq != queue) {                                      // a tile of another queue: its records start elsewhere
+      queue = nq;
+      p = xcd_queues ? Q->first_problem[queue] : p;
+    }
   }
 }
 
@@ -1388,6 +1449,13 @@ int gps_split3_points(int b, int n, int c, const float *xyz, const float *feats,
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
+static int g_wgrad_xcd_queues = 1;
+int gps_gemm_wgrad_grouped_set_xcd_queues(int on) {
+  const int prev = g_wgrad_xcd_queues;
+  if (on >= 0) g_wgrad_xcd_queues = on ? 1 : 0;
+  return prev;
+}
+
 int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gps_stream_t stream) {
   using namespace gps_gemm;
   if (n_problems < 0 || (n_problems > 0 && !problems)) return GPS_ERR_INVALID_ARGUMENT;
@@ -1440,6 +1508,55 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
     for (int i = 0; i < cnt; ++i) all_tiles += (long long)((problems[order[i]].M + 255) / 256) * ((problems[order[i]].N + 255) / 256);
     if (all_tiles > 0x3FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
     const int grid = all_tiles < n_cu ? (int)all_tiles : n_cu;
+    // XCD-local queues (see WgradQueueState): the problems of one class -- same reduction length, same device extent,
+    // i.e. tiles that take the same time whatever the live row count turns out to be -- are dealt to the queue that
+    // holds the fewest tiles of that class so far (ties: fewest tiles overall).  Inside a queue: longest first.
+    WgradQueueArgs qa = {};
+    const bool queues = g_wgrad_xcd_queues && grid >= 2 * kWgradQueues && grid % kWgradQueues == 0;
+    if (queues) {
+      int qof[kWgradMaxProblems];
+      long long q_class[kWgradQueues], q_all[kWgradQueues] = {};
+      for (int i = 0; i < cnt;) {
+        int j = i;
+        while (j < cnt && problems[order[j]].K == problems[order[i]].K && problems[order[j]].extent_dev == problems[order[i]].extent_dev) ++j;
+        for (int x = 0; x < kWgradQueues; ++x) q_class[x] = 0;
+        // within a class: most tiles first, so the big problems are placed before the small ones fill the gaps
+        for (int a = i + 1; a < j; ++a) {
+          const int v = order[a];
+          const long long tv = (long long)((problems[v].M + 255) / 256) * ((problems[v].N + 255) / 256);
+          int b = a - 1;
+          while (b >= i && (long long)((problems[order[b]].M + 255) / 256) * ((problems[order[b]].N + 255) / 256) < tv) { order[b + 1] = order[b]; --b; }
+          order[b + 1] = v;
+        }
+        for (int a = i; a < j; ++a) {
+          const gps_wgrad_problem &q = problems[order[a]];
+          const long long tl = (long long)((q.M + 255) / 256) * ((q.N + 255) / 256);
+          int best = 0;
+          for (int x = 1; x < kWgradQueues; ++x)
+            if (q_class[x] < q_class[best] || (q_class[x] == q_class[best] && q_all[x] < q_all[best])) best = x;
+          qof[a] = best;
+          q_class[best] += tl;
+          q_all[best] += tl;
+        }
+        i = j;
+      }
+      // records queue by queue (stable: the K-descending order survives inside a queue)
+      int order2[kWgradMaxProblems], n2 = 0;
+      long long tiles_before = 0;
+      for (int x = 0; x < kWgradQueues; ++x) {
+        qa.begin[x] = (int)tiles_before;
+        qa.first_problem[x] = n2;
+        for (int a = 0; a < cnt; ++a)
+          if (qof[a] == x) {
+            order2[n2++] = order[a];
+            tiles_before += (long long)((problems[order[a]].M + 255) / 256) * ((problems[order[a]].N + 255) / 256);
+          }
+        qa.end[x] = (int)tiles_before;
+        if (qa.first_problem[x] >= cnt) qa.first_problem[x] = cnt - 1;
+      }
+      for (int a = 0; a < cnt; ++a) order[a] = order2[a];
+      qa.enabled = 1;
+    }
     long long tile0 = 0;
     for (int c0 = 0; c0 < cnt; c0 += kWgradChunk) {
       WgradChunkArgs args = {};
@@ -1453,11 +1570,11 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
         r.flags = q.accumulate ? 1 : 0;
         tile0 += (long long)((q.M + 255) / 256) * ((q.N + 255) / 256);
       }
-      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, args, slot, c0, n, grid);
+      hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, args, slot, c0, n, grid, qa, grid);
       if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
     }
     const int total = (int)tile0;
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)grid), dim3(512), LDS, s, slot, cnt, total);
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)grid), dim3(512), LDS, s, slot, cnt, total, queues ? 1 : 0);
     if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
   }
   return GPS_OK;

@@ -372,7 +372,16 @@ def _grouped(probs):
     _native.check(st, "gemm_wgrad_grouped")
 
 
-def test_grouped_weight_gradients_against_fp32():
+@pytest.fixture(params=[1, 0], ids=["xcd_queues", "one_queue"])
+def wgrad_queues(request):
+    """Both tile schedules of gps_gemm_wgrad_grouped (XCD-local queues = the default; one global queue)."""
+    lib = _native.load()
+    prev = lib.gps_gemm_wgrad_grouped_set_xcd_queues(request.param)
+    yield request.param
+    lib.gps_gemm_wgrad_grouped_set_xcd_queues(prev)
+
+
+def test_grouped_weight_gradients_against_fp32(wgrad_queues):
     """gps_gemm_wgrad_grouped: many dW = dY^T X (+ column sums of dY) in one persistent launch, no split over K: ragged
     M / N / K, a 72-row problem, strided operands (column slices of a packed dY), a device-side row extent with NaN rows
     behind it, plain stores and read-modify-write into buffers that already hold a gradient, more tiles than CUs."""
@@ -413,6 +422,51 @@ def test_grouped_weight_gradients_against_fp32():
     torch.cuda.synchronize()
     for a, p in zip(again, probs):
         assert torch.equal(a["C"], p["C"])
+
+
+def test_grouped_schedules_give_the_same_bits_on_a_step_sized_problem_set():
+    """~60 problems / ~900 tiles in three reduction-length classes (one with a device-side extent), i.e. several rounds
+    of every XCD-local queue plus tiles taken from other XCDs' queues at the end: every tile is computed by exactly one
+    workgroup with the same code whoever takes it, so the XCD-local schedule, the single global queue and a second run
+    agree bit for bit -- and with the fp32 formulation on sampled problems."""
+    lib = _native.load()
+    torch.manual_seed(11)
+    live = torch.tensor([6100], dtype=torch.int32, device=DEV)
+    probs = []
+
+    def add(T, parts, N, ext=None, seed=0):
+        dyb = _rand16(T, sum(parts), scale=0.5, seed=seed)
+        x = _rand16(T, N, seed=seed + 1)
+        r = 0
+        for m in parts:
+            probs.append(dict(dy=dyb[:, r:r + m], x=x, C=None, colsum=None, accumulate=0, extent=ext, T=T if ext is None else 6100))
+            r += m
+    for l in range(3):
+        add(9600, [768, 768, 768], 768, live, 100 + 10 * l), add(9600, [768], 768, live, 101 + 10 * l)
+        add(9600, [3072], 768, live, 102 + 10 * l), add(9600, [768], 3072, live, 103 + 10 * l)
+        add(2560, [768, 768, 768, 72], 768, None, 104 + 10 * l), add(2560, [2048], 768, None, 105 + 10 * l), add(2560, [768], 2048, None, 106 + 10 * l)
+        add(4160, [2304], 768, None, 107 + 10 * l), add(4160, [768], 768, None, 108 + 10 * l), add(4160, [768], 2048, None, 109 + 10 * l)
+    results = []
+    for mode in (1, 0, 1):
+        prev = lib.gps_gemm_wgrad_grouped_set_xcd_queues(mode)
+        try:
+            run = [dict(p, C=torch.full((p["dy"].shape[1], p["x"].shape[1]), float("nan"), device=DEV),
+                        colsum=torch.full((p["dy"].shape[1],), float("nan"), device=DEV)) for p in probs]
+            _grouped(run)
+            torch.cuda.synchronize()
+        finally:
+            lib.gps_gemm_wgrad_grouped_set_xcd_queues(prev)
+        results.append(run)
+    for a, b, c in zip(*results):
+        assert torch.equal(a["C"], b["C"]) and torch.equal(a["C"], c["C"])
+        assert torch.equal(a["colsum"], b["colsum"]) and torch.equal(a["colsum"], c["colsum"])
+    for i in range(0, len(probs), 5):
+        p, T = results[0][i], probs[i]["T"]
+        ref = p["dy"][:T].float().t() @ p["x"][:T].float()
+        err = (p["C"] - ref).abs().max().item()
+        assert err <= 1e-4 * ref.abs().max().item() + 1e-5, (i, err)
+        ref_cs = p["dy"][:T].float().sum(0)
+        assert (p["colsum"] - ref_cs).abs().max().item() <= 1e-4 * ref_cs.abs().max().item() + 1e-4
 
 
 def test_grouped_weight_gradients_equal_the_autograd_ones():
