@@ -913,13 +913,13 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[q >> 1][q & 1][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias gradient of the TN form: column sums of A over k, on the vector ALU beside the MFMAs (wave column 0 of tile
-  // column 0 only): lane (i, g) adds the 8 k values it holds of row i of every A fragment with four v_dot2c against
-  // bf16 ones (exact products, fp32 sums) -- one register per fragment row block instead of an MFMA accumulator
-  const bool do_colsum = COLSUM && P.colsum != nullptr && tile_n == 0 && wc == 0;
-  float csum[2][4];
-#pragma unroll
-  for (int a = 0; a < 8; ++a) csum[a >> 2][a & 3] = 0.f;
+  // bias gradient of the TN form: column sums of A over k, on the vector ALU beside the MFMAs (tile column 0 only).
+  // The four waves of a wave row hold the SAME A fragments; wave column wc sums fragment row block a = wc (rows
+  // 64 wr + 16 wc + [0, 16) of each half): lane (i, g) adds the 8 k values it holds of row i with four v_dot2c against
+  // bf16 ones (exact products, fp32 sums) -- two registers per wave and 8 instead of 32 dot instructions per phase and
+  // wave (all of them on wave column 0 stretched phases 1 and 3 of every tile of column 0 by half).
+  const bool do_colsum = COLSUM && P.colsum != nullptr && tile_n == 0;
+  float csum[2] = {0.f, 0.f};
   bf16x8 aq[2][4], bq0[2][2], bq1[2][2];
 
   auto read_a = [&](const unsigned char *half) {
@@ -944,21 +944,22 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
         for (int b = 0; b < 2; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][b], aq[ks][a], c[a][b], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
-  auto colsum8 = [&](float (&cs)[4]) {
+  auto colsum8 = [&](float &cs) {
     if constexpr (COLSUM) {
       if (do_colsum) {
         typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
         const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const bf16x8 f = aq[ks][a];
-            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, cs[a], false);
-            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, cs[a], false);
-            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, cs[a], false);
-            cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, cs[a], false);
-          }
+        auto add8 = [&](const bf16x8 f) {
+          cs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, cs, false);
+          cs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, cs, false);
+          cs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, cs, false);
+          cs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, cs, false);
+        };
+        // (wc is wave-uniform: scalar branches, no selects)
+        if (wc == 0) { add8(aq[0][0]); add8(aq[1][0]); }
+        else if (wc == 1) { add8(aq[0][1]); add8(aq[1][1]); }
+        else if (wc == 2) { add8(aq[0][2]); add8(aq[1][2]); }
+        else { add8(aq[0][3]); add8(aq[1][3]); }
       }
     }
   };
@@ -1043,11 +1044,11 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
   if constexpr (COLSUM) {
     if (do_colsum) {
 #pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        float v = csum[a >> 2][a & 3];
+      for (int hf = 0; hf < 2; ++hf) {
+        float v = csum[hf];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        const int m = m0 + 128 * (a >> 2) + 64 * wr + 16 * (a & 3) + (lane & 15);
+        const int m = m0 + 128 * hf + 64 * wr + 16 * wc + (lane & 15);
         if (lane < 16 && m < P.M) {
           float *cs = P.colsum + (size_t)split * P.M + m;
           *cs = (P.accumulate && P.splits == 1) ? *cs + v : v;
