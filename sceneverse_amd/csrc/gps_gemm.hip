@@ -1192,7 +1192,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_p
   for (;;) {
     if (t >= total_tiles) break;
     while (p + 1 < n_problems && tab[p + 1].tile0 <= t) ++p;
-    const WgradRec rec = tab[p];
+    // The record is the same for the whole workgroup, but it arrives through vector loads: every field goes back to
+    // scalar registers here.  Left in VGPRs, the operand pointers make the buffer descriptors of the stage copies
+    // "divergent" and the compiler wraps EVERY buffer_load ... lds of the main loop in a waterfall loop (4
+    // v_readfirstlane + 2 v_cmp + saveexec + branch per copy: 83 instead of 30 vector and 93 instead of 45 scalar
+    // instructions per K tile and wave, profiles/r4/pmc_wgrad_grouped_*.txt).
+    const WgradRec rec_v = tab[p];
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni_ptr = [&](const void *q) {
+      const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+      const unsigned int lo = (unsigned int)uni((int)(unsigned int)u), hi = (unsigned int)uni((int)(unsigned int)(u >> 32));
+      return reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    };
+    WgradRec rec;
+    rec.A = (const uint16_t *)uni_ptr(rec_v.A); rec.B = (const uint16_t *)uni_ptr(rec_v.B);
+    rec.C = (float *)uni_ptr(rec_v.C); rec.colsum = (float *)uni_ptr(rec_v.colsum);
+    rec.extent = (const int *)uni_ptr(rec_v.extent);
+    rec.lda = uni(rec_v.lda); rec.ldb = uni(rec_v.ldb); rec.ldc = uni(rec_v.ldc);
+    rec.M = uni(rec_v.M); rec.N = uni(rec_v.N); rec.K = uni(rec_v.K);
+    rec.tile0 = uni(rec_v.tile0); rec.flags = uni(rec_v.flags);
     Params P = {};
     P.M = rec.M; P.N = rec.N; P.K = rec.K;
     P.A = rec.A; P.lda = rec.lda;
