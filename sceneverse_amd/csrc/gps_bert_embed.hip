@@ -335,20 +335,23 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
     o_scal[1] = cu[S_full];                        // live rows of the fully-read texts
     o_scal[2] = cu[S_full] + (S - S_full);         // rows of the last layer's tail batch
   }
-  // (d) the compaction itself
+  // (d) the compaction itself: one wave per sequence, 64 consecutive positions per step (coalesced, no divisions)
   int64_t *o_ids = i64_out, *o_pos = i64_out + A.n_tok, *o_inv = i64_out + 2 * A.n_tok, *o_sel = i64_out + 3 * A.n_tok;
   for (int ti = 0; ti < A.n_texts; ++ti) {
     const PlanText &T = A.t[ti];
-    const long long n = (long long)T.n_seq * T.len;
-    for (long long i = tid; i < n; i += kPlanThreads) {
-      const int b = (int)(i / T.len), j = (int)(i - (long long)b * T.len), s = T.seq0 + b;
-      const long long e = T.tok0 + i;
-      const bool ok = j < lens[s];
-      const long long c = ok ? (long long)cu[s] + j : (long long)n_valid + e - cu[s + 1];
-      o_ids[c] = T.ids[i];
-      o_pos[c] = j;
-      o_inv[e] = c;
-      valid_out[e] = ok ? 1 : 0;
+    for (int b = wave; b < T.n_seq; b += n_waves) {
+      const int s = T.seq0 + b, len_s = lens[s];
+      const long long c_valid = cu[s];                                   // compact row of the sequence's first token
+      const long long row0 = (long long)b * T.len, e0 = T.tok0 + row0;   // first position: inside the text / flat
+      const long long c_pad = (long long)n_valid + e0 - cu[s + 1];       // compact row of flat position e0 if it were padding
+      for (int j = lane; j < T.len; j += 64) {
+        const bool ok = j < len_s;
+        const long long c = (ok ? c_valid : c_pad) + j;
+        o_ids[c] = T.ids[row0 + j];
+        o_pos[c] = j;
+        o_inv[e0 + j] = c;
+        valid_out[e0 + j] = ok ? 1 : 0;
+      }
     }
   }
   // (e) row selection of the last layer's tail batch: first row of every [CLS]-only sequence, then the fully-read rows
