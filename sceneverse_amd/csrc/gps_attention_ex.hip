@@ -587,7 +587,7 @@ __global__ __launch_bounds__(1024) void attn_fp8_fwd_kernel(const PX P) {
             const float *plp = P.pl + ((row0q + qi) * Lk + t) * 5;
 #pragma unroll
             for (int d = 0; d < 5; ++d) z = fmaf(w[1 + d], plp[d], z);
-            const float sig = kt[r] < 0.f ? 0.f : 1.f / (1.f + __expf(-z));
+            const float sig = kt[r] < 0.f ? 0.f : __builtin_amdgcn_rcpf(1.f + __expf(-z));
             v += __logf(fmaxf(sig, 1e-6f));
           }
         }

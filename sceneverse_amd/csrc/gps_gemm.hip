@@ -114,7 +114,7 @@ __device__ __forceinline__ unsigned int rng_u32(unsigned long long seed, unsigne
 // instead of libm erff's ~40; the one exponential exp(-x^2 / 2) serves both erf(x / sqrt 2) and the Gaussian density.
 __device__ __forceinline__ void erf_terms(float x, float &erf_abs, float &e) {      // erf(|x| / sqrt 2), exp(-x^2 / 2)
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));   // v_rcp_f32, 1 ulp (__frcp_rn: a 10-instruction IEEE division per element)
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
@@ -1422,7 +1422,12 @@ inline int pick_variant(int form, int M, int N, int K, int splits) {
   // long reductions over >= 140 tiles of 256 x 256 (more than half the CUs busy in the last round): the two-group kernel
   // (12 608 x 768 x 3072: 62.5 vs 71.7 us forward, 71.1 vs 86.0 us input gradient; at K = 768 its per-tile prologue and
   // 128 KB store tail cancel the gain -- profiles/r3/gemm_8p_shapes.log)
-  if (K % 64 == 0 && K >= 1536 && tiles256 >= 140) return 12;
+  static const int min_k_8p = [] {                      // GPS_GEMM_8P_MIN_K: A/B of the threshold (tools, bench runs)
+    const char *e = getenv("GPS_GEMM_8P_MIN_K");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 1536;
+  }();
+  if (K % 64 == 0 && K >= min_k_8p && tiles256 >= 140) return 12;
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * splits;
   return tiles >= 384 ? 7 : 6;
 }

@@ -1,6 +1,7 @@
 """Compile every HIP source of libgps_hip.so to gfx950 assembly and list, per kernel, what the source does not show:
 VGPRs, scratch bytes and scratch instructions (register arrays indexed at run time, spills), v_readfirstlane counts
-(VGPR-resident descriptors -> waterfall loops around buffer loads) and full-drain waits (`s_waitcnt vmcnt(0)`).
+(VGPR-resident descriptors -> waterfall loops around buffer loads), full-drain waits (`s_waitcnt vmcnt(0)`) and IEEE
+division sequences (`v_div_scale_f32`: `1.f / x` and `__frcp_rn` are ~10 instructions, `__builtin_amdgcn_rcpf` is one).
 
     python tools/asm_audit.py [--out profiles/r4/asm_audit.txt] [file.hip ...]
 
@@ -40,7 +41,8 @@ def audit(path, tmp):
         if name not in meta:
             continue
         rows.append((name, *meta[name], len(re.findall(r"\bscratch_", body)), len(re.findall(r"v_readfirstlane", body)),
-                     len(re.findall(r"s_waitcnt vmcnt\(0\)", body)), len(re.findall(r"v_mfma", body))))
+                     len(re.findall(r"s_waitcnt vmcnt\(0\)", body)), len(re.findall(r"v_mfma", body)),
+                     len(re.findall(r"v_div_scale_f32", body)) // 2))
     return rows
 
 
@@ -50,14 +52,14 @@ def main():
     ap.add_argument("files", nargs="*")
     a = ap.parse_args()
     files = a.files or sorted(glob.glob(os.path.join(ROOT, "sceneverse_amd", "csrc", "*.hip")))
-    lines = [f"{'vgpr':>5} {'scr_B':>6} {'s_sp':>4} {'v_sp':>4} {'scr_i':>5} {'rfl':>4} {'vm0':>4} {'mfma':>5}  kernel"]
+    lines = [f"{'vgpr':>5} {'scr_B':>6} {'s_sp':>4} {'v_sp':>4} {'scr_i':>5} {'rfl':>4} {'vm0':>4} {'mfma':>5} {'div':>4}  kernel"]
     with tempfile.TemporaryDirectory() as tmp:
         for f in files:
             rows = audit(f, tmp)
             names = demangle([r[0] for r in rows])
             lines.append(f"-- {os.path.relpath(f, ROOT)}")
             for r, n in zip(rows, names):
-                lines.append(f"{r[1]:5d} {r[2]:6d} {r[3]:4d} {r[4]:4d} {r[5]:5d} {r[6]:4d} {r[7]:4d} {r[8]:5d}  {n[:150]}")
+                lines.append(f"{r[1]:5d} {r[2]:6d} {r[3]:4d} {r[4]:4d} {r[5]:5d} {r[6]:4d} {r[7]:4d} {r[8]:5d} {r[9]:4d}  {n[:150]}")
     out = "\n".join(lines) + "\n"
     sys.stdout.write(out)
     if a.out:
