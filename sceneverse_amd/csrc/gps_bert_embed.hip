@@ -286,9 +286,13 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
     const PlanText &T = A.t[ti];
     for (int b = wave; b < T.n_seq; b += n_waves) {
       int cnt = 0;
-      for (int j0 = 0; j0 < T.len; j0 += 64) {
-        const int j = j0 + lane;
-        cnt += __popcll(__ballot(j < T.len && mask_set(T.mask, (size_t)b * T.len + min(j, T.len - 1), T.elem_bytes, T.is_float)));
+      for (int j0 = 0; j0 < T.len; j0 += 256) {             // four independent mask loads per trip
+        bool set[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          set[u] = mask_set(T.mask, (size_t)b * T.len + min(j0 + 64 * u + lane, T.len - 1), T.elem_bytes, T.is_float);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += __popcll(__ballot(j0 + 64 * u + lane < T.len && set[u]));
       }
       if (lane == 0) lens[T.seq0 + b] = cnt;
     }
@@ -344,13 +348,24 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
       const long long c_valid = cu[s];                                   // compact row of the sequence's first token
       const long long row0 = (long long)b * T.len, e0 = T.tok0 + row0;   // first position: inside the text / flat
       const long long c_pad = (long long)n_valid + e0 - cu[s + 1];       // compact row of flat position e0 if it were padding
-      for (int j = lane; j < T.len; j += 64) {
-        const bool ok = j < len_s;
-        const long long c = (ok ? c_valid : c_pad) + j;
-        o_ids[c] = T.ids[row0 + j];
-        o_pos[c] = j;
-        o_inv[e0 + j] = c;
-        valid_out[e0 + j] = ok ? 1 : 0;
+      // four steps per trip, their id loads first (clamped, unconditional): the stores below may alias the ids as far
+      // as the compiler knows, so a load placed behind them would wait for its own round trip every 64 positions
+      for (int j0 = lane; j0 < T.len + lane; j0 += 256) {
+        int64_t idv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) idv[u] = T.ids[row0 + min(j0 + 64 * u, T.len - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + 64 * u;
+          if (j < T.len) {
+            const bool ok = j < len_s;
+            const long long c = (ok ? c_valid : c_pad) + j;
+            o_ids[c] = idv[u];
+            o_pos[c] = j;
+            o_inv[e0 + j] = c;
+            valid_out[e0 + j] = ok ? 1 : 0;
+          }
+        }
       }
     }
   }
