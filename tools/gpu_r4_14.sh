@@ -2,7 +2,7 @@
 # round 4: hardware counters of the grouped weight-gradient launch (and everything else in tools/pmc_workload.py)
 set -u
 REPO=$PWD
-OUT=$REPO/gpurun_out/r4_14; mkdir -p $OUT
+OUT=$REPO/gpurun_out/${1:-r4_14}; mkdir -p $OUT
 export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
