@@ -21,6 +21,10 @@ HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)
 def _asm(name):
     tmp = tempfile.mkdtemp(prefix="gps_asm_")
     out = os.path.join(tmp, name + ".s")
