@@ -89,3 +89,10 @@ def test_grouped_weight_gradient_main_loop_has_no_waterfall_and_no_spill():
     assert "v_readfirstlane" not in loop and "scratch_" not in loop
     # every LDS-DMA stage copy takes its descriptor from scalar registers: no exec-mask loop around it
     assert not re.search(r"s_and_saveexec_b64[^\n]*\n\s*buffer_load_dwordx4", loop)
+
+
+def test_gemm_epilogues_have_no_ieee_division_sequences():
+    """`__frcp_rn` / `1.f / x` compile to v_div_scale x2 + v_rcp + 4 v_fma + v_div_fmas + v_div_fixup per element -- a third of
+    the GELU epilogue's vector instructions before round 4 replaced them by one v_rcp_f32."""
+    text = _asm("gps_gemm")
+    assert "v_div_scale_f32" not in text
