@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 7
+#define GPS_HIP_ABI_VERSION 8
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -433,7 +433,9 @@ GPS_API int gps_bert_position_grad(int n_seq, int n_pos, int d, const int *cu_ro
 GPS_API int gps_bert_embed_forward(int n_rows, int d, const long long *ids, const long long *pos, const float *word,
                                    const float *pos_table, const float *type_row, const float *gamma, const float *beta,
                                    float eps, float p_drop, unsigned long long seed, const void *seed_dev, float *y,
-                                   void *y_bf16, float *mean, float *rstd, const int *rows_dev, gps_stream_t stream);
+                                   void *y_bf16, float *mean, float *rstd, const int *rows_dev, const int *poison_dev,
+                                   gps_stream_t stream);
+/* poison_dev (optional device word, e.g. gps_varlen_plan's violation word): non-zero -> every output row is NaN. */
 GPS_API int gps_bert_embed_backward(int n_rows, int d, const float *dy, const void *dy_bf16, const long long *ids,
                                     const long long *pos, const float *word, const float *pos_table, const float *type_row,
                                     const float *gamma, const float *mean, const float *rstd, float p_drop,
@@ -444,9 +446,11 @@ GPS_API int gps_bert_embed_backward(int n_rows, int d, const float *dy, const vo
  * padded batch, modules/language/bert.py:26-30 -- this is what lets the encoder stack skip padded rows): from the
  * attention masks of n_texts texts (text i = n_seq x len ids + mask, masks NON-EMPTY PREFIXES of their rows -- the
  * caller's promise), S = sum n_seq sequences and T = sum n_seq * len token positions, ONE launch writes
- *   i32_out [4 S + 4]: lens[S] | cu_rows[S + 1] (row offsets of the compacted sequences) | order[S] (sequence indices,
+ *   i32_out [4 S + 5]: lens[S] | cu_rows[S + 1] (row offsets of the compacted sequences) | order[S] (sequence indices,
  *            longest first, ties by index) | q_limit[S] (lens for the first n_seq_full sequences, 1 behind them) |
- *            n_valid | live rows of the first n_seq_full sequences | that + (S - n_seq_full)
+ *            n_valid | live rows of the first n_seq_full sequences | that + (S - n_seq_full) | violation (1 when some
+ *            mask is NOT a non-empty prefix of its row -- an empty row, a hole, left padding: the plan then differs from
+ *            the torch formulation; consumers poison their output with it, see gps_bert_embed_forward's poison_dev)
  *   i64_out [3 T + (S - n_seq_full) + T_full]: ids of the compacted rows (valid tokens in flat order, then the padded
  *            positions in flat order) | their positions inside their row | inv (compact row of every flat position) |
  *            sel = cu_rows[n_seq_full .. S) followed by 0 .. T_full - 1 (T_full = token positions of the first
@@ -567,7 +571,11 @@ GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
  * (the destination already holds a gradient); every output element has one writer, results are deterministic.
  * extent_dev: as in gps_gemm_args (the reduction stops after the first *extent_dev rows).  Requirements as form TN:
  * M, N, lda, ldb multiples of 8, ldc of 4, 16-byte aligned A, B, C, K * ld* * 2 < 2^31.  The problem array is host
- * memory and is consumed before the call returns (capturable: the table travels as kernel arguments). */
+ * memory and is consumed before the call returns (capturable: the table travels as kernel arguments).
+ * Threading / streams: the launcher keeps process-wide state (the tile-queue counters and a small ring of device
+ * tables): calls must be issued from ONE host thread at a time and on ONE stream (or on streams ordered after one
+ * another) of ONE device; two launches in flight on unordered streams would share queue counters.  A captured launch
+ * keeps its ring slot for the life of the graph. */
 typedef struct gps_wgrad_problem {
   int M, N, K, accumulate;
   const void *A;

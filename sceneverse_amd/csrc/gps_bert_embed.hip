@@ -69,10 +69,14 @@ __global__ __launch_bounds__(kBlock) void fwd_kernel(int n_rows, int d, const in
                                                      float p_drop, unsigned int thr, unsigned long long seed,
                                                      const unsigned long long *__restrict__ seed_dev, float *__restrict__ y,
                                                      uint16_t *__restrict__ y16, float *__restrict__ mean_out,
-                                                     float *__restrict__ rstd_out, const int *__restrict__ rows_dev) {
+                                                     float *__restrict__ rstd_out, const int *__restrict__ rows_dev,
+                                                     const int *__restrict__ poison_dev) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rows_dev) n_rows = min(n_rows, *rows_dev);        // device-side count of leading rows that carry work
-  const float scale = thr ? 1.f / (1.f - p_drop) : 1.f;
+  // a plan built from masks that break its precondition (gps_varlen_plan's violation word): every row leaves as NaN, so
+  // that the loss of the step is NaN instead of silently wrong
+  const float poison = (poison_dev && *poison_dev != 0) ? __builtin_nanf("") : 1.f;
+  const float scale = (thr ? 1.f / (1.f - p_drop) : 1.f) * poison;
   const unsigned long long sd = seed + ((thr && seed_dev) ? *seed_dev : 0ull);
   const float inv_d = 1.f / (float)d;
   for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
@@ -280,21 +284,31 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
                                                                    uint8_t *__restrict__ valid_out) {
   extern __shared__ int plan_lds[];            // lens[S] | cu[S + 1]
   int *lens = plan_lds, *cu = plan_lds + A.n_seq;
+  __shared__ int violation;                    // some mask is not a non-empty prefix of its row
   const int S = A.n_seq, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kPlanThreads / 64;
+  if (tid == 0) violation = 0;
+  __syncthreads();
   // (a) sequence lengths: one wave per sequence, 64 mask elements per step
   for (int ti = 0; ti < A.n_texts; ++ti) {
     const PlanText &T = A.t[ti];
     for (int b = wave; b < T.n_seq; b += n_waves) {
-      int cnt = 0;
+      int cnt = 0, end = 0;                                  // set elements | one past the last set element
       for (int j0 = 0; j0 < T.len; j0 += 256) {             // four independent mask loads per trip
         bool set[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           set[u] = mask_set(T.mask, (size_t)b * T.len + min(j0 + 64 * u + lane, T.len - 1), T.elem_bytes, T.is_float);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cnt += __popcll(__ballot(j0 + 64 * u + lane < T.len && set[u]));
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long bits = __ballot(j0 + 64 * u + lane < T.len && set[u]);
+          cnt += __popcll(bits);
+          if (bits) end = j0 + 64 * u + 64 - __clzll(bits);
+        }
       }
-      if (lane == 0) lens[T.seq0 + b] = cnt;
+      if (lane == 0) {
+        lens[T.seq0 + b] = cnt;
+        if (cnt == 0 || cnt != end) violation = 1;          // empty row, a hole, or left padding (benign race: all write 1)
+      }
     }
   }
   __syncthreads();
@@ -338,6 +352,7 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
     o_scal[0] = n_valid;
     o_scal[1] = cu[S_full];                        // live rows of the fully-read texts
     o_scal[2] = cu[S_full] + (S - S_full);         // rows of the last layer's tail batch
+    o_scal[3] = violation;                         // != 0: the plan is NOT what the torch formulation would give
   }
   // (d) the compaction itself: one wave per sequence, 64 consecutive positions per step (coalesced, no divisions)
   int64_t *o_ids = i64_out, *o_pos = i64_out + A.n_tok, *o_inv = i64_out + 2 * A.n_tok, *o_sel = i64_out + 3 * A.n_tok;
@@ -386,7 +401,7 @@ int gps_bert_embed_partial_rows(int n_rows) { return gps_bert_embed::grid_rows(n
 int gps_bert_embed_forward(int n_rows, int d, const long long *ids, const long long *pos, const float *word,
                            const float *pos_table, const float *type_row, const float *gamma, const float *beta, float eps,
                            float p_drop, unsigned long long seed, const void *seed_dev, float *y, void *y_bf16, float *mean,
-                           float *rstd, const int *rows_dev, gps_stream_t stream) {
+                           float *rstd, const int *rows_dev, const int *poison_dev, gps_stream_t stream) {
   using namespace gps_bert_embed;
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
   if ((d & 255) || d > 1024) return GPS_ERR_UNSUPPORTED;
@@ -401,7 +416,7 @@ int gps_bert_embed_forward(int n_rows, int d, const long long *ids, const long l
 #define GPS_BE_FWD(IT)                                                                                                     \
   hipLaunchKernelGGL((fwd_kernel<IT>), grid, block, 0, s, n_rows, d, (const int64_t *)ids, (const int64_t *)pos, word,   \
                      pos_table, type_row, gamma, beta, eps, p_drop, thr, seed, (const unsigned long long *)seed_dev, y, \
-                     (uint16_t *)y_bf16, mean, rstd, rows_dev)
+                     (uint16_t *)y_bf16, mean, rstd, rows_dev, poison_dev)
   switch (d >> 8) {
     case 1: GPS_BE_FWD(1); break;
     case 2: GPS_BE_FWD(2); break;

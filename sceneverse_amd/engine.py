@@ -86,9 +86,8 @@ class GPSTrainStep:
             # its gradient ("... break CUDA graph capture ...").  Round 3 silenced that warning; it was the root cause of
             # the corrupted split-graph steps (see _work_stream below).  It is an ERROR here: a captured backward must be
             # a linear chain of nodes.
-            import warnings
+            # (scoped to this engine's steps: `_strict_accumulate_grad` -- no process-wide warning filter)
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
-            warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
         self.graph_warmup = max(1, int(graph_warmup))
         self._graph = None
         self._static = None
@@ -155,10 +154,11 @@ class GPSTrainStep:
         # `grad += dW` is then issued on THAT stream.  Inside a capture this forks the graph (the accumulations become
         # parallel branches of the compute chain), and ROCm 7's multi-queue graph executor does not keep such graphs in
         # order: the text encoder's saved activations were overwritten by later kernels of the same graph (wrong
-        # gradients, memory-aperture violations; root-caused with tools/probes/post_addend_corruption_probe.py, DESIGN.md
-        # section 9).  With one stream every capture is a linear chain of nodes.
+        # gradients, memory-aperture violations; regression test: tests/test_gpu_graph_chain.py, DESIGN.md
+        # section 9a).  With one stream every capture is a linear chain of nodes.
         self._work_stream = None
-        # diagnostics only (tools/probes): called with a stage name at the capture / replay points of the split-graph step
+        self._acc_hooks, self._autograd_written = None, set()
+        # tests / diagnostics: called with a stage name at the capture / replay points of the split-graph step
         self.stage_hook = None
         if self.graph_dp and dist_utils.is_dist():
             with torch.no_grad():                      # what DDP does at construction
@@ -302,6 +302,12 @@ class GPSTrainStep:
             # eager warm-up with the same exchange points (lazy inits, hipBLASLt heuristics, ...)
             side = self._stream()
             side.wait_stream(cur)
+            if self._acc_hooks is None:
+                # which parameters does AUTOGRAD accumulate into during the warm-up steps?  Those must keep their zero
+                # fill even if a grouped launch also writes them (a tied weight, a module also used through F.linear):
+                # the "plain store" shortcut below is for parameters whose ONLY writer is the grouped launch
+                self._acc_hooks = [p.register_post_accumulate_grad_hook(lambda q: self._autograd_written.add(id(q)))
+                                   for p in self.model.parameters() if p.requires_grad]
             with torch.cuda.stream(side):
                 self._begin_step()
                 with self._autocast():
@@ -330,7 +336,10 @@ class GPSTrainStep:
             # parameters whose gradient the grouped weight-gradient launch writes (learnt in the warm-up steps): their
             # part of the flat buffer is never zero-filled, the launch stores instead of adding (gemm.mark_stale_grads)
             from .modules.layers import gemm as _gemm
-            direct_ids = _gemm.grouped_written_ids() if self.wgrad_group else set()
+            direct_ids = (_gemm.grouped_written_ids() - self._autograd_written) if self.wgrad_group else set()
+            for h in self._acc_hooks or []:
+                h.remove()
+            self._acc_hooks = []
             # gradients live as views of ONE flat fp32 buffer (only for parameters that do receive a
             # gradient: the never-used ones keep grad None, as under DDP / eager AdamW)
             used = [p for p in self.model.parameters() if p.grad is not None]
@@ -373,7 +382,7 @@ class GPSTrainStep:
                 p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
                 off += pad4(p.numel())
             torch.cuda.synchronize(self.device)
-            g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
+            g1, g2a, g3 = (self._new_graph() for _ in range(3))
             # thread-local capture mode: RCCL's watchdog thread polls its events (hipEventQuery) while we capture; in the
             # default global mode any such call from another thread invalidates the capture
             ws = self._stream()
@@ -411,30 +420,14 @@ class GPSTrainStep:
             self._stage("captured_g2a", out=out, total=total)
             if segmented:
                 live = [t for t in boundary if t.grad is not None]
-                # boundary tensors by the encoder that produced them (OpenVocab lists the text outputs first, the object
-                # encoder's output last): one backward graph per encoder, text first (see the ranges above).
-                # `_debug_joint_bottom` (probes): both in ONE backward call, as round 3 did.
-                groups = [[t for t in live if t is not boundary[-1]], [t for t in live if t is boundary[-1]]]
-                if getattr(self, "_debug_joint_bottom", False) or not all(groups) or not all(bottom_segs):
-                    groups = [live]
+                groups = self._bottom_groups(live, boundary, bottom_segs)
                 self._bottom_graphs_per_range = len(groups) == 2
                 g2b = []
-                dbg_inputs = getattr(self, "_debug_bottom_inputs", None)        # probes: restrict the bottom backward
-                bot_in = bottom if dbg_inputs is None else \
-                    [p for p in bottom if any(p is q for q in getattr(self.model, dbg_inputs).parameters())]
-                if getattr(self, "_debug_eager_g2b", False):
-                    self._eager_g2b = (live, bot_in)                            # probes: run it uncaptured at every step
-                    groups = []
-                for gi, grp in enumerate(groups):
-                    gg = torch.cuda.CUDAGraph()
-                    if getattr(self, "_debug_dump_graphs", None):
-                        gg.enable_debug_mode()
-                    with torch.cuda.graph(gg, pool=g1.pool(), stream=ws, capture_error_mode=_CAPTURE_MODE), self._wgrad_ctx(only=bot_in):
-                        roots = [t.grad.clone() for t in grp] if getattr(self, "_debug_clone_roots", False) else [t.grad for t in grp]
-                        torch.autograd.backward(grp, grad_tensors=roots, inputs=bot_in)
+                for grp in groups:
+                    gg = self._new_graph()
+                    with torch.cuda.graph(gg, pool=g1.pool(), stream=ws, capture_error_mode=_CAPTURE_MODE), self._wgrad_ctx(only=bottom):
+                        torch.autograd.backward(grp, grad_tensors=[t.grad for t in grp], inputs=bottom)
                     torch.cuda.synchronize(self.device)
-                    if getattr(self, "_debug_dump_graphs", None):
-                        gg.debug_dump(f"{self._debug_dump_graphs}/g2b_{gi}.dot")
                     g2b.append(gg)
                 self._stage("captured_g2b")
             else:
@@ -469,11 +462,6 @@ class GPSTrainStep:
                 self._stage("replayed_g2b" if gi + 1 == len(g2b) else f"replayed_g2b_part{gi}")
                 if getattr(self, "_bottom_graphs_per_range", False) and gi + 1 < len(g2b):
                     handles.append(self._allreduce_async(self._seg_ends[gi], self._seg_ends[gi + 1]))
-            if getattr(self, "_eager_g2b", None) is not None:                   # probes only
-                live, bot_in = self._eager_g2b
-                with self._wgrad_ctx(only=bot_in):
-                    torch.autograd.backward(live, grad_tensors=[t.grad for t in live], inputs=bot_in, retain_graph=True)
-                self._stage("replayed_g2b")
             done = self._seg_ends[len(handles) - 1]                    # ranges already on their way
             handles.append(self._allreduce_async(done, self._flat_grad.numel()))
             self._wait_allreduce(*handles)
@@ -482,10 +470,49 @@ class GPSTrainStep:
         g3.replay()
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
 
+    def _new_graph(self):
+        """Every graph of the captured steps is made here (tests subclass this to keep the hipGraph_t for inspection)."""
+        return torch.cuda.CUDAGraph()
+
+    @staticmethod
+    def _bottom_groups(live, boundary, bottom_segs):
+        """Boundary tensors by the encoder that produced them (OpenVocab lists the text outputs first, the object
+        encoder's output last): one backward graph per encoder, text first, so that the text range of the flat gradient
+        buffer travels beside the object encoder's backward.  One group when either encoder has nothing to train."""
+        groups = [[t for t in live if t is not boundary[-1]], [t for t in live if t is boundary[-1]]]
+        return groups if all(groups) and all(bottom_segs) else [live]
+
     def _stream(self):
         if self._work_stream is None:
             self._work_stream = torch.cuda.Stream(device=self.device)
         return self._work_stream
+
+    @contextlib.contextmanager
+    def _strict_accumulate_grad(self):
+        """Inside: torch's "AccumulateGrad node's stream does not match" warning is an exception (a captured backward
+        must be a linear chain of nodes, see `_work_stream`).  The filter lives for the duration of this engine's own
+        warm-up / capture / replay calls only -- user code and other engines keep the process's warning state."""
+        import warnings
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
+            yield
+
+    def _rebind_lr(self) -> None:
+        """Graph modes: every param group's `lr` must BE a view of `_lr_dev` (the word the captured AdamW reads and the
+        scheduler writes).  `Optimizer.load_state_dict` replaces it with a copy carrying the checkpoint's value: adopt
+        the value, restore the alias.  Runs before every step that is not a replay (a load after capture is refused by
+        GpsAdamW itself)."""
+        if self._lr_dev is None:
+            return
+        for gi, g in enumerate(self.optimizer.param_groups):
+            lr, word = g["lr"], self._lr_dev[gi]
+            if torch.is_tensor(lr) and lr.device == word.device and lr.data_ptr() == word.data_ptr():
+                continue
+            with torch.no_grad():
+                word.fill_(float(lr))
+            g["lr"] = word
+            if hasattr(self.optimizer, "_sig"):
+                self.optimizer._sig = None               # tables hold the learning-rate words' addresses
 
     def _sched_step(self) -> None:
         """`scheduler.step()`; with device-resident learning rates (graph modes) and a LambdaLR: the same bookkeeping and
@@ -583,7 +610,7 @@ class GPSTrainStep:
             static_dict.update(self._static)
             self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
+            g = self._new_graph()
             with torch.cuda.graph(g, stream=self._stream()):
                 total, losses = self._eager_body(static_dict)
             self._drop_previous_graph()
@@ -622,7 +649,10 @@ class GPSTrainStep:
         if self.graph or self.graph_dp:
             data_dict['cur_step'] = 0
             data_dict['total_steps'] = 1 << 30
-            total, losses = self._graph_dp_step(data_dict) if self.graph_dp else self._graph_step(data_dict)
+            if self._graph is None:
+                self._rebind_lr()
+            with self._strict_accumulate_grad():
+                total, losses = self._graph_dp_step(data_dict) if self.graph_dp else self._graph_step(data_dict)
             self._sched_step()
             self.global_step += 1
             return total, losses

@@ -58,7 +58,7 @@ class _GPSBase(BaseModel):
         return groups
 
 
-_OBJ_FIRST = False
+_OBJ_FIRST = False           # tests: run the object encoder before the text encoder (order of the bottom backward graph)
 
 
 @MODEL_REGISTRY.register()
@@ -75,7 +75,7 @@ class OpenVocab(_GPSBase):
             data_dict['total_steps'] = 1
 
         scene_txt = None
-        pre = self._encode_objects(data_dict) if _OBJ_FIRST else None      # probes only: encoder order in autograd's eyes
+        pre = self._encode_objects(data_dict) if _OBJ_FIRST else None
         if self.use_scene_cap and hasattr(self.lang_encoder, "forward_pair"):
             # the sentence and the scene caption go through the text encoder's layers as one row batch
             txt, scene_txt = self.lang_encoder.forward_pair(data_dict['txt_ids'], data_dict['txt_masks'],

@@ -95,6 +95,7 @@ class BERTLanguageEncoder(nn.Module):
         self.last_path = None
         self._varlen_masks_ok = True
         self._prefix_checks_left = _PREFIX_CHECKS
+        self._varlen_violation = None        # device word of the last variable-length forward (see check_varlen_masks)
 
     def _fast_ok(self, txt_ids) -> bool:
         from ..layers.transformers import _bf16_mode
@@ -120,10 +121,13 @@ class BERTLanguageEncoder(nn.Module):
     def _masks_are_prefixes(self, texts) -> bool:
         """The variable-length form promises `gps_bert_position_grad` that every text's valid tokens are a non-empty
         PREFIX of its row (position = offset inside the compacted sequence; the [CLS] row exists).  Right-padded
-        tokenizer output (the reference: BertTokenizer(..., padding='max_length')) always is.  The property is data,
-        so it is checked on the host -- one sync -- in the first `_PREFIX_CHECKS` eager forwards of an encoder (the
-        warm-up steps that precede any graph capture; never inside a capture); a batch with holes, left padding or an
-        empty text switches this encoder to the padded row batch for good, which handles any mask like HF does."""
+        tokenizer output (the reference: BertTokenizer(..., padding='max_length')) always is.  The property is data.
+        EVERY batch is checked on the device: the plan kernel writes a violation word (gps_varlen_plan) that turns the
+        embedding block's output -- hence the loss -- into NaN (`poison_dev`), inside captured graphs too, and that
+        `check_varlen_masks()` reads at logging / evaluation points.  In addition the first `_PREFIX_CHECKS` eager
+        forwards of an encoder (the warm-up steps that precede any graph capture) check on the host -- one sync -- and a
+        batch with holes, left padding or an empty text switches this encoder to the padded row batch for good, which
+        handles any mask like HF does."""
         if not self._varlen_masks_ok:
             return False
         if self._prefix_checks_left > 0 and not torch.cuda.is_current_stream_capturing():
@@ -136,6 +140,15 @@ class BERTLanguageEncoder(nn.Module):
                     "variable-length path is disabled for this encoder, the padded row batch is used instead")
                 self._varlen_masks_ok = False
         return self._varlen_masks_ok
+
+    def check_varlen_masks(self) -> None:
+        """Raise if the last variable-length forward (eager or a graph replay) saw an attention mask that is not a
+        non-empty prefix of its row; its outputs are NaN by construction.  One host sync: call at logging / evaluation
+        points, not per step."""
+        v = self._varlen_violation
+        if v is not None and bool(v.item()):
+            raise RuntimeError("BERT variable-length path: an attention mask has a hole, left padding or an empty row; "
+                               "the outputs of that forward are NaN.  Use right-padded masks or set_varlen(False).")
 
     def _fast_forward_varlen(self, texts, cls_only=()):
         """The encoder stack over the VALID tokens only (see _VARLEN above).  texts = [(ids (B_i, L_i), masks), ...];
@@ -167,12 +180,15 @@ class BERTLanguageEncoder(nn.Module):
             # "valid rows first" permutation has a closed form)
             plan = fused_embedding.varlen_plan(texts, S_full)
             lens, cu, order, n_valid, valid = plan.lens, plan.cu, plan.order, plan.n_valid, plan.valid
+            violation = plan.violation
             ids_c, pos_c = plan.ids, plan.pos
             if cls_tail:
                 sel, rows_tail, q_limit = plan.sel, plan.rows_tail, plan.q_limit
         else:
             ids_all = torch.cat([ids.reshape(-1) for ids, _ in texts])
             valid = torch.cat([(masks != 0).reshape(-1) for _, masks in texts])
+            violation = torch.stack([(((m[:, 1:] != 0) > (m[:, :-1] != 0)).any() | (m[:, 0] == 0).any())
+                                     for _, m in texts]).any().to(torch.int32).reshape(1)
             lens = torch.cat([(masks != 0).sum(dim=1) for _, masks in texts]).to(torch.int32)
             pos = torch.cat([torch.arange(ids.shape[1], device=dev).repeat(ids.shape[0]) for ids, _ in texts])
             n_valid = valid.sum(dtype=torch.int32).reshape(1)
@@ -187,11 +203,13 @@ class BERTLanguageEncoder(nn.Module):
                 rows_tail = n_live_full + (S - S_full)
                 # last-layer attention: every query of the fully-read sequences, the first one of the [CLS]-only ones
                 q_limit = torch.cat([lens[:S_full], torch.ones(S - S_full, dtype=torch.int32, device=dev)])
+        self._varlen_violation = violation
         # embedding block on the compacted tokens (HF BertEmbeddings with token type 0): rows past n_valid hold pad ids
         training = self.training
         if fused_embedding.rows_supported(emb):
             # one launch: lookups + LayerNorm + dropout, fp32 and bf16 outputs, live rows only (gps_bert_embed_forward)
-            x, x16 = fused_embedding.bert_embeddings_rows(emb, ids_c, pos_c, rows_dev=n_valid, training=training, cu_rows=cu)
+            x, x16 = fused_embedding.bert_embeddings_rows(emb, ids_c, pos_c, rows_dev=n_valid, training=training, cu_rows=cu,
+                                                          poison_dev=violation)
         else:
             pad = emb.word_embeddings.padding_idx
             x = _WordLookup.apply(ids_c, emb.word_embeddings.weight, -1 if pad is None else int(pad))
@@ -199,6 +217,7 @@ class BERTLanguageEncoder(nn.Module):
             x = x + emb.position_embeddings.weight.index_select(0, pos_c)
             x = emb.dropout(emb.LayerNorm(x))
             x = _ZeroDeadRows.apply(x, n_valid)
+            x = x + torch.where(violation != 0, float("nan"), 0.0).to(x.dtype)      # same poison as the fused launch
             x16 = x
         last = len(m.encoder.layer) - 1
         for li, layer in enumerate(m.encoder.layer):

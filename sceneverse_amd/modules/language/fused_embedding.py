@@ -100,7 +100,7 @@ class _BertEmbedRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, pos, word_w, pos_w, type_w, gamma, beta, eps: float, p_drop: float, seed_dev, rows_dev,
-                padding_idx: int, cu_rows=None):
+                padding_idx: int, cu_rows=None, poison_dev=None):
         n, d = ids.numel(), word_w.shape[1]
         dev = word_w.device
         ids = ids.reshape(-1).to(torch.int64).contiguous()
@@ -117,7 +117,8 @@ class _BertEmbedRows(torch.autograd.Function):
             st = _native.load().gps_bert_embed_forward(
                 n, d, ids.data_ptr(), pos.data_ptr(), word_w.data_ptr(), pos_w.data_ptr(), type0.data_ptr(),
                 gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_drop), 0, _ptr(seed_dev), y.data_ptr(),
-                y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(rows_dev), torch.cuda.current_stream(dev).cuda_stream)
+                y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(rows_dev), _ptr(poison_dev),
+                torch.cuda.current_stream(dev).cuda_stream)
         _native.check(st, "bert_embed_forward")
         ctx.save_for_backward(ids, pos, word_w, pos_w, type0, gamma, mean, rstd, seed_dev, rows_dev, cu_rows)
         ctx.meta = (float(p_drop), int(padding_idx), type_w.shape[0])
@@ -163,7 +164,7 @@ class _BertEmbedRows(torch.autograd.Function):
             d_pos = embedding_grad(pos, dz, pos_w.shape[0], -1)
         d_type = torch.zeros((n_types, d), dtype=torch.float32, device=dev)
         d_type[0] = d_pos.sum(0)                 # every row has exactly one position: sum of all rows' dz
-        return None, None, d_word, d_pos, d_type, sums[0], sums[1], None, None, None, None, None, None
+        return None, None, d_word, d_pos, d_type, sums[0], sums[1], None, None, None, None, None, None, None
 
 
 def rows_supported(emb) -> bool:
@@ -176,11 +177,13 @@ def rows_supported(emb) -> bool:
             and not emb.word_embeddings.sparse)
 
 
-def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=None, training: bool = False, cu_rows=None):
+def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=None, training: bool = False, cu_rows=None,
+                         poison_dev=None):
     """HF BertEmbeddings for a flat list of (token id, position) rows -> (y fp32 (n, d), y bf16 (n, d)); rows at or past
     the device-side count `rows_dev` are left unwritten.  cu_rows (int32, n_seq + 1): promise that the live rows are whole
     sequences laid end to end (sequence s = rows cu_rows[s] .. cu_rows[s + 1] - 1) with pos = offset inside the sequence
-    -- the position-table gradient then takes the per-position form (gps_bert_position_grad)."""
+    -- the position-table gradient then takes the per-position form (gps_bert_position_grad).  poison_dev (int32 device
+    word, the plan's `violation`): non-zero turns every output row into NaN."""
     p = float(emb.dropout.p) if training else 0.0
     seed_dev = None
     if p > 0.0:
@@ -190,13 +193,13 @@ def bert_embeddings_rows(emb, ids: torch.Tensor, pos: torch.Tensor, rows_dev=Non
     ln = emb.LayerNorm
     return _BertEmbedRows.apply(ids, pos, emb.word_embeddings.weight, emb.position_embeddings.weight,
                                 emb.token_type_embeddings.weight, ln.weight, ln.bias, ln.eps, p, seed_dev, rows_dev,
-                                -1 if pad is None else int(pad), cu_rows)
+                                -1 if pad is None else int(pad), cu_rows, poison_dev)
 
 
 class VarlenPlan:
     """Index tensors of the variable-length text path (gps_varlen_plan, one launch): views into three allocations."""
     __slots__ = ("lens", "cu", "order", "q_limit", "n_valid", "n_live_full", "rows_tail", "ids", "pos", "inv", "sel",
-                 "valid")
+                 "valid", "violation")
 
 
 def varlen_plan_supported(texts) -> bool:
@@ -220,7 +223,7 @@ def varlen_plan(texts, n_seq_full: int = 0) -> VarlenPlan:
         T_full += ids.numel()
     tail = 0 < n_seq_full < S
     n_sel = (S - n_seq_full) + T_full if tail else 0
-    i32 = torch.empty(4 * S + 4, dtype=torch.int32, device=dev)
+    i32 = torch.empty(4 * S + 5, dtype=torch.int32, device=dev)
     i64 = torch.empty(3 * T + n_sel, dtype=torch.int64, device=dev)
     valid = torch.empty(T, dtype=torch.bool, device=dev)
     arr = (_native.VarlenText * len(texts))()
@@ -239,6 +242,7 @@ def varlen_plan(texts, n_seq_full: int = 0) -> VarlenPlan:
     p = VarlenPlan()
     p.lens, p.cu, p.order, p.q_limit = i32[:S], i32[S:2 * S + 1], i32[2 * S + 1:3 * S + 1], i32[3 * S + 1:4 * S + 1]
     p.n_valid, p.n_live_full, p.rows_tail = i32[4 * S + 1:4 * S + 2], i32[4 * S + 2:4 * S + 3], i32[4 * S + 3:4 * S + 4]
+    p.violation = i32[4 * S + 4:4 * S + 5]
     p.ids, p.pos, p.inv = i64[:T], i64[T:2 * T], i64[2 * T:3 * T]
     p.sel = i64[3 * T:] if tail else None
     p.valid = valid

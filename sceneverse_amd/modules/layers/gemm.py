@@ -371,7 +371,8 @@ def flush_grouped_wgrads() -> None:
                 gb, acc_b = _grad_buffer(b, force_existing=bool(acc))
                 if gb is None or bool(acc_b) != bool(acc):
                     gw = None
-            if gw is None or (n & 7):                     # a gradient buffer the kernel cannot address: classic path
+            if gw is None or (n & 7) or (r & 7) or (K_in & 7):   # a block the kernel cannot address (buffer, or a 16-byte
+                #                                               misaligned row offset / pitch): classic path
                 fallback.append((dy16, x16, w, b, r, n, rows_dev))
             else:
                 q = WgradProblem()

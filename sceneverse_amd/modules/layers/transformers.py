@@ -362,12 +362,11 @@ def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout, want_b
 # allocation pattern moved the damage (sceneverse_amd/engine.py `_work_stream`, tests/test_gpu_graph_chain.py,
 # DESIGN.md section 9).  On by default since.
 _FUSE_POST_ADD = True
-_FUSE_POST_ONLY = None          # probes: "spatial" = object encoder layers only, "plain" = unified encoder layers only
 
 
-def set_fuse_post_add(flag: bool, only=None) -> None:
-    global _FUSE_POST_ADD, _FUSE_POST_ONLY
-    _FUSE_POST_ADD, _FUSE_POST_ONLY = bool(flag), only
+def set_fuse_post_add(flag: bool) -> None:
+    global _FUSE_POST_ADD
+    _FUSE_POST_ADD = bool(flag)
 
 
 def _gemm_input(x: Tensor) -> Tensor:
@@ -383,8 +382,7 @@ def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add):
     copy leave the same launch; the copy travels as an attribute of the fp32 result for the next layer's `_gemm_input`."""
     if post_add is None:
         return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2)
-    fuse = _FUSE_POST_ADD and (_FUSE_POST_ONLY is None or (_FUSE_POST_ONLY == "spatial") == hasattr(layer.self_attn, "lang_cond_fc"))
-    if fuse and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
+    if _FUSE_POST_ADD and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
         y, y16 = _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2, want_bf16=True, post=post_add)
         if y16 is not y:
             y._gps_bf16 = y16

@@ -270,3 +270,41 @@ def test_varlen_bert_is_the_same_with_and_without_the_plan_kernel():
     assert g1.keys() == g0.keys()
     for k in g1:
         assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.parametrize("defect", ["hole", "left_padding", "empty_row", "none"])
+def test_plan_kernel_flags_masks_that_are_not_prefixes(defect):
+    """gps_varlen_plan's violation word (i32_out[4 S + 4]): set for a hole, left padding or an empty row anywhere in the
+    batch -- EVERY batch, not only the first eager forwards -- and clear for right-padded masks."""
+    from sceneverse_amd.modules.language import fused_embedding as FE
+    texts = _texts(B=6, La=50, Lb=300, seed=5)
+    ids, mask = texts[1]
+    mask = mask.clone()
+    if defect == "hole":
+        mask[3, 7] = 0                      # row 3 is at least 30 tokens long
+    elif defect == "left_padding":
+        mask[2, 0] = 0
+    elif defect == "empty_row":
+        mask[4, :] = 0
+    plan = FE.varlen_plan([texts[0], (ids, mask)], 0)
+    assert int(plan.violation.item()) == (0 if defect == "none" else 1)
+
+
+def test_a_later_batch_with_a_hole_poisons_the_output_instead_of_being_silently_wrong():
+    """After the host-side warm-up checks are used up (the state of a long run, or of a captured graph), a mask with a
+    hole must not produce plausible numbers: the embedding block's rows -- hence every output -- are NaN, and
+    check_varlen_masks() raises."""
+    enc = _encoder()
+    enc._prefix_checks_left = 0
+    texts = _texts(B=4, seed=9)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a, b = enc.forward_pair(texts[0][0], texts[0][1], texts[1][0], texts[1][1], cls_second=True)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    enc.check_varlen_masks()
+    bad = texts[1][1].clone()
+    bad[1, 5] = 0
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a, b = enc.forward_pair(texts[0][0], texts[0][1], texts[1][0], bad, cls_second=True)
+    assert torch.isnan(a[texts[0][1].bool()]).all() and torch.isnan(b[:, 0]).all()
+    with pytest.raises(RuntimeError, match="hole"):
+        enc.check_varlen_masks()

@@ -9,6 +9,7 @@ Tolerances (stated per north_star "features/logits/loss within a stated fp toler
                within 1 % of max|ref|; losses within 3 % -- bf16 autocast of every Linear (CPU
                bf16 autocast of the same model lands at 0.044 / 0.2 % of max, so these bounds
                are ~2-5x the bf16 floor); FPS/ball-query indices are fp32 and stay bit-exact."""
+import os
 import pytest
 import torch
 import torch.nn as nn
@@ -210,14 +211,14 @@ def test_segmented_graph_gradients_equal_single_graph_and_eager(post_add, obj_fi
     from sceneverse_amd.engine import GPSTrainStep
     from sceneverse_amd.modules.layers import transformers as T
     from sceneverse_amd.modules.layers.transformers import MultiheadSelfAttention
-    was = (T._FUSE_POST_ADD, T._FUSE_POST_ONLY, OV._OBJ_FIRST)
+    was = (T._FUSE_POST_ADD, OV._OBJ_FIRST)
     T.set_fuse_post_add(post_add)
     OV._OBJ_FIRST = obj_first
     try:
         _segmented_gradient_parity(gps_pretrain_cfg, _lang_dir, synth_batch, GPSTrainStep, MultiheadSelfAttention)
     finally:
-        T.set_fuse_post_add(was[0], was[1])
-        OV._OBJ_FIRST = was[2]
+        T.set_fuse_post_add(was[0])
+        OV._OBJ_FIRST = was[1]
 
 
 def _segmented_gradient_parity(gps_pretrain_cfg, _lang_dir, synth_batch, GPSTrainStep, MultiheadSelfAttention):
@@ -425,7 +426,17 @@ def _bench_slice(n_scenes=2):
     return {k: (v[:n_scenes].clone() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 64 else v) for k, v in full.items()}
 
 
-_BF16_STEP_BOUNDS = {}          # filled from the measured values below
+def _bf16_step_bounds():
+    """Per-quantity bounds of the bf16-vs-fp32 step comparison: 1.5 x what was MEASURED on an MI355X (the committed
+    tests/golden/bf16_step_measured.json; re-measure with `pytest -s -k fp32_oracle_port` and the [bf16-vs-fp32] lines),
+    with a floor for quantities whose error is at the noise level, and never looser than the blanket bounds they replace
+    (3 % losses, 5 % gradient norms, 6 % relative L2 of a gradient tensor)."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "bf16_step_measured.json")) as f:
+        measured = json.load(f)["measured"]
+    blanket = lambda k: 3e-2 if k.startswith("loss") else (5e-2 if k.startswith("norm") else 6e-2)  # noqa: E731
+    floor = lambda k: 1e-3 if k.startswith("loss") else (2e-3 if k.startswith("norm") else 1e-2)  # noqa: E731
+    return {k: min(blanket(k), max(1.5 * v, floor(k))) for k, v in measured.items()}, blanket
 
 
 @pytest.mark.timeout(900)
@@ -506,9 +517,11 @@ def test_bench_config_step_against_the_fp32_oracle_port():
     measured["rel bert " + bert_probe] = ((g - ref_bert_grad).norm() / (ref_bert_grad.norm() + 1e-20)).item()
     for k, v in measured.items():
         print(f"[bf16-vs-fp32] {k}: {v:.4f}")
-    # bounds PER QUANTITY = what round 4 measured on an MI355X (profiles/r4/bf16_step_bounds.txt) x 1.5, not one loose
-    # number for everything; anything not listed keeps the old bound
-    bound = lambda k: _BF16_STEP_BOUNDS.get(k, 3e-2 if k.startswith("loss") else (5e-2 if k.startswith("norm") else 6e-2))  # noqa: E731
+    # bounds PER QUANTITY (measured x 1.5, tests/golden/bf16_step_measured.json); a quantity without a measurement is a
+    # test bug, not a reason for a loose bound
+    bounds, _ = _bf16_step_bounds()
+    assert set(measured) <= set(bounds), sorted(set(measured) - set(bounds))
+    bound = bounds.__getitem__
     bad = {k: (v, bound(k)) for k, v in measured.items() if v > bound(k)}
     assert not bad, bad
 
