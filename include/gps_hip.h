@@ -117,6 +117,13 @@ GPS_API int gps_three_interpolate_grad(int b, int c, int n, int m, const float *
  *   (l,t), d = sqrt(|c_l-c_t|^2 + eps), d_max = per-scene maximum over all l*l pairs.
  * Operation order of the reference's torch formulation; agrees with it to <= 1e-6 (features in [-1,1]). */
 GPS_API int gps_pairwise_locs(int b, int l, const float *centers, float eps, float *out, gps_stream_t stream);
+/* The same launch also writing the PLANE form the spatial attention kernels read (gps_attn_args.pl_planes):
+ * planes (b, 5, l, ld_pl) fp16, planes[s][d][i][t] = out[s][i][t][d] rounded to nearest, columns l .. ld_pl - 1 zero;
+ * ld_pl a multiple of 4 >= l.  out may be NULL (planes only). */
+GPS_API int gps_pairwise_locs_planes(int b, int l, const float *centers, float eps, float *out, void *planes, int ld_pl,
+                                     gps_stream_t stream);
+/* planes from an existing (b, l, l, 5) fp32 pairwise tensor (callers that built it themselves). */
+GPS_API int gps_pairwise_to_planes(int b, int l, const float *pl, void *planes, int ld_pl, gps_stream_t stream);
 
 /* ---- fused set-abstraction level (frozen encoder) --------------------------------------------
  * Additions to the nine reference entry points: one launch for what the reference runs as
@@ -258,6 +265,16 @@ typedef struct gps_attn_args {
    * no contribution to dk / dv).  For consumers that read a sequence at a few leading rows only (a caption read at
    * [CLS] in its last layer).  NULL = every row. */
   const int *q_limit;
+  /* PLANE FORM of the spatial term (bf16 self-attention, Lq == Lk <= 144, p_drop == 0; replaces sw / pl / dsw, which
+   * must then be NULL): pl_planes (B, 5, Lq, ld_pl) fp16 = the pairwise tensor as five planes, pl_planes[b][d][l][t] =
+   * pl[b][l][t][d] (gps_pairwise_locs_planes / gps_pairwise_to_planes write it; ld_pl a multiple of 4 >= Lk, base 8-byte
+   * aligned, columns >= Lk finite); sw16 = the conditioning vector in bf16, row (b, l) at sw16 + (b Lq + l) ld_sw, head h
+   * at + 6 h (i.e. read in place from the packed projection output; ld_sw even); dsw16 / ld_dsw (backward): its
+   * gradient, bf16, addressed the same way.  The backward call needs `out`.  Served by gps_attention_sp.hip: every
+   * operand of a query strip is requested at kernel entry, results leave as 8-byte stores. */
+  const void *pl_planes; int ld_pl;
+  const void *sw16; int ld_sw;
+  void *dsw16; int ld_dsw;
 } gps_attn_args;
 GPS_API int gps_attn_forward_ex(const gps_attn_args *args, gps_stream_t stream);
 GPS_API int gps_attn_backward_ex(const gps_attn_args *args, gps_stream_t stream);

@@ -62,7 +62,8 @@ class AttnArgs(ctypes.Structure):
                 ("p_drop", _f), ("seed", ctypes.c_ulonglong), ("seed_dev", _vp),
                 ("out", _vp), ("ld_o", _i), ("lse", _vp),
                 ("dout", _vp), ("dq", _vp), ("ld_dq", _i), ("dk", _vp), ("dv", _vp), ("ld_dkv", _i), ("dsw", _vp),
-                ("cu_rows", _vp), ("seq_order", _vp), ("q_limit", _vp)]
+                ("cu_rows", _vp), ("seq_order", _vp), ("q_limit", _vp),
+                ("pl_planes", _vp), ("ld_pl", _i), ("sw16", _vp), ("ld_sw", _i), ("dsw16", _vp), ("ld_dsw", _i)]
 
 
 ATTN_BF16, ATTN_F32 = 0, 1
@@ -89,6 +90,8 @@ SIGNATURES = {
     "gps_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gps_pairwise_locs": [_i, _i, _vp, _f, _vp, _vp],
+    "gps_pairwise_locs_planes": [_i, _i, _vp, _f, _vp, _vp, _i, _vp],
+    "gps_pairwise_to_planes": [_i, _i, _vp, _vp, _i, _vp],
     "gps_sa_mlp_pack_layer": [_i, _i, _vp, _vp, _vp, _vp],
     "gps_sa_mlp_forward": [_i] * 8 + [_vp] * 7,
     "gps_sa_mlp_pack_layer_bf16x3": [_i, _i, _vp, _vp, _vp, _vp],

@@ -17,6 +17,7 @@ SOURCES = [
     ("gps_sa_mlp.hip", []),
     ("gps_attention.hip", []),
     ("gps_attention_ex.hip", []),
+    ("gps_attention_sp.hip", []),
     ("gps_losses.hip", []),
     ("gps_layernorm.hip", []),
     ("gps_objects.hip", []),

@@ -1382,6 +1382,12 @@ int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
   if (a->head_dim != DH) return GPS_ERR_UNSUPPORTED;
   if (a->B == 0 || a->Lq == 0) return GPS_OK;
   if (a->Lk == 0) return GPS_ERR_INVALID_ARGUMENT;              // a softmax over no keys
+  if (a->pl_planes) {                                            // plane form of the spatial term: gps_attention_sp.hip
+    if (!a->q || !a->k || !a->v || !a->out || !a->lse || a->pl || a->sw || a->dsw) return GPS_ERR_INVALID_ARGUMENT;
+    if (backward && (!a->dout || !a->dq || !a->dk || !a->dv || a->ld_dq < a->H * 64 || a->ld_dkv < a->H * 64)) return GPS_ERR_INVALID_ARGUMENT;
+    if ((a->ld_q & 7) || (a->ld_kv & 7) || (a->ld_o & 3) || (backward && ((a->ld_dq & 3) || (a->ld_dkv & 3)))) return GPS_ERR_UNSUPPORTED;
+    return run_spatial_planes(a, backward, s);
+  }
   if (!a->q || !a->k || !a->v || !a->out || !a->lse || ((a->sw == nullptr) != (a->pl == nullptr))) return GPS_ERR_INVALID_ARGUMENT;
   if (a->sw && a->Lq != a->Lk) return GPS_ERR_INVALID_ARGUMENT;  // the pairwise term is a self-attention term
   if (a->cu_rows && (a->Lq != a->Lk || a->sw || a->mask || a->dtype != GPS_ATTN_BF16 || a->compute != GPS_ATTN_COMPUTE_NATIVE))

@@ -794,7 +794,8 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_grad_kernel(
 // compiled -ffp-contract=off): agrees with it to a few ulp (<= 1e-6 on features in [-1, 1]).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void pairwise_locs_kernel(int L, const float *__restrict__ centers, float eps,
-                                                                float *__restrict__ out) {
+                                                                float *__restrict__ out, _Float16 *__restrict__ planes,
+                                                                int ld_pl) {
   extern __shared__ float pw_c[];                 // L * 3 centres | kWavesPerBlock partial maxima
   float *pw_red = pw_c + L * 3;
   const int scene = blockIdx.x;
@@ -819,20 +820,47 @@ __global__ __launch_bounds__(kBlock) void pairwise_locs_kernel(int L, const floa
   float dmax = pw_red[0];
 #pragma unroll
   for (int w = 1; w < kWavesPerBlock; ++w) dmax = pw_red[w] > dmax ? pw_red[w] : dmax;
-  float *o = out + (size_t)scene * pairs * 5;
-  for (int e = threadIdx.x; e < pairs; e += kBlock) {
-    const int l = e / L, t = e - l * L;
+  float *o = out ? out + (size_t)scene * pairs * 5 : nullptr;
+  // plane form (gps_attn_args.pl_planes): planes[scene][d][l][t], t contiguous (pitch ld_pl), fp16 round-to-nearest of the
+  // same fp32 values; the pad columns L .. ld_pl - 1 are zero
+  _Float16 *pp = planes ? planes + (size_t)scene * 5 * L * ld_pl : nullptr;
+  const int cols = planes ? ld_pl : L;
+  for (int e = threadIdx.x; e < L * cols; e += kBlock) {
+    const int l = e / cols, t = e - l * cols;
+    if (t >= L) {
+#pragma unroll
+      for (int d5 = 0; d5 < 5; ++d5) pp[((size_t)d5 * L + l) * ld_pl + t] = (_Float16)0.f;
+      continue;
+    }
     const float dx = pw_c[l * 3 + 0] - pw_c[t * 3 + 0], dy = pw_c[l * 3 + 1] - pw_c[t * 3 + 1],
                 dz = pw_c[l * 3 + 2] - pw_c[t * 3 + 2];
     const float xy2 = dx * dx + dy * dy;
     const float d = sqrtf((xy2 + dz * dz) + eps);
     const float dxy = sqrtf(xy2 + eps);
-    float *p = o + (size_t)e * 5;
-    p[0] = d / dmax;
-    p[1] = dz / d;
-    p[2] = dxy / d;
-    p[3] = dy / dxy;
-    p[4] = dx / dxy;
+    const float f[5] = {d / dmax, dz / d, dxy / d, dy / dxy, dx / dxy};
+    if (o) {
+      float *p = o + ((size_t)l * L + t) * 5;
+#pragma unroll
+      for (int d5 = 0; d5 < 5; ++d5) p[d5] = f[d5];
+    }
+    if (pp) {
+#pragma unroll
+      for (int d5 = 0; d5 < 5; ++d5) pp[((size_t)d5 * L + l) * ld_pl + t] = (_Float16)f[d5];
+    }
+  }
+}
+
+// planes from an existing (B, L, L, 5) fp32 tensor (callers that built the pairwise tensor themselves)
+__global__ __launch_bounds__(kBlock) void pairwise_to_planes_kernel(int L, const float *__restrict__ pl, _Float16 *__restrict__ planes,
+                                                                     int ld_pl) {
+  const int scene = blockIdx.x;
+  const float *src = pl + (size_t)scene * L * L * 5;
+  _Float16 *pp = planes + (size_t)scene * 5 * L * ld_pl;
+  for (int e = threadIdx.x; e < L * ld_pl; e += kBlock) {
+    const int l = e / ld_pl, t = e - l * ld_pl;
+#pragma unroll
+    for (int d5 = 0; d5 < 5; ++d5)
+      pp[((size_t)d5 * L + l) * ld_pl + t] = t < L ? (_Float16)src[((size_t)l * L + t) * 5 + d5] : (_Float16)0.f;
   }
 }
 
@@ -1107,7 +1135,28 @@ int gps_pairwise_locs(int b, int l, const float *centers, float eps, float *out,
   if (l > 2048) return GPS_ERR_UNSUPPORTED;
   const size_t lds = ((size_t)l * 3 + gps::kWavesPerBlock) * sizeof(float);
   hipLaunchKernelGGL(gps::pairwise_locs_kernel, dim3(b), dim3(gps::kBlock), lds, (hipStream_t)stream, l, centers,
-                     eps, out);
+                     eps, out, (_Float16 *)nullptr, 0);
+  return finish_launch();
+}
+
+int gps_pairwise_locs_planes(int b, int l, const float *centers, float eps, float *out, void *planes, int ld_pl,
+                             gps_stream_t stream) {
+  if (b < 0 || l < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0 || l == 0) return GPS_OK;
+  if (!centers || !planes || ld_pl < l || (ld_pl & 3)) return GPS_ERR_INVALID_ARGUMENT;
+  if (l > 2048) return GPS_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)l * 3 + gps::kWavesPerBlock) * sizeof(float);
+  hipLaunchKernelGGL(gps::pairwise_locs_kernel, dim3(b), dim3(gps::kBlock), lds, (hipStream_t)stream, l, centers,
+                     eps, out, (_Float16 *)planes, ld_pl);
+  return finish_launch();
+}
+
+int gps_pairwise_to_planes(int b, int l, const float *pl, void *planes, int ld_pl, gps_stream_t stream) {
+  if (b < 0 || l < 0) return GPS_ERR_INVALID_ARGUMENT;
+  if (b == 0 || l == 0) return GPS_OK;
+  if (!pl || !planes || ld_pl < l || (ld_pl & 3)) return GPS_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(gps::pairwise_to_planes_kernel, dim3(b), dim3(gps::kBlock), 0, (hipStream_t)stream, l, pl,
+                     (_Float16 *)planes, ld_pl);
   return finish_launch();
 }
 

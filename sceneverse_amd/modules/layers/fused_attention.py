@@ -46,6 +46,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr() if t is not None else None
 
 
+MAX_LEN_PLANES = 144          # spatial self-attention rows served by gps_attention_sp.hip (plane form of the pairwise term)
+_PLANES = True                # False: the general kernels with the interleaved fp32 pairwise tensor (A/B runs, tests)
+
+
+def set_spatial_planes(flag: bool) -> None:
+    global _PLANES
+    _PLANES = bool(flag)
+
+
 _FP8 = False        # attention-core products (Q K^T, P V) of the bf16 forward on the OCP e4m3 MFMA (bench.py --fp8)
 
 
@@ -103,15 +112,29 @@ class _FusedSelfAttention(torch.autograd.Function):
         assert W == 3 * D + (n_head * SPATIAL_VEC if spatial else 0), (W, D, spatial)
         assert packed.is_cuda and packed.is_contiguous()
         dt = _dtype_code(packed)
-        sw = packed[..., 3 * D:].float().contiguous() if spatial else None
-        if spatial:
-            pl = pl.float().contiguous()
-            assert pl.shape == (B, L, L, 5), pl.shape
         m8 = _mask8(mask)
         out = torch.empty((B, L, D), dtype=packed.dtype, device=packed.device)
         lse = torch.empty((B, n_head, L), dtype=torch.float32, device=packed.device)
         base, esz = packed.data_ptr(), packed.element_size()
         fp8 = _FP8 and dt == _native.ATTN_BF16
+        if spatial:
+            assert pl.shape == (B, L, L, 5), pl.shape
+        if spatial and _PLANES and dt == _native.ATTN_BF16 and p_drop == 0.0 and L <= MAX_LEN_PLANES and not fp8:
+            # plane form: fp16 planes of the pairwise tensor, the conditioning vector read in place from `packed`
+            from ..utils import pairwise_planes
+            planes = pairwise_planes(pl)
+            nbytes = esz * B * L * 4 * D + planes.numel() * 2 + B * L * n_head * 6 * 2
+            with torch.cuda.device(packed.device):
+                _call(False, f"attn_forward(L={L},spatial=1)", nbytes, 4 * B * n_head * L * L * HEAD_DIM,
+                      B=B, H=n_head, Lq=L, Lk=L, head_dim=HEAD_DIM, dtype=dt, compute=_native.ATTN_COMPUTE_NATIVE,
+                      q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W, mask=_ptr(m8), p_drop=0.0, seed=0,
+                      out=out, ld_o=D, lse=lse, pl_planes=planes, ld_pl=planes.shape[-1], sw16=base + 3 * D * esz, ld_sw=W)
+            ctx.save_for_backward(packed, planes, m8, lse, out)
+            ctx.meta = (n_head, 0.0, 0, "planes")
+            return out
+        sw = packed[..., 3 * D:].float().contiguous() if spatial else None
+        if spatial:
+            pl = pl.float().contiguous()
         # algorithmic work: q,k,v,out once (+ pairwise/cond vector), 2 x L x L x 64 MACs per head
         nbytes = esz * B * L * 4 * D + (B * L * L * 5 * 4 + B * L * n_head * 6 * 4 if spatial else 0)
         with torch.cuda.device(packed.device):
@@ -127,8 +150,24 @@ class _FusedSelfAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout: torch.Tensor):
-        packed, sw, pl, m8, lse, seed_dev, out = ctx.saved_tensors
         n_head, p_drop, seed, spatial = ctx.meta
+        if spatial == "planes":
+            packed, planes, m8, lse, out = ctx.saved_tensors
+            B, L, W = packed.shape
+            D = n_head * HEAD_DIM
+            dout = dout.to(packed.dtype).contiguous()
+            dpacked = torch.empty_like(packed)
+            base, esz, gbase = packed.data_ptr(), packed.element_size(), dpacked.data_ptr()
+            nbytes = esz * B * L * 9 * D + planes.numel() * 2 + 2 * B * L * n_head * 6 * 2
+            with torch.cuda.device(packed.device):
+                _call(True, f"attn_backward(L={L},spatial=1)", nbytes, 10 * B * n_head * L * L * HEAD_DIM,
+                      B=B, H=n_head, Lq=L, Lk=L, head_dim=HEAD_DIM, dtype=_native.ATTN_BF16, compute=_native.ATTN_COMPUTE_NATIVE,
+                      q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W, mask=_ptr(m8), p_drop=0.0, seed=0,
+                      out=out, ld_o=D, lse=lse, dout=dout, dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz,
+                      ld_dkv=W, pl_planes=planes, ld_pl=planes.shape[-1], sw16=base + 3 * D * esz, ld_sw=W,
+                      dsw16=gbase + 3 * D * esz, ld_dsw=W)
+            return dpacked, None, None, None, None, None, None
+        packed, sw, pl, m8, lse, seed_dev, out = ctx.saved_tensors
         B, L, W = packed.shape
         D = n_head * HEAD_DIM
         dt = _dtype_code(packed)

@@ -81,13 +81,40 @@ def calc_pairwise_locs(obj_centers, obj_whls, eps=1e-10, pairwise_rel_type='cent
 
 
 def _pairwise_locs_native(obj_centers: torch.Tensor, eps: float) -> torch.Tensor:
-    """One launch of libgps_hip.so's gps_pairwise_locs (within 1e-6 of the torch formulation above)."""
+    """One launch of libgps_hip.so's gps_pairwise_locs_planes (within 1e-6 of the torch formulation above).  The same
+    launch writes the tensor a second time as five fp16 planes (b, 5, l, ld) -- the layout the spatial attention kernels
+    read (include/gps_hip.h gps_attn_args.pl_planes); it travels as the attribute `_gps_planes` of the result."""
     from .. import _native
     c = obj_centers.contiguous()
     b, l, _ = c.shape
     out = torch.empty((b, l, l, 5), dtype=torch.float32, device=c.device)
+    ld = (l + 3) // 4 * 4
+    planes = torch.empty((b, 5, l, ld), dtype=torch.float16, device=c.device)
     with torch.cuda.device(c.device):
-        st = _native.load().gps_pairwise_locs(b, l, c.data_ptr(), float(eps), out.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream)
+        st = _native.load().gps_pairwise_locs_planes(b, l, c.data_ptr(), float(eps), out.data_ptr(), planes.data_ptr(), ld,
+                                                     torch.cuda.current_stream().cuda_stream)
     _native.check(st, "pairwise_locs")
+    out._gps_planes = planes
     return out
+
+
+def pairwise_planes(pl: torch.Tensor) -> torch.Tensor:
+    """The fp16 plane form (B, 5, L, ld) of a (B, L, L, 5) pairwise tensor: the one `calc_pairwise_locs` attached, else one
+    conversion launch (gps_pairwise_to_planes) whose result is cached on the tensor object."""
+    planes = getattr(pl, "_gps_planes", None)
+    if planes is not None and planes.device == pl.device:
+        return planes
+    from .. import _native
+    b, l = pl.shape[0], pl.shape[1]
+    src = pl.detach().float().contiguous()
+    ld = (l + 3) // 4 * 4
+    planes = torch.empty((b, 5, l, ld), dtype=torch.float16, device=pl.device)
+    with torch.cuda.device(pl.device):
+        st = _native.load().gps_pairwise_to_planes(b, l, src.data_ptr(), planes.data_ptr(), ld,
+                                                   torch.cuda.current_stream().cuda_stream)
+    _native.check(st, "pairwise_to_planes")
+    try:
+        pl._gps_planes = planes
+    except AttributeError:
+        pass
+    return planes

@@ -66,21 +66,28 @@ CASES = [(3, 80, True), (8, 80, True), (2, 130, False), (8, 130, False), (2, 37,
          (1, 145, True), (2, 177, False)]
 
 
-@pytest.fixture(params=["default", "resident", "streaming"])
+@pytest.fixture(params=["default", "resident", "streaming", "planes"])
 def family(request):
-    """Which kernels serve L <= 144: the default split (plain -> streaming, spatial -> register-resident), all
-    register-resident, or all streaming (gps_attn_set_stream_min_tiles); longer rows always stream."""
+    """Which kernels serve L <= 144.  "planes": the product default -- the spatial form on gps_attention_sp.hip (fp16
+    planes of the pairwise tensor, bf16 conditioning vector read in place), the plain form streaming.  The other three
+    run the GENERAL kernels (interleaved fp32 pairwise tensor): their default split (plain -> streaming, spatial ->
+    register-resident), all register-resident, or all streaming (gps_attn_set_stream_min_tiles); longer rows always stream."""
     from sceneverse_amd import _native
+    from sceneverse_amd.modules.layers import fused_attention as FA
     lib = _native.load()
-    lib.gps_attn_set_stream_min_tiles(*{"default": (1, 10), "resident": (10, 10), "streaming": (1, 1)}[request.param])
+    lib.gps_attn_set_stream_min_tiles(*{"default": (1, 10), "resident": (10, 10), "streaming": (1, 1), "planes": (1, 10)}[request.param])
+    FA.set_spatial_planes(request.param == "planes")
     yield request.param
     lib.gps_attn_set_stream_min_tiles(1, 10)
+    FA.set_spatial_planes(True)
 
 
 @pytest.mark.parametrize("B,L,spatial", CASES)
 def test_forward_backward_match_fp32_formulation(B, L, spatial, family):
     if family != "default" and L > 144:
         pytest.skip("rows above 144 tokens stream in every setting")
+    if family == "planes" and not spatial:
+        pytest.skip("the plane form is the spatial term's")
     packed, pl, mask = _inputs(B, L, spatial, seed=B * 1000 + L)
     ref_in = packed.float().requires_grad_(True)
     ref = ref_attention(ref_in, pl, mask)
@@ -128,6 +135,8 @@ def test_streaming_and_resident_kernels_agree_at_the_switch():
 def test_dropout_is_reproducible_linear_and_adjoint(L, family):
     if family != "default" and L > 144:
         pytest.skip("rows above 144 tokens stream in every setting")
+    if family == "planes":
+        pytest.skip("dropout on the spatial form is served by the general kernels (covered by the other families)")
     B = 2
     packed, pl, mask = _inputs(B, L, True, seed=9)
     pl, mask = pl.to(DEV), mask.to(DEV)
@@ -289,3 +298,62 @@ def test_fused_core_against_the_pinned_oracle_formulation(L, spatial):
     for what, a, b in checks:
         assert _rel_l2(a, b) <= 1e-2, (what, _rel_l2(a, b))
         _close(a, b, 4e-2, what)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# plane form of the spatial term (gps_attention_sp.hip) against the general kernels on the SAME inputs
+# ---------------------------------------------------------------------------------------------------------------
+def _run_spatial(packed, pl, mask, go, planes):
+    from sceneverse_amd.modules.layers import fused_attention as FA
+    FA.set_spatial_planes(planes)
+    try:
+        x = packed.clone().requires_grad_(True)
+        out = _FusedSelfAttention.apply(x, pl, mask, H, 0.0, 0, None)
+        out.backward(go)
+        return out.detach().float(), x.grad.detach().float()
+    finally:
+        FA.set_spatial_planes(True)
+
+
+@pytest.mark.parametrize("B,L", [(64, 80), (3, 80), (2, 16), (2, 17), (1, 1), (2, 50), (8, 81), (2, 144), (5, 100), (2, 79)])
+@pytest.mark.parametrize("w_scale", [2.0, 40.0])
+def test_plane_form_equals_the_general_kernels(B, L, w_scale):
+    """Same bf16 q / k / v / conditioning vector, same key-padding mask.  Differences allowed: the pairwise features are
+    rounded to fp16 (<= 2.5e-4 absolute on values in [-1, 1], against 4e-3 relative of the bf16 conditioning weights they
+    multiply) and delta = rowsum(dO * O) from the bf16 forward output instead of rowsum(P dP) -- both below the bf16
+    rounding of the results: |diff| <= 1.5e-2 max|ref| per tensor (w_scale 40 drives most pairs into the clamp
+    log(1e-6) / the saturated sigmoid, where the gate of the spatial gradient must be exactly 0)."""
+    g = torch.Generator().manual_seed(L * 31 + B)
+    packed = torch.randn(B, L, 3 * D + 6 * H, generator=g)
+    packed[..., 3 * D:] *= w_scale
+    packed = packed.to(torch.bfloat16).to(DEV)
+    pl = (torch.rand(B, L, L, 5, generator=g) * 2 - 1).to(DEV)
+    n_real = torch.randint(1, L + 1, (B,), generator=g)
+    n_real[0] = L
+    mask = (torch.arange(L)[None, :] >= n_real[:, None]).to(DEV)
+    go = torch.randn(B, L, D, generator=g).to(torch.bfloat16).to(DEV)
+    o_ref, g_ref = _run_spatial(packed, pl, mask, go, planes=False)
+    o_new, g_new = _run_spatial(packed, pl, mask, go, planes=True)
+    assert torch.isfinite(o_new).all() and torch.isfinite(g_new).all()
+    _close(o_new, o_ref, 1.5e-2, "out")
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D)), ("dsw", slice(3 * D, None))):
+        _close(g_new[..., sl], g_ref[..., sl], 1.5e-2, name)
+    assert g_new[..., D:3 * D][mask].abs().max().item() == 0.0 if mask.any() else True
+
+
+def test_pairwise_planes_are_the_fp16_image_of_the_pairwise_tensor():
+    """gps_pairwise_locs_planes (the attribute calc_pairwise_locs attaches) and gps_pairwise_to_planes (tensors built
+    elsewhere): planes[b][d][l][t] == fp16(pl[b][l][t][d]) exactly, pad columns zero."""
+    from sceneverse_amd.modules.utils import calc_pairwise_locs, pairwise_planes
+    for L in (80, 37, 6):
+        centers = (torch.rand(3, L, 3, generator=torch.Generator().manual_seed(L)) * 8 - 4).to(DEV)
+        pl = calc_pairwise_locs(centers, None)
+        planes = pl._gps_planes
+        ld = planes.shape[-1]
+        assert planes.shape == (3, 5, L, ld) and ld % 4 == 0 and ld >= L
+        want = pl.permute(0, 3, 1, 2).to(torch.float16)
+        assert torch.equal(planes[..., :L], want) and (planes[..., L:] == 0).all()
+        again = pairwise_planes(pl.clone())                      # no attribute on the clone: the conversion launch
+        assert torch.equal(again, planes)
+        ref = calc_pairwise_locs(centers.cpu(), None)            # the torch formulation
+        assert (pl.cpu() - ref).abs().max().item() <= 1e-6
