@@ -209,6 +209,10 @@ GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, c
  * at least `plain` (no pairwise term) / `spatial` (with it) tiles take the streaming kernels, shorter ones the
  * register-resident kernels.  Defaults 1 and 10.  Results agree to bf16 rounding either way; process-wide. */
 GPS_API void gps_attn_set_stream_min_tiles(int plain, int spatial);
+/* Plain form (no pairwise term), bf16: 1 (default) = the block-streaming kernels of gps_attention_fa.hip (64 queries or
+ * keys per workgroup, the other side streamed through LDS in 64-row blocks, online softmax; any length), 0 = the
+ * whole-sequence kernels above (A/B runs, tests); < 0 = query.  Returns the previous setting.  Process-wide. */
+GPS_API int gps_attn_set_plain_blocks(int on);
 GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                               int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
                               float p_drop, unsigned long long seed, const void *seed_dev,
@@ -270,11 +274,15 @@ typedef struct gps_attn_args {
    * pl[b][l][t][d] (gps_pairwise_locs_planes / gps_pairwise_to_planes write it; ld_pl a multiple of 4 >= Lk, base 8-byte
    * aligned, columns >= Lk finite); sw16 = the conditioning vector in bf16, row (b, l) at sw16 + (b Lq + l) ld_sw, head h
    * at + 6 h (i.e. read in place from the packed projection output; ld_sw even); dsw16 / ld_dsw (backward): its
-   * gradient, bf16, addressed the same way.  The backward call needs `out`.  Served by gps_attention_sp.hip: every
+   * gradient, bf16, addressed the same way.  Served by gps_attention_sp.hip: every
    * operand of a query strip is requested at kernel entry, results leave as 8-byte stores. */
   const void *pl_planes; int ld_pl;
   const void *sw16; int ld_sw;
   void *dsw16; int ld_dsw;
+  /* backward of the PLAIN form (no pairwise term), block-streaming kernels (gps_attention_fa.hip): (B, H, Lq) fp32
+   * scratch -- the dQ launch writes delta = rowsum(dout * out) per query, the dK / dV launch reads it.  NULL: the
+   * backward call takes the whole-sequence kernels of gps_attention.hip instead (same results to bf16 rounding). */
+  float *delta_ws;
 } gps_attn_args;
 GPS_API int gps_attn_forward_ex(const gps_attn_args *args, gps_stream_t stream);
 GPS_API int gps_attn_backward_ex(const gps_attn_args *args, gps_stream_t stream);

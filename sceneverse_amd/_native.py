@@ -63,7 +63,8 @@ class AttnArgs(ctypes.Structure):
                 ("out", _vp), ("ld_o", _i), ("lse", _vp),
                 ("dout", _vp), ("dq", _vp), ("ld_dq", _i), ("dk", _vp), ("dv", _vp), ("ld_dkv", _i), ("dsw", _vp),
                 ("cu_rows", _vp), ("seq_order", _vp), ("q_limit", _vp),
-                ("pl_planes", _vp), ("ld_pl", _i), ("sw16", _vp), ("ld_sw", _i), ("dsw16", _vp), ("ld_dsw", _i)]
+                ("pl_planes", _vp), ("ld_pl", _i), ("sw16", _vp), ("ld_sw", _i), ("dsw16", _vp), ("ld_dsw", _i),
+                ("delta_ws", _vp)]
 
 
 ATTN_BF16, ATTN_F32 = 0, 1
@@ -125,6 +126,7 @@ SIGNATURES = {
     "gps_add_dropout_layernorm_forward_post": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 8,
     "gps_add_dropout_layernorm_backward_post": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 8,
     "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i, _vp, _vp],
+    "gps_attn_set_plain_blocks": [_i],
     "gps_attn_forward_ex": [ctypes.POINTER(AttnArgs), _vp],
     "gps_attn_backward_ex": [ctypes.POINTER(AttnArgs), _vp],
     "gps_attn_backward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i] + [_vp] * 7,

@@ -18,6 +18,7 @@ SOURCES = [
     ("gps_attention.hip", []),
     ("gps_attention_ex.hip", []),
     ("gps_attention_sp.hip", []),
+    ("gps_attention_fa.hip", []),
     ("gps_losses.hip", []),
     ("gps_layernorm.hip", []),
     ("gps_objects.hip", []),

@@ -1336,6 +1336,7 @@ int launch(const Params &P, bool backward, hipStream_t s) {
 }
 
 static int g_stream_min_nt[2] = {-1, -1};      // [plain, spatial]; -1 = not read yet
+static int g_plain_blocks = 1;                 // plain form on the block-streaming kernels of gps_attention_fa.hip
 
 int dispatch(Params &P, bool backward, hipStream_t s) {
   P.nt = (P.L + 15) / 16;
@@ -1402,6 +1403,8 @@ int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
   if ((a->ld_q & 7) || (a->ld_kv & 7) || (a->ld_o & 7) || (backward && ((a->ld_dq & 7) || (a->ld_dkv & 7)))) return GPS_ERR_UNSUPPORTED;
   if (a->compute == GPS_ATTN_COMPUTE_FP8 && !backward) return run_fp8_forward(a, s);
   if (a->compute != GPS_ATTN_COMPUTE_NATIVE && a->compute != GPS_ATTN_COMPUTE_FP8) return GPS_ERR_UNSUPPORTED;
+  // plain form: block-streaming kernels (the backward call needs the forward output and the delta scratch)
+  if (!a->sw && g_plain_blocks && (!backward || (a->out && a->delta_ws))) return run_plain_blocks(a, backward, s);
   Params P = {};
   P.B = a->B; P.H = a->H; P.L = a->Lk; P.Lq = a->Lq; P.ld_qkv = a->ld_kv; P.ld_q = a->ld_q; P.ld_o = a->ld_o;
   P.q = (const uint16_t *)a->q; P.k = (const uint16_t *)a->k; P.v = (const uint16_t *)a->v;
@@ -1429,6 +1432,12 @@ int gps_attn_forward_ex(const gps_attn_args *a, gps_stream_t stream) {
 }
 int gps_attn_backward_ex(const gps_attn_args *a, gps_stream_t stream) {
   return gps_attn::run_ex(a, true, (hipStream_t)stream);
+}
+
+int gps_attn_set_plain_blocks(int on) {
+  const int was = gps_attn::g_plain_blocks;
+  if (on >= 0) gps_attn::g_plain_blocks = on ? 1 : 0;
+  return was;
 }
 
 void gps_attn_set_stream_min_tiles(int plain, int spatial) {

@@ -22,7 +22,8 @@
 //     tile; the probabilities and dS are parked ROW-major per query (one 8-byte LDS write per tile) and read back the same
 //     way; an odd number of 16-token tiles ends in a 16-deep MFMA (v_mfma_f32_16x16x16_bf16) instead of zero padding, which
 //     brings the backward kernel's LDS to 51.5 KB at L = 80: three workgroups per CU, the whole grid resident at once;
-//   * delta = rowsum(dO * O) (the forward output is an argument), so the backward evaluates every score ONCE, in one sweep.
+//   * the backward evaluates every score ONCE (P and dS parked in LDS for the dK / dV pass); delta = rowsum(P dP) stays in
+//     fp32 (rowsum(dO * O) from the bf16 forward output costs 1e-2 on the conditioning-vector gradient, see bwd_strip).
 // No dropout on this path (the reference's MultiHeadAttentionSpatial takes a `dropout` argument and never applies it,
 // transformers.py:188-239); callers that want it use the general kernels of gps_attention.hip.
 #include <hip/hip_runtime.h>
@@ -365,13 +366,11 @@ constexpr int kBwdEarlyTiles = NT <= 5 ? 3 : NT;       // planes of that many ti
 template <int NT>
 struct BwdStrip {
   bf16x8 bq[2], bdo[2];
-  u32x4 ov[2];            // the forward output row (for delta), dead after bwd_delta
   Spatial<NT> S;
-  float lse2, delta;
+  float lse2;             // natural log; +inf for queries past L
 };
 template <int NT>
-__device__ __forceinline__ void bwd_request(const Params &P, const uint16_t *qb, const uint16_t *dob, const uint16_t *ob,
-                                            const float *lse, int b, int h, int s, int m, int g, BwdStrip<NT> &F) {
+__device__ __forceinline__ void bwd_request(const Params &P, const uint16_t *qb, const uint16_t *dob, const float *lse, int b, int h, int s, int m, int g, BwdStrip<NT> &F) {
   const int qi = 16 * s + m, qc = min(qi, P.L - 1);
   load_cond<NT>(P, b, h, qc, F.S);
   load_planes<NT, 0, kBwdEarlyTiles<NT>>(P, b, qc, g, F.S);
@@ -379,72 +378,85 @@ __device__ __forceinline__ void bwd_request(const Params &P, const uint16_t *qb,
   for (int c = 0; c < 2; ++c) {
     F.bq[c] = as_frag(load_frag(qb, qc, P.ld_qkv, 32 * c + 8 * g));
     F.bdo[c] = as_frag(load_frag(dob, qc, P.ld_o, 32 * c + 8 * g));
-    F.ov[c] = load_frag(ob, qc, P.ld_o, 32 * c + 8 * g);
   }
   F.lse2 = qi < P.L ? lse[qc] : INFINITY;                   // natural log here; queries past L: p = 2^(x - inf) = 0
 }
-// delta = sum_d dO[q][d] O[q][d]  (= rowsum(P dP)): this lane's 16 columns, then across the four lane groups
-template <int NT>
-__device__ __forceinline__ void bwd_delta(BwdStrip<NT> &F) {
-  float delta = 0.f;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const u32x4 dv = __builtin_bit_cast(u32x4, F.bdo[c]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      delta = fmaf(bf2f(dv[e] & 0xFFFFu), bf2f(F.ov[c][e] & 0xFFFFu), delta);
-      delta = fmaf(__uint_as_float(dv[e] & 0xFFFF0000u), __uint_as_float(F.ov[c][e] & 0xFFFF0000u), delta);
-    }
-  }
-  F.delta = xor_sum_g(delta);
-  F.lse2 *= kLog2e;
-}
-// query strip s: scores and dP one 16-key tile at a time (spatial term, P and dS parked in LDS, d cond-vector), then
-// dQ^T = K^T dS^T from the parked rows of the strip
+// query strip s: all score and dP tiles (MFMA), then two elementwise sweeps -- (A) spatial term, probabilities,
+// delta = rowsum(P dP) in fp32, the gate of the spatial gradient; (B) dS, P and dS parked in LDS, d cond-vector -- then
+// dQ^T = K^T dS^T from the parked rows of the strip.  delta is NOT taken from rowsum(dO * O): the bf16 roundings of P and O
+// in the forward pass put 1e-3 relative on it, which the cancellation in p (dp - delta) turns into 1e-2 on the gradient
+// of the conditioning vector (measured against the fp32 formulation).
 template <int NT>
 __device__ __forceinline__ void bwd_strip(const Params &P, const uint16_t *Ks, const uint16_t *Vs, uint16_t *PS, uint16_t *dSS,
                                           const float *mbs, int b, int h, int s, int lane, BwdStrip<NT> &F) {
   constexpr int TP = NT * 16 + 8;
   const int m = lane & 15, g = lane >> 4, L = P.L;
   const int qi = 16 * s + m;
-  // the planes of the later tiles: requested now, consumed after the first tiles' arithmetic (register budget)
+  // the planes of the later tiles: requested now, consumed after the MFMA section (register budget)
   load_planes<NT, kBwdEarlyTiles<NT>, NT>(P, b, min(qi, L - 1), g, F.S);
-  float w[6], dw[6];
-  cond_vector<NT>(F.S, w);
-#pragma unroll
-  for (int d = 0; d < 6; ++d) dw[d] = 0.f;
-  uint16_t *prow = PS + (16 * s + m) * TP + 4 * g, *drow = dSS + (16 * s + m) * TP + 4 * g;
+  f32x4 pr[NT], dp[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    f32x4 acc = zero_acc(), dacc = zero_acc();
+    pr[j] = zero_acc();
+    dp[j] = zero_acc();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
       const u32x4 av = *reinterpret_cast<const u32x4 *>(Vs + (16 * j + m) * KS + 32 * c + 8 * g);
-      acc = mfma32(as_frag(a), F.bq[c], acc);           // S^T
-      dacc = mfma32(as_frag(av), F.bdo[c], dacc);       // (dO V^T)^T
+      pr[j] = mfma32(as_frag(a), F.bq[c], pr[j]);       // S^T
+      dp[j] = mfma32(as_frag(av), F.bdo[c], dp[j]);     // (dO V^T)^T
     }
+    __builtin_amdgcn_sched_barrier(0);            // one tile's fragments in flight, not all 4 NT of them (registers)
+  }
+  float w[6], dw[6];
+  cond_vector<NT>(F.S, w);
+  const float lse2 = F.lse2 * kLog2e;
+  unsigned int gate2[NT][2];                       // the gate e / (1 + e) of the spatial gradient, bf16 pairs
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {                   // sweep A
     const f32x4 kt = *reinterpret_cast<const f32x4 *>(mbs + 16 * j + 4 * g);
-    f32x4 pj, dsj;
+    float gt[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float e = __builtin_amdgcn_exp2f(spatial_u<NT>(F.S, w, j, r));
       const float ope = 1.f + e;
       const float bias2 = fmaxf(-__builtin_amdgcn_logf(ope), kClamp2);
-      const float p = __builtin_amdgcn_exp2f(fmaf(acc[r], kC, bias2) + (kt[r] - F.lse2));
-      const float dl = p * (dacc[r] - F.delta);                                // d loss / d logit
+      const float p = __builtin_amdgcn_exp2f(fmaf(pr[j][r], kC, bias2) + (kt[r] - lse2));
       // d/dz log(clamp(sigmoid z, 1e-6)) = 1 - sigmoid z = e / (1 + e) where sigmoid z > 1e-6, else 0
-      const float gate = ope < 1e6f ? e * __builtin_amdgcn_rcpf(ope) : 0.f;
+      gt[r] = ope < 1e6f ? e * __builtin_amdgcn_rcpf(ope) : 0.f;
+      pr[j][r] = p;
+      delta = fmaf(p, dp[j][r], delta);
+    }
+    gate2[j][0] = pack2(gt[0], gt[1]);
+    gate2[j][1] = pack2(gt[2], gt[3]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  delta = xor_sum_g(delta);
+#pragma unroll
+  for (int d = 0; d < 6; ++d) dw[d] = 0.f;
+  uint16_t *prow = PS + (16 * s + m) * TP + 4 * g, *drow = dSS + (16 * s + m) * TP + 4 * g;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {                   // sweep B
+    // the fp16 planes are used by both sweeps: without this the compiler converts all 20 NT values to fp32 once and
+    // keeps them (20 NT more registers) instead of issuing mixed-precision fmas on the packed halves again
+#pragma unroll
+    for (int d = 0; d < 5; ++d) asm volatile("" : "+v"(F.S.pl[d][j]));
+    f32x4 dsj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dl = pr[j][r] * (dp[j][r] - delta);                          // d loss / d logit
+      const unsigned int gw = gate2[j][r >> 1];
+      const float gate = (r & 1) ? __uint_as_float(gw & 0xFFFF0000u) : bf2f(gw & 0xFFFFu);
       const float dz = dl * gate;
       dw[0] += dz;
 #pragma unroll
       for (int d = 0; d < 5; ++d) dw[1 + d] = fmaf((float)__builtin_bit_cast(f16x4, F.S.pl[d][j])[r], dz, dw[1 + d]);
-      pj[r] = p;
       dsj[r] = dl;
     }
-    *reinterpret_cast<u32x2 *>(prow + 16 * j) = pack_tile(pj);
+    *reinterpret_cast<u32x2 *>(prow + 16 * j) = pack_tile(pr[j]);
     *reinterpret_cast<u32x2 *>(drow + 16 * j) = pack_tile(dsj);
-    __builtin_amdgcn_sched_barrier(0);            // keep the tiles apart: interleaving them only lengthens live ranges
+    __builtin_amdgcn_sched_barrier(0);
   }
   // gradient of the conditioning vector: sum over the lane groups, one 12-byte bf16 store per (query, head)
 #pragma unroll
@@ -503,7 +515,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, O
   const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
   const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
   const uint16_t *dob = P.dout + row0 * P.ld_o + h * DH;
-  const uint16_t *ob = P.out + row0 * P.ld_o + h * DH;
   const float *lse = P.lse + ((size_t)b * P.H + h) * L;
 
   // ---------------- pass 1: query strips -> dQ, d cond-vector, P and dS tiles ----------------
@@ -511,7 +522,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, O
   StagePair<R> st;
   const bool live = wave < nt;
   st.issue(kb, P.ld_qkv, vb, P.ld_qkv, L);
-  if (live) bwd_request<NT>(P, qb, dob, ob, lse, b, h, wave, m, g, F);
+  if (live) bwd_request<NT>(P, qb, dob, lse, b, h, wave, m, g, F);
   st.commit(Ks, Vs);
   for (int t = threadIdx.x; t < R; t += kThreads) mbs[t] = (t < L && !(P.mask && P.mask[row0 + t])) ? 0.f : -INFINITY;
   if (nt < NT) {            // query tiles no strip writes are still read by pass 2: zeros
@@ -520,14 +531,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(OCC, O
     z = reinterpret_cast<u32x4 *>(dSS + nt * 16 * TP);
     for (int e = threadIdx.x; e < (NT - nt) * 16 * TP / 8; e += kThreads) z[e] = zero4();
   }
-  if (live) bwd_delta<NT>(F);
   __syncthreads();
   if (live) bwd_strip<NT>(P, Ks, Vs, PS, dSS, mbs, b, h, wave, lane, F);
   if (NT > 5) {
     const int s = wave + 5;
     if (s < nt) {
-      bwd_request<NT>(P, qb, dob, ob, lse, b, h, s, m, g, F);
-      bwd_delta<NT>(F);
+      bwd_request<NT>(P, qb, dob, lse, b, h, s, m, g, F);
       bwd_strip<NT>(P, Ks, Vs, PS, dSS, mbs, b, h, s, lane, F);
     }
   }
@@ -608,7 +617,7 @@ int launch(const Params &P, bool backward, hipStream_t s) {
     granted[backward ? 1 : 0] = true;
   }
   if (!backward) hipLaunchKernelGGL((fwd_kernel<NT>), grid, block, lds, s, P);
-  else if (alt) hipLaunchKernelGGL((bwd_kernel<NT, 3>), grid, block, lds, s, P);
+  else if (alt) hipLaunchKernelGGL((bwd_kernel<NT, (NT <= 5 ? 3 : kOccBig)>), grid, block, lds, s, P);
   else hipLaunchKernelGGL((bwd_kernel<NT, kOccBig>), grid, block, lds, s, P);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
@@ -623,7 +632,7 @@ int run_spatial_planes(const gps_attn_args *a, bool backward, hipStream_t s) {
   if (!a->sw16 || a->sw || a->ld_q != a->ld_kv || (a->ld_pl & 3) || a->ld_pl < a->Lk || (a->ld_sw & 1) || a->ld_sw < a->H * 6)
     return GPS_ERR_INVALID_ARGUMENT;
   if (((uintptr_t)a->pl_planes & 7) || ((uintptr_t)a->sw16 & 3)) return GPS_ERR_UNSUPPORTED;
-  if (backward && (!a->out || !a->dsw16 || (a->ld_dsw & 1) || a->ld_dsw < a->H * 6 || ((uintptr_t)a->dsw16 & 3) || a->ld_dq != a->ld_dkv))
+  if (backward && (!a->dsw16 || (a->ld_dsw & 1) || a->ld_dsw < a->H * 6 || ((uintptr_t)a->dsw16 & 3) || a->ld_dq != a->ld_dkv))
     return GPS_ERR_INVALID_ARGUMENT;
   gps_attn_sp::Params P = {};
   P.B = a->B; P.H = a->H; P.L = a->Lk; P.nt = (a->Lk + 15) / 16;

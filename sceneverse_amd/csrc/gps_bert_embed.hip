@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void fwd_kernel(int n_rows, int d, const in
   // a plan built from masks that break its precondition (gps_varlen_plan's violation word): every row leaves as NaN, so
   // that the loss of the step is NaN instead of silently wrong
   const float poison = (poison_dev && *poison_dev != 0) ? __builtin_nanf("") : 1.f;
-  const float scale = (thr ? 1.f / (1.f - p_drop) : 1.f) * poison;
+  const float scale = thr ? 1.f / (1.f - p_drop) : 1.f;
   const unsigned long long sd = seed + ((thr && seed_dev) ? *seed_dev : 0ull);
   const float inv_d = 1.f / (float)d;
   for (int row = blockIdx.x * kWaves + wave; row < n_rows; row += gridDim.x * kWaves) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void fwd_kernel(int n_rows, int d, const in
       const float a = z[i].x - mean, b = z[i].y - mean, c = z[i].z - mean, e = z[i].w - mean;
       v += (a * a + b * b) + (c * c + e * e);
     }
-    const float rstd = rsqrtf(wave_sum(v) * inv_d + eps);
+    const float rstd = rsqrtf(wave_sum(v) * inv_d + eps) * poison;       // poisoned plan: NaN into every element
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     const size_t base = (size_t)row * d;
 #pragma unroll

@@ -177,13 +177,14 @@ class _FusedSelfAttention(torch.autograd.Function):
         base, esz = packed.data_ptr(), packed.element_size()
         gbase = dpacked.data_ptr()
         nbytes = esz * B * L * 8 * D + (B * L * L * 5 * 4 + 2 * B * L * n_head * 6 * 4 if spatial else 0)
+        delta = _delta_ws(B, n_head, L, packed.device) if (not spatial and dt == _native.ATTN_BF16) else None
         with torch.cuda.device(packed.device):
             _call(True, f"attn_backward(L={L},spatial={int(spatial)})" + ("[fp32]" if dt else ""),
                   nbytes, 10 * B * n_head * L * L * HEAD_DIM,
                   B=B, H=n_head, Lq=L, Lk=L, head_dim=HEAD_DIM, dtype=dt, compute=_native.ATTN_COMPUTE_NATIVE,
                   q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W, sw=_ptr(sw), pl=_ptr(pl), mask=_ptr(m8),
                   p_drop=p_drop, seed=seed, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
-                  dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz, ld_dkv=W, dsw=_ptr(dsw))
+                  dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz, ld_dkv=W, dsw=_ptr(dsw), delta_ws=_ptr(delta))
         if spatial:
             dpacked[..., 3 * D:] = dsw
         return dpacked, None, None, None, None, None, None
@@ -236,7 +237,8 @@ class _FusedCrossAttention(torch.autograd.Function):
                   B=B, H=n_head, Lq=Lq, Lk=Lk, head_dim=HEAD_DIM, dtype=dt, compute=_native.ATTN_COMPUTE_NATIVE,
                   q=q, ld_q=D, k=kv.data_ptr(), v=kv.data_ptr() + D * esz, ld_kv=2 * D, mask=_ptr(m8),
                   p_drop=p_drop, seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
-                  dq=dq, ld_dq=D, dk=dkv.data_ptr(), dv=dkv.data_ptr() + D * esz, ld_dkv=2 * D)
+                  dq=dq, ld_dq=D, dk=dkv.data_ptr(), dv=dkv.data_ptr() + D * esz, ld_dkv=2 * D,
+                  delta_ws=_ptr(_delta_ws(B, n_head, Lq, q.device) if dt == _native.ATTN_BF16 else None))
         return dq, dkv, None, None, None, None
 
 
@@ -291,10 +293,21 @@ class _FusedVarlenSelfAttention(torch.autograd.Function):
                   compute=_native.ATTN_COMPUTE_NATIVE, q=base, ld_q=W, k=base + D * esz, v=base + 2 * D * esz, ld_kv=W,
                   p_drop=p_drop, seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
                   dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz, ld_dkv=W, cu_rows=cu_rows,
-                  seq_order=_ptr(order), q_limit=_ptr(q_limit))
+                  seq_order=_ptr(order), q_limit=_ptr(q_limit), delta_ws=_delta_ws(n_seq, n_head, cap, packed.device))
         if _debug.ENABLED:
             _debug.tap("vattn.dpacked", dpacked)
         return dpacked, None, None, None, None, None, None, None, None
+
+
+def _delta_ws(n_seq: int, n_head: int, cap: int, device) -> torch.Tensor:
+    """(n_seq, H, cap) fp32 scratch of the block-streaming backward (gps_attn_args.delta_ws): the dQ launch writes
+    rowsum(dout * out) per query, the dK / dV launch reads it."""
+    return torch.empty((n_seq, n_head, cap), dtype=torch.float32, device=device)
+
+
+def set_plain_blocks(flag: bool) -> bool:
+    """Plain form on the block-streaming kernels (gps_attention_fa.hip; default) or the whole-sequence kernels."""
+    return bool(_native.load().gps_attn_set_plain_blocks(1 if flag else 0))
 
 
 def _varlen_fraction(cu_rows: torch.Tensor, n_seq: int, cap: int):

@@ -77,7 +77,13 @@ if legacy:
 def hook(stage, step, **kw):
     if stage == "captured_g2b":
         torch.cuda.synchronize()
-        shapes = [graph_shape(g.raw_cuda_graph()) for g in step._made]
+        shapes = []
+        for g in step._made:
+            try:
+                raw = g.raw_cuda_graph()
+            except RuntimeError:                   # created but not captured yet (the clip + AdamW graph)
+                continue
+            shapes.append(graph_shape(raw))
         print("captured " + json.dumps(shapes), flush=True)
         os._exit(0)
 

@@ -66,28 +66,39 @@ CASES = [(3, 80, True), (8, 80, True), (2, 130, False), (8, 130, False), (2, 37,
          (1, 145, True), (2, 177, False)]
 
 
-@pytest.fixture(params=["default", "resident", "streaming", "planes"])
+@pytest.fixture(params=["default", "resident", "streaming", "planes", "blocks"])
 def family(request):
-    """Which kernels serve L <= 144.  "planes": the product default -- the spatial form on gps_attention_sp.hip (fp16
-    planes of the pairwise tensor, bf16 conditioning vector read in place), the plain form streaming.  The other three
-    run the GENERAL kernels (interleaved fp32 pairwise tensor): their default split (plain -> streaming, spatial ->
-    register-resident), all register-resident, or all streaming (gps_attn_set_stream_min_tiles); longer rows always stream."""
+    """Which kernels serve a call.  The two PRODUCT defaults:
+      "planes"  the spatial form on gps_attention_sp.hip (fp16 planes of the pairwise tensor, bf16 conditioning vector
+                read in place; L <= 144),
+      "blocks"  the plain form on the block-streaming kernels of gps_attention_fa.hip (any length).
+    The other three run the GENERAL kernels of gps_attention.hip (interleaved fp32 pairwise tensor, whole-sequence
+    workgroups): their own split (plain -> streaming, spatial -> register-resident), all register-resident, or all
+    streaming (gps_attn_set_stream_min_tiles); rows above 144 tokens always stream there."""
     from sceneverse_amd import _native
     from sceneverse_amd.modules.layers import fused_attention as FA
     lib = _native.load()
-    lib.gps_attn_set_stream_min_tiles(*{"default": (1, 10), "resident": (10, 10), "streaming": (1, 1), "planes": (1, 10)}[request.param])
+    lib.gps_attn_set_stream_min_tiles(*{"resident": (10, 10), "streaming": (1, 1)}.get(request.param, (1, 10)))
     FA.set_spatial_planes(request.param == "planes")
+    FA.set_plain_blocks(request.param == "blocks")
     yield request.param
     lib.gps_attn_set_stream_min_tiles(1, 10)
     FA.set_spatial_planes(True)
+    FA.set_plain_blocks(True)
+
+
+def _skip_duplicates(family, L, spatial):
+    if family in ("resident", "streaming") and L > 144:
+        pytest.skip("rows above 144 tokens stream in every setting of the general kernels")
+    if family == "planes" and (not spatial or L > 144):
+        pytest.skip("the plane form is the spatial term's, up to 144 tokens")
+    if family == "blocks" and spatial:
+        pytest.skip("the block-streaming kernels serve the plain form")
 
 
 @pytest.mark.parametrize("B,L,spatial", CASES)
 def test_forward_backward_match_fp32_formulation(B, L, spatial, family):
-    if family != "default" and L > 144:
-        pytest.skip("rows above 144 tokens stream in every setting")
-    if family == "planes" and not spatial:
-        pytest.skip("the plane form is the spatial term's")
+    _skip_duplicates(family, L, spatial)
     packed, pl, mask = _inputs(B, L, spatial, seed=B * 1000 + L)
     ref_in = packed.float().requires_grad_(True)
     ref = ref_attention(ref_in, pl, mask)
@@ -119,6 +130,8 @@ def test_streaming_and_resident_kernels_agree_at_the_switch():
     """L = 144 runs the register-resident kernels, L = 145 the streaming ones: same inputs (one padded token
     more) must give the same first 144 rows to bf16 rounding, with dropout active (one shared RNG stream)."""
     from sceneverse_amd import _native
+    from sceneverse_amd.modules.layers import fused_attention as FA
+    FA.set_plain_blocks(False)                                # the general kernels' own two families
     _native.load().gps_attn_set_stream_min_tiles(10, 10)      # the plain form streams from one tile on by default
     packed, _, _ = _inputs(2, 145, False, seed=31, pad=False)
     mask = torch.zeros(2, 145, dtype=torch.bool)
@@ -128,15 +141,15 @@ def test_streaming_and_resident_kernels_agree_at_the_switch():
     o145 = _FusedSelfAttention.apply(x145, None, mask.to(DEV), H, 0.0, 0, None)
     o144 = _FusedSelfAttention.apply(x144, None, None, H, 0.0, 0, None)
     _native.load().gps_attn_set_stream_min_tiles(1, 10)
+    FA.set_plain_blocks(True)
     _close(o145[:, :144], o144, 1e-2, "switch")
 
 
 @pytest.mark.parametrize("L", [80, 200, 300])
 def test_dropout_is_reproducible_linear_and_adjoint(L, family):
-    if family != "default" and L > 144:
-        pytest.skip("rows above 144 tokens stream in every setting")
-    if family == "planes":
-        pytest.skip("dropout on the spatial form is served by the general kernels (covered by the other families)")
+    if family in ("planes", "blocks"):
+        pytest.skip("this test drives the SPATIAL form with dropout: served by the general kernels (other families)")
+    _skip_duplicates(family, L, True)
     B = 2
     packed, pl, mask = _inputs(B, L, True, seed=9)
     pl, mask = pl.to(DEV), mask.to(DEV)

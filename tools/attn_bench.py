@@ -1,33 +1,73 @@
 """Attention-core microbenchmark at the bench configuration's shapes (B = 64 scenes): every launch family of the step,
-forward and backward, GPU time per launch from a replayed HIP graph of `iters` launches.
+forward and backward, GPU time per launch from a replayed HIP graph of `iters` launches (eager timing as the fallback).
 
   spatial   (B, 80, 12 x 64) with the pairwise term: gps_attention_sp.hip (plane form) vs the general kernels
-  joint     (B, 130) plain form with a key-padding mask (unified encoder)
-  text      128 variable-length sequences packed back to back (64 sentences <= 50, 64 captions <= 300 tokens)
+  joint     (B, 130) plain form with a key-padding mask (unified encoder): block-streaming vs whole-sequence kernels
+  text      128 variable-length sequences packed back to back (64 sentences <= 50, 64 captions <= 300 tokens): the same
 
 Checks each new path against the one it replaces (max |diff| relative to max |ref|) before timing it.
     python tools/attn_bench.py [--json out.json] [--iters 20]
 GPS_ATTN_SP_BWD_OCC=3|4 selects the register budget of the spatial backward kernel (process-wide)."""
 import argparse
+import faulthandler
 import json
 import os
 import sys
 
+faulthandler.enable()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
 from sceneverse_amd.modules.layers import fused_attention as FA  # noqa: E402
-from tools.kernel_bench import timeit  # noqa: E402
 
 H, D = 12, 768
 DEV = "cuda"
 
 
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return round(s.elapsed_time(e) * 1e3 / iters, 2)
+    except Exception as ex:  # noqa: BLE001
+        print("  (graph capture failed, eager timing)", repr(ex)[:120], flush=True)
+        torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return round(s.elapsed_time(e) * 1e3 / iters, 2)
+
+
 def rel(a, b):
     a, b = a.float(), b.float()
-    return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
+    return round(((a - b).abs().max() / (b.abs().max() + 1e-20)).item(), 5)
+
+
+def time_fwd_bwd(make_out, x, go, iters):
+    """make_out(x) -> output through the autograd Function; times the forward launch (no grad) and the backward launch
+    (autograd.grad on a retained graph: one backward call = the kernel launches + an empty_like)."""
+    with torch.no_grad():
+        t_f = timeit(lambda: make_out(x), iters)
+    xr = x.detach().clone().requires_grad_(True)
+    o = make_out(xr)
+    t_b = timeit(lambda: torch.autograd.grad(o, xr, go, retain_graph=True), iters)
+    return t_f, t_b
 
 
 def spatial_case(B, L, iters):
@@ -42,26 +82,17 @@ def spatial_case(B, L, iters):
     n_real = torch.randint(20, L + 1, (B,), generator=g)
     mask = (torch.arange(L)[None, :] >= n_real[:, None]).to(DEV)
     go = torch.randn(B, L, D, generator=g).to(torch.bfloat16).to(DEV)
-    res = {}
-    outs = {}
+    res, outs = {}, {}
     for name, planes in (("general", False), ("planes", True)):
         FA.set_spatial_planes(planes)
+        print("  spatial", name, flush=True)
         x = packed.clone().requires_grad_(True)
         out = FA._FusedSelfAttention.apply(x, pl, mask, H, 0.0, 0, None)
         out.backward(go)
+        torch.cuda.synchronize()
         outs[name] = (out.detach(), x.grad.detach())
-        xf = packed.clone().requires_grad_(True)
-
-        def fwd():
-            return FA._FusedSelfAttention.apply(xf, pl, mask, H, 0.0, 0, None)
-        o = fwd()
-
-        def bwd():
-            xf.grad = None
-            o.backward(go, retain_graph=True)
-        with torch.no_grad():
-            res[name + "_fwd_us"] = timeit(lambda: FA._FusedSelfAttention.apply(packed, pl, mask, H, 0.0, 0, None), iters)
-        res[name + "_bwd_us"] = timeit(bwd, iters)
+        res[name + "_fwd_us"], res[name + "_bwd_us"] = time_fwd_bwd(
+            lambda t: FA._FusedSelfAttention.apply(t, pl, mask, H, 0.0, 0, None), packed, go, iters)
     FA.set_spatial_planes(True)
     valid = ~mask
     res["out_vs_general"] = rel(outs["planes"][0][valid], outs["general"][0][valid])
@@ -76,18 +107,24 @@ def joint_case(B, L, iters):
     n_real = torch.randint(L // 2, L + 1, (B,), generator=g)
     mask = (torch.arange(L)[None, :] >= n_real[:, None]).to(DEV)
     go = torch.randn(B, L, D, generator=g).to(torch.bfloat16).to(DEV)
-    res = {}
+    res, outs = {}, {}
+    seed_dev = FA._next_device_seed(torch.device(DEV))
+    for name, blocks in (("whole", False), ("blocks", True)):
+        FA.set_plain_blocks(blocks)
+        print("  joint", name, flush=True)
+        for p in (0.0, 0.1):
+            x = packed.clone().requires_grad_(True)
+            out = FA._FusedSelfAttention.apply(x, None, mask, H, p, 0, seed_dev if p else None)
+            out.backward(go)
+            torch.cuda.synchronize()
+            outs[(name, p)] = (out.detach(), x.grad.detach())
+            res[f"{name}_fwd_us_p{p}"], res[f"{name}_bwd_us_p{p}"] = time_fwd_bwd(
+                lambda t: FA._FusedSelfAttention.apply(t, None, mask, H, p, 0, seed_dev if p else None), packed, go, iters)
+    FA.set_plain_blocks(True)
+    valid = ~mask
     for p in (0.0, 0.1):
-        xf = packed.clone().requires_grad_(True)
-        o = FA._FusedSelfAttention.apply(xf, None, mask, H, p, 0, FA._next_device_seed(torch.device(DEV)) if p else None)
-
-        def bwd():
-            xf.grad = None
-            o.backward(go, retain_graph=True)
-        with torch.no_grad():
-            res[f"fwd_us_p{p}"] = timeit(lambda: FA._FusedSelfAttention.apply(
-                packed, None, mask, H, p, 0, FA._next_device_seed(torch.device(DEV)) if p else None), iters)
-        res[f"bwd_us_p{p}"] = timeit(bwd, iters)
+        res[f"out_vs_whole_p{p}"] = rel(outs[("blocks", p)][0][valid], outs[("whole", p)][0][valid])
+        res[f"grad_vs_whole_p{p}"] = rel(outs[("blocks", p)][1][valid], outs[("whole", p)][1][valid])
     return res
 
 
@@ -104,17 +141,24 @@ def text_case(iters, full=False):
     go = torch.randn(T, D, generator=g).to(torch.bfloat16).to(DEV)
     cu = cu.to(DEV)
     res = {"rows": T, "sum_len_sq": int((lens.double() ** 2).sum())}
+    outs = {}
+    seed_dev = FA._next_device_seed(torch.device(DEV))
+    for name, blocks in (("whole", False), ("blocks", True)):
+        FA.set_plain_blocks(blocks)
+        print("  text", name, flush=True)
+        for p in (0.0, 0.1):
+            def run(t):
+                return FA._FusedVarlenSelfAttention.apply(t, cu, 128, 300, H, p, seed_dev if p else None, order, None)
+            x = packed.clone().requires_grad_(True)
+            out = run(x)
+            out.backward(go)
+            torch.cuda.synchronize()
+            outs[(name, p)] = (out.detach(), x.grad.detach())
+            res[f"{name}_fwd_us_p{p}"], res[f"{name}_bwd_us_p{p}"] = time_fwd_bwd(run, packed, go, iters)
+    FA.set_plain_blocks(True)
     for p in (0.0, 0.1):
-        xf = packed.clone().requires_grad_(True)
-        o = FA.fused_varlen_self_attention(xf, cu, 128, 300, H, dropout_p=p, training=True, order=order)
-
-        def bwd():
-            xf.grad = None
-            o.backward(go, retain_graph=True)
-        with torch.no_grad():
-            res[f"fwd_us_p{p}"] = timeit(lambda: FA.fused_varlen_self_attention(packed, cu, 128, 300, H, dropout_p=p,
-                                                                              training=True, order=order), iters)
-        res[f"bwd_us_p{p}"] = timeit(bwd, iters)
+        res[f"out_vs_whole_p{p}"] = rel(outs[("blocks", p)][0], outs[("whole", p)][0])
+        res[f"grad_vs_whole_p{p}"] = rel(outs[("blocks", p)][1], outs[("whole", p)][1])
     return res
 
 
@@ -123,18 +167,23 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--only", default="")
     args = ap.parse_args()
     out = {"bwd_occ_env": os.environ.get("GPS_ATTN_SP_BWD_OCC", "")}
-    out["spatial_L80"] = spatial_case(args.batch, 80, args.iters)
-    print("spatial_L80", out["spatial_L80"], flush=True)
-    out["spatial_L130"] = spatial_case(8, 130, args.iters)
-    print("spatial_L130", out["spatial_L130"], flush=True)
-    out["joint_L130"] = joint_case(args.batch, 130, args.iters)
-    print("joint_L130", out["joint_L130"], flush=True)
-    out["text_varlen"] = text_case(args.iters)
-    print("text_varlen", out["text_varlen"], flush=True)
-    out["text_full"] = text_case(args.iters, full=True)
-    print("text_full", out["text_full"], flush=True)
+    cases = [("spatial_L80", lambda: spatial_case(args.batch, 80, args.iters)),
+             ("spatial_L130", lambda: spatial_case(8, 130, args.iters)),
+             ("joint_L130", lambda: joint_case(args.batch, 130, args.iters)),
+             ("text_varlen", lambda: text_case(args.iters)),
+             ("text_full", lambda: text_case(args.iters, full=True))]
+    for name, fn in cases:
+        if args.only and not name.startswith(args.only):
+            continue
+        print(name, "...", flush=True)
+        try:
+            out[name] = fn()
+        except Exception as ex:  # noqa: BLE001
+            out[name] = {"error": repr(ex)[:300]}
+        print(name, out[name], flush=True)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(out, f, indent=1)
