@@ -349,8 +349,10 @@ def test_plane_form_equals_the_general_kernels(B, L, w_scale):
     o_new, g_new = _run_spatial(packed, pl, mask, go, planes=True)
     assert torch.isfinite(o_new).all() and torch.isfinite(g_new).all()
     _close(o_new, o_ref, 1.5e-2, "out")
+    scale = g_ref.abs().max().item()              # one key: dq / dk / dsw are 0 up to p (1 - p) ~ 1e-6 of the cotangent
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D)), ("dsw", slice(3 * D, None))):
-        _close(g_new[..., sl], g_ref[..., sl], 1.5e-2, name)
+        err = (g_new[..., sl] - g_ref[..., sl]).abs().max().item()
+        assert err <= 1.5e-2 * g_ref[..., sl].abs().max().item() + 1e-5 * scale, (name, err)
     assert g_new[..., D:3 * D][mask].abs().max().item() == 0.0 if mask.any() else True
 
 

@@ -27,25 +27,15 @@ DEV = "cuda"
 
 
 def timeit(fn, iters=20, warm=3):
+    """Average time of one call in us, back-to-back eager launches between two events.  Launches shorter than the host's
+    launch path (~12 us through ctypes) are host-bound here: the per-kernel GPU times are the rocprofv3 rows of the same
+    run (tools/gpu_r5_*.sh runs this script under `rocprofv3 --kernel-trace --stats`).  (A HIP-graph replay would remove
+    the host from the timing, but hipStreamEndCapture segfaults on this ROCm build when the capture follows eager
+    launches made on the legacy default stream -- gpurun_out/r5_3/gdb.log.)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    try:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(iters):
-                fn()
-        g.replay()
-        torch.cuda.synchronize()
-        s.record()
-        g.replay()
-        e.record()
-        torch.cuda.synchronize()
-        return round(s.elapsed_time(e) * 1e3 / iters, 2)
-    except Exception as ex:  # noqa: BLE001
-        print("  (graph capture failed, eager timing)", repr(ex)[:120], flush=True)
-        torch.cuda.synchronize()
     s.record()
     for _ in range(iters):
         fn()
@@ -170,6 +160,8 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     out = {"bwd_occ_env": os.environ.get("GPS_ATTN_SP_BWD_OCC", "")}
+    if os.environ.get("GPS_BENCH_WARM"):
+        print("warm:", float((torch.zeros(4, device=DEV) + 1).sum()), flush=True)
     cases = [("spatial_L80", lambda: spatial_case(args.batch, 80, args.iters)),
              ("spatial_L130", lambda: spatial_case(8, 130, args.iters)),
              ("joint_L130", lambda: joint_case(args.batch, 130, args.iters)),
