@@ -209,10 +209,17 @@ GPS_API int gps_attn_forward(int B, int H, int L, int head_dim, const void *q, c
  * at least `plain` (no pairwise term) / `spatial` (with it) tiles take the streaming kernels, shorter ones the
  * register-resident kernels.  Defaults 1 and 10.  Results agree to bf16 rounding either way; process-wide. */
 GPS_API void gps_attn_set_stream_min_tiles(int plain, int spatial);
-/* Plain form (no pairwise term), bf16: 1 (default) = the block-streaming kernels of gps_attention_fa.hip (64 queries or
- * keys per workgroup, the other side streamed through LDS in 64-row blocks, online softmax; any length), 0 = the
- * whole-sequence kernels above (A/B runs, tests); < 0 = query.  Returns the previous setting.  Process-wide. */
-GPS_API int gps_attn_set_plain_blocks(int on);
+/* Which kernels serve the PLAIN form (no pairwise term), bf16 -- a bit mask:
+ *   1  forward calls on the block-streaming kernels of gps_attention_fa.hip (64 queries per workgroup, the keys streamed
+ *      through LDS in 64-row blocks, online softmax; any length, variable-length batches, cross-attention),
+ *   2  backward calls on them too (two launches: dQ per query block, dK / dV per key block; needs `out` and `delta_ws`),
+ *   4  fixed-length self-attention up to 144 tokens on the K / V-resident kernels of gps_attention_sp.hip (one query strip
+ *      per wave, probabilities and dS parked in LDS for the dK / dV pass: every score evaluated once).
+ * Calls no set bit covers take the whole-sequence kernels of gps_attention.hip.  Default 1 | 4 (measured, profiles/r5:
+ * the block-streaming backward ties the whole-sequence one on the variable-length text batches).  All families share lse
+ * and the dropout stream, so forward and backward may come from different ones.  mode < 0 = query.  Returns the previous
+ * mode.  Process-wide. */
+GPS_API int gps_attn_set_plain_blocks(int mode);
 GPS_API int gps_attn_backward(int B, int H, int L, int head_dim, const void *q, const void *k, const void *v,
                               int ld_qkv, const float *sw, const float *pl, const unsigned char *mask,
                               float p_drop, unsigned long long seed, const void *seed_dev,

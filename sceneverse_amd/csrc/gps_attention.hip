@@ -1336,7 +1336,9 @@ int launch(const Params &P, bool backward, hipStream_t s) {
 }
 
 static int g_stream_min_nt[2] = {-1, -1};      // [plain, spatial]; -1 = not read yet
-static int g_plain_blocks = 1;                 // plain form on the block-streaming kernels of gps_attention_fa.hip
+// plain form (no pairwise term), bits: 1 = forward on the block-streaming kernels of gps_attention_fa.hip, 2 = backward
+// on them too, 4 = fixed-length self-attention up to 144 tokens on the K / V-resident kernels of gps_attention_sp.hip
+static int g_plain_mode = 1 | 4;
 
 int dispatch(Params &P, bool backward, hipStream_t s) {
   P.nt = (P.L + 15) / 16;
@@ -1403,8 +1405,14 @@ int run_ex(const gps_attn_args *a, bool backward, hipStream_t s) {
   if ((a->ld_q & 7) || (a->ld_kv & 7) || (a->ld_o & 7) || (backward && ((a->ld_dq & 7) || (a->ld_dkv & 7)))) return GPS_ERR_UNSUPPORTED;
   if (a->compute == GPS_ATTN_COMPUTE_FP8 && !backward) return run_fp8_forward(a, s);
   if (a->compute != GPS_ATTN_COMPUTE_NATIVE && a->compute != GPS_ATTN_COMPUTE_FP8) return GPS_ERR_UNSUPPORTED;
-  // plain form: block-streaming kernels (the backward call needs the forward output and the delta scratch)
-  if (!a->sw && g_plain_blocks && (!backward || (a->out && a->delta_ws))) return run_plain_blocks(a, backward, s);
+  // plain form: K / V-resident kernels for short fixed-length rows, block-streaming kernels otherwise (their backward
+  // call needs the forward output and the delta scratch), else the whole-sequence kernels below
+  if (!a->sw) {
+    if ((g_plain_mode & 4) && a->Lq == a->Lk && a->Lk <= 144 && !a->cu_rows && a->ld_q == a->ld_kv && (!backward || a->ld_dq == a->ld_dkv) &&
+        !(a->ld_o & 3) && (!backward || !(a->ld_dq & 3)))
+      return run_plain_resident(a, backward, s);
+    if (!backward ? (g_plain_mode & 1) : ((g_plain_mode & 2) && a->out && a->delta_ws)) return run_plain_blocks(a, backward, s);
+  }
   Params P = {};
   P.B = a->B; P.H = a->H; P.L = a->Lk; P.Lq = a->Lq; P.ld_qkv = a->ld_kv; P.ld_q = a->ld_q; P.ld_o = a->ld_o;
   P.q = (const uint16_t *)a->q; P.k = (const uint16_t *)a->k; P.v = (const uint16_t *)a->v;
@@ -1434,9 +1442,9 @@ int gps_attn_backward_ex(const gps_attn_args *a, gps_stream_t stream) {
   return gps_attn::run_ex(a, true, (hipStream_t)stream);
 }
 
-int gps_attn_set_plain_blocks(int on) {
-  const int was = gps_attn::g_plain_blocks;
-  if (on >= 0) gps_attn::g_plain_blocks = on ? 1 : 0;
+int gps_attn_set_plain_blocks(int mode) {
+  const int was = gps_attn::g_plain_mode;
+  if (mode >= 0) gps_attn::g_plain_mode = mode & 7;
   return was;
 }
 

@@ -11,4 +11,5 @@ int run_f32(const gps_attn_args *a, bool backward, hipStream_t s);      // gps_a
 int run_fp8_forward(const gps_attn_args *a, hipStream_t s);             // gps_attention_ex.hip
 int run_spatial_planes(const gps_attn_args *a, bool backward, hipStream_t s);   // gps_attention_sp.hip
 int run_plain_blocks(const gps_attn_args *a, bool backward, hipStream_t s);     // gps_attention_fa.hip
+int run_plain_resident(const gps_attn_args *a, bool backward, hipStream_t s);   // gps_attention_sp.hip
 }  // namespace gps_attn

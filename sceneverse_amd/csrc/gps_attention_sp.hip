@@ -68,6 +68,11 @@ struct Params {
   const uint16_t *dout;            // (B, L, ld_o)
   uint16_t *dq, *dk, *dv;          // (B, L, ld_dqkv)
   uint16_t *dsw;                   // bf16, addressed like sw with ld_dsw
+  // plain form only: dropout on the probabilities
+  float p_drop;
+  unsigned int drop_thr;
+  unsigned long long seed;
+  const unsigned long long *seed_dev;
 };
 
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {     // v_cvt_pk_bf16_f32: round to nearest even
@@ -103,14 +108,14 @@ constexpr int kThreads = 320;                    // five waves: one query strip 
 // Two row-major tiles (head h's 64 columns of rows [0, R) of two bf16 matrices; rows >= rows_valid zero) -> LDS [R][KS], in
 // two steps: issue() requests every 16-byte piece of BOTH tiles, commit() writes them to LDS.  The kernels put the
 // strip's own operand requests between the two, so that everything a wave needs from global memory is one round trip.
-template <int R>
+template <int R, int THREADS = kThreads>
 struct StagePair {
-  static constexpr int N = (R * 8 + kThreads - 1) / kThreads;
+  static constexpr int N = (R * 8 + THREADS - 1) / THREADS;
   u32x4 va[N], vb[N];
   __device__ __forceinline__ void issue(const uint16_t *src_a, int ld_a, const uint16_t *src_b, int ld_b, int rows_valid) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int e = threadIdx.x + i * kThreads, r = e >> 3, ch = e & 7;
+      const int e = threadIdx.x + i * THREADS, r = e >> 3, ch = e & 7;
       va[i] = zero4();
       vb[i] = zero4();
       if (r < rows_valid) {
@@ -122,8 +127,8 @@ struct StagePair {
   __device__ __forceinline__ void commit(uint16_t *dst_a, uint16_t *dst_b) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int e = threadIdx.x + i * kThreads, r = e >> 3, ch = e & 7;
-      if ((R * 8) % kThreads == 0 || r < R) {
+      const int e = threadIdx.x + i * THREADS, r = e >> 3, ch = e & 7;
+      if ((R * 8) % THREADS == 0 || r < R) {
         *reinterpret_cast<u32x4 *>(dst_a + r * KS + ch * 8) = va[i];
         *reinterpret_cast<u32x4 *>(dst_b + r * KS + ch * 8) = vb[i];
       }
@@ -622,6 +627,309 @@ int launch(const Params &P, bool backward, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
+
+// ==========================================================================================
+// PLAIN form (no pairwise term) for short fixed-length rows -- the 130-token joint sequences of the unified encoder
+// (nn.MultiheadAttention with key_padding_mask and dropout on the probabilities, modules/layers/transformers.py:141):
+// the same single-sweep structure (K / V resident, one query strip per wave, P and dS parked in LDS, dK / dV as pure
+// MFMA), dropout from the streaming kernels' stream (one hash per (query, key pair): gps_attention.hip pair_rng), so a
+// forward of this family pairs with a backward of any other.
+// ==========================================================================================
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {
+  x ^= x >> 16;
+  x *= 0x21F0AAADu;
+  x ^= x >> 15;
+  x *= 0x735A2D97u;
+  x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ unsigned int seed_fold(unsigned long long seed) {
+  return mix32((unsigned int)seed ^ mix32((unsigned int)(seed >> 32) + 0x9E3779B9u));
+}
+__device__ __forceinline__ unsigned int pair_rng(unsigned int seedmix, unsigned int row_pair_base, int t) {
+  return mix32((row_pair_base + (unsigned int)(t >> 1)) ^ seedmix);
+}
+struct Drop {                 // dropout state of a query row
+  bool on;
+  float keep_scale;
+  unsigned int seedmix, thr16, rp;
+  __device__ __forceinline__ void init(const Params &P, int b, int h, int qi) {
+    on = P.drop_thr != 0u;
+    keep_scale = on ? 1.f / (1.f - P.p_drop) : 1.f;
+    seedmix = on ? seed_fold(P.seed + (P.seed_dev ? *P.seed_dev : 0ull)) : 0u;
+    thr16 = P.drop_thr >> 16;
+    rp = (((unsigned int)b * P.H + h) * P.L + qi) * (unsigned int)((P.L + 1) >> 1);
+  }
+  // keep flags of keys t0 .. t0 + 3 (t0 a multiple of 4): two hashes
+  __device__ __forceinline__ void keep4(int t0, bool (&k)[4]) const {
+    const unsigned int r01 = pair_rng(seedmix, rp, t0), r23 = pair_rng(seedmix, rp, t0 + 2);
+    k[0] = (r01 & 0xFFFFu) >= thr16;
+    k[1] = (r01 >> 16) >= thr16;
+    k[2] = (r23 & 0xFFFFu) >= thr16;
+    k[3] = (r23 >> 16) >= thr16;
+  }
+};
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void pfwd_kernel(const Params P) {
+  constexpr int R = NT * 16, THREADS = 64 * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *Vs = Ks + R * KS;
+  float *mbs = reinterpret_cast<float *>(Vs + R * KS);
+  int b, h;
+  block_to_bh(P.B, P.H, b, h);
+  const int L = P.L, nt = P.nt;
+  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;       // one query strip per wave
+  const int m = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)b * L;
+  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
+  const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
+  const int qi = 16 * s + m, qc = min(qi, L - 1);
+
+  StagePair<R, THREADS> st;
+  st.issue(kb, P.ld_qkv, vb, P.ld_qkv, L);
+  bf16x8 bq[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) bq[c] = as_frag(load_frag(qb, qc, P.ld_qkv, 32 * c + 8 * g));
+  st.commit(Ks, Vs);
+  for (int t = threadIdx.x; t < R; t += THREADS) mbs[t] = (t < L && !(P.mask && P.mask[row0 + t])) ? 0.f : -INFINITY;
+  __syncthreads();
+  if (s >= nt) return;
+  Drop dr;
+  dr.init(P, b, h, qi);
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    acc[j] = *reinterpret_cast<const f32x4 *>(mbs + 16 * j + 4 * g);       // key term (0 / -inf) under the scores
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
+      acc[j] = mfma32(as_frag(a), bq[c], acc[j]);
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) mx = fmaxf(fmaxf(mx, fmaxf(acc[j][0], acc[j][1])), fmaxf(acc[j][2], acc[j][3]));
+  mx = xor_max_g(mx);
+  const float mxc = mx * kC;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(acc[j][r], kC, -mxc));
+      acc[j][r] = p;
+      sum += p;
+    }
+    if (dr.on) {
+      bool k[4];
+      dr.keep4(16 * j + 4 * g, k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][r] = k[r] ? acc[j][r] : 0.f;
+    }
+  }
+  sum = xor_sum_g(sum);
+  if (g == 0 && qi < L) P.lse[((size_t)b * P.H + h) * L + qi] = (mxc + __builtin_amdgcn_logf(sum)) * kLn2;
+  const float sc = dr.keep_scale * __builtin_amdgcn_rcpf(sum);
+  f32x4 o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = zero_acc();
+#pragma unroll
+  for (int c = 0; c < NT / 2; ++c) {
+    const bf16x8 pb = pack_tiles(acc[2 * c], acc[2 * c + 1]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = mfma32(tr_frag_perm(Vs, KS, c, 16 * n, lane), pb, o[n]);
+  }
+  if (NT & 1) {
+    const u32x2 pb = pack_tile(acc[NT - 1]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = mfma16(tr4(Vs, KS, 16 * (NT - 1) + 4 * g, 16 * n, lane), pb, o[n]);
+  }
+  if (qi < L) {
+    uint16_t *op = P.out + (row0 + qi) * P.ld_o + h * DH + 4 * g;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const u32x2 v = {pack2(o[n][0] * sc, o[n][1] * sc), pack2(o[n][2] * sc, o[n][3] * sc)};
+      *reinterpret_cast<u32x2 *>(op + 16 * n) = v;
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void pbwd_kernel(const Params P) {
+  constexpr int R = NT * 16, TP = R + 8, THREADS = 64 * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t *Ks = reinterpret_cast<uint16_t *>(smem);
+  uint16_t *Vs = Ks + R * KS;
+  uint16_t *PS = Vs + R * KS;
+  uint16_t *dSS = PS + R * TP;
+  float *mbs = reinterpret_cast<float *>(dSS + R * TP);
+  int b, h;
+  block_to_bh(P.B, P.H, b, h);
+  const int L = P.L, nt = P.nt;
+  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const size_t row0 = (size_t)b * L;
+  const uint16_t *qb = P.q + row0 * P.ld_qkv + h * DH;
+  const uint16_t *kb = P.k + row0 * P.ld_qkv + h * DH;
+  const uint16_t *vb = P.v + row0 * P.ld_qkv + h * DH;
+  const uint16_t *dob = P.dout + row0 * P.ld_o + h * DH;
+  const int qi = 16 * s + m, qc = min(qi, L - 1);
+  const bool live = s < nt;
+
+  StagePair<R, THREADS> st;
+  st.issue(kb, P.ld_qkv, vb, P.ld_qkv, L);
+  bf16x8 bq[2], bdo[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    bq[c] = as_frag(load_frag(qb, qc, P.ld_qkv, 32 * c + 8 * g));
+    bdo[c] = as_frag(load_frag(dob, qc, P.ld_o, 32 * c + 8 * g));
+  }
+  float lse2 = qi < L ? P.lse[((size_t)b * P.H + h) * L + qc] : INFINITY;     // queries past L: p = 0
+  st.commit(Ks, Vs);
+  for (int t = threadIdx.x; t < R; t += THREADS) mbs[t] = (t < L && !(P.mask && P.mask[row0 + t])) ? 0.f : -INFINITY;
+  if (nt < NT) {            // query tiles no strip writes are still read by pass 2: zeros
+    u32x4 *z = reinterpret_cast<u32x4 *>(PS + nt * 16 * TP);
+    for (int e = threadIdx.x; e < (NT - nt) * 16 * TP / 8; e += THREADS) z[e] = zero4();
+    z = reinterpret_cast<u32x4 *>(dSS + nt * 16 * TP);
+    for (int e = threadIdx.x; e < (NT - nt) * 16 * TP / 8; e += THREADS) z[e] = zero4();
+  }
+  __syncthreads();
+  Drop dr;
+  dr.init(P, b, h, qi);
+  if (live) {
+    lse2 *= kLog2e;
+    f32x4 pr[NT], dp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      pr[j] = zero_acc();
+      dp[j] = zero_acc();
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(Ks + (16 * j + m) * KS + 32 * c + 8 * g);
+        const u32x4 av = *reinterpret_cast<const u32x4 *>(Vs + (16 * j + m) * KS + 32 * c + 8 * g);
+        pr[j] = mfma32(as_frag(a), bq[c], pr[j]);         // S^T
+        dp[j] = mfma32(as_frag(av), bdo[c], dp[j]);       // (dO V^T)^T
+      }
+    }
+    // sweep A: probabilities; dropped keys keep their probability with the sign flipped (P itself is wanted for dS,
+    // the dropped P for dV) and lose their dP; delta = rowsum(P' dP') of the dropped, rescaled pair
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const f32x4 kt = *reinterpret_cast<const f32x4 *>(mbs + 16 * j + 4 * g);
+      bool k[4] = {true, true, true, true};
+      if (dr.on) dr.keep4(16 * j + 4 * g, k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(pr[j][r], kC, kt[r] - lse2));
+        const float dpk = k[r] ? dp[j][r] : 0.f;
+        delta = fmaf(p, dpk, delta);
+        pr[j][r] = k[r] ? p : -p;
+        dp[j][r] = dpk;
+      }
+    }
+    delta = xor_sum_g(delta) * dr.keep_scale;
+    uint16_t *prow = PS + (16 * s + m) * TP + 4 * g, *drow = dSS + (16 * s + m) * TP + 4 * g;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {                 // sweep B
+      f32x4 pk, dsj;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pk[r] = fmaxf(pr[j][r], 0.f);                                          // 1 / (1 - p) goes onto dV below
+        dsj[r] = fabsf(pr[j][r]) * fmaf(dp[j][r], dr.keep_scale, -delta);      // 1/8 goes onto dQ / dK below
+      }
+      *reinterpret_cast<u32x2 *>(prow + 16 * j) = pack_tile(pk);
+      *reinterpret_cast<u32x2 *>(drow + 16 * j) = pack_tile(dsj);
+    }
+    // dQ^T strip = K^T dS^T from the row this wave just parked
+    f32x4 o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = zero_acc();
+    const uint16_t *dq_row = dSS + (16 * s + m) * TP + 8 * g;
+#pragma unroll
+    for (int c = 0; c < NT / 2; ++c) {
+      const bf16x8 db = as_frag(*reinterpret_cast<const u32x4 *>(dq_row + 32 * c));
+#pragma unroll
+      for (int n = 0; n < 4; ++n) o[n] = mfma32(tr_frag_nat(Ks, KS, c, 16 * n, lane), db, o[n]);
+    }
+    if (NT & 1) {
+      const u32x2 db = *reinterpret_cast<const u32x2 *>(dSS + (16 * s + m) * TP + 16 * (NT - 1) + 4 * g);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) o[n] = mfma16(tr4(Ks, KS, 16 * (NT - 1) + 4 * g, 16 * n, lane), db, o[n]);
+    }
+    if (qi < L) {
+      uint16_t *op = P.dq + (row0 + qi) * P.ld_dqkv + h * DH + 4 * g;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const u32x2 v = {pack2(o[n][0] * 0.125f, o[n][1] * 0.125f), pack2(o[n][2] * 0.125f, o[n][3] * 0.125f)};
+        *reinterpret_cast<u32x2 *>(op + 16 * n) = v;
+      }
+    }
+  }
+  st.issue(qb, P.ld_qkv, dob, P.ld_o, L);
+  __syncthreads();
+  st.commit(Ks, Vs);
+  __syncthreads();
+  if (!live) return;
+  // pass 2: key strip s, MFMA only
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    dk[n] = zero_acc();
+    dv[n] = zero_acc();
+  }
+#pragma unroll
+  for (int c = 0; c < NT / 2; ++c) {
+    const bf16x8 bp = tr_frag_nat(PS, TP, c, 16 * s, lane);
+    const bf16x8 bs = tr_frag_nat(dSS, TP, c, 16 * s, lane);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      dv[n] = mfma32(tr_frag_nat(Vs, KS, c, 16 * n, lane), bp, dv[n]);
+      dk[n] = mfma32(tr_frag_nat(Ks, KS, c, 16 * n, lane), bs, dk[n]);
+    }
+  }
+  if (NT & 1) {
+    const int q0 = 16 * (NT - 1) + 4 * g;
+    const u32x2 bp = tr4(PS, TP, q0, 16 * s, lane), bs = tr4(dSS, TP, q0, 16 * s, lane);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      dv[n] = mfma16(tr4(Vs, KS, q0, 16 * n, lane), bp, dv[n]);
+      dk[n] = mfma16(tr4(Ks, KS, q0, 16 * n, lane), bs, dk[n]);
+    }
+  }
+  const int t = 16 * s + m;
+  if (t < L) {
+    const float ks = dr.keep_scale;
+    uint16_t *pk = P.dk + (row0 + t) * P.ld_dqkv + h * DH + 4 * g;
+    uint16_t *pv = P.dv + (row0 + t) * P.ld_dqkv + h * DH + 4 * g;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const u32x2 vk = {pack2(dk[n][0] * 0.125f, dk[n][1] * 0.125f), pack2(dk[n][2] * 0.125f, dk[n][3] * 0.125f)};
+      const u32x2 vv = {pack2(dv[n][0] * ks, dv[n][1] * ks), pack2(dv[n][2] * ks, dv[n][3] * ks)};
+      *reinterpret_cast<u32x2 *>(pk + 16 * n) = vk;
+      *reinterpret_cast<u32x2 *>(pv + 16 * n) = vv;
+    }
+  }
+}
+
+template <int NT>
+int launch_plain(const Params &P, bool backward, hipStream_t s) {
+  const dim3 grid(P.B * P.H), block(64 * NT);
+  const size_t lds = backward ? bwd_lds<NT>() : fwd_lds<NT>();
+  static bool granted[2] = {false, false};
+  if (lds > 64 * 1024 && !granted[backward ? 1 : 0]) {
+    const void *fn = backward ? (const void *)&pbwd_kernel<NT> : (const void *)&pfwd_kernel<NT>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPS_ERR_LAUNCH;
+    granted[backward ? 1 : 0] = true;
+  }
+  if (backward) hipLaunchKernelGGL((pbwd_kernel<NT>), grid, block, lds, s, P);
+  else hipLaunchKernelGGL((pfwd_kernel<NT>), grid, block, lds, s, P);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
 }  // namespace gps_attn_sp
 
 namespace gps_attn {
@@ -645,6 +953,26 @@ int run_spatial_planes(const gps_attn_args *a, bool backward, hipStream_t s) {
     P.ld_dqkv = a->ld_dq; P.dsw = (uint16_t *)a->dsw16; P.ld_dsw = a->ld_dsw;
   }
   return P.nt <= 5 ? gps_attn_sp::launch<5>(P, backward, s) : gps_attn_sp::launch<9>(P, backward, s);
+}
+
+
+// plain form (no pairwise term), fixed-length self-attention up to 144 tokens, K / V resident (argument checks by run_ex)
+int run_plain_resident(const gps_attn_args *a, bool backward, hipStream_t s) {
+  if (a->Lq != a->Lk || a->Lk > 144 || a->dtype != GPS_ATTN_BF16 || a->cu_rows || a->sw || a->pl || a->pl_planes ||
+      a->ld_q != a->ld_kv || (backward && a->ld_dq != a->ld_dkv))
+    return GPS_ERR_UNSUPPORTED;
+  gps_attn_sp::Params P = {};
+  P.B = a->B; P.H = a->H; P.L = a->Lk; P.nt = (a->Lk + 15) / 16;
+  P.ld_qkv = a->ld_kv; P.ld_o = a->ld_o;
+  P.q = (const uint16_t *)a->q; P.k = (const uint16_t *)a->k; P.v = (const uint16_t *)a->v;
+  P.mask = a->mask; P.out = (uint16_t *)a->out; P.lse = a->lse;
+  P.p_drop = a->p_drop; P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
+  P.drop_thr = a->p_drop > 0.f ? (unsigned int)((double)a->p_drop * 4294967296.0) : 0u;
+  if (backward) {
+    P.dout = (const uint16_t *)a->dout; P.dq = (uint16_t *)a->dq; P.dk = (uint16_t *)a->dk; P.dv = (uint16_t *)a->dv;
+    P.ld_dqkv = a->ld_dq;
+  }
+  return P.nt <= 5 ? gps_attn_sp::launch_plain<5>(P, backward, s) : gps_attn_sp::launch_plain<9>(P, backward, s);
 }
 
 }  // namespace gps_attn

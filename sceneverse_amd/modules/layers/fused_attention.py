@@ -305,9 +305,20 @@ def _delta_ws(n_seq: int, n_head: int, cap: int, device) -> torch.Tensor:
     return torch.empty((n_seq, n_head, cap), dtype=torch.float32, device=device)
 
 
-def set_plain_blocks(flag: bool) -> bool:
-    """Plain form on the block-streaming kernels (gps_attention_fa.hip; default) or the whole-sequence kernels."""
-    return bool(_native.load().gps_attn_set_plain_blocks(1 if flag else 0))
+PLAIN_DEFAULT = 1 | 4
+
+
+def set_plain_mode(mode: int = PLAIN_DEFAULT) -> int:
+    """Kernel families of the plain form (include/gps_hip.h gps_attn_set_plain_blocks): bit 1 = block-streaming forward,
+    2 = block-streaming backward, 4 = K / V-resident kernels for fixed-length rows up to 144 tokens; 0 = the
+    whole-sequence kernels for everything.  Returns the previous mode."""
+    return int(_native.load().gps_attn_set_plain_blocks(int(mode)))
+
+
+def set_plain_blocks(flag: bool) -> int:
+    """True: block-streaming kernels for forward AND backward, nothing resident (tests of that family); False: the
+    whole-sequence kernels.  `set_plain_mode()` restores the product default."""
+    return set_plain_mode(3 if flag else 0)
 
 
 def _varlen_fraction(cu_rows: torch.Tensor, n_seq: int, cap: int):

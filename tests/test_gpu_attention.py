@@ -66,12 +66,15 @@ CASES = [(3, 80, True), (8, 80, True), (2, 130, False), (8, 130, False), (2, 37,
          (1, 145, True), (2, 177, False)]
 
 
-@pytest.fixture(params=["default", "resident", "streaming", "planes", "blocks"])
+@pytest.fixture(params=["default", "resident", "streaming", "planes", "blocks", "kv-resident"])
 def family(request):
     """Which kernels serve a call.  The two PRODUCT defaults:
       "planes"  the spatial form on gps_attention_sp.hip (fp16 planes of the pairwise tensor, bf16 conditioning vector
                 read in place; L <= 144),
-      "blocks"  the plain form on the block-streaming kernels of gps_attention_fa.hip (any length).
+      "blocks"  the plain form on the block-streaming kernels of gps_attention_fa.hip (any length; forward AND backward --
+                the product takes their forward only where "kv-resident" does not apply),
+      "kv-resident"  the plain form of fixed-length rows up to 144 tokens on the K / V-resident kernels of
+                gps_attention_sp.hip.
     The other three run the GENERAL kernels of gps_attention.hip (interleaved fp32 pairwise tensor, whole-sequence
     workgroups): their own split (plain -> streaming, spatial -> register-resident), all register-resident, or all
     streaming (gps_attn_set_stream_min_tiles); rows above 144 tokens always stream there."""
@@ -80,11 +83,11 @@ def family(request):
     lib = _native.load()
     lib.gps_attn_set_stream_min_tiles(*{"resident": (10, 10), "streaming": (1, 1)}.get(request.param, (1, 10)))
     FA.set_spatial_planes(request.param == "planes")
-    FA.set_plain_blocks(request.param == "blocks")
+    FA.set_plain_mode({"blocks": 3, "kv-resident": 4}.get(request.param, 0))
     yield request.param
     lib.gps_attn_set_stream_min_tiles(1, 10)
     FA.set_spatial_planes(True)
-    FA.set_plain_blocks(True)
+    FA.set_plain_mode()
 
 
 def _skip_duplicates(family, L, spatial):
@@ -94,6 +97,8 @@ def _skip_duplicates(family, L, spatial):
         pytest.skip("the plane form is the spatial term's, up to 144 tokens")
     if family == "blocks" and spatial:
         pytest.skip("the block-streaming kernels serve the plain form")
+    if family == "kv-resident" and (spatial or L > 144):
+        pytest.skip("the K / V-resident plain kernels serve fixed-length rows up to 144 tokens")
 
 
 @pytest.mark.parametrize("B,L,spatial", CASES)
@@ -131,7 +136,7 @@ def test_streaming_and_resident_kernels_agree_at_the_switch():
     more) must give the same first 144 rows to bf16 rounding, with dropout active (one shared RNG stream)."""
     from sceneverse_amd import _native
     from sceneverse_amd.modules.layers import fused_attention as FA
-    FA.set_plain_blocks(False)                                # the general kernels' own two families
+    FA.set_plain_mode(0)                                      # the general kernels' own two families
     _native.load().gps_attn_set_stream_min_tiles(10, 10)      # the plain form streams from one tile on by default
     packed, _, _ = _inputs(2, 145, False, seed=31, pad=False)
     mask = torch.zeros(2, 145, dtype=torch.bool)
@@ -141,13 +146,13 @@ def test_streaming_and_resident_kernels_agree_at_the_switch():
     o145 = _FusedSelfAttention.apply(x145, None, mask.to(DEV), H, 0.0, 0, None)
     o144 = _FusedSelfAttention.apply(x144, None, None, H, 0.0, 0, None)
     _native.load().gps_attn_set_stream_min_tiles(1, 10)
-    FA.set_plain_blocks(True)
+    FA.set_plain_mode()
     _close(o145[:, :144], o144, 1e-2, "switch")
 
 
 @pytest.mark.parametrize("L", [80, 200, 300])
 def test_dropout_is_reproducible_linear_and_adjoint(L, family):
-    if family in ("planes", "blocks"):
+    if family in ("planes", "blocks", "kv-resident"):
         pytest.skip("this test drives the SPATIAL form with dropout: served by the general kernels (other families)")
     _skip_duplicates(family, L, True)
     B = 2

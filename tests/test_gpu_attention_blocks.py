@@ -4,7 +4,8 @@ inputs -- same dropout stream (one hash per (query, key pair)), same lse -- so t
 dropout ON, for every call form of the step: fixed-length self-attention with a key-padding mask (unified encoder),
 packed variable-length sequences with dispatch order and query limit (BERT), cross-attention (decoder layers).
 The fp32 formulation itself is the oracle of tests/test_gpu_attention.py / test_gpu_attention_ex.py, which run on the
-block-streaming kernels by default."""
+block-streaming kernels by default.  The K / V-resident plain kernels of gps_attention_sp.hip (fixed-length rows up to 144
+tokens: the joint sequences) take the same comparison (mode 4)."""
 import pytest
 import torch
 
@@ -22,20 +23,25 @@ def _close(a, b, tol, what):
     assert err <= tol * ref + 1e-6, (what, err, ref)
 
 
-def _both(run):
+def _both(run, new_mode=3):
+    """run() on the whole-sequence kernels (mode 0) and on `new_mode` (3 = block-streaming forward + backward,
+    4 = K / V-resident)."""
     res = {}
-    for name, flag in (("whole", False), ("blocks", True)):
-        FA.set_plain_blocks(flag)
+    for name, mode in (("whole", 0), ("new", new_mode)):
+        FA.set_plain_mode(mode)
         try:
             res[name] = run()
         finally:
-            FA.set_plain_blocks(True)
-    return res["whole"], res["blocks"]
+            FA.set_plain_mode()
+    return res["whole"], res["new"]
 
 
-@pytest.mark.parametrize("B,L", [(8, 130), (3, 130), (2, 64), (2, 65), (1, 1), (2, 300), (2, 512), (5, 37)])
+@pytest.mark.parametrize("B,L", [(8, 130), (3, 130), (2, 64), (2, 65), (1, 1), (2, 300), (2, 512), (5, 37), (64, 130), (2, 144), (3, 80), (2, 81)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_self_attention_with_mask_and_dropout(B, L, p):
+@pytest.mark.parametrize("mode", [3, 4])
+def test_self_attention_with_mask_and_dropout(B, L, p, mode):
+    if mode == 4 and L > 144:
+        pytest.skip("the K / V-resident kernels serve rows up to 144 tokens")
     g = torch.Generator().manual_seed(B * 100 + L)
     packed = torch.randn(B, L, 3 * D, generator=g).to(torch.bfloat16).to(DEV)
     n_real = torch.randint(1, L + 1, (B,), generator=g)
@@ -49,7 +55,7 @@ def test_self_attention_with_mask_and_dropout(B, L, p):
         out = FA._FusedSelfAttention.apply(x, None, mask, H, p, 77, seed_dev if p else None)
         out.backward(go)
         return out.detach(), x.grad.detach()
-    (o_w, g_w), (o_b, g_b) = _both(run)
+    (o_w, g_w), (o_b, g_b) = _both(run, mode)
     valid = ~mask
     assert torch.isfinite(o_b[valid]).all() and torch.isfinite(g_b).all()
     _close(o_b[valid], o_w[valid], 1e-2, "out")

@@ -464,6 +464,12 @@ def test_bench_config_step_against_the_fp32_oracle_port():
         cfgb = model.lang_encoder.model.config
         cfgb.hidden_dropout_prob = cfgb.attention_probs_dropout_prob = 0.0
 
+    # A/B runs of the attention kernel families (tools/gpu_r5_ab.sh): GPS_TEST_SPATIAL_PLANES=0 / GPS_TEST_PLAIN_MODE=<mask>
+    from sceneverse_amd.modules.layers import fused_attention as FA
+    if os.environ.get("GPS_TEST_SPATIAL_PLANES"):
+        FA.set_spatial_planes(os.environ["GPS_TEST_SPATIAL_PLANES"] != "0")
+    if os.environ.get("GPS_TEST_PLAIN_MODE"):
+        FA.set_plain_mode(int(os.environ["GPS_TEST_PLAIN_MODE"]))
     lp = _lang_dir()
     data = _bench_slice(2)
     eager = GPSTrainStep(gps_pretrain_cfg(lp), device=DEV, ddp=False, graph=False, seed=11)

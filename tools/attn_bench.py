@@ -99,8 +99,8 @@ def joint_case(B, L, iters):
     go = torch.randn(B, L, D, generator=g).to(torch.bfloat16).to(DEV)
     res, outs = {}, {}
     seed_dev = FA._next_device_seed(torch.device(DEV))
-    for name, blocks in (("whole", False), ("blocks", True)):
-        FA.set_plain_blocks(blocks)
+    for name, mode in (("whole", 0), ("blocks", 3), ("resident", 4)):
+        FA.set_plain_mode(mode)
         print("  joint", name, flush=True)
         for p in (0.0, 0.1):
             x = packed.clone().requires_grad_(True)
@@ -110,11 +110,12 @@ def joint_case(B, L, iters):
             outs[(name, p)] = (out.detach(), x.grad.detach())
             res[f"{name}_fwd_us_p{p}"], res[f"{name}_bwd_us_p{p}"] = time_fwd_bwd(
                 lambda t: FA._FusedSelfAttention.apply(t, None, mask, H, p, 0, seed_dev if p else None), packed, go, iters)
-    FA.set_plain_blocks(True)
+    FA.set_plain_mode()
     valid = ~mask
     for p in (0.0, 0.1):
-        res[f"out_vs_whole_p{p}"] = rel(outs[("blocks", p)][0][valid], outs[("whole", p)][0][valid])
-        res[f"grad_vs_whole_p{p}"] = rel(outs[("blocks", p)][1][valid], outs[("whole", p)][1][valid])
+        for fam in ("blocks", "resident"):
+            res[f"{fam}_out_vs_whole_p{p}"] = rel(outs[(fam, p)][0][valid], outs[("whole", p)][0][valid])
+            res[f"{fam}_grad_vs_whole_p{p}"] = rel(outs[(fam, p)][1][valid], outs[("whole", p)][1][valid])
     return res
 
 
@@ -133,8 +134,8 @@ def text_case(iters, full=False):
     res = {"rows": T, "sum_len_sq": int((lens.double() ** 2).sum())}
     outs = {}
     seed_dev = FA._next_device_seed(torch.device(DEV))
-    for name, blocks in (("whole", False), ("blocks", True)):
-        FA.set_plain_blocks(blocks)
+    for name, mode in (("whole", 0), ("blocks", 3)):
+        FA.set_plain_mode(mode)
         print("  text", name, flush=True)
         for p in (0.0, 0.1):
             def run(t):
@@ -145,7 +146,7 @@ def text_case(iters, full=False):
             torch.cuda.synchronize()
             outs[(name, p)] = (out.detach(), x.grad.detach())
             res[f"{name}_fwd_us_p{p}"], res[f"{name}_bwd_us_p{p}"] = time_fwd_bwd(run, packed, go, iters)
-    FA.set_plain_blocks(True)
+    FA.set_plain_mode()
     for p in (0.0, 0.1):
         res[f"out_vs_whole_p{p}"] = rel(outs[("blocks", p)][0], outs[("whole", p)][0])
         res[f"grad_vs_whole_p{p}"] = rel(outs[("blocks", p)][1], outs[("whole", p)][1])
