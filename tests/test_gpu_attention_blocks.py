@@ -59,8 +59,12 @@ def test_self_attention_with_mask_and_dropout(B, L, p, mode):
     valid = ~mask
     assert torch.isfinite(o_b[valid]).all() and torch.isfinite(g_b).all()
     _close(o_b[valid], o_w[valid], 1e-2, "out")
+    # scale = the whole gradient tensor's: with one live key dq and dk are exactly 0 in exact arithmetic and whatever the
+    # family's delta (rowsum(dO * O) from the bf16 output, or rowsum(P dP) in fp32) leaves of the cancellation otherwise
+    scale = g_w[valid].abs().max().item()
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
-        _close(g_b[valid][..., sl], g_w[valid][..., sl], 1.5e-2, name)
+        err = (g_b[valid][..., sl].float() - g_w[valid][..., sl].float()).abs().max().item()
+        assert err <= 1.5e-2 * scale + 1e-6, (name, err, scale)
     assert g_b[..., D:][mask].abs().max().item() == 0.0 if mask.any() else True      # padded keys: no dk / dv
 
 
