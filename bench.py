@@ -247,28 +247,44 @@ def _cpu_baseline_inproc(batch_size: int, steps: int, n_obj: int, n_pts: int, th
 
 
 def cpu_baseline(batch_size: int, steps: int, n_obj: int, n_pts: int) -> dict:
-    """Runs the CPU baseline in a child process with a wall-clock bound, on min(64, host cores) torch threads: with all
-    256 threads of the GPU box's host the small operators of this model thrash and the sample does not finish in
-    120 s (measured in round 2), so that attempt only runs when GPS_CPU_BASELINE_THREADS asks for it.  The returned
-    record says how many threads were used (`cores`) and how many the host has (`host_cores`)."""
+    """The CPU baseline, each kind in its own child process with a wall-clock bound, on min(64, host cores) torch threads
+    (with all 256 threads of the GPU box's host the small operators of this model thrash and the sample does not finish
+    in 120 s -- measured in round 2 -- so that attempt only runs when GPS_CPU_BASELINE_THREADS asks for it):
+      kind "reference"  the reference's OWN model.openvocab.OpenVocab / modules/ / optim.loss.Loss, imported unmodified
+                        (oracle/ref_cpu_baseline.py: /root/reference, or oracle/_ref/ref_python.zip on the GPU box), its
+                        point ops on the CPU oracle -- what SURVEY.md 8(d) defines as the baseline;
+      kind "port"       the functional fp32 restatement of the same step (oracle/gps_torch_reference.py), reported beside
+                        it under "port" (and alone, with a note, where the reference's files are not available).
+    The record says how many threads were used (`cores`) and how many the host has (`host_cores`)."""
     import subprocess
     total = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = int(os.environ.get("GPS_CPU_BASELINE_THREADS", str(min(64, total))))
     limit = float(os.environ.get("GPS_CPU_BASELINE_LIMIT_S", "150"))
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
-           json.dumps([batch_size, steps, n_obj, n_pts, threads])]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode == 0 and lines:
-            out = json.loads(lines[-1])
-            out["host_cores"] = total
-            return out
-        note = f"{threads} threads: worker failed ({r.stderr[-200:]!r})"
-    except subprocess.TimeoutExpired:
-        note = f"{threads} threads: no result within {limit:.0f} s"
+
+    def worker(kind):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
+               json.dumps([batch_size, steps, n_obj, n_pts, threads, kind])]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                out = json.loads(lines[-1])
+                out["host_cores"] = total
+                return out, None
+            return None, f"{kind}, {threads} threads: worker failed ({r.stderr[-200:]!r})"
+        except subprocess.TimeoutExpired:
+            return None, f"{kind}, {threads} threads: no result within {limit:.0f} s"
+
+    ref, ref_note = worker("reference")
+    port, port_note = worker("port")
+    if ref is not None:
+        ref["port"] = port if port is not None else {"value": None, "note": port_note}
+        return ref
+    if port is not None:
+        port["note"] = f"kind 'reference' not measured: {ref_note}"
+        return port
     return {"value": None, "unit": "pairs/s", "cores": None, "kind": "port", "sample": "not measured", "host_cores": total,
-            "note": note}
+            "note": f"{ref_note}; {port_note}"}
 
 
 def _free_port() -> int:
@@ -430,8 +446,12 @@ def main() -> None:
     args = ap.parse_args()
 
     if args.cpu_baseline_worker:
-        b, st, no, npts, th = json.loads(args.cpu_baseline_worker)
-        print(json.dumps(_cpu_baseline_inproc(b, st, no, npts, th)), flush=True)
+        b, st, no, npts, th, kind = json.loads(args.cpu_baseline_worker)
+        if kind == "reference":            # the reference's own modules/ + model/ on the CPU oracle ops
+            from oracle import ref_cpu_baseline
+            print(json.dumps(ref_cpu_baseline.run(b, st, no, npts, th)), flush=True)
+        else:
+            print(json.dumps(_cpu_baseline_inproc(b, st, no, npts, th)), flush=True)
         return
     preset = WORKLOADS[args.config]
     args.batch = preset["batch"] if args.batch is None else args.batch

@@ -6,6 +6,8 @@ tests/test_reference_trainer_dropin.py (the reference's unmodified `DefaultTrain
 libgps_hip.so) had never executed anywhere.  This script packs the packages that test imports
 
     trainer/  optim/  evaluator/  common/  data/          (python files only)
+    modules/  model/                                       (the reference's own model: bench.py's CPU baseline of kind
+                                                            "reference", oracle/ref_cpu_baseline.py -- SURVEY.md 8(d))
 
 from where they lie into a zip the test puts on sys.path (zipimport) when /root/reference is absent.  Nothing is
 unpacked into the repository, the archive is git-ignored (oracle/_ref/), and no product module ever opens it.
@@ -19,7 +21,7 @@ import zipfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref", "ref_python.zip")
 REF = "/root/reference"
-PACKAGES = ("trainer", "optim", "evaluator", "common", "data")
+PACKAGES = ("trainer", "optim", "evaluator", "common", "data", "modules", "model")
 
 
 def built_path() -> str | None:
