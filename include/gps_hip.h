@@ -533,6 +533,10 @@ GPS_API int gps_loc_embed_backward(int n_rows, int k_in, int d, const float *dy,
  *   GPS_GEMM_EPI_BIAS_RELU  C = dropout(relu(acc + bias))
  *   GPS_GEMM_EPI_DGELU      C = acc * gelu'(aux) * dropout-mask              (aux (M,N) bf16 = saved pre)
  *   GPS_GEMM_EPI_DRELU      C = acc * (aux != 0 ? 1/(1-p) : 0)               (aux (M,N) bf16 = saved dropout(relu()))
+ *   GPS_GEMM_EPI_BIAS_GELU_FACTOR  C as GPS_GEMM_EPI_BIAS_GELU; aux_out = bf16(gelu'(pre) * dropout-mask / (1 - p)): the
+ *                           factor the backward pass multiplies by (it costs the forward epilogue four more vector
+ *                           instructions per element -- the erf terms are shared -- and saves the backward ~30)
+ *   GPS_GEMM_EPI_MUL_AUX    C = acc * aux                                    (aux (M,N) bf16 = that saved factor)
  *   GPS_GEMM_EPI_RELU_SPLIT v = relu(acc + bias) written as a bf16 pair hi = rne(v), lo = rne(v - hi):
  *                           C[m][n] = hi, C[m][N + n] = lo, C[m][2N + n] = hi (ldc >= 3N): the [hi | lo | hi] operand
  *                           that, against weights laid out [W_hi | W_hi | W_lo] along K, gives the next layer's
@@ -553,6 +557,8 @@ GPS_API int gps_loc_embed_backward(int n_rows, int k_in, int d, const float *dy,
 #define GPS_GEMM_NT 0
 #define GPS_GEMM_NN 1
 #define GPS_GEMM_TN 2
+#define GPS_GEMM_EPI_BIAS_GELU_FACTOR 8
+#define GPS_GEMM_EPI_MUL_AUX 9
 #define GPS_GEMM_EPI_BIAS 0
 #define GPS_GEMM_EPI_BIAS_GELU 1
 #define GPS_GEMM_EPI_BIAS_RELU 2

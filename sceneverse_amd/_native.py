@@ -72,6 +72,7 @@ ATTN_COMPUTE_NATIVE, ATTN_COMPUTE_FP8 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32 = 0, 1, 2, 3, 4, 5
 EPI_RELU_SPLIT, EPI_RELU_MAX16 = 6, 7
+EPI_BIAS_GELU_FACTOR, EPI_MUL_AUX = 8, 9
 
 # name -> argtypes, mirroring include/gps_hip.h one to one
 SIGNATURES = {

@@ -51,6 +51,9 @@ enum Epi : int {
   EPI_F32 = 5,         // C fp32 = acc (splits == 1) or partial[split] = acc; optional column sums of A
   EPI_RELU_SPLIT = 6,  // v = relu(acc + bias) as a bf16 pair (hi, lo = v - hi): C[m][n | N + n | 2N + n] = hi | lo | hi
   EPI_RELU_MAX16 = 7,  // C fp32 [m / 16][n] = max over the 16 rows of the block of relu(acc + bias)
+  EPI_BIAS_GELU_FACTOR = 8,  // as EPI_BIAS_GELU, but aux_out bf16 = gelu'(bf16(pre)) * dropout-mask / (1 - p): the factor the
+                             // backward pass multiplies by, computed here from the erf terms the activation needs anyway
+  EPI_MUL_AUX = 9,     // C bf16 = acc * aux                                        (aux = that saved factor)
 };
 
 struct Params {
@@ -131,6 +134,13 @@ __device__ __forceinline__ float dgelu_f(float x) {
   float er, e;
   erf_terms(x, er, e);
   return 0.5f * (1.f + copysignf(er, x)) + x * 0.3989422804014327f * e;
+}
+__device__ __forceinline__ void gelu_and_dgelu(float x, float &g, float &dg) {    // both from one set of erf terms
+  float er, e;
+  erf_terms(x, er, e);
+  const float cdf = 0.5f * (1.f + copysignf(er, x));
+  g = x * cdf;
+  dg = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 __device__ __forceinline__ void glds16(const void *src, void *lds_dst) {
@@ -436,6 +446,29 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
       v[1] = gelu_f(bf2f((uint16_t)(pre[0] >> 16)));
       v[2] = gelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
       v[3] = gelu_f(bf2f((uint16_t)(pre[1] >> 16)));
+    } else if (EPI == EPI_BIAS_GELU_FACTOR) {
+      // the activation from the bf16-rounded pre-activation (as EPI_BIAS_GELU), and the backward factor beside it
+      const u32x2 pr = pack4(v);
+      f32x4 fac;
+      gelu_and_dgelu(bf2f((uint16_t)(pr[0] & 0xFFFFu)), v[0], fac[0]);
+      gelu_and_dgelu(bf2f((uint16_t)(pr[0] >> 16)), v[1], fac[1]);
+      gelu_and_dgelu(bf2f((uint16_t)(pr[1] & 0xFFFFu)), v[2], fac[2]);
+      gelu_and_dgelu(bf2f((uint16_t)(pr[1] >> 16)), v[3], fac[3]);
+      if (dropout) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float k = rng_u32(seed, idx + r) >= P.drop_thr ? P.keep_scale : 0.f;
+          v[r] *= k;
+          fac[r] *= k;
+        }
+      }
+      pre = pack4(fac);
+      return pack4(v);
+    } else if (EPI == EPI_MUL_AUX) {
+      v[0] *= bf2f((uint16_t)(aux4[0] & 0xFFFFu));
+      v[1] *= __uint_as_float(aux4[0] & 0xFFFF0000u);
+      v[2] *= bf2f((uint16_t)(aux4[1] & 0xFFFFu));
+      v[3] *= __uint_as_float(aux4[1] & 0xFFFF0000u);
     } else if (EPI == EPI_BIAS_RELU) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -468,8 +501,9 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
     }
     return pack4(v);
   };
-  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_RELU_SPLIT;
-  constexpr bool HAS_AUX = EPI == EPI_DGELU || EPI == EPI_DRELU;
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_RELU_SPLIT || EPI == EPI_BIAS_GELU_FACTOR;
+  constexpr bool HAS_AUX = EPI == EPI_DGELU || EPI == EPI_DRELU || EPI == EPI_MUL_AUX;
+  constexpr bool HAS_PRE = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FACTOR;      // second bf16 output through aux_out
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins: device pass only
   // Everything goes through buffer descriptors with exact sizes: rows past M fall outside the descriptor and are
   // dropped (stores) or read as zero (loads) by the hardware, columns past N are sent there on purpose (kOOB) --
@@ -480,7 +514,7 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   const auto bytes_of = [&](long long ld) { return (unsigned int)((((long long)P.M - 1) * ld + P.N) * 2); };
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, bytes_of(P.ldc) + (EPI == EPI_RELU_SPLIT ? 4u * P.N : 0u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(P.aux), 0, HAS_AUX ? bytes_of(P.ldaux) : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rPre = __builtin_amdgcn_make_buffer_rsrc(P.aux_out, 0, (EPI == EPI_BIAS_GELU && P.aux_out) ? bytes_of(P.ldaux_out) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rPre = __builtin_amdgcn_make_buffer_rsrc(P.aux_out, 0, (HAS_PRE && P.aux_out) ? bytes_of(P.ldaux_out) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.bias), 0, (HAS_BIAS && P.bias) ? 4u * P.N : 0u, 0x00020000);
   // Pairs of adjacent 16-column fragments leave as 16-byte stores: inside a pair, the even lane groups (g = 0, 2)
   // send their 4 columns of fragment b + 1 to the odd group next to them and receive that group's 4 columns of
@@ -488,7 +522,7 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   // natural 8-byte form (the epilogue is store-ISSUE bound, guide T21).  Needs whole 8-column groups (N % 8 == 0)
   // and 16-byte aligned rows; otherwise the 8-byte form below.
   const bool wide = (TN % 2 == 0) && (P.N % 8 == 0) && (P.ldc % 8 == 0) &&
-                    (EPI != EPI_BIAS_GELU || P.aux_out == nullptr || P.ldaux_out % 8 == 0);
+                    (!HAS_PRE || P.aux_out == nullptr || P.ldaux_out % 8 == 0);
   if (EPI == EPI_RELU_SPLIT && !wide) return;        // the C entry point only admits N % 8 == 0 == ldc % 8 for this form
   // ---- all loads first ----
   f32x4 bias[TN];
@@ -524,7 +558,7 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
         const u32x4 out = odd ? u32x4{recv[0], recv[1], o1[0], o1[1]} : u32x4{o0[0], o0[1], recv[0], recv[1]};
         const unsigned int off = (unsigned int)(((long long)m * P.ldc + n_out) * 2) | col_ok;
         __builtin_amdgcn_raw_buffer_store_b128(out, rC, off, 0, 0);
-        if (EPI == EPI_RELU_SPLIT || EPI == EPI_BIAS_GELU) {
+        if (EPI == EPI_RELU_SPLIT || HAS_PRE) {
           const u32x2 sp = odd ? pre0 : pre1;
           const u32x2 rp = {(unsigned int)__shfl_xor((int)sp[0], 16, 64), (unsigned int)__shfl_xor((int)sp[1], 16, 64)};
           const u32x4 po = odd ? u32x4{rp[0], rp[1], pre1[0], pre1[1]} : u32x4{pre0[0], pre0[1], rp[0], rp[1]};
@@ -548,7 +582,7 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
       const int m = m0 + wm0 + 16 * a + i;
       u32x2 pre = {0u, 0u};
       const u32x2 o = finish(acc[a][b], m, n, bias[b], aux[a][b], pre);
-      if (EPI == EPI_BIAS_GELU)
+      if (HAS_PRE)
         __builtin_amdgcn_raw_buffer_store_b64(pre, rPre, (unsigned int)(((long long)m * P.ldaux_out + n) * 2) | col_ok, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b64(o, rC, (unsigned int)(((long long)m * P.ldc + n) * 2) | col_ok, 0, 0);
     }
@@ -1607,7 +1641,7 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
 int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   using namespace gps_gemm;
   if (!a || a->M < 0 || a->N < 0 || a->K < 0) return GPS_ERR_INVALID_ARGUMENT;
-  if (a->form < 0 || a->form > 2 || a->epilogue < 0 || a->epilogue > 7) return GPS_ERR_INVALID_ARGUMENT;
+  if (a->form < 0 || a->form > 2 || a->epilogue < 0 || a->epilogue > 9) return GPS_ERR_INVALID_ARGUMENT;
   if (a->M == 0 || a->N == 0) return GPS_OK;
   if (!a->A || !a->B || !a->C) return GPS_ERR_INVALID_ARGUMENT;
   // 16-byte global chunks and 8 / 16-byte stores: leading dimensions in multiples of 8 elements, N of 4, K of 8
@@ -1635,7 +1669,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   if (a->ldc & 3) return GPS_ERR_UNSUPPORTED;
   if (a->form == GPS_GEMM_TN && (a->M & 7)) return GPS_ERR_UNSUPPORTED;     // A is M-contiguous there
   if (a->form != GPS_GEMM_NT && (a->N & 7)) return GPS_ERR_UNSUPPORTED;     // B is N-contiguous there
-  if ((a->epilogue == GPS_GEMM_EPI_DGELU || a->epilogue == GPS_GEMM_EPI_DRELU) && (!a->aux || (a->ldaux & 3)))
+  if ((a->epilogue == GPS_GEMM_EPI_DGELU || a->epilogue == GPS_GEMM_EPI_DRELU || a->epilogue == GPS_GEMM_EPI_MUL_AUX) && (!a->aux || (a->ldaux & 3)))
     return GPS_ERR_INVALID_ARGUMENT;
   if (a->aux_out && (a->ldaux_out & 3)) return GPS_ERR_UNSUPPORTED;
   if (a->p_drop < 0.f || a->p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
@@ -1682,6 +1716,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
       case GPS_GEMM_EPI_BIAS: st = launch_variant<false, false, EPI_BIAS>(P, variant, s); break;
       case GPS_GEMM_EPI_BIAS_GELU: st = launch_variant<false, false, EPI_BIAS_GELU>(P, variant, s); break;
       case GPS_GEMM_EPI_BIAS_RELU: st = launch_variant<false, false, EPI_BIAS_RELU>(P, variant, s); break;
+      case GPS_GEMM_EPI_BIAS_GELU_FACTOR: st = launch_variant<false, false, EPI_BIAS_GELU_FACTOR>(P, variant, s); break;
       // the split-bf16 MLP forms exist for the two default tile configurations and the two-group 256 x 256 kernel only
       case GPS_GEMM_EPI_RELU_SPLIT:
         st = (variant == 12 && P.K % BK == 0 && P.K >= BK) ? launch_8p<false, false, EPI_RELU_SPLIT>(P, s)
@@ -1700,6 +1735,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
       case GPS_GEMM_EPI_BIAS: st = launch_variant<false, true, EPI_BIAS>(P, variant, s); break;
       case GPS_GEMM_EPI_DGELU: st = launch_variant<false, true, EPI_DGELU>(P, variant, s); break;
       case GPS_GEMM_EPI_DRELU: st = launch_variant<false, true, EPI_DRELU>(P, variant, s); break;
+      case GPS_GEMM_EPI_MUL_AUX: st = launch_variant<false, true, EPI_MUL_AUX>(P, variant, s); break;
       case GPS_GEMM_EPI_F32: {
         if (P.splits > 1) {
           if (!a->workspace) return GPS_ERR_INVALID_ARGUMENT;

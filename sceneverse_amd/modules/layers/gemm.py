@@ -27,7 +27,8 @@ from typing import Optional, Sequence
 import torch
 
 from ... import _native
-from ..._native import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32, EPI_RELU_MAX16, EPI_RELU_SPLIT,
+from ..._native import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_FACTOR, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32, EPI_MUL_AUX,
+                        EPI_RELU_MAX16, EPI_RELU_SPLIT,
                         GEMM_NN, GEMM_NT,
                         GEMM_TN, GemmArgs)
 
@@ -113,6 +114,8 @@ def linear_forward(x16: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Te
                    p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None, want_pre: bool = False,
                    rows_dev: Optional[torch.Tensor] = None):
     """x16 (T, K) bf16, w16 (N, K) bf16, bias (N) fp32 -> y (T, N) bf16 [, pre-activation (T, N) bf16].
+    want_pre = "factor" (gelu): the second output is gelu'(pre) x dropout-mask / (1 - p) instead -- what the backward
+    pass multiplies by (`linear_dgrad(act="factor")`), from the erf terms the activation computes anyway.
     rows_dev (all three contractions): int32 device word, the number of leading token rows that carry work; tiles of
     rows past it are skipped (their output rows stay unwritten), the weight gradient sums the live rows only."""
     T, K = x16.shape
@@ -120,6 +123,8 @@ def linear_forward(x16: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Te
     y = torch.empty((T, N), dtype=torch.bfloat16, device=x16.device)
     pre = torch.empty_like(y) if (want_pre and act == "gelu") else None
     epi = {None: EPI_BIAS, "gelu": EPI_BIAS_GELU, "relu": EPI_BIAS_RELU}[act]
+    if want_pre == "factor" and act == "gelu":
+        epi = EPI_BIAS_GELU_FACTOR
     gemm(GEMM_NT, epi, T, N, K, x16, x16.stride(0), w16, w16.stride(0), y, N, bias=bias, aux_out=pre, ldaux_out=N,
          p_drop=p_drop if act else 0.0, seed_dev=seed_dev, extent_dev=rows_dev)
     return (y, pre) if want_pre else y
@@ -129,13 +134,14 @@ def linear_dgrad(dy16: torch.Tensor, w16: torch.Tensor, act: Optional[str] = Non
                  p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None,
                  rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy16 (T, N) bf16, w16 (N, K) bf16 -> dx (T, K) bf16 = dy W, optionally times the derivative of the
-    activation that PRODUCED this layer's input (aux = its saved pre-activation (gelu) / output (relu))."""
+    activation that PRODUCED this layer's input (aux = its saved pre-activation (gelu) / output (relu)), or -- act
+    "factor" -- times aux itself (the factor `linear_forward(want_pre="factor")` saved: derivative x dropout mask)."""
     T, N = dy16.shape
     K = w16.shape[1]
     dx = torch.empty((T, K), dtype=torch.bfloat16, device=dy16.device)
-    epi = {None: EPI_BIAS, "gelu": EPI_DGELU, "relu": EPI_DRELU}[act]
+    epi = {None: EPI_BIAS, "gelu": EPI_DGELU, "relu": EPI_DRELU, "factor": EPI_MUL_AUX}[act]
     gemm(GEMM_NN, epi, T, K, N, dy16, dy16.stride(0), w16, w16.stride(0), dx, K, aux=aux,
-         ldaux=aux.stride(0) if aux is not None else 0, p_drop=p_drop if act else 0.0, seed_dev=seed_dev,
+         ldaux=aux.stride(0) if aux is not None else 0, p_drop=p_drop if act in ("gelu", "relu") else 0.0, seed_dev=seed_dev,
          extent_dev=rows_dev)
     return dx
 
@@ -749,6 +755,14 @@ def packed_linear(x: torch.Tensor, layers: Sequence[torch.nn.Linear], rows_dev: 
     return _LinearFn.apply(x, len(layers), *[m.weight for m in layers], *[m.bias for m in layers], *extra)
 
 
+_GELU_FACTOR = True          # False: save the pre-activation and recompute gelu' and the mask in the backward epilogue (A/B, tests)
+
+
+def set_gelu_factor(flag: bool) -> None:
+    global _GELU_FACTOR
+    _GELU_FACTOR = bool(flag)
+
+
 class _FFNFn(torch.autograd.Function):
     """y = dropout(act(x W1^T + b1)) W2^T + b2 : two forward GEMMs, four backward GEMMs, no elementwise launch."""
 
@@ -757,7 +771,11 @@ class _FFNFn(torch.autograd.Function):
         w1_16, b1_32 = shadow_of((w1,), (b1,))
         w2_16, b2_32 = shadow_of((w2,), (b2,))
         x16 = _as_rows16(x)
-        h, pre = linear_forward(x16, w1_16, b1_32, act=act, p_drop=p_drop, seed_dev=seed_dev, want_pre=True, rows_dev=rows_dev)
+        # gelu: the forward epilogue saves gelu'(pre) x dropout-mask / (1 - p) (one multiply per element in the backward
+        # epilogue instead of the erf terms and the mask hash: gps_gemm.hip EPI_BIAS_GELU_FACTOR / EPI_MUL_AUX)
+        h, pre = linear_forward(x16, w1_16, b1_32, act=act, p_drop=p_drop, seed_dev=seed_dev,
+                                want_pre="factor" if (act == "gelu" and _GELU_FACTOR) else True, rows_dev=rows_dev)
+        ctx.gelu_factor = act == "gelu" and _GELU_FACTOR
         y = linear_forward(h, w2_16, b2_32, rows_dev=rows_dev)
         ctx.rows_dev = rows_dev
         ctx.save_for_backward(x16, w1_16, w2_16, h, pre, seed_dev)
@@ -777,7 +795,8 @@ class _FFNFn(torch.autograd.Function):
         rd = ctx.rows_dev
         if not (all_w and _wgrad_to_params(dy16, h, (w2,), (b2,), (w2.shape[0],), rd)):
             dw2, db2 = linear_wgrad(dy16, h, want_bias=has_b2, rows_dev=rd)
-        dpre = linear_dgrad(dy16, w2_16, act=act, aux=pre if act == "gelu" else h, p_drop=p_drop, seed_dev=seed_dev, rows_dev=rd)
+        dpre = linear_dgrad(dy16, w2_16, act="factor" if ctx.gelu_factor else act, aux=pre if act == "gelu" else h, p_drop=p_drop,
+                            seed_dev=seed_dev, rows_dev=rd)
         if not (all_w and _wgrad_to_params(dpre, x16, (w1,), (b1,), (w1.shape[0],), rd)):
             dw1, db1 = linear_wgrad(dpre, x16, want_bias=has_b1, rows_dev=rd)
         dx = None

@@ -163,6 +163,31 @@ def test_activation_epilogues_forward_and_backward(act, p, forced_variant):
         _close16(dpre, ref, f"d{act} p={p}")
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gelu_factor_epilogues_equal_the_recomputing_pair(p, forced_variant):
+    """EPI_BIAS_GELU_FACTOR / EPI_MUL_AUX (the forward epilogue saves gelu'(pre) x dropout-mask / (1 - p), the backward
+    multiplies by it) against EPI_BIAS_GELU / EPI_DGELU (pre-activation saved, derivative and mask recomputed): the same
+    hidden activations bit for bit, the same input gradient to the bf16 rounding of the saved factor."""
+    T, Kin, Hid = (1300, 136, 264) if forced_variant < 0 else ((9000, 128, 1024) if forced_variant in (11, 12) else (9000, 136, 1032))
+    x, w1 = _rand16(T, Kin, seed=11), _rand16(Hid, Kin, scale=0.2, seed=12)
+    b1 = torch.randn(Hid, device=DEV)
+    seed_dev = torch.tensor([123456789], dtype=torch.int64, device=DEV)
+    h_a, pre = G.linear_forward(x, w1, b1, act="gelu", p_drop=p, seed_dev=seed_dev, want_pre=True)
+    h_b, fac = G.linear_forward(x, w1, b1, act="gelu", p_drop=p, seed_dev=seed_dev, want_pre="factor")
+    assert torch.equal(h_a, h_b)
+    z = pre.float().requires_grad_(True)
+    F.gelu(z).sum().backward()
+    mask = (h_a != 0) | (F.gelu(pre.float()).abs() < 1e-3) if p > 0 else torch.ones_like(h_a, dtype=torch.bool)
+    sel = F.gelu(pre.float()).abs() >= 1e-3 if p > 0 else mask
+    want = z.grad * mask.float() / (1 - p)
+    _close16(torch.where(sel, fac.float(), torch.zeros_like(want)), torch.where(sel, want, torch.zeros_like(want)), "saved factor")
+    Out = 128 if forced_variant in (11, 12) else 72
+    dy, w2 = _rand16(T, Out, seed=13), _rand16(Out, Hid, scale=0.2, seed=14)
+    d_a = G.linear_dgrad(dy, w2, act="gelu", aux=pre, p_drop=p, seed_dev=seed_dev)
+    d_b = G.linear_dgrad(dy, w2, act="factor", aux=fac)
+    _close16(d_b, d_a, f"input gradient p={p}")
+
+
 def _rel_l2(a, b):
     return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
 
