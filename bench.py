@@ -429,6 +429,8 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="N > 1: skip the start-up comparison of the split-graph step with eager torch DDP")
     ap.add_argument("--detail", default=None, help="where the per-kernel detail JSON goes (default gpurun_out/bench_detail.json)")
     ap.add_argument("--fp8", action="store_true",
                     help="attention-core products (QK^T, PV) on the OCP e4m3 MFMA path (BASELINE configs[4]: --config stress --fp8)")
@@ -498,6 +500,45 @@ def main() -> None:
     # backward | bottom backward | clip + AdamW as HIP graphs around the eager RCCL all-gather and the two all-reduces);
     # --eager-ddp keeps torch DDP in eager mode (~1 200 launches per step from Python) for A/B.
     use_graph = not args.no_graph and not (world > 1 and args.eager_ddp)
+    # N > 1, split-graph step: before anything is timed, the same engine class (dropout zeroed, a few scenes) runs its
+    # eager warm-up steps, its captures and a first replay beside torch DDP in eager mode from the same weights; losses,
+    # parameter checksums and the cross-rank identity of the parameters must agree (sceneverse_amd.engine.dp_self_check).
+    # A failed check does not abort the run: it falls back to --eager-ddp and says so in the line.
+    self_check = None
+    if world > 1 and use_graph and not args.no_self_check:
+        from sceneverse_amd.engine import dp_self_check
+
+        def make_engine(eager_ddp):
+            c = gps_pretrain_cfg(_lang_dir(), num_gpu=world, workload=args.config)
+            e = GPSTrainStep(c, device=dev, amp_dtype=None if args.fp32 else torch.bfloat16, graph=not eager_ddp, seed=4321,
+                             native_gemm=not args.no_native_gemm, wgrad_group=not args.no_wgrad_group)
+            for m in e.model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+                if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+                    m.dropout = 0.0
+            lm = getattr(getattr(e.model, "lang_encoder", None), "model", None)
+            if lm is not None:
+                lm.config.hidden_dropout_prob = lm.config.attention_probs_dropout_prob = 0.0
+                for m in lm.modules():
+                    if hasattr(m, "dropout") and hasattr(m.dropout, "p"):
+                        m.dropout.p = 0.0
+            return e
+        nb = min(args.batch, 8)
+        check_batches = []
+        for i in range(4):
+            cb = synth_batch(nb, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=900 + 10 * i + rank, device=dev)
+            if not preset["scene_cap"]:
+                cb.pop("scene_txt_ids"), cb.pop("scene_txt_masks")
+            check_batches.append(cb)
+        self_check = dp_self_check(make_engine, check_batches)
+        del check_batches
+        torch.cuda.empty_cache()
+        if not self_check["ok"]:
+            if rank == 0:
+                print(f"[bench] WARNING: split-graph data-parallel self-check FAILED ({self_check['reason']}); "
+                      "falling back to torch DDP in eager mode", file=sys.stderr)
+            args.eager_ddp, use_graph = True, False
     if args.wgrad_one_queue:
         from sceneverse_amd import _native as _nat
         _nat.load().gps_gemm_wgrad_grouped_set_xcd_queues(0)
@@ -506,6 +547,8 @@ def main() -> None:
                         grad_compress=("bf16_fp32acc" if (world > 1 and not share and args.bf16_grads) else None),
                         wgrad_overlap=args.wgrad_overlap, wgrad_group=not args.no_wgrad_group)
     use_graph = step.graph or step.graph_dp
+    if step.graph_dp:
+        step.time_exchange(True)
     batch = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank,
                         device=dev)
     if not preset["scene_cap"]:
@@ -549,6 +592,7 @@ def main() -> None:
         loss, _ = step.step(dict(batch))
     barrier()
     dt = time.perf_counter() - t0
+    exposed_ms = step.exposed_allreduce_ms() if step.graph_dp else None     # of the last timed step
     # The same step with EVERY sentence at 50 and every caption at 300 tokens (no padded text rows at all): what the
     # variable-length text path gains depends on the caption-length distribution of the synthetic batch (U{30..300}),
     # so the fully-populated figure is measured beside `value`, same process, same graphs (the row counts live on the
@@ -853,6 +897,8 @@ def main() -> None:
                                             "beside the next backward graph" if step.graph_dp
                            else "bf16 on the wire, fp32 accumulation (all-to-all + all-gather)"
                            if (args.bf16_grads and not share) else "fp32 all-reduce (DDP buckets)"} if world > 1 else {}),
+                       **({"dp_self_check": self_check} if self_check is not None else {}),
+                       **({"exposed_allreduce_ms": round(exposed_ms, 3)} if exposed_ms is not None else {}),
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
             "headline": headline,

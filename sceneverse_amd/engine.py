@@ -158,6 +158,7 @@ class GPSTrainStep:
         # section 9a).  With one stream every capture is a linear chain of nodes.
         self._work_stream = None
         self._acc_hooks, self._autograd_written = None, set()
+        self._exchange_events = None          # (start, end) events around the EXPOSED part of the gradient exchange
         # tests / diagnostics: called with a stage name at the capture / replay points of the split-graph step
         self.stage_hook = None
         if self.graph_dp and dist_utils.is_dist():
@@ -455,6 +456,7 @@ class GPSTrainStep:
         self._stage("replayed_gather")
         g2a.replay()
         self._stage("replayed_g2a")
+        ev = self._exchange_events
         if g2b is not None:
             handles = [self._allreduce_async(0, self._n_top)]          # overlaps the bottom segments' backward graphs
             for gi, gg in enumerate(g2b):
@@ -463,12 +465,31 @@ class GPSTrainStep:
                 if getattr(self, "_bottom_graphs_per_range", False) and gi + 1 < len(g2b):
                     handles.append(self._allreduce_async(self._seg_ends[gi], self._seg_ends[gi + 1]))
             done = self._seg_ends[len(handles) - 1]                    # ranges already on their way
+            if ev is not None:
+                ev[0].record()                                         # the last backward graph ends here
             handles.append(self._allreduce_async(done, self._flat_grad.numel()))
             self._wait_allreduce(*handles)
         else:
+            if ev is not None:
+                ev[0].record()
             self._allreduce_grads()
+        if ev is not None:
+            ev[1].record()                                             # every range reduced: clip + AdamW may start
         g3.replay()
         return total.detach().clone(), {k: v.detach().clone() for k, v in losses.items()}
+
+    def time_exchange(self, on: bool = True) -> None:
+        """Split-graph step: record an event pair around the part of the gradient exchange nothing overlaps (from the end
+        of the last backward graph to the moment every range is reduced); `exposed_allreduce_ms()` reads the last step's."""
+        self._exchange_events = ((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                 if on and self.device.type == "cuda" else None)
+
+    def exposed_allreduce_ms(self):
+        ev = self._exchange_events
+        if ev is None or self._graph is None or not self.graph_dp:
+            return None
+        ev[1].synchronize()
+        return float(ev[0].elapsed_time(ev[1]))
 
     def _new_graph(self):
         """Every graph of the captured steps is made here (tests subclass this to keep the hipGraph_t for inspection)."""
@@ -725,3 +746,63 @@ def scanrefer_accuracy(og3d_logits: torch.Tensor, iou25_onehot: torch.Tensor,
     hit50 = torch.gather(iou50_onehot, 1, pick).squeeze(1).bool()
     n = float(max(1, pred.shape[0]))
     return {"og_acc_iou25": hit25.sum().item() / n, "og_acc_iou50": hit50.sum().item() / n}
+
+
+def dp_self_check(make_engine, batches, rtol_loss: float = 2e-3, rtol_sum: float = 2e-3) -> dict:
+    """Start-up check of a data-parallel engine against torch DDP in eager mode, before anything is timed (bench.py
+    --gpus N): the first real contact of the split-graph step with an RCCL ring must fail LOUDLY, not hang or drift.
+
+    make_engine(eager_ddp: bool) -> GPSTrainStep built from the SAME seed with every dropout probability zeroed (so the
+    two runs are comparable step for step); batches: this rank's batches, enough to take the candidate through its eager
+    warm-up steps, its capture and a first replay.  Both engines run them in order.  Checked on every rank, reduced
+    over ranks:
+      * the losses of every step agree (candidate vs eager DDP) to rtol_loss,
+      * after the last step the sum and the sum of squares of all parameters agree to rtol_sum (the flat-gradient
+        checksum, integrated over the steps: a range that was reduced late, twice or not at all moves it),
+      * every rank holds the same parameters (max - min of the per-rank checksums is exactly 0 for the candidate:
+        identical initial weights + identical averaged gradients -- the invariant of data parallelism; a rank that
+        applied its own, un-reduced gradient breaks it).
+    -> {"ok": bool, "loss_rel_diff", "param_sum_rel_diff", "cross_rank_spread", "steps", "reason"}; collective: every
+    rank must call it."""
+    import torch.distributed as dist
+    world = dist_utils.get_world_size()
+
+    def run(eager_ddp):
+        eng = make_engine(eager_ddp)
+        losses = []
+        for b in batches:
+            loss, _ = eng.step(dict(b))
+            losses.append(float(loss))
+        with torch.no_grad():
+            ps = [p.detach().double() for p in eng.model.parameters() if p.requires_grad]
+            chk = torch.stack([sum(p.sum() for p in ps), sum((p * p).sum() for p in ps)])
+        replayed = getattr(eng, "_graph", None) is not None
+        del eng
+        return losses, chk, replayed
+
+    cand_losses, cand_chk, replayed = run(False)
+    ref_losses, ref_chk, _ = run(True)
+    dev = cand_chk.device
+    loss_diff = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(cand_losses, ref_losses))
+    sum_diff = float(((cand_chk - ref_chk).abs() / ref_chk.abs().clamp_min(1e-30)).max())
+    stats = torch.tensor([loss_diff, sum_diff, 0.0], dtype=torch.float64, device=dev)
+    spread = 0.0
+    if dist_utils.is_dist() and world > 1:
+        lo, hi = cand_chk.clone(), cand_chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
+        stats[2] = spread
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    loss_diff, sum_diff, spread = (float(x) for x in stats.tolist())
+    reasons = []
+    if not all(map(lambda v: v == v and abs(v) != float("inf"), cand_losses)):
+        reasons.append("non-finite loss")
+    if loss_diff > rtol_loss:
+        reasons.append(f"losses differ from eager DDP by {loss_diff:.2e}")
+    if sum_diff > rtol_sum:
+        reasons.append(f"parameter checksums differ from eager DDP by {sum_diff:.2e}")
+    if spread > 0.0:
+        reasons.append(f"ranks hold different parameters (spread {spread:.2e})")
+    return {"ok": not reasons, "loss_rel_diff": loss_diff, "param_sum_rel_diff": sum_diff, "cross_rank_spread": spread,
+            "steps": len(batches), "replayed_a_graph": bool(replayed), "reason": "; ".join(reasons) or None}

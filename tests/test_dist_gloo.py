@@ -233,6 +233,34 @@ def _worker(rank, world, port, tmp):
         for i in range(2):
             ddp.step(dict(synth_batch(2, n_obj=6, n_pts=1024, scene_txt_len=40,
                                       seed=200 + 10 * i + rank, min_real=3)))
+        # -- bench.py's start-up self-check (sceneverse_amd.engine.dp_self_check): the candidate data-parallel engine beside
+        #    eager torch DDP from the same weights.  On the CPU both are DDP (the split-graph form needs a GPU): the check
+        #    itself -- losses, parameter checksums, cross-rank identity -- runs over gloo with world 2; a rank that applies
+        #    an un-reduced update must be flagged.
+        from sceneverse_amd.engine import dp_self_check
+
+        def make_engine(eager_ddp, sabotage=False):
+            e = GPSTrainStep(_small_cfg(lp, world), device="cpu", ddp=True, seed=9)
+            for m in e.model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+                if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+                    m.dropout = 0.0
+            lm = e.model.lang_encoder.model
+            lm.config.hidden_dropout_prob = lm.config.attention_probs_dropout_prob = 0.0
+            if sabotage and not eager_ddp and rank == 1:
+                orig = e.step
+
+                def bad_step(d):                     # this rank drifts: what a lost all-reduce looks like
+                    out = orig(d)
+                    with torch.no_grad():
+                        next(p for p in e.model.parameters() if p.requires_grad).add_(1e-3)
+                    return out
+                e.step = bad_step
+            return e
+        cb = [synth_batch(2, n_obj=6, n_pts=1024, scene_txt_len=40, seed=300 + 10 * i + rank, min_real=3) for i in range(2)]
+        result["self_check"] = dp_self_check(make_engine, cb)
+        result["self_check_sabotaged"] = dp_self_check(lambda eager: make_engine(eager, sabotage=True), cb)
         flat = torch.cat([p.detach().flatten()[:64] for p in ddp.model.parameters()])
         both = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
@@ -263,3 +291,6 @@ def test_ddp_world_size_2_gloo():
         assert r["frozen_sets_equal"] and r["lm_head_kept"] and r["n_frozen_agreed"] >= 13, r
         assert r["probe_keeps_rng"] and r["probe_keeps_buffers"], r
         assert r["hook_vs_fp32_sum"] <= 2.0 ** -8 and r["hook_vs_exact"] <= 2.0 ** -7, r
+        assert r["self_check"]["ok"] and r["self_check"]["cross_rank_spread"] == 0.0 and r["self_check"]["steps"] == 2, r["self_check"]
+        bad = r["self_check_sabotaged"]                   # the same verdict on every rank (the statistics are reduced)
+        assert not bad["ok"] and bad["cross_rank_spread"] > 0.0 and "different parameters" in bad["reason"], bad

@@ -396,6 +396,11 @@ def test_bench_n2_code_path_on_one_gpu(extra):
     assert out["value"] > 0 and abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) < 0.02 * out["value"]
     assert "cpu_baseline" not in out and out["roofline"] is not None
     assert out["config"]["final_loss"] == out["config"]["final_loss"]
+    # the start-up self-check of the split-graph step against eager torch DDP ran and passed; the exposed part of the
+    # gradient exchange is reported
+    chk = out["config"]["dp_self_check"]
+    assert chk["ok"] and chk["replayed_a_graph"] and chk["cross_rank_spread"] == 0.0, chk
+    assert out["config"]["exposed_allreduce_ms"] >= 0.0
 
 
 def test_bench_self_spawns_its_ranks():
