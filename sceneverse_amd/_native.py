@@ -156,6 +156,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         except Exception as e:  # noqa: BLE001
             if not os.path.exists(LIB_PATH):
                 raise GpsNativeError(f"libgps_hip.so is missing and could not be built: {e}") from e
+            # a library that is OLDER than its sources must never be loaded silently (a source that no longer compiles
+            # would otherwise be "tested" through yesterday's binary); only a machine without hipcc may use what it has
+            if getattr(_build, "hipcc_available", lambda: True)():
+                raise GpsNativeError(f"libgps_hip.so is out of date and the rebuild failed: {e}") from e
     if not os.path.exists(LIB_PATH):
         raise GpsNativeError(f"{LIB_PATH} not found; run `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = ctypes.CDLL(LIB_PATH)

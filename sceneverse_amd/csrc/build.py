@@ -40,6 +40,10 @@ def hipcc() -> str:
     return exe
 
 
+def hipcc_available() -> bool:
+    return bool(shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

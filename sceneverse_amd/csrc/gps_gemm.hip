@@ -450,10 +450,15 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
       // the activation from the bf16-rounded pre-activation (as EPI_BIAS_GELU), and the backward factor beside it
       const u32x2 pr = pack4(v);
       f32x4 fac;
-      gelu_and_dgelu(bf2f((uint16_t)(pr[0] & 0xFFFFu)), v[0], fac[0]);
-      gelu_and_dgelu(bf2f((uint16_t)(pr[0] >> 16)), v[1], fac[1]);
-      gelu_and_dgelu(bf2f((uint16_t)(pr[1] & 0xFFFFu)), v[2], fac[2]);
-      gelu_and_dgelu(bf2f((uint16_t)(pr[1] >> 16)), v[3], fac[3]);
+      const float xin[4] = {bf2f((uint16_t)(pr[0] & 0xFFFFu)), bf2f((uint16_t)(pr[0] >> 16)), bf2f((uint16_t)(pr[1] & 0xFFFFu)),
+                            bf2f((uint16_t)(pr[1] >> 16))};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float gv, dgv;
+        gelu_and_dgelu(xin[r], gv, dgv);
+        v[r] = gv;
+        fac[r] = dgv;
+      }
       if (dropout) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
