@@ -429,6 +429,8 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true",
                     help="single-GPU runs replay the step as one HIP graph by default; this keeps it eager")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--sa-bf16", action="store_true",
+                    help="set-abstraction MLPs with ONE bf16 product per multiply-accumulate (opt-in; default: split-bf16 x3)")
     ap.add_argument("--no-self-check", action="store_true",
                     help="N > 1: skip the start-up comparison of the split-graph step with eager torch DDP")
     ap.add_argument("--detail", default=None, help="where the per-kernel detail JSON goes (default gpurun_out/bench_detail.json)")
@@ -480,6 +482,9 @@ def main() -> None:
     # a shape the fused attention core stops supporting must FAIL the run, not fall back to torch ops silently
     from sceneverse_amd.modules.layers import transformers as _tf
     _tf.set_attention_backend("hip")
+    if args.sa_bf16:
+        from sceneverse_amd.pointnet2 import pointnet2_modules as _sam
+        _sam.set_sa_precision("bf16")
     if args.fp8:
         # BASELINE configs[4]: Q K^T and P V of every bf16 attention call on the OCP e4m3 MFMA (forward)
         from sceneverse_amd.modules.layers import fused_attention as _fa
@@ -579,13 +584,13 @@ def main() -> None:
         for k, v in static.items():
             v.copy_(batch[k])
         batch = {**batch, **static}
-    lang = getattr(step.model, "lang_encoder", None)
-    want_path = "padded" if args.no_varlen else "varlen"
-    if lang is not None and hasattr(lang, "last_path") and not args.fp32 and lang.last_path != want_path:
-        raise SystemExit(f"bench: the text encoder ran its '{lang.last_path}' formulation, expected '{want_path}' "
-                         f"(libgps_hip.so fast path): refusing to report a number measured on a fallback")
     for _ in range(args.warmup):
         step.step(dict(batch))
+    lang = getattr(step.model, "lang_encoder", None)
+    want_path = "padded" if args.no_varlen else "varlen"
+    if lang is not None and hasattr(lang, "last_path") and not args.fp32 and lang.last_path not in (want_path, None):
+        raise SystemExit(f"bench: the text encoder ran its '{lang.last_path}' formulation, expected '{want_path}' "
+                         f"(libgps_hip.so fast path): refusing to report a number measured on a fallback")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -886,6 +891,7 @@ def main() -> None:
                                     f"fwd+loss+bwd+clip+AdamW"),
                        "preset": args.config,
                        **({"eval": eval_metrics} if eval_metrics is not None else {}),
+                       **({"sa_mlp": "single bf16 product (opt-in)"} if args.sa_bf16 else {}),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo: test mode)" if share else ""),
                        "text_rows": "padded (B, L) batch" if args.no_varlen else "valid tokens only (variable-length BERT path)",
@@ -910,7 +916,8 @@ def main() -> None:
             result["cpu_baseline"]["text_rows"] = "padded (B, L) batch; compare with value_full_length_text"
         detail = dict(result)
         detail["config"] = dict(result["config"],
-                                point_ops="fp32-accurate split-bf16 MFMA (libgps_hip.so)",
+                                point_ops=("single bf16 product per MAC, fp32 accumulate (opt-in --sa-bf16)" if args.sa_bf16
+                                           else "fp32-accurate split-bf16 MFMA (libgps_hip.so)"),
                                 gemms="hipBLASLt (A/B run)" if args.no_native_gemm else "libgps_hip.so bf16 MFMA (gps_gemm_bf16)",
                                 kernel_timing="HIP events around each native launch in three eager steps right after the timed region")
         detail.update({"headline": headline_full, "kernel_families": kernel_families, "kernels": kernels,

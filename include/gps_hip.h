@@ -164,6 +164,12 @@ GPS_API int gps_sa_mlp_forward(int b, int n, int npoint, int nsample, int c_feat
  * (~2^-16 relative error per product, ~5x fewer matrix-pipe cycles than the fp32 MFMA form).  The
  * packed buffer has its own format: pack with gps_sa_mlp_pack_layer_bf16x3. */
 GPS_API long long gps_sa_mlp_layer_floats_bf16x3(int c_in, int c_out);
+/* Products per fp32 multiply-accumulate of gps_sa_mlp_forward_bf16x3[_pm]: 3 (default) = W_hi X_hi + W_hi X_lo + W_lo X_hi,
+ * 2^-16 relative per product: within 1e-4 of the fp32 op-by-op path; 1 = W_hi X_hi only: bf16 operands, fp32
+ * accumulation -- what torch's bf16 autocast computes for the reference's Conv2d stacks (pytorch_utils.py:11-36), a
+ * third of the MFMA work, features within 2e-2 of the fp32 path's scale (tests/test_gpu_sa_fused.py states the
+ * measured figure).  Opt-in, process-wide; anything else = query.  Returns the previous setting. */
+GPS_API int gps_sa_mlp_set_products(int n);
 GPS_API int gps_sa_mlp_pack_layer_bf16x3(int c_in, int c_out, const float *w, const float *shift, float *dst,
                                          gps_stream_t stream);
 GPS_API int gps_sa_mlp_forward_bf16x3(int b, int n, int npoint, int nsample, int c_feat, int c1, int c2,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "gps_add_dropout_layernorm_backward_post": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 8,
     "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i, _vp, _vp],
     "gps_attn_set_plain_blocks": [_i],
+    "gps_sa_mlp_set_products": [_i],
     "gps_attn_forward_ex": [ctypes.POINTER(AttnArgs), _vp],
     "gps_attn_backward_ex": [ctypes.POINTER(AttnArgs), _vp],
     "gps_attn_backward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i] + [_vp] * 7,

@@ -406,7 +406,9 @@ __device__ __forceinline__ void split8(const f32x8 &v, bf16x8 &hi, bf16x8 &lo) {
   hi = __builtin_bit_cast(bf16x8, h);
   lo = __builtin_bit_cast(bf16x8, l);
 }
-template <int STEPS, bool TRANSPOSED = false>
+// NPROD = 3: the three products above (fp32-accurate); NPROD = 1: W_hi X_hi only -- plain bf16 operands with fp32
+// accumulation, what torch's bf16 autocast computes for the reference's Conv2d stacks (opt-in: gps_sa_mlp_set_products)
+template <int STEPS, bool TRANSPOSED = false, int NPROD = 3>
 __device__ __forceinline__ f32x16 mfma_tile16(const float *__restrict__ tile, const bf16x8 (&Bhi)[STEPS],
                                               const bf16x8 (&Blo)[STEPS], int lane) {
   f32x16 acc;
@@ -422,7 +424,13 @@ __device__ __forceinline__ f32x16 mfma_tile16(const float *__restrict__ tile, co
   const bf16x8 *frag = reinterpret_cast<const bf16x8 *>(tile) + lane;
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
-    const bf16x8 ahi = frag[s * 128], alo = frag[s * 128 + 64];
+    const bf16x8 ahi = frag[s * 128];
+    if (NPROD == 1) {
+      acc = TRANSPOSED ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bhi[s], ahi, acc, 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, Bhi[s], acc, 0, 0, 0);
+      continue;
+    }
+    const bf16x8 alo = frag[s * 128 + 64];
     if (TRANSPOSED) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bhi[s], alo, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Blo[s], ahi, acc, 0, 0, 0);
@@ -444,7 +452,7 @@ __device__ __forceinline__ f32x16 mfma_tile16(const float *__restrict__ tile, co
 // PM: the features arrive point-major -- feats[(obj * n + p) * ld_feat + c], e.g. the rgb columns of an interleaved
 // (B, N, 3 + C) cloud (pointer at column 3, ld_feat = 6) -- and are transposed into the channel-major LDS image while
 // they are staged, instead of by a separate full-cloud transpose copy in HBM (63 us per step at SA1).
-template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM = false>
+template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM = false, int NPROD = 3>
 __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
     int b, int n, int npoint, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ feats, const int32_t *__restrict__ idx,
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
 #pragma unroll
     for (int mt = 0; mt < M1; ++mt, ++g) {
       const float *wt = stage_begin(rd, g);
-      const f32x16 acc = mfma_tile16<S1>(wt, a0h, a0l, lane);
+      const f32x16 acc = mfma_tile16<S1, false, NPROD>(wt, a0h, a0l, lane);
       if (mt > 0) split_tile(prev, a1h[2 * mt - 2], a1l[2 * mt - 2], a1h[2 * mt - 1], a1l[2 * mt - 1]);
       prev = acc;
       stage_end();
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
 #pragma unroll
     for (int mt = 0; mt < M2; ++mt, ++g) {
       const float *wt = stage_begin(rd, g);
-      const f32x16 acc = mfma_tile16<S2>(wt, a1h, a1l, lane);
+      const f32x16 acc = mfma_tile16<S2, false, NPROD>(wt, a1h, a1l, lane);
       if (mt > 0) split_tile(prev, a2h[2 * mt - 2], a2l[2 * mt - 2], a2h[2 * mt - 1], a2l[2 * mt - 1]);
       prev = acc;
       stage_end();
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
     split_tile(prev, a2h[2 * M2 - 2], a2l[2 * M2 - 2], a2h[2 * M2 - 1], a2l[2 * M2 - 1]);
     for (int mt = 0; mt < M3; ++mt, ++g) {
       const float *wt = stage_begin(rd, g);
-      const f32x16 acc = mfma_tile16<S3, true>(wt, a2h, a2l, lane);
+      const f32x16 acc = mfma_tile16<S3, true, NPROD>(wt, a2h, a2l, lane);
       if (mt > 0) pool_tile(prev, mt - 1);
       prev = acc;
       stage_end();
@@ -615,9 +623,23 @@ __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
   }
 }
 
+static int g_products = 3;      // 3 = split-bf16 triple product (fp32-accurate, default); 1 = single bf16 product (opt-in)
+
+template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM, int NPROD>
+int launch_sa_x3_n(int b, int n, int npoint, const float *xyz, const float *new_xyz, const float *feats,
+                   const int32_t *idx, const float *wpack, float *out, hipStream_t s, int ld_feat);
+
 template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM = false>
 int launch_sa_x3(int b, int n, int npoint, const float *xyz, const float *new_xyz, const float *feats,
                  const int32_t *idx, const float *wpack, float *out, hipStream_t s, int ld_feat = 0) {
+  return g_products == 1
+             ? launch_sa_x3_n<CF, C1, C2, C3, WAVES, RESIDENT, PM, 1>(b, n, npoint, xyz, new_xyz, feats, idx, wpack, out, s, ld_feat)
+             : launch_sa_x3_n<CF, C1, C2, C3, WAVES, RESIDENT, PM, 3>(b, n, npoint, xyz, new_xyz, feats, idx, wpack, out, s, ld_feat);
+}
+
+template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM, int NPROD>
+int launch_sa_x3_n(int b, int n, int npoint, const float *xyz, const float *new_xyz, const float *feats,
+                   const int32_t *idx, const float *wpack, float *out, hipStream_t s, int ld_feat) {
   constexpr int CIN = 3 + CF;
   constexpr int T1 = tile_floats16(CIN), T2 = tile_floats16(C1), T3 = tile_floats16(C2);
   constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
@@ -628,12 +650,12 @@ int launch_sa_x3(int b, int n, int npoint, const float *xyz, const float *new_xy
   if (lds > 160 * 1024) return GPS_ERR_UNSUPPORTED;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT, PM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT, PM, NPROD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GPS_ERR_LAUNCH;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT, PM>), dim3(b), dim3(WAVES * 64), lds, s, b, n,
+  hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT, PM, NPROD>), dim3(b), dim3(WAVES * 64), lds, s, b, n,
                      npoint, xyz, new_xyz, feats, idx, wpack, out, ld_feat);
   return GPS_OK;
 }
@@ -662,6 +684,12 @@ int gps_sa_mlp_pack_layer(int c_in, int c_out, const float *w, const float *shif
   hipLaunchKernelGGL(gps_sa::pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, c_in, c_out, w, shift, dst);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_sa_mlp_set_products(int n) {
+  const int was = gps_sa::x3::g_products;
+  if (n == 1 || n == 3) gps_sa::x3::g_products = n;
+  return was;
 }
 
 long long gps_sa_mlp_layer_floats_bf16x3(int c_in, int c_out) {

@@ -43,10 +43,17 @@ _SA_PRECISION = "bf16x3"
 
 
 def set_sa_precision(name: str) -> None:
+    """"bf16x3" (default: split-bf16 triple products, within 1e-4 of the fp32 op-by-op path), "fp32" (fp32 MFMA), or
+    "bf16" -- OPT-IN: the bf16x3 kernels with ONE product per multiply-accumulate (bf16 operands, fp32 accumulation: what
+    torch's bf16 autocast computes for the reference's Conv2d stacks, pytorch_utils.py:11-36); a third of the matrix work,
+    features within 2e-2 of the fp32 path's scale (tests/test_gpu_sa_fused.py; include/gps_hip.h gps_sa_mlp_set_products).
+    The split-operand group-all level keeps its three products in every mode."""
     global _SA_PRECISION
-    if name not in ("fp32", "bf16x3"):
+    if name not in ("fp32", "bf16x3", "bf16"):
         raise ValueError(name)
-    _SA_PRECISION = name
+    from .. import _native
+    _native.load().gps_sa_mlp_set_products(1 if name == "bf16" else 3)
+    _SA_PRECISION = "bf16x3" if name == "bf16" else name
 
 
 def fold_shared_mlp(mlp: "pt_utils.SharedMLP"):
