@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void bwd_dq_kernel(const Params P) {
 // ==========================================================================================
 // backward, launch 2: workgroup = 64 keys -> dK, dV; query blocks (Q, dO, lse, delta) streamed
 // ==========================================================================================
-__global__ __launch_bounds__(kThreads) void bwd_dkv_kernel(const Params P) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_dkv_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *Qb = reinterpret_cast<uint16_t *>(smem);            // [2][64][KS]
   uint16_t *Ob = Qb + 2 * kTile;                                 // [2][64][KS]  dO rows
@@ -519,53 +519,57 @@ __global__ __launch_bounds__(kThreads) void bwd_dkv_kernel(const Params P) {
     if (active) {
       const uint16_t *Qc = Qb + cur * kTile, *Oc = Ob + cur * kTile;
       const float *lc = ls + cur * BLK, *dc = dl + cur * BLK;
-      f32x4 pt[4], ds[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {          // query tiles of the block
-        f32x4 sacc = zero_acc(), dacc = zero_acc();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const u32x4 vq = *reinterpret_cast<const u32x4 *>(Qc + (16 * i + m) * KS + 32 * c + 8 * g);
-          const u32x4 vo = *reinterpret_cast<const u32x4 *>(Oc + (16 * i + m) * KS + 32 * c + 8 * g);
-          sacc = mfma32(as_frag(vq), bk[c], sacc);       // S[query 16 i + 4 g + r][key t]
-          dacc = mfma32(as_frag(vo), bv[c], dacc);       // dO V^T
-        }
-        const f32x4 lq = *reinterpret_cast<const f32x4 *>(lc + 16 * i + 4 * g);
-        const f32x4 dq4 = *reinterpret_cast<const f32x4 *>(dc + 16 * i + 4 * g);
-        bool keep[4] = {true, true, true, true};
-        if (dropout) {
-          // hashes of (query q0 + r, key pair t >> 1): this lane computes two of the four, the lane of the other key of
-          // the pair (m ^ 1) the other two
-          const int q0 = qbi * BLK + 16 * i + 4 * g, par = m & 1;
-          const unsigned int qa = (unsigned int)(q0 + 2 * par);
-          const unsigned int ha = pair_rng(seedmix, (bh_base + qa) * pitch2, t);
-          const unsigned int hb = pair_rng(seedmix, (bh_base + qa + 1u) * pitch2, t);
-          const unsigned int oa = (unsigned int)__shfl_xor((int)ha, 1, 64), ob2 = (unsigned int)__shfl_xor((int)hb, 1, 64);
-          const unsigned int hr0 = par ? oa : ha, hr1 = par ? ob2 : hb, hr2 = par ? ha : oa, hr3 = par ? hb : ob2;
-          const unsigned int sh = par ? 16u : 0u;
-          keep[0] = ((hr0 >> sh) & 0xFFFFu) >= thr16;
-          keep[1] = ((hr1 >> sh) & 0xFFFFu) >= thr16;
-          keep[2] = ((hr2 >> sh) & 0xFFFFu) >= thr16;
-          keep[3] = ((hr3 >> sh) & 0xFFFFu) >= thr16;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], kC, kt) - lq[r]);
-          const float dp = keep[r] ? dacc[r] : 0.f;
-          pt[i][r] = keep[r] ? p : 0.f;                                   // 1 / (1 - p) goes onto dV below
-          ds[i][r] = p * fmaf(dp, keep_scale, -dq4[r]);                   // 1/8 goes onto dK below
-        }
-      }
-      // dV^T += dO^T P,  dK^T += Q^T dS  (reduction over the block's queries, in the order pack_tiles lays them out)
+      // 32 queries at a time: scores, dP, probabilities and dS of two query tiles, then their share of dV^T += dO^T P and
+      // dK^T += Q^T dS (reduction over those 32 queries, in the order pack_tiles lays them out) -- two tiles of P / dS
+      // live at once, not four (registers: three waves per SIMD)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const bf16x8 pb = pack_tiles(pt[2 * c], pt[2 * c + 1]);
-        const bf16x8 db = pack_tiles(ds[2 * c], ds[2 * c + 1]);
+        f32x4 pt[2], ds[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = 2 * c + ii;            // query tile of the block
+          f32x4 sacc = zero_acc(), dacc = zero_acc();
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const u32x4 vq = *reinterpret_cast<const u32x4 *>(Qc + (16 * i + m) * KS + 32 * cc + 8 * g);
+            const u32x4 vo = *reinterpret_cast<const u32x4 *>(Oc + (16 * i + m) * KS + 32 * cc + 8 * g);
+            sacc = mfma32(as_frag(vq), bk[cc], sacc);       // S[query 16 i + 4 g + r][key t]
+            dacc = mfma32(as_frag(vo), bv[cc], dacc);       // dO V^T
+          }
+          const f32x4 lq = *reinterpret_cast<const f32x4 *>(lc + 16 * i + 4 * g);
+          const f32x4 dq4 = *reinterpret_cast<const f32x4 *>(dc + 16 * i + 4 * g);
+          bool keep[4] = {true, true, true, true};
+          if (dropout) {
+            // hashes of (query q0 + r, key pair t >> 1): this lane computes two of the four, the lane of the other key of
+            // the pair (m ^ 1) the other two
+            const int q0 = qbi * BLK + 16 * i + 4 * g, par = m & 1;
+            const unsigned int qa = (unsigned int)(q0 + 2 * par);
+            const unsigned int ha = pair_rng(seedmix, (bh_base + qa) * pitch2, t);
+            const unsigned int hb = pair_rng(seedmix, (bh_base + qa + 1u) * pitch2, t);
+            const unsigned int oa = (unsigned int)__shfl_xor((int)ha, 1, 64), ob2 = (unsigned int)__shfl_xor((int)hb, 1, 64);
+            const unsigned int hr0 = par ? oa : ha, hr1 = par ? ob2 : hb, hr2 = par ? ha : oa, hr3 = par ? hb : ob2;
+            const unsigned int sh = par ? 16u : 0u;
+            keep[0] = ((hr0 >> sh) & 0xFFFFu) >= thr16;
+            keep[1] = ((hr1 >> sh) & 0xFFFFu) >= thr16;
+            keep[2] = ((hr2 >> sh) & 0xFFFFu) >= thr16;
+            keep[3] = ((hr3 >> sh) & 0xFFFFu) >= thr16;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], kC, kt) - lq[r]);
+            const float dp = keep[r] ? dacc[r] : 0.f;
+            pt[ii][r] = keep[r] ? p : 0.f;                                  // 1 / (1 - p) goes onto dV below
+            ds[ii][r] = p * fmaf(dp, keep_scale, -dq4[r]);                  // 1/8 goes onto dK below
+          }
+        }
+        const bf16x8 pb = pack_tiles(pt[0], pt[1]);
+        const bf16x8 db = pack_tiles(ds[0], ds[1]);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           dv[n] = mfma32(tr_frag_perm(Oc, c, 16 * n, lane), pb, dv[n]);
           dk[n] = mfma32(tr_frag_perm(Qc, c, 16 * n, lane), db, dk[n]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (more) {
