@@ -1338,7 +1338,10 @@ int launch(const Params &P, bool backward, hipStream_t s) {
 static int g_stream_min_nt[2] = {-1, -1};      // [plain, spatial]; -1 = not read yet
 // plain form (no pairwise term), bits: 1 = forward on the block-streaming kernels of gps_attention_fa.hip, 2 = backward
 // on them too, 4 = fixed-length self-attention up to 144 tokens on the K / V-resident kernels of gps_attention_sp.hip
-static int g_plain_mode = 1 | 4;
+static int g_plain_mode = [] {
+  const char *e = getenv("GPS_ATTN_PLAIN_MODE");            // A/B runs of whole bench commands
+  return e ? (atoi(e) & 7) : (1 | 4);
+}();
 
 int dispatch(Params &P, bool backward, hipStream_t s) {
   P.nt = (P.L + 15) / 16;

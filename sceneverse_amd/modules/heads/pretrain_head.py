@@ -48,10 +48,12 @@ class BertLMPredictionHead(nn.Module):
     def forward(self, hidden_states):
         if _FUSED_LM_LOSS and self.training and hidden_states.is_cuda:
             from ...optim.loss import fused_lm_loss as F_lm
-            h = self.transform(hidden_states)
-            if F_lm.usable(h, self.decoder.weight):
-                return F_lm.LazyLMLogits(h, self.decoder.weight, self.bias)
-            return F.linear(h, self.decoder.weight, self.bias)
+            if F_lm.usable(hidden_states, self.decoder.weight):
+                if F_lm.transform_supported(self.transform, hidden_states):
+                    # dense -> gelu -> LayerNorm is row-wise: it runs behind the loss's row selection, on the labelled rows
+                    return F_lm.LazyLMLogits(hidden_states, self.decoder.weight, self.bias, transform=self.transform)
+                return F_lm.LazyLMLogits(self.transform(hidden_states), self.decoder.weight, self.bias)
+            return F.linear(self.transform(hidden_states), self.decoder.weight, self.bias)
         # decoder(h) + bias (ref :29) as ONE GEMM with the bias in its epilogue: under bf16 autocast the separate
         # add promoted the (tokens x vocab) logits to fp32 (a 390 MB round trip forward, the same again backward)
         return F.linear(self.transform(hidden_states), self.decoder.weight, self.bias)

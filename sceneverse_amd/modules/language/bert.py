@@ -68,6 +68,28 @@ class _ZeroDeadRows(torch.autograd.Function):
         return torch.where(live, dy, torch.zeros((), dtype=dy.dtype, device=dy.device)), None
 
 
+class _UnpadRows(torch.autograd.Function):
+    """out[e] = x[src[e]] where live[e], else 0 -- the compact token rows back in a text's (B x L) layout.  The map from
+    live positions to compact rows is injective, so the backward pass is a row COPY (dead positions into a dump row), not
+    the zero-fill + atomic index_add_ autograd derives for index_select (39 us on the 3 264 x 768 tail batch)."""
+
+    @staticmethod
+    def forward(ctx, x, src, live):
+        ctx.save_for_backward(src, live)
+        ctx.rows = x.shape[0]
+        rows = x.index_select(0, src)
+        return torch.where(live, rows, torch.zeros((), dtype=rows.dtype, device=rows.device))
+
+    @staticmethod
+    def backward(ctx, dout):
+        src, live = ctx.saved_tensors
+        n = ctx.rows
+        dx = torch.zeros((n + 1, dout.shape[1]), dtype=dout.dtype, device=dout.device)     # row n: dump
+        dst = torch.where(live[:, 0], src, torch.full_like(src, n))
+        dx.index_copy_(0, dst, dout.contiguous())
+        return dx[:n], None, None
+
+
 def set_fused_embedding(flag: bool) -> None:
     """Word-table gradient through libgps_hip.so (fused_embedding.py) inside the fast path; off = HF module."""
     global _FAST_EMB
@@ -258,9 +280,7 @@ class BERTLanguageEncoder(nn.Module):
                 src = inv[r0:r0 + B * L]
                 if cls_tail:      # tail batch: compact row c of a fully-read text sits at (S - S_full) + c; padded tokens
                     src = (src + (S - S_full)).clamp(max=x.shape[0] - 1)      # (masked below) may point past the batch
-                rows = x.index_select(0, src)
-                live = valid[r0:r0 + B * L, None]
-                outs.append(torch.where(live, rows, torch.zeros((), dtype=rows.dtype, device=dev)).view(B, L, -1))
+                outs.append(_UnpadRows.apply(x, src, valid[r0:r0 + B * L, None]).view(B, L, -1))
             r0 += B * L
             s0 += B
         return outs

@@ -755,6 +755,45 @@ def packed_linear(x: torch.Tensor, layers: Sequence[torch.nn.Linear], rows_dev: 
     return _LinearFn.apply(x, len(layers), *[m.weight for m in layers], *[m.bias for m in layers], *extra)
 
 
+class _LinearGeluFn(torch.autograd.Function):
+    """y = gelu(x W^T + b) for the rows below a device-side count: one forward GEMM whose epilogue also saves gelu'(pre)
+    (EPI_BIAS_GELU_FACTOR), backward = one elementwise multiply + the input- and weight-gradient GEMMs (the masked-LM
+    head's transform on the labelled rows only: optim/loss/fused_lm_loss.py)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rows_dev):
+        w16, b32 = shadow_of((weight,), (bias,))
+        x16 = _as_rows16(x)
+        y, fac = linear_forward(x16, w16, b32, act="gelu", want_pre="factor", rows_dev=rows_dev)
+        ctx.rows_dev = rows_dev
+        ctx.save_for_backward(x16, w16, fac)
+        ctx.meta = (x.shape, x.dtype, bias is not None)
+        ctx.params = (weight, bias)
+        return y.view(*x.shape[:-1], w16.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w16, fac = ctx.saved_tensors
+        x_shape, x_dtype, has_b = ctx.meta
+        weight, bias = ctx.params
+        rd = ctx.rows_dev
+        dpre = _as_rows16(dy) * fac               # rows past the count hold garbage on both sides: never read below
+        dw = db = None
+        if not (ctx.needs_input_grad[1] and (not has_b or ctx.needs_input_grad[2])
+                and _wgrad_to_params(dpre, x16, (weight,), (bias,), (weight.shape[0],), rd)):
+            dw, db = linear_wgrad(dpre, x16, want_bias=has_b, rows_dev=rd)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dpre, w16, rows_dev=rd).view(x_shape)
+            if dx.dtype != x_dtype:
+                dx = dx.to(x_dtype)
+        return dx, dw, db, None
+
+
+def linear_gelu(x: torch.Tensor, linear: torch.nn.Linear, rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _LinearGeluFn.apply(x, linear.weight, linear.bias, rows_dev)
+
+
 _GELU_FACTOR = True          # False: save the pre-activation and recompute gelu' and the mask in the backward epilogue (A/B, tests)
 
 

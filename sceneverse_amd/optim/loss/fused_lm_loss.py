@@ -31,21 +31,51 @@ def _padded_shadow(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     return G.shadow_of([weight], [bias], pad_rows=8)
 
 
+def row_plan(labels: torch.Tensor, vocab: int, ignore_index: int):
+    """-> (perm, labels in permuted order, n_valid): the token rows permuted so that the labelled ones come first
+    (stable), the device-side count of labelled rows."""
+    labels = labels.reshape(-1).to(torch.int64)
+    valid = (labels != ignore_index) & (labels >= 0) & (labels < vocab)
+    n_valid = valid.sum(dtype=torch.int32).reshape(1)
+    perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)
+    lp = torch.where(valid, labels, torch.full_like(labels, ignore_index)).index_select(0, perm).contiguous()
+    return perm, lp, n_valid
+
+
+class _PermuteLiveRows(torch.autograd.Function):
+    """x (n, D) -> x[perm] (labelled rows first); backward scatters the gradient rows back and ZEROES the rows past the
+    device-side count (the extent-aware kernels downstream never write them: undefined memory)."""
+
+    @staticmethod
+    def forward(ctx, x, perm, n_valid):
+        ctx.save_for_backward(perm, n_valid)
+        return x.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, dy):
+        perm, n_valid = ctx.saved_tensors
+        live = (torch.arange(dy.shape[0], device=dy.device) < n_valid)[:, None]
+        dy = torch.where(live, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
+        dx = torch.empty_like(dy)
+        dx.index_copy_(0, perm, dy)                        # perm is a bijection: every row is written
+        return dx, None, None
+
+
 class _SparseLMLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, weight, bias, labels, ignore_index: int):
+    def forward(ctx, h, weight, bias, labels, ignore_index: int, plan=None):
         n, D = h.shape
         V = weight.shape[0]
         w16, b32 = _padded_shadow(weight, bias)
         Vp = w16.shape[0]
         lib = _native.load()
         dev = h.device
-        labels = labels.reshape(-1).to(torch.int64)
-        valid = (labels != ignore_index) & (labels >= 0) & (labels < V)
-        n_valid = valid.sum(dtype=torch.int32).reshape(1)
-        perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)       # labelled rows first
-        hp = h.detach().to(torch.bfloat16).index_select(0, perm).contiguous()
-        lp = torch.where(valid, labels, torch.full_like(labels, ignore_index)).index_select(0, perm).contiguous()
+        if plan is None:
+            perm, lp, n_valid = row_plan(labels, V, ignore_index)
+            hp = h.detach().to(torch.bfloat16).index_select(0, perm).contiguous()
+        else:                                               # h arrives permuted already (rows past n_valid undefined)
+            perm, lp, n_valid = None, plan[1], plan[2]
+            hp = h.detach().to(torch.bfloat16).contiguous()
         logits = torch.empty((n, Vp), dtype=torch.bfloat16, device=dev)
         G.gemm(_native.GEMM_NT, _native.EPI_BIAS, n, Vp, D, hp, D, w16, D, logits, Vp, bias=b32, extent_dev=n_valid)
         rows = torch.empty(n, dtype=torch.float32, device=dev)
@@ -58,6 +88,7 @@ class _SparseLMLoss(torch.autograd.Function):
         loss = (rows.sum() / nv).reshape(())
         ctx.save_for_backward(hp, w16, logits, lp, lse, perm, n_valid, nv)
         ctx.meta = (n, D, V, Vp, int(ignore_index), h.dtype, bias is not None)
+        ctx.prepermuted = plan is not None
         return loss
 
     @staticmethod
@@ -83,10 +114,13 @@ class _SparseLMLoss(torch.autograd.Function):
             dxp = torch.empty((n, D), dtype=torch.float32, device=dev)
             G.gemm(_native.GEMM_NN, _native.EPI_F32, n, D, Vp, dlogits, Vp, w16, D, dxp, D, workspace=ws, splits=splits,
                    extent_dev=n_valid)
-            live = (torch.arange(n, device=dev) < n_valid)[:, None]          # rows past the extent were never written
-            dxp = torch.where(live, dxp, torch.zeros((), dtype=torch.float32, device=dev))
-            dh = torch.empty((n, D), dtype=h_dtype, device=dev)
-            dh.index_copy_(0, perm, dxp.to(h_dtype))
+            if ctx.prepermuted:                              # the caller's _PermuteLiveRows zeroes and scatters
+                dh = dxp.to(h_dtype)
+            else:
+                live = (torch.arange(n, device=dev) < n_valid)[:, None]      # rows past the extent were never written
+                dxp = torch.where(live, dxp, torch.zeros((), dtype=torch.float32, device=dev))
+                dh = torch.empty((n, D), dtype=h_dtype, device=dev)
+                dh.index_copy_(0, perm, dxp.to(h_dtype))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dwp = torch.empty((Vp, D), dtype=torch.float32, device=dev)
             dbp = torch.empty(Vp, dtype=torch.float32, device=dev)
@@ -94,7 +128,7 @@ class _SparseLMLoss(torch.autograd.Function):
                    extent_dev=n_valid)
             dw = dwp[:V]
             db = dbp[:V] if has_bias else None
-        return dh, dw, db, None, None
+        return dh, dw, db, None, None, None
 
 
 def sparse_lm_loss(h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], labels: torch.Tensor,
@@ -108,20 +142,47 @@ def usable(h: torch.Tensor, weight: torch.Tensor) -> bool:
     return G.usable(h, weight.shape[1], (weight.shape[0] + 7) // 8 * 8) and weight.shape[1] % 8 == 0
 
 
-class LazyLMLogits:
-    """What the masked-LM head hands to the loss when the fused path is on: the transformed hidden states and the
-    decoder parameters.  `lm_cls_loss` turns it into the loss without full logits; anything else that wants the
-    (B, L, V) tensor calls `materialize()`."""
+def transform_supported(transform, hidden: torch.Tensor) -> bool:
+    """Can the head's transform (dense -> gelu -> LayerNorm, modules/heads/pretrain_head.py:8-20) run on the labelled rows
+    only, on the native kernels?"""
+    from ...modules.layers import fused_norm
+    d = hidden.shape[-1]
+    dense, norm = transform.dense, transform.LayerNorm
+    probe = torch.empty(0, dtype=torch.bfloat16, device=hidden.device)
+    return (getattr(transform.transform_act_fn, "__name__", "") == "gelu" and dense.in_features == d == dense.out_features
+            and G.usable(probe, d, d) and fused_norm.supported(hidden.reshape(-1, d)[:1].float(), probe.new_empty((1, d)), norm))
 
-    def __init__(self, hidden: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
-        self.hidden, self.weight, self.bias = hidden, weight, bias
+
+class LazyLMLogits:
+    """What the masked-LM head hands to the loss when the fused path is on: the hidden states and the head's parameters.
+    `lm_cls_loss` turns it into the loss without full logits; anything else that wants the (B, L, V) tensor calls
+    `materialize()`.  With `transform` (the head's dense -> gelu -> LayerNorm, row-wise) given, `hidden` is the head's
+    INPUT and the transform itself runs behind the row selection, on the ~15 % of token rows that carry a label -- the
+    other rows' transform outputs reach no loss (reference: pretrain_head.py:22-30 computes them for every token)."""
+
+    def __init__(self, hidden: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], transform=None):
+        self.hidden, self.weight, self.bias, self.transform = hidden, weight, bias, transform
 
     @property
     def shape(self):
         return (*self.hidden.shape[:-1], self.weight.shape[0])
 
     def materialize(self) -> torch.Tensor:
-        return torch.nn.functional.linear(self.hidden, self.weight, self.bias)
+        h = self.hidden if self.transform is None else self.transform(self.hidden)
+        return torch.nn.functional.linear(h, self.weight, self.bias)
 
     def loss(self, labels: torch.Tensor, ignore_index: int = -1) -> torch.Tensor:
-        return sparse_lm_loss(self.hidden, self.weight, self.bias, labels, ignore_index)
+        if self.transform is None:
+            return sparse_lm_loss(self.hidden, self.weight, self.bias, labels, ignore_index)
+        from ...modules.layers.fused_norm import add_dropout_layer_norm
+        D = self.hidden.shape[-1]
+        x = self.hidden.reshape(-1, D)
+        plan = row_plan(labels, self.weight.shape[0], int(ignore_index))
+        perm, _, n_valid = plan
+        xs = _PermuteLiveRows.apply(x, perm, n_valid)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            y = G.linear_gelu(xs, self.transform.dense, rows_dev=n_valid)
+        # LayerNorm(y) through the residual kernel with a zero residual: y fp32 = LN(0 + y) on the live rows
+        zero = torch.zeros((x.shape[0], D), dtype=torch.float32, device=x.device)
+        h = add_dropout_layer_norm(zero, y, self.transform.LayerNorm, 0.0, False, rows_dev=n_valid)
+        return _SparseLMLoss.apply(h, self.weight, self.bias, labels.reshape(-1), int(ignore_index), plan)

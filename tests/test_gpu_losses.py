@@ -81,3 +81,48 @@ def test_fused_lm_head_loss_matches_linear_plus_cross_entropy(n, V, frac):
     assert rel(gh, hr.grad) <= 2e-2 and rel(gw, w.grad) <= 2e-2 and rel(gb, b.grad) <= 2e-2, \
         (rel(gh, hr.grad), rel(gw, w.grad), rel(gb, b.grad))
     assert gh[labels < 0].abs().max().item() == 0.0 if (labels < 0).any() else True
+
+
+@pytest.mark.parametrize("frac", [0.15, 1.0])
+def test_lm_head_with_the_transform_behind_the_row_selection(frac):
+    """BertLMPredictionHead in training mode inside fused_lm_loss(): the head's dense -> gelu -> LayerNorm runs on the
+    labelled rows only (LazyLMLogits with `transform`), then decoder + cross-entropy.  Against the reference formulation
+    F.cross_entropy(decoder(LayerNorm(gelu(dense(x)))) + bias) in fp32 on the same parameters: the loss and the
+    gradients of the hidden states (exactly zero on unlabelled rows), of the transform's and of the decoder's parameters."""
+    import copy
+    from sceneverse_amd.modules.heads.pretrain_head import BertLMPredictionHead, fused_lm_loss
+    from sceneverse_amd.optim.loss.fused_lm_loss import LazyLMLogits
+    B, L, D, V = 64, 50, 768, 30522
+    torch.manual_seed(3)
+    head = BertLMPredictionHead(D, V).to(DEV).train()
+    with torch.no_grad():
+        head.transform.LayerNorm.weight.add_(0.1 * torch.randn(D, device=DEV))
+        head.transform.LayerNorm.bias.add_(0.1 * torch.randn(D, device=DEV))
+        head.bias.add_(0.1 * torch.randn(V, device=DEV))
+    ref_head = copy.deepcopy(head).float()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, D, generator=g).to(DEV)
+    labels = torch.randint(0, V, (B, L), generator=g)
+    labels[torch.rand(B, L, generator=g) >= frac] = -1
+    labels = labels.to(DEV)
+    xf = x.clone().requires_grad_(True)
+    with fused_lm_loss(True), torch.autocast("cuda", dtype=torch.bfloat16):
+        lazy = head(xf)
+        assert isinstance(lazy, LazyLMLogits) and lazy.transform is head.transform
+        loss = lazy.loss(labels, -1)
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    ref = F.cross_entropy(ref_head(xr).permute(0, 2, 1), labels, ignore_index=-1)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 5e-3 * abs(ref.item()) + 1e-4, (loss.item(), ref.item())
+
+    def rel(a, r):
+        return ((a.float() - r.float()).norm() / (r.float().norm() + 1e-12)).item()
+    assert rel(xf.grad, xr.grad) <= 3e-2, rel(xf.grad, xr.grad)
+    assert xf.grad[labels < 0].abs().max().item() == 0.0 if (labels < 0).any() else True
+    for (n, p), (_, q) in zip(head.named_parameters(), ref_head.named_parameters()):
+        assert p.grad is not None and rel(p.grad, q.grad) <= 3e-2, (n, rel(p.grad, q.grad))
+    # evaluation / metrics: the full logits through the same object
+    with torch.no_grad():
+        _close = (lazy.materialize().float() - ref_head(x)).abs().max().item()
+    assert _close <= 5e-2, _close
