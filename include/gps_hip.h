@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 8
+#define GPS_HIP_ABI_VERSION 9
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -315,6 +315,55 @@ GPS_API int gps_masked_ce_backward(int n_rows, int vocab, int logits_bf16, const
                                    const long long *labels, long long ignore_index, const float *lse,
                                    const float *grad_rows, void *dlogits, long long ldd,
                                    gps_stream_t stream);
+/* The same two with a DEVICE-side row extent (rows_dev, may be NULL = n_rows): rows at or past *rows_dev are neither read
+ * nor written (the masked-LM head orders the labelled rows first -- gps_lm_row_plan -- and its extent-aware GEMMs never
+ * read the rest).  bf16 rows with a pitch that is a multiple of 8 elements and 16-byte aligned bases take 16-byte
+ * accesses (the backward form then also writes zeros to the pad columns [vocab, 8 ceil(vocab / 8)), which ldd must
+ * cover); with rows_dev set, any other layout returns GPS_ERR_UNSUPPORTED. */
+GPS_API int gps_masked_ce_forward_rows(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
+                                       const long long *labels, long long ignore_index, const int *rows_dev,
+                                       float *loss_rows, float *lse, gps_stream_t stream);
+GPS_API int gps_masked_ce_backward_rows(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
+                                        const long long *labels, long long ignore_index, const int *rows_dev,
+                                        const float *lse, const float *grad_rows, void *dlogits, long long ldd,
+                                        gps_stream_t stream);
+/* Row plan of the masked-LM head (replaces the valid-mask / argsort / index_select chain in front of lm_cls_loss,
+ * optim/loss/loss.py:56-61): perm[n_rows] = the STABLE permutation of the token rows that puts those whose label is a
+ * class id in [0, vocab) (and != ignore_index) first, labels_out[i] = label of row perm[i] (ignore_index for the rest),
+ * *n_valid = their count.  One workgroup; all pointers device memory. */
+GPS_API int gps_lm_row_plan(int n_rows, int vocab, const long long *labels, long long ignore_index, long long *perm,
+                            long long *labels_out, int *n_valid, gps_stream_t stream);
+
+/* ---- contrastive losses (optim/loss/contra_loss.py), one launch per direction ------------------------------------------
+ * fp32, contiguous rows, D a multiple of 4 (<= 8192), 16-byte aligned feature pointers.  `ticket`: one unsigned int of
+ * device memory per call site, ZERO before the first launch and left zero by every launch (the last workgroup to
+ * arrive takes the mean in row order: no atomics on floats, run-to-run identical).  grad_out: the upstream gradient of
+ * the loss, a device float.  Gradients are those of the RAW rows (the normalisations are folded in, torch clamp_min
+ * semantics for norms below eps).
+ *
+ * TextObjWithinBatch (:22-43, the cross-entropy branch): obj (B, O, D), text (B, D), labels (B) int64 in [0, O) (or
+ * ignore_index: the scene does not count), masks (B, O) bytes (0 = padded object: logit -inf).
+ * forward: cosv / prob / inv_o (B, O), inv_t (B), loss_rows (B) scratch, scal[0] = the loss (mean over the counted
+ * scenes), scal[1] = their number.  backward: dobj (B, O, D) and / or dtext (B, D) (either may be NULL). */
+GPS_API int gps_text_obj_ce_forward(int B, int O, int D, const float *obj, const float *text, const long long *labels,
+                                    const unsigned char *masks, float eps, long long ignore_index, float *cosv,
+                                    float *prob, float *inv_o, float *inv_t, float *loss_rows, float *scal,
+                                    unsigned int *ticket, gps_stream_t stream);
+GPS_API int gps_text_obj_ce_backward(int B, int O, int D, const float *obj, const float *text, const long long *labels,
+                                     float eps, long long ignore_index, const float *cosv, const float *prob,
+                                     const float *inv_o, const float *inv_t, const float *scal, const float *grad_out,
+                                     float *dobj, float *dtext, gps_stream_t stream);
+/* _symmetric_clip_loss (:11-17) with the F.normalize of its two inputs (:60, :82-83; normalize = 0: rows taken as they
+ * are) and s = min(*scale, max_scale) (the clamp of :57, :79).  a, b (n, D).  forward: M (n, n) = a_n b_n^T, lse_row /
+ * lse_col / inv_a / inv_b / loss_rows (n), loss[0].  backward: da, db (n, D) (both or neither), dscale[0] (0 when the
+ * clamp is active), ds_rows (n) scratch. */
+GPS_API int gps_clip_loss_forward(int n, int D, int normalize, const float *a, const float *b, const float *scale,
+                                  float max_scale, float eps, float *M, float *lse_row, float *lse_col, float *inv_a,
+                                  float *inv_b, float *loss_rows, float *loss, unsigned int *ticket, gps_stream_t stream);
+GPS_API int gps_clip_loss_backward(int n, int D, int normalize, const float *a, const float *b, const float *scale,
+                                   float max_scale, float eps, const float *M, const float *lse_row, const float *lse_col,
+                                   const float *inv_a, const float *inv_b, const float *grad_out, float *da, float *db,
+                                   float *dscale, float *ds_rows, unsigned int *ticket, gps_stream_t stream);
 
 /* ---- y = x / max(||x||_2, eps) per row and its backward ------------------------------------------------------------
  * Replaces F.normalize(x, dim=-1, p=2) in the contrastive losses (optim/loss/contra_loss.py:38-39, 60, 82-83): torch runs

@@ -20,6 +20,7 @@ SOURCES = [
     ("gps_attention_sp.hip", []),
     ("gps_attention_fa.hip", []),
     ("gps_losses.hip", []),
+    ("gps_contrastive.hip", []),
     ("gps_layernorm.hip", []),
     ("gps_objects.hip", []),
     ("gps_reduce.hip", []),

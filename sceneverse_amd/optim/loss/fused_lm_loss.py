@@ -33,12 +33,16 @@ def _padded_shadow(weight: torch.Tensor, bias: Optional[torch.Tensor]):
 
 def row_plan(labels: torch.Tensor, vocab: int, ignore_index: int):
     """-> (perm, labels in permuted order, n_valid): the token rows permuted so that the labelled ones come first
-    (stable), the device-side count of labelled rows."""
-    labels = labels.reshape(-1).to(torch.int64)
-    valid = (labels != ignore_index) & (labels >= 0) & (labels < vocab)
-    n_valid = valid.sum(dtype=torch.int32).reshape(1)
-    perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)
-    lp = torch.where(valid, labels, torch.full_like(labels, ignore_index)).index_select(0, perm).contiguous()
+    (stable), the device-side count of labelled rows.  One launch (gps_lm_row_plan)."""
+    labels = labels.reshape(-1).to(torch.int64).contiguous()
+    n = labels.numel()
+    perm = torch.empty(n, dtype=torch.int64, device=labels.device)
+    lp = torch.empty(n, dtype=torch.int64, device=labels.device)
+    n_valid = torch.empty(1, dtype=torch.int32, device=labels.device)
+    with torch.cuda.device(labels.device):
+        st = _native.load().gps_lm_row_plan(n, int(vocab), labels.data_ptr(), int(ignore_index), perm.data_ptr(),
+                                            lp.data_ptr(), n_valid.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _native.check(st, "lm_row_plan")
     return perm, lp, n_valid
 
 
@@ -81,8 +85,9 @@ class _SparseLMLoss(torch.autograd.Function):
         rows = torch.empty(n, dtype=torch.float32, device=dev)
         lse = torch.empty(n, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            st = lib.gps_masked_ce_forward(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), int(ignore_index),
-                                           rows.data_ptr(), lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            st = lib.gps_masked_ce_forward_rows(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), int(ignore_index),
+                                                n_valid.data_ptr(), rows.data_ptr(), lse.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
         _native.check(st, "masked_ce_forward")
         nv = n_valid.to(torch.float32)
         loss = (rows.sum() / nv).reshape(())
@@ -100,11 +105,11 @@ class _SparseLMLoss(torch.autograd.Function):
         stream = torch.cuda.current_stream().cuda_stream
         grad_rows = (g.reshape(1).float() / nv).expand(n).contiguous()
         dlogits = torch.empty((n, Vp), dtype=torch.bfloat16, device=dev)
-        if Vp > V:
-            dlogits[:, V:].zero_()                         # padding columns meet zero weight rows, but must be finite
         with torch.cuda.device(dev):
-            st = lib.gps_masked_ce_backward(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), ignore_index, lse.data_ptr(),
-                                            grad_rows.data_ptr(), dlogits.data_ptr(), Vp, stream)
+            # rows past n_valid stay unwritten: the two GEMMs below stop at the extent (their ragged tail reads zeros)
+            st = lib.gps_masked_ce_backward_rows(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), ignore_index,
+                                                 n_valid.data_ptr(), lse.data_ptr(), grad_rows.data_ptr(),
+                                                 dlogits.data_ptr(), Vp, stream)
         _native.check(st, "masked_ce_backward")
         dh = dw = db = None
         if ctx.needs_input_grad[0]:

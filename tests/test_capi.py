@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gps_hip.h but not exported"
     assert set(_native.SIGNATURES) <= set(declared)
-    assert lib.gps_abi_version() == 8
+    assert lib.gps_abi_version() == 9
     assert lib.gps_error_string(0) == b"ok"
     assert b"not supported" in lib.gps_error_string(-2)
 
@@ -46,6 +46,16 @@ def test_argument_validation_without_gpu():
     assert lib.gps_attn_forward(2, 12, 600, 64, 1, 1, 1, 2304, None, None, None, 0.0, 0, None, 1, 768, 1, None) == -2
     assert lib.gps_masked_ce_forward(0, 30522, 1, None, 30522, None, -1, None, None, None) == 0
     assert lib.gps_masked_ce_forward(4, 30522, 1, 1, 100, 1, -1, 1, 1, None) == -1                   # ld < vocab
+    assert lib.gps_masked_ce_forward_rows(0, 30522, 1, None, 30528, None, -1, None, None, None, None) == 0
+    assert lib.gps_masked_ce_backward_rows(4, 30522, 1, 1, 30528, 1, -1, None, 1, 1, 1, 100, None) == -1   # ldd < vocab
+    assert lib.gps_lm_row_plan(8, 0, 1, -1, 1, 1, 1, None) == -1                                     # vocab < 1
+    assert lib.gps_lm_row_plan(8, 10, None, -1, 1, 1, 1, None) == -1
+    assert lib.gps_text_obj_ce_forward(0, 80, 768, None, None, None, None, 1e-12, -100, None, None, None, None, None, None,
+                                       None, None) == 0
+    assert lib.gps_text_obj_ce_forward(4, 80, 770, 16, 16, 1, 1, 1e-12, -100, 1, 1, 1, 1, 1, 1, 1, None) == -2   # D % 4
+    assert lib.gps_text_obj_ce_backward(4, 80, 768, 16, 16, 1, 1e-12, -100, 1, 1, 1, 1, 1, None, 16, 16, None) == -1
+    assert lib.gps_clip_loss_forward(0, 768, 1, 16, 16, 1, 100.0, 1e-12, 1, 1, 1, 1, 1, 1, 1, 1, None) == -1     # n < 1
+    assert lib.gps_clip_loss_backward(4, 768, 1, 16, 16, 1, 100.0, 1e-12, 1, 1, 1, 1, 1, 1, 16, None, 1, 1, 1, None) == -1
     assert lib.gps_add_dropout_layernorm_forward(4, 100, 0, 1, 1, 1, 1, 1, 1e-5, 0.0, 0, None, 1, None, 1, 1,
                                                  None) == -2                                          # width
     assert lib.gps_add_dropout_layernorm_forward(0, 768, 0, 1, None, None, None, None, 1e-5, 0.0, 0, None, None,

@@ -126,3 +126,84 @@ def test_lm_head_with_the_transform_behind_the_row_selection(frac):
     with torch.no_grad():
         _close = (lazy.materialize().float() - ref_head(x)).abs().max().item()
     assert _close <= 5e-2, _close
+
+
+@pytest.mark.parametrize("n,V,frac", [(3200, 30522, 0.15), (1, 7, 1.0), (63, 100, 0.5), (1024, 30522, 0.0), (1025, 607, 1.0),
+                                      (5000, 30522, 0.3), (0, 10, 0.0)])
+def test_row_plan_kernel_is_the_stable_partition(n, V, frac):
+    """gps_lm_row_plan against the torch chain it replaces: valid mask -> count -> stable argsort -> permuted labels.
+    Out-of-range labels and ignore_index rows are the second class.  Bit-exact (integers)."""
+    from sceneverse_amd.optim.loss.fused_lm_loss import row_plan
+    g = torch.Generator().manual_seed(17 * n + V)
+    labels = torch.randint(0, V, (n,), generator=g)
+    labels[torch.rand(n, generator=g) >= frac] = -1
+    if n > 8:
+        labels[5] = V + 3                                  # out of range: treated as ignored
+        labels[7] = -5
+    lab = labels.to(DEV)
+    perm, lp, n_valid = row_plan(lab, V, -1)
+    valid = (lab != -1) & (lab >= 0) & (lab < V)
+    ref_perm = torch.argsort(valid.logical_not().to(torch.uint8), stable=True)
+    ref_lp = torch.where(valid, lab, torch.full_like(lab, -1)).index_select(0, ref_perm)
+    assert int(n_valid.item()) == int(valid.sum().item())
+    assert torch.equal(perm, ref_perm) and torch.equal(lp, ref_lp)
+
+
+@pytest.mark.parametrize("n,V,n_live", [(640, 30522, 97), (64, 607, 64), (33, 1000, 0), (200, 30522, 200)])
+def test_cross_entropy_with_a_device_side_row_extent(n, V, n_live):
+    """gps_masked_ce_{forward,backward}_rows (16-byte bf16 accesses, rows past *rows_dev dead) against the scalar entry
+    points on the same padded bf16 rows: per-row loss / lse within 1e-5 relative, gradient within one bf16 rounding of the
+    scalar form's; pad columns of live rows are zero; dead rows of dlogits are NOT touched (sentinel survives) and their
+    per-row outputs are 0."""
+    from sceneverse_amd import _native
+    lib = _native.load()
+    Vp = (V + 7) // 8 * 8
+    g = torch.Generator().manual_seed(n + V)
+    logits = torch.zeros(n, Vp, dtype=torch.bfloat16)
+    logits[:, :V] = (torch.randn(n, V, generator=g) * 3).to(torch.bfloat16)
+    logits[:, V:] = 77.0                                   # pad columns must never be read as classes
+    labels = torch.randint(0, V, (n,), generator=g)
+    labels[n_live:] = -1
+    if n_live > 4:
+        labels[2] = -1                                     # an ignored row inside the live range
+    logits, labels = logits.to(DEV), labels.to(DEV)
+    rows_dev = torch.tensor([n_live], dtype=torch.int32, device=DEV)
+    grad_rows = (torch.rand(n, generator=g) + 0.5).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(fwd, bwd, extra):
+        loss = torch.full((n,), -7.0, device=DEV)
+        lse = torch.full((n,), -7.0, device=DEV)
+        d = torch.full((n, Vp), 5.0, dtype=torch.bfloat16, device=DEV)
+        assert fwd(n, V, 1, logits.data_ptr(), Vp, labels.data_ptr(), -1, *extra, loss.data_ptr(), lse.data_ptr(), st) == 0
+        assert bwd(n, V, 1, logits.data_ptr(), Vp, labels.data_ptr(), -1, *extra, lse.data_ptr(), grad_rows.data_ptr(),
+                   d.data_ptr(), Vp, st) == 0
+        torch.cuda.synchronize()
+        return loss, lse, d
+
+    # reference: the scalar kernels on an UNPADDED copy (pitch V is not a multiple of 8 for these V, or is forced scalar
+    # by the odd pitch Vp + 1)
+    wide = torch.zeros(n, Vp + 1, dtype=torch.bfloat16, device=DEV)
+    wide[:, :Vp] = logits
+    loss_r = torch.empty(n, device=DEV); lse_r = torch.empty(n, device=DEV)
+    d_r = torch.zeros(n, Vp + 1, dtype=torch.bfloat16, device=DEV)
+    assert lib.gps_masked_ce_forward(n, V, 1, wide.data_ptr(), Vp + 1, labels.data_ptr(), -1, loss_r.data_ptr(),
+                                     lse_r.data_ptr(), st) == 0
+    assert lib.gps_masked_ce_backward(n, V, 1, wide.data_ptr(), Vp + 1, labels.data_ptr(), -1, lse_r.data_ptr(),
+                                      grad_rows.data_ptr(), d_r.data_ptr(), Vp + 1, st) == 0
+    loss, lse, d = run(lib.gps_masked_ce_forward_rows, lib.gps_masked_ce_backward_rows, (rows_dev.data_ptr(),))
+    live = slice(0, n_live)
+    assert torch.allclose(loss[live], loss_r[live], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(lse[live], lse_r[live], rtol=1e-5, atol=1e-5)
+    assert (loss[n_live:] == 0).all() and (lse[n_live:] == 0).all()
+    dl, dr = d[live, :V].float(), d_r[live, :V].float()
+    scale = max(dr.abs().max().item(), 1e-6) if n_live else 1.0
+    assert n_live == 0 or (dl - dr).abs().max().item() <= 2 ** -7 * scale
+    assert n_live == 0 or (d[live, V:] == 0).all()
+    assert (d[n_live:] == 5.0).all()                       # dead rows: never written
+    # without an extent the 16-byte forms cover every row (ignored ones zero-filled)
+    loss2, lse2, d2 = run(lib.gps_masked_ce_forward_rows, lib.gps_masked_ce_backward_rows, (None,))
+    assert torch.equal(loss2[live], loss[live]) and (d2[n_live:] == 0).all()
+    # a layout the 16-byte form cannot take + an extent -> refused, not silently wrong
+    assert lib.gps_masked_ce_forward_rows(n, V, 1, wide.data_ptr(), Vp + 1, labels.data_ptr(), -1, rows_dev.data_ptr(),
+                                          loss_r.data_ptr(), lse_r.data_ptr(), st) == -2
