@@ -58,6 +58,12 @@ GPS_API const char *gps_last_hip_error(void);
 #define GPS_FPS_MAX_RESIDENT_N 2048
 GPS_API int gps_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                 int32_t *idxs, gps_stream_t stream);
+/* The same sampling, also writing the sampled points: new_xyz (b,m,3) f32 = dataset[i][idxs[i][j]] -- what
+ * PointnetSAModule gets from transpose -> gather_operation -> transpose on the indices
+ * (pointnet2_modules.py:47-54), out of the launch that picked them.  n <= GPS_FPS_MAX_RESIDENT_N
+ * (GPS_ERR_UNSUPPORTED above it: use the two calls). */
+GPS_API int gps_furthest_point_sampling_xyz(int b, int n, int m, const float *dataset, int32_t *idxs,
+                                            float *new_xyz, gps_stream_t stream);
 
 /* out[i,l,j] = points[i,l,idx[i,j]].  Replaces gather_points_kernel_wrapper
  * (src/sampling.cpp:4-6, kernel src/sampling_gpu.cu:8-20).
@@ -491,8 +497,12 @@ GPS_API int gps_colsum_bf16(int rows, int cols, const void *x, long long ld, flo
  * modules/language/bert.py:21-26; torch: sort + segment reduction + scatter).  ids (n) int64, dy (n, ld >= d)
  * fp32, out (num_rows, d) fp32 = for every table row the sum of dy[t] over the tokens t with ids[t] == row
  * (zero for rows never referenced and for row padding_idx; pass -1 for "no padding row"; ids outside
- * [0, num_rows) are ignored).  Duplicates are added in ascending token order: the result is deterministic.
- * scratch: 2 * num_rows int32.  d and ld multiples of 4, d <= 2048, dy / out 16-byte aligned. */
+ * [0, num_rows) are ignored).  Deterministic: no floating-point atomics, a fixed order of additions.
+ * scratch: gps_embedding_grad_scratch_ints(n, num_rows, d) int32, 16-byte aligned (first occurrence + count per row, the
+ * list of tokens whose id occurs more than once, token lists and partial rows of the ids with >= 64 tokens).  Ids with
+ * fewer than 64 tokens are added in ascending token order; heavier ones 64 rows per partial sum, the partial sums in
+ * order -- a fixed association either way.  d and ld multiples of 4, d <= 2048, dy / out 16-byte aligned. */
+GPS_API long long gps_embedding_grad_scratch_ints(int n, int num_rows, int d);
 GPS_API int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids, const float *dy, long long ld,
                                long long padding_idx, int32_t *scratch, float *out, gps_stream_t stream);
 

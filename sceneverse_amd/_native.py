@@ -83,6 +83,7 @@ SIGNATURES = {
     "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
     "gps_gemm_wgrad_grouped": [ctypes.POINTER(WgradProblem), _i, _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_furthest_point_sampling_xyz": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
@@ -101,6 +102,7 @@ SIGNATURES = {
     "gps_sa_mlp_forward_bf16x3_pm": [_i] * 8 + [_vp] * 3 + [ctypes.c_longlong] + [_vp] * 4,
     "gps_obj_processing_post": [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp],
+    "gps_embedding_grad_scratch_ints": [_i, _i, _i],
     "gps_embedding_grad": [_i, _i, _i, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_loc_embed_partial_rows": [_i],
     "gps_loc_embed_forward": [_i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
@@ -179,6 +181,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_error_string.argtypes = [_i]
     lib.gps_last_hip_error.restype = ctypes.c_char_p
     lib.gps_sa_mlp_wpack_floats.restype = ctypes.c_longlong
+    lib.gps_embedding_grad_scratch_ints.restype = ctypes.c_longlong
     lib.gps_sa_mlp_wpack_floats.argtypes = [_i, _i, _i, _i]
     lib.gps_sa_mlp_layer_floats.restype = ctypes.c_longlong
     lib.gps_sa_mlp_layer_floats.argtypes = [_i, _i]

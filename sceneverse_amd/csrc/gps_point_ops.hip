@@ -110,12 +110,16 @@ __host__ __device__ __forceinline__ int fps_point_index(int L, int r, int p, int
 template <int R>
 __global__ __launch_bounds__(kBlock) void fps_resident_kernel(int b, int n, int m, int p, int Q,
                                                                const float *__restrict__ dataset,
-                                                               int32_t *__restrict__ idxs) {
+                                                               int32_t *__restrict__ idxs,
+                                                               float *__restrict__ centres) {
   const int obj = blockIdx.x * kWavesPerBlock + wave_id();
   if (obj >= b) return;  // whole wave exits together
   const int L = lane_id();
   const float *ds = dataset + (size_t)obj * n * 3;
   int32_t *out = idxs + (size_t)obj * m;
+  // [r5] optional (b, m, 3): the sampled points themselves, written with the indices (the host side otherwise ran
+  // index cast -> expand -> gather, four launches per level, for what is 384 bytes per object)
+  float *cen = centres ? centres + (size_t)obj * m * 3 : nullptr;
 
   float x[R], y[R], z[R];
   int t[R];  // fp32 bit patterns, see above
@@ -177,11 +181,21 @@ __global__ __launch_bounds__(kBlock) void fps_resident_kernel(int b, int n, int 
     if (L == (j & 63)) mine = old;
     if ((j & 63) == 63) {
       out[j - 63 + L] = mine;  // j-63 .. j, all < m
+      if (cen) {
+        float *c = cen + (size_t)(j - 63 + L) * 3;
+        c[0] = ds[mine * 3 + 0]; c[1] = ds[mine * 3 + 1]; c[2] = ds[mine * 3 + 2];
+      }
       mine = 0;
     }
   }
   const int base = (m - 1) & ~63;  // first index of the unflushed tail (covers idx[0] = 0 too)
-  if (((m - 1) & 63) != 63 && base + L < m) out[base + L] = mine;
+  if (((m - 1) & 63) != 63 && base + L < m) {
+    out[base + L] = mine;
+    if (cen) {
+      float *c = cen + (size_t)(base + L) * 3;
+      c[0] = ds[mine * 3 + 0]; c[1] = ds[mine * 3 + 1]; c[2] = ds[mine * 3 + 2];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -926,8 +940,8 @@ const char *gps_error_string(int status) {
 
 const char *gps_last_hip_error(void) { return g_last_hip_error; }
 
-int gps_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
-                                int32_t *idxs, gps_stream_t stream) {
+static int fps_launch(int b, int n, int m, const float *dataset, float *temp, int32_t *idxs, float *centres,
+                      gps_stream_t stream) {
   if (b < 0 || n < 0 || m < 0) return GPS_ERR_INVALID_ARGUMENT;
   if (b == 0 || m == 0) return GPS_OK;
   if (n < 1 || !dataset || !idxs) return GPS_ERR_INVALID_ARGUMENT;
@@ -939,7 +953,7 @@ int gps_furthest_point_sampling(int b, int n, int m, const float *dataset, float
   const dim3 grid((b + gps::kWavesPerBlock - 1) / gps::kWavesPerBlock), block(gps::kBlock);
 #define GPS_FPS_CASE(R_)                                                                       \
   hipLaunchKernelGGL(gps::fps_resident_kernel<R_>, grid, block, 0, s, b, n, m, p, Q, dataset, \
-                     idxs)
+                     idxs, centres)
   if (need <= 1) GPS_FPS_CASE(1);
   else if (need <= 2) GPS_FPS_CASE(2);
   else if (need <= 4) GPS_FPS_CASE(4);
@@ -947,12 +961,24 @@ int gps_furthest_point_sampling(int b, int n, int m, const float *dataset, float
   else if (need <= 16) GPS_FPS_CASE(16);
   else if (need <= 32) GPS_FPS_CASE(32);
   else {
+    if (centres) return GPS_ERR_UNSUPPORTED;     // the streaming form (n > 2048) writes indices only
     if (!temp) return GPS_ERR_INVALID_ARGUMENT;  // streaming form needs the (b,n) scratch
     hipLaunchKernelGGL(gps::fps_streaming_kernel, dim3(b), dim3(512), 0, s, b, n, m, dataset, temp,
                        idxs);
   }
 #undef GPS_FPS_CASE
   return finish_launch();
+}
+
+int gps_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int32_t *idxs, gps_stream_t stream) {
+  return fps_launch(b, n, m, dataset, temp, idxs, nullptr, stream);
+}
+
+int gps_furthest_point_sampling_xyz(int b, int n, int m, const float *dataset, int32_t *idxs, float *new_xyz,
+                                    gps_stream_t stream) {
+  if (b > 0 && m > 0 && !new_xyz) return GPS_ERR_INVALID_ARGUMENT;
+  return fps_launch(b, n, m, dataset, nullptr, idxs, new_xyz, stream);
 }
 
 int gps_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,

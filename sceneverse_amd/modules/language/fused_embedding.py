@@ -46,7 +46,7 @@ def embedding_grad(ids: torch.Tensor, dy: torch.Tensor, num_rows: int, padding_i
         ids1 = ids1.to(torch.int64).contiguous()
     n = ids1.numel()
     out = torch.empty((num_rows, d), dtype=torch.float32, device=dy2.device)
-    scratch = torch.empty(2 * num_rows, dtype=torch.int32, device=dy2.device)
+    scratch = torch.empty(int(_native.load().gps_embedding_grad_scratch_ints(n, num_rows, d)), dtype=torch.int32, device=dy2.device)
     from ...pointnet2._ext import _timed
     with torch.cuda.device(dy2.device), _timed(f"embedding_grad(n={n},rows={num_rows},d={d})",
                                                4 * n * d + 8 * n + 4 * num_rows * d):

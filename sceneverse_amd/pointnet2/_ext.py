@@ -134,6 +134,23 @@ def furthest_point_sampling(points: torch.Tensor, nsamples: int) -> torch.Tensor
     return out
 
 
+def furthest_point_sampling_xyz(points: torch.Tensor, nsamples: int):
+    """-> (indices (b, m) int32, sampled points (b, m, 3) fp32) from one launch; None when the cloud is too large for the
+    register-resident form (the caller then samples and gathers)."""
+    _chk(points, "points", torch.float32)
+    b, n, _ = points.shape
+    m = int(nsamples)
+    if n > 2048:
+        return None
+    out = torch.empty((b, m), dtype=torch.int32, device=points.device)
+    cen = torch.empty((b, m, 3), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device), _timed(f"furthest_point_sampling(n={n},m={m})", 4 * (b * n * 3 + b * m * 4)):
+        st = _native.load().gps_furthest_point_sampling_xyz(b, n, m, points.data_ptr(), out.data_ptr(), cen.data_ptr(),
+                                                            _stream())
+    _native.check(st, "furthest_point_sampling_xyz")
+    return out, cen
+
+
 def three_nn(unknowns: torch.Tensor, knows: torch.Tensor):
     _chk(unknowns, "unknowns", torch.float32)
     _chk(knows, "knows", torch.float32)

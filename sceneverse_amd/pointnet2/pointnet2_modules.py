@@ -105,6 +105,12 @@ class _PointnetSAModuleBase(nn.Module):
         """(B,N,3) -> (B,npoint,3) FPS centres, or None for a group-all level."""
         if self.npoint is None:
             return None
+        if xyz.is_cuda and not xyz.requires_grad and xyz.dtype == torch.float32 and xyz.is_contiguous() \
+                and hasattr(pointnet2_utils._ext, "furthest_point_sampling_xyz"):
+            # indices and the points they name from the launch that picks them
+            both = pointnet2_utils._ext.furthest_point_sampling_xyz(xyz, self.npoint)
+            if both is not None:
+                return both[1]
         inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         if xyz.is_cuda and not xyz.requires_grad:
             # the reference's transpose -> gather_operation -> transpose (pointnet2_modules.py:47-54) is a pure row

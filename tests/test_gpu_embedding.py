@@ -31,12 +31,23 @@ def ref_grad(ids, dy, num_rows, padding_idx):
     ((3000,), 4, 256, -1, "dense"),              # long duplicate runs (750 per row)
     ((33, 17), 1000, 1028, 5, "random"),         # d not a multiple of 256, padding row in the middle
     ((1, 1), 10, 4, -1, "random"),
+    ((7000,), 100, 1028, -1, "dense"),           # ~70 tokens per row: more heavy ids (>= 64 tokens) than the 64 the parallel path takes
+    ((64, 350), 30522, 768, 0, "masked"),        # the bench text: 15 % [MASK] (one id ~2 000 times), CLS / SEP x 64
 ])
 def test_embedding_grad_matches_torch_and_fp64(shape, num_rows, d, padding_idx, kind):
     g = torch.Generator(device="cpu").manual_seed(sum(shape) + num_rows)
     if kind == "bert":
         B, L = shape
         ids = torch.randint(1000, num_rows, shape, generator=g)
+        lens = torch.randint(6, L + 1, (B,), generator=g)
+        ids[:, 0] = 101
+        for b in range(B):
+            ids[b, lens[b] - 1] = 102
+            ids[b, lens[b]:] = 0
+    elif kind == "masked":
+        B, L = shape
+        ids = torch.randint(1000, num_rows, shape, generator=g)
+        ids[torch.rand(shape, generator=g) < 0.15] = 103
         lens = torch.randint(6, L + 1, (B,), generator=g)
         ids[:, 0] = 101
         for b in range(B):

@@ -38,6 +38,19 @@ def test_fps_shapes(n, m):
     assert torch.equal(got, ref), _mismatch(got, ref)
 
 
+@pytest.mark.parametrize("n,m", [(1024, 32), (32, 16), (2048, 130), (100, 64), (7, 7), (1500, 1)])
+def test_fps_with_the_sampled_points_from_the_same_launch(n, m):
+    """gps_furthest_point_sampling_xyz: the oracle's indices (bit-exact) and xyz[b, idx[b, j]] for every (b, j) -- what the
+    reference gets from transpose -> gather_operation -> transpose (pointnet2_modules.py:47-54)."""
+    x = generic_cloud(5, n, seed=n * 11 + m)
+    ref = OracleExt.furthest_point_sampling(x, m)
+    idx, cen = hip.furthest_point_sampling_xyz(x.to(DEV), m)
+    assert torch.equal(idx.cpu(), ref), _mismatch(idx.cpu(), ref)
+    want = torch.gather(x, 1, ref.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(cen.cpu(), want)
+    assert hip.furthest_point_sampling_xyz(torch.zeros(1, 4096, 3, device=DEV), 8) is None     # streaming form: two calls
+
+
 def test_ball_query_sa1_sa2_chain():
     x = sa1_cloud()
     fps = OracleExt.furthest_point_sampling(x, 32)
