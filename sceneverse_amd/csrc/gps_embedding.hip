@@ -4,7 +4,7 @@
 // modules/language/bert.py:21-26; 30 522 x 768 table, 3 200 + 19 200 token ids per step) whose backward
 // torch runs as sort -> segment bookkeeping -> sum_and_scatter (~60 launches, 1.27 ms/step for the two
 // BERT passes, profiles/r1/bench_z_kernel_stats.csv).  Here:
-//   memset   first[] = +big, count[] = 0
+//   init     first[] = +big, count[] = 0
 //   mark     one thread per token: atomicMin(first[id], t), atomicAdd(count[id], 1)  (order-independent)
 //   heavy    [r5] ids with >= 64 tokens ([MASK]: ~1 500 at the bench workload, [CLS] / [SEP]: 128): found in the count
 //            table (one workgroup), their tokens listed in ascending order (one workgroup per id), summed 64 rows per
@@ -28,6 +28,12 @@ namespace gps_emb {
 
 constexpr int kBlock = 256;
 constexpr int kMaxChunks = 8;                   // d <= 8 * 256 floats
+
+// first[] = +big, count[] = 0 (a kernel, not two hipMemsetAsync calls: one launch, and no memset nodes in a captured graph)
+__global__ __launch_bounds__(kBlock) void init_kernel(int num_rows, int32_t *__restrict__ first, int32_t *__restrict__ count) {
+  const int r = blockIdx.x * kBlock + threadIdx.x;
+  if (r < num_rows) { first[r] = 0x7F7F7F7F; count[r] = 0; }
+}
 
 __global__ __launch_bounds__(kBlock) void mark_kernel(int n, int num_rows, const int64_t *__restrict__ ids,
                                                       long long padding_idx, int32_t *__restrict__ first,
@@ -381,8 +387,7 @@ extern "C" int gps_embedding_grad(int n, int d, int num_rows, const int64_t *ids
   h = reinterpret_cast<int32_t *>((reinterpret_cast<uintptr_t>(h) + 15u) & ~(uintptr_t)15u);      // float4 rows
   H.partial = reinterpret_cast<float *>(h);
   if (n == 0) return hipMemsetAsync(out, 0, (size_t)num_rows * d * sizeof(float), s) == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
-  if (hipMemsetAsync(first, 0x7F, (size_t)num_rows * sizeof(int32_t), s) != hipSuccess) return GPS_ERR_LAUNCH;
-  if (hipMemsetAsync(count, 0, (size_t)num_rows * sizeof(int32_t), s) != hipSuccess) return GPS_ERR_LAUNCH;
+  hipLaunchKernelGGL(init_kernel, dim3((num_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, s, num_rows, first, count);
   const int chunks = (d + 255) / 256;
   hipLaunchKernelGGL(mark_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, num_rows, ids, padding_idx, first,
                      count);

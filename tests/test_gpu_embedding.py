@@ -245,3 +245,30 @@ def test_position_gradient_per_position_form_equals_the_scatter_form():
         a, b = grads[0][k], grads[1][k]
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item()), k
     assert torch.all(grads[1]["position_embeddings.weight"][300:] == 0)
+
+
+def test_embedding_grad_inside_a_replayed_graph():
+    """The whole call (init, mark, heavy / duplicate lists, fill, sums) captured into a HIP graph over poisoned pool
+    memory and replayed: every replay equals the eager result bit for bit.  (Round 5: the two adjacent hipMemsetAsync
+    calls this entry point used to make left `count` with a wrong pattern in REPLAYS of the training step's graph -- not
+    in eager runs and not in a small capture like this one -- which the old kernel survived slowly and the new heavy
+    path did not; the tables are now initialised by a kernel.)"""
+    g0 = torch.Generator(device="cpu").manual_seed(3)
+    ids = torch.randint(1000, 30522, (64, 350), generator=g0)
+    ids[torch.rand(64, 350, generator=g0) < 0.15] = 103
+    ids[:, 0] = 101
+    ids[:, 200:] = 0
+    ids = ids.to(DEV)
+    dy = torch.randn(64 * 350, 768, generator=g0).to(DEV)
+    ref = FE.embedding_grad(ids, dy, 30522, 0).clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            poison = torch.empty(16 << 20, dtype=torch.int32, device=DEV).fill_(0x7F7F7F7F)
+            del poison
+            out = FE.embedding_grad(ids, dy, 30522, 0)
+        for _ in range(4):
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
