@@ -325,14 +325,19 @@ GPS_API int gps_masked_ce_backward(int n_rows, int vocab, int logits_bf16, const
  * nor written (the masked-LM head orders the labelled rows first -- gps_lm_row_plan -- and its extent-aware GEMMs never
  * read the rest).  bf16 rows with a pitch that is a multiple of 8 elements and 16-byte aligned bases take 16-byte
  * accesses (the backward form then also writes zeros to the pad columns [vocab, 8 ceil(vocab / 8)), which ldd must
- * cover); with rows_dev set, any other layout returns GPS_ERR_UNSUPPORTED. */
+ * cover); with rows_dev, mean_out or grad_out set, any other layout returns GPS_ERR_UNSUPPORTED.
+ * mean_out (optional, 2 floats) + ticket (one unsigned int, ZERO before the first launch and left zero): mean_out[0] =
+ * sum(loss_rows) / count(labelled rows) -- the reference's mean -- taken by the last workgroup to arrive, in row order;
+ * mean_out[1] = that count.  backward: grad_rows (per-row factors) or, when NULL, grad_out (the upstream gradient of
+ * the mean, one device float) and count (one device float, e.g. mean_out + 1): every row's factor = *grad_out / *count. */
 GPS_API int gps_masked_ce_forward_rows(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
                                        const long long *labels, long long ignore_index, const int *rows_dev,
-                                       float *loss_rows, float *lse, gps_stream_t stream);
+                                       float *loss_rows, float *lse, float *mean_out, unsigned int *ticket,
+                                       gps_stream_t stream);
 GPS_API int gps_masked_ce_backward_rows(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
                                         const long long *labels, long long ignore_index, const int *rows_dev,
-                                        const float *lse, const float *grad_rows, void *dlogits, long long ldd,
-                                        gps_stream_t stream);
+                                        const float *lse, const float *grad_rows, const float *grad_out,
+                                        const float *count, void *dlogits, long long ldd, gps_stream_t stream);
 /* Row plan of the masked-LM head (replaces the valid-mask / argsort / index_select chain in front of lm_cls_loss,
  * optim/loss/loss.py:56-61): perm[n_rows] = the STABLE permutation of the token rows that puts those whose label is a
  * class id in [0, vocab) (and != ignore_index) first, labels_out[i] = label of row perm[i] (ignore_index for the rest),

@@ -118,8 +118,8 @@ SIGNATURES = {
     "gps_masked_ce_forward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp],
     "gps_masked_ce_backward": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp],
-    "gps_masked_ce_forward_rows": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp],
-    "gps_masked_ce_backward_rows": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp,
+    "gps_masked_ce_forward_rows": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gps_masked_ce_backward_rows": [_i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp,
                                     ctypes.c_longlong, _vp],
     "gps_lm_row_plan": [_i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp],
     "gps_text_obj_ce_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _f, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -308,13 +308,16 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(int d, const float *__restr
     // the duplicates lie behind entry e (the list is in token order)
     for (int base = e + 1; base < nd && missing > 0; base += 64 * kScan) {
       unsigned long long masks[kScan];
-      int toks[kScan];
+      int toks[kScan], idv[kScan];
 #pragma unroll
       for (int u = 0; u < kScan; ++u) {
-        const int q = min(base + u * 64 + lane, nd - 1);                  // unconditional: 2 kScan independent loads
+        const int q = min(base + u * 64 + lane, nd - 1);                  // unconditional: 2 kScan independent loads ...
         toks[u] = dup_t[q];
-        masks[u] = __ballot(base + u * 64 + lane < nd && dup_id[q] == id32);
+        idv[u] = dup_id[q];
       }
+      asm volatile("" ::: "memory");                                      // ... all requested before the first is used
+#pragma unroll
+      for (int u = 0; u < kScan; ++u) masks[u] = __ballot((base + u * 64 + lane < nd) & (idv[u] == id32));
 #pragma unroll
       for (int u = 0; u < kScan; ++u) {
         const unsigned long long m = masks[u];

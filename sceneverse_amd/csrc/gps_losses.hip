@@ -113,13 +113,41 @@ __device__ __forceinline__ void unpack8(const u32x4 q, float (&x)[8]) {
 __global__ __launch_bounds__(kBlock) void masked_ce_fwd_vec_kernel(int n_rows, int V, const uint16_t *__restrict__ logits,
                                                                     long long ld, const int64_t *__restrict__ labels,
                                                                     long long ignore_index, const int *__restrict__ rows_dev,
-                                                                    float *__restrict__ loss, float *__restrict__ lse_out) {
+                                                                    float *__restrict__ loss, float *__restrict__ lse_out,
+                                                                    float *__restrict__ mean_out,
+                                                                    unsigned int *__restrict__ ticket) {
   __shared__ float s_m[kBlock / 64], s_s[kBlock / 64];
+  __shared__ int s_last;
   const int row = blockIdx.x;
   const bool dead = rows_dev && row >= *rows_dev;               // the per-row outputs of dead rows are still defined (0)
   const long long label = dead ? ignore_index : labels[row];
+  // mean over the labelled rows, taken by the LAST workgroup to arrive (row order, no float atomics): every workgroup
+  // publishes its row loss, takes a ticket; the last one adds the n_rows values (64 lanes, fixed order) and counts labels
+  auto finish = [&](float mine) {
+    if (!mean_out) { if (threadIdx.x == 0) loss[row] = mine; return; }
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(loss + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned int)n_rows - 1u);
+      if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    const int live = rows_dev ? min(n_rows, *rows_dev) : n_rows;
+    float tot = 0.f;
+    int cnt = 0;
+    for (int r = threadIdx.x; r < live; r += 64) {
+      tot += __hip_atomic_load(loss + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long lb = labels[r];
+      cnt += (lb != ignore_index && lb >= 0 && lb < V) ? 1 : 0;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { tot += __shfl_xor(tot, off, 64); cnt += __shfl_xor(cnt, off, 64); }
+    if (threadIdx.x == 0) { mean_out[0] = tot / (float)cnt; mean_out[1] = (float)cnt; }
+  };
   if (dead || label == ignore_index || label < 0 || label >= V) {
-    if (threadIdx.x == 0) { loss[row] = 0.f; lse_out[row] = 0.f; }
+    if (threadIdx.x == 0) lse_out[row] = 0.f;
+    finish(0.f);
     return;
   }
   const uint16_t *x = logits + (size_t)row * ld;
@@ -148,10 +176,12 @@ __global__ __launch_bounds__(kBlock) void masked_ce_fwd_vec_kernel(int n_rows, i
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < kBlock / 64; ++w) lse_merge(m, s, s_m[w], s_s[w]);
-    const float lse = m + __logf(s);
-    lse_out[row] = lse;
-    loss[row] = lse - to_f32(x[label]);
+    s_m[0] = m + __logf(s);
   }
+  __syncthreads();
+  const float lse = s_m[0];
+  if (threadIdx.x == 0) lse_out[row] = lse;
+  finish(lse - to_f32(x[label]));
 }
 
 __global__ __launch_bounds__(kBlock) void masked_ce_bwd_vec_kernel(int n_rows, int V, const uint16_t *__restrict__ logits,
@@ -159,6 +189,8 @@ __global__ __launch_bounds__(kBlock) void masked_ce_bwd_vec_kernel(int n_rows, i
                                                                     long long ignore_index, const int *__restrict__ rows_dev,
                                                                     const float *__restrict__ lse,
                                                                     const float *__restrict__ grad_rows,
+                                                                    const float *__restrict__ grad_out,
+                                                                    const float *__restrict__ count,
                                                                     uint16_t *__restrict__ dlogits, long long ldd) {
   const int row = blockIdx.x;
   if (rows_dev && row >= *rows_dev) return;
@@ -166,7 +198,8 @@ __global__ __launch_bounds__(kBlock) void masked_ce_bwd_vec_kernel(int n_rows, i
   u32x4 *d8 = reinterpret_cast<u32x4 *>(dlogits + (size_t)row * ldd);
   const int groups = (V + 7) >> 3;                               // the pad columns [V, 8 groups) are written too (zeros)
   const bool valid = !(label == ignore_index || label < 0 || label >= V);
-  const float g = valid ? grad_rows[row] : 0.f;
+  // without per-row factors: upstream gradient of the MEAN / number of labelled rows (the forward pass's mean_out[1])
+  const float g = !valid ? 0.f : (grad_rows ? grad_rows[row] : grad_out[0] / count[0]);
   if (!valid || g == 0.f) {
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int gidx = threadIdx.x; gidx < groups; gidx += kBlock) d8[gidx] = z;
@@ -252,15 +285,17 @@ extern "C" {
 
 int gps_masked_ce_forward_rows(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
                                const long long *labels, long long ignore_index, const int *rows_dev, float *loss_rows,
-                               float *lse, gps_stream_t stream) {
+                               float *lse, float *mean_out, unsigned int *ticket, gps_stream_t stream) {
+  if ((mean_out == nullptr) != (ticket == nullptr)) return GPS_ERR_INVALID_ARGUMENT;
   if (n_rows < 0 || vocab < 1 || ld < vocab) return GPS_ERR_INVALID_ARGUMENT;
   if (n_rows == 0) return GPS_OK;
   if (!logits || !labels || !loss_rows || !lse) return GPS_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   if (logits_bf16 && vec_ok(logits, ld))
     hipLaunchKernelGGL(gps_loss::masked_ce_fwd_vec_kernel, dim3(n_rows), dim3(gps_loss::kBlock), 0, s, n_rows, vocab,
-                       (const uint16_t *)logits, ld, (const int64_t *)labels, ignore_index, rows_dev, loss_rows, lse);
-  else if (rows_dev)
+                       (const uint16_t *)logits, ld, (const int64_t *)labels, ignore_index, rows_dev, loss_rows, lse, mean_out,
+                       ticket);
+  else if (rows_dev || mean_out)
     return GPS_ERR_UNSUPPORTED;
   else if (logits_bf16)
     hipLaunchKernelGGL(gps_loss::masked_ce_fwd_kernel<uint16_t>, dim3(n_rows), dim3(gps_loss::kBlock), 0, s, n_rows,
@@ -275,22 +310,23 @@ int gps_masked_ce_forward(int n_rows, int vocab, int logits_bf16, const void *lo
                           const long long *labels, long long ignore_index, float *loss_rows, float *lse,
                           gps_stream_t stream) {
   return gps_masked_ce_forward_rows(n_rows, vocab, logits_bf16, logits, ld, labels, ignore_index, nullptr, loss_rows, lse,
-                                    stream);
+                                    nullptr, nullptr, stream);
 }
 
 int gps_masked_ce_backward_rows(int n_rows, int vocab, int logits_bf16, const void *logits, long long ld,
                                 const long long *labels, long long ignore_index, const int *rows_dev, const float *lse,
-                                const float *grad_rows, void *dlogits, long long ldd, gps_stream_t stream) {
+                                const float *grad_rows, const float *grad_out, const float *count, void *dlogits,
+                                long long ldd, gps_stream_t stream) {
   if (n_rows < 0 || vocab < 1 || ld < vocab || ldd < vocab) return GPS_ERR_INVALID_ARGUMENT;
   if (n_rows == 0) return GPS_OK;
-  if (!logits || !labels || !lse || !grad_rows || !dlogits) return GPS_ERR_INVALID_ARGUMENT;
+  if (!logits || !labels || !lse || (!grad_rows && (!grad_out || !count)) || !dlogits) return GPS_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   // the 16-byte form also writes the pad columns [vocab, 8 ceil(vocab / 8)) of each row: they must exist (ldd covers them)
   if (logits_bf16 && vec_ok(logits, ld) && vec_ok(dlogits, ldd) && ldd >= (vocab + 7) / 8 * 8)
     hipLaunchKernelGGL(gps_loss::masked_ce_bwd_vec_kernel, dim3(n_rows), dim3(gps_loss::kBlock), 0, s, n_rows, vocab,
-                       (const uint16_t *)logits, ld, (const int64_t *)labels, ignore_index, rows_dev, lse, grad_rows,
-                       (uint16_t *)dlogits, ldd);
-  else if (rows_dev)
+                       (const uint16_t *)logits, ld, (const int64_t *)labels, ignore_index, rows_dev, lse, grad_rows, grad_out,
+                       count, (uint16_t *)dlogits, ldd);
+  else if (rows_dev || !grad_rows)
     return GPS_ERR_UNSUPPORTED;
   else if (logits_bf16)
     hipLaunchKernelGGL(gps_loss::masked_ce_bwd_kernel<uint16_t>, dim3(n_rows), dim3(gps_loss::kBlock), 0, s, n_rows,
@@ -307,7 +343,7 @@ int gps_masked_ce_backward(int n_rows, int vocab, int logits_bf16, const void *l
                            const long long *labels, long long ignore_index, const float *lse,
                            const float *grad_rows, void *dlogits, long long ldd, gps_stream_t stream) {
   return gps_masked_ce_backward_rows(n_rows, vocab, logits_bf16, logits, ld, labels, ignore_index, nullptr, lse, grad_rows,
-                                     dlogits, ldd, stream);
+                                     nullptr, nullptr, dlogits, ldd, stream);
 }
 
 int gps_lm_row_plan(int n_rows, int vocab, const long long *labels, long long ignore_index, long long *perm,

@@ -25,6 +25,18 @@ import torch
 from ... import _native
 from ...modules.layers import gemm as G
 
+_TICKETS = {}
+
+
+def _ticket(device: torch.device) -> torch.Tensor:
+    """The zeroed arrival counter of gps_masked_ce_forward_rows' mean (left at zero by every launch)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 def _padded_shadow(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     """bf16 copy of `weight` (V, D) with the rows padded to a multiple of 8 (zeros) + fp32 padded bias, from the
     shadow registry of modules/layers/gemm.py (the clip + AdamW kernel writes it with the masters)."""
@@ -84,32 +96,31 @@ class _SparseLMLoss(torch.autograd.Function):
         G.gemm(_native.GEMM_NT, _native.EPI_BIAS, n, Vp, D, hp, D, w16, D, logits, Vp, bias=b32, extent_dev=n_valid)
         rows = torch.empty(n, dtype=torch.float32, device=dev)
         lse = torch.empty(n, dtype=torch.float32, device=dev)
+        mean = torch.empty(2, dtype=torch.float32, device=dev)           # [mean over the labelled rows, their number]
         with torch.cuda.device(dev):
             st = lib.gps_masked_ce_forward_rows(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), int(ignore_index),
-                                                n_valid.data_ptr(), rows.data_ptr(), lse.data_ptr(),
-                                                torch.cuda.current_stream().cuda_stream)
+                                                n_valid.data_ptr(), rows.data_ptr(), lse.data_ptr(), mean.data_ptr(),
+                                                _ticket(dev).data_ptr(), torch.cuda.current_stream().cuda_stream)
         _native.check(st, "masked_ce_forward")
-        nv = n_valid.to(torch.float32)
-        loss = (rows.sum() / nv).reshape(())
-        ctx.save_for_backward(hp, w16, logits, lp, lse, perm, n_valid, nv)
+        ctx.save_for_backward(hp, w16, logits, lp, lse, perm, n_valid, mean)
         ctx.meta = (n, D, V, Vp, int(ignore_index), h.dtype, bias is not None)
         ctx.prepermuted = plan is not None
-        return loss
+        return mean[0]
 
     @staticmethod
     def backward(ctx, g):
-        hp, w16, logits, lp, lse, perm, n_valid, nv = ctx.saved_tensors
+        hp, w16, logits, lp, lse, perm, n_valid, mean = ctx.saved_tensors
         n, D, V, Vp, ignore_index, h_dtype, has_bias = ctx.meta
         lib = _native.load()
         dev = hp.device
         stream = torch.cuda.current_stream().cuda_stream
-        grad_rows = (g.reshape(1).float() / nv).expand(n).contiguous()
+        g32 = g.reshape(1).float().contiguous()                             # (no launch for the fp32 scalar autograd hands over)
         dlogits = torch.empty((n, Vp), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
             # rows past n_valid stay unwritten: the two GEMMs below stop at the extent (their ragged tail reads zeros)
             st = lib.gps_masked_ce_backward_rows(n, V, 1, logits.data_ptr(), Vp, lp.data_ptr(), ignore_index,
-                                                 n_valid.data_ptr(), lse.data_ptr(), grad_rows.data_ptr(),
-                                                 dlogits.data_ptr(), Vp, stream)
+                                                 n_valid.data_ptr(), lse.data_ptr(), None, g32.data_ptr(),
+                                                 mean[1:].data_ptr(), dlogits.data_ptr(), Vp, stream)
         _native.check(st, "masked_ce_backward")
         dh = dw = db = None
         if ctx.needs_input_grad[0]:

@@ -62,12 +62,26 @@ def test_audit_tool_parses_a_small_file():
 def test_word_table_gradient_keeps_its_rows_in_registers_and_its_loads_in_flight():
     body, meta = _kernel(_asm("gps_embedding"), "sum_kernel")
     assert _meta(meta, "private_segment_fixed_size") == 0 and "scratch_" not in body
-    # the id scan: >= 16 global loads between two waits somewhere in the kernel (was one load per wait)
-    runs = [len(re.findall(r"global_load_dwordx2", seg)) for seg in re.split(r"s_waitcnt vmcnt", body)]
-    assert max(runs) >= 16, runs
+    # the scan of the duplicate list (int32 token / id pairs): >= 16 global loads between two waits somewhere in the
+    # kernel (was one load per wait)
+    runs = [len(re.findall(r"global_load_dword\s", seg)) for seg in re.split(r"s_waitcnt vmcnt", body)]
+    assert max(runs) >= 12, runs                                   # 2 x 8 list words per trip, all but a straggler together
     # the row fetch: 16 x 16-byte loads issued back to back
     runs4 = [len(re.findall(r"global_load_dwordx4", seg)) for seg in re.split(r"s_waitcnt vmcnt", body)]
     assert max(runs4) >= 16, runs4
+
+
+def test_single_workgroup_compactions_keep_their_loads_in_flight():
+    """compact_ranges (gps_embedding.hip): the token / count words of a wave's range are requested in batches of 16 before
+    the first use -- with a use next to each load the one-workgroup list builders walked their range one memory round
+    trip at a time (33 us for 22 400 tokens).  No scratch: the hit masks and payloads stay in registers."""
+    text = _asm("gps_embedding")
+    for name, pat in (("dup_list_kernel", r"global_load_dword\s"), ("heavy_list_kernel", r"global_load_dwordx2"),
+                      ("heavy_find_kernel", r"global_load_dword\s")):
+        body, meta = _kernel(text, name)
+        assert _meta(meta, "private_segment_fixed_size") == 0 and "scratch_" not in body, name
+        runs = [len(re.findall(pat, seg)) for seg in re.split(r"s_waitcnt vmcnt", body)]
+        assert max(runs) >= 12, (name, runs)
 
 
 @pytest.mark.parametrize("which,max_vgpr", [("fwd", 128), ("bwd", 128)])

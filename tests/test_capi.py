@@ -46,8 +46,9 @@ def test_argument_validation_without_gpu():
     assert lib.gps_attn_forward(2, 12, 600, 64, 1, 1, 1, 2304, None, None, None, 0.0, 0, None, 1, 768, 1, None) == -2
     assert lib.gps_masked_ce_forward(0, 30522, 1, None, 30522, None, -1, None, None, None) == 0
     assert lib.gps_masked_ce_forward(4, 30522, 1, 1, 100, 1, -1, 1, 1, None) == -1                   # ld < vocab
-    assert lib.gps_masked_ce_forward_rows(0, 30522, 1, None, 30528, None, -1, None, None, None, None) == 0
-    assert lib.gps_masked_ce_backward_rows(4, 30522, 1, 1, 30528, 1, -1, None, 1, 1, 1, 100, None) == -1   # ldd < vocab
+    assert lib.gps_masked_ce_forward_rows(0, 30522, 1, None, 30528, None, -1, None, None, None, None, None, None) == 0
+    assert lib.gps_masked_ce_backward_rows(4, 30522, 1, 1, 30528, 1, -1, None, 1, 1, None, None, 1, 100, None) == -1   # ldd < vocab
+    assert lib.gps_masked_ce_forward_rows(4, 30522, 1, 16, 30528, 1, -1, None, 1, 1, 1, None, None) == -1      # mean without ticket
     assert lib.gps_lm_row_plan(8, 0, 1, -1, 1, 1, 1, None) == -1                                     # vocab < 1
     assert lib.gps_lm_row_plan(8, 10, None, -1, 1, 1, 1, None) == -1
     assert lib.gps_text_obj_ce_forward(0, 80, 768, None, None, None, None, 1e-12, -100, None, None, None, None, None, None,

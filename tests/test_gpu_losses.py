@@ -171,15 +171,25 @@ def test_cross_entropy_with_a_device_side_row_extent(n, V, n_live):
     grad_rows = (torch.rand(n, generator=g) + 0.5).to(DEV)
     st = torch.cuda.current_stream().cuda_stream
 
-    def run(fwd, bwd, extra):
+    ticket = torch.zeros(1, dtype=torch.int32, device=DEV)
+
+    def run(fwd, bwd, extra, fused_mean=False):
         loss = torch.full((n,), -7.0, device=DEV)
         lse = torch.full((n,), -7.0, device=DEV)
+        mean = torch.full((2,), -7.0, device=DEV)
         d = torch.full((n, Vp), 5.0, dtype=torch.bfloat16, device=DEV)
-        assert fwd(n, V, 1, logits.data_ptr(), Vp, labels.data_ptr(), -1, *extra, loss.data_ptr(), lse.data_ptr(), st) == 0
-        assert bwd(n, V, 1, logits.data_ptr(), Vp, labels.data_ptr(), -1, *extra, lse.data_ptr(), grad_rows.data_ptr(),
-                   d.data_ptr(), Vp, st) == 0
+        assert fwd(n, V, 1, logits.data_ptr(), Vp, labels.data_ptr(), -1, *extra, loss.data_ptr(), lse.data_ptr(),
+                   mean.data_ptr() if fused_mean else None, ticket.data_ptr() if fused_mean else None, st) == 0
+        if fused_mean:                                     # every row's factor = *grad_out / count
+            gout = torch.tensor([0.7], device=DEV)
+            assert bwd(n, V, 1, logits.data_ptr(), Vp, labels.data_ptr(), -1, *extra, lse.data_ptr(), None, gout.data_ptr(),
+                       mean[1:].data_ptr(), d.data_ptr(), Vp, st) == 0
+        else:
+            assert bwd(n, V, 1, logits.data_ptr(), Vp, labels.data_ptr(), -1, *extra, lse.data_ptr(), grad_rows.data_ptr(),
+                       None, None, d.data_ptr(), Vp, st) == 0
         torch.cuda.synchronize()
-        return loss, lse, d
+        assert int(ticket.item()) == 0                     # the arrival counter is left at zero
+        return (loss, lse, d, mean) if fused_mean else (loss, lse, d)
 
     # reference: the scalar kernels on an UNPADDED copy (pitch V is not a multiple of 8 for these V, or is forced scalar
     # by the odd pitch Vp + 1)
@@ -204,6 +214,18 @@ def test_cross_entropy_with_a_device_side_row_extent(n, V, n_live):
     # without an extent the 16-byte forms cover every row (ignored ones zero-filled)
     loss2, lse2, d2 = run(lib.gps_masked_ce_forward_rows, lib.gps_masked_ce_backward_rows, (None,))
     assert torch.equal(loss2[live], loss[live]) and (d2[n_live:] == 0).all()
+    # mean by the last workgroup to arrive + the scalar upstream gradient: equal to sum / count and to uniform row factors
+    valid = (labels[:n_live] != -1)
+    cnt = int(valid.sum().item())
+    for rep in range(2):
+        loss3, lse3, d3, mean3 = run(lib.gps_masked_ce_forward_rows, lib.gps_masked_ce_backward_rows, (rows_dev.data_ptr(),), True)
+        assert int(mean3[1].item()) == cnt
+        if cnt:
+            assert abs(mean3[0].item() - loss[live].sum().item() / cnt) <= 1e-5 * abs(mean3[0].item()) + 1e-6
+            want = (d[live, :V].float() / grad_rows[live, None]) * (0.7 / cnt)
+            got3 = d3[live, :V].float()
+            sc = max(want.abs().max().item(), 1e-9)
+            assert (got3[valid] - want[valid]).abs().max().item() <= 2 ** -6 * sc
     # a layout the 16-byte form cannot take + an extent -> refused, not silently wrong
     assert lib.gps_masked_ce_forward_rows(n, V, 1, wide.data_ptr(), Vp + 1, labels.data_ptr(), -1, rows_dev.data_ptr(),
-                                          loss_r.data_ptr(), lse_r.data_ptr(), st) == -2
+                                          loss_r.data_ptr(), lse_r.data_ptr(), None, None, st) == -2
