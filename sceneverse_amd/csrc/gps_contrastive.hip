@@ -86,21 +86,31 @@ __global__ __launch_bounds__(kBlock) void text_obj_fwd_kernel(int B, int O, int 
     tn4[i] = v;
   }
   __syncthreads();
-  for (int o = w; o < O; o += kWaves) {
-    const float4 *x4 = reinterpret_cast<const float4 *>(obj + ((size_t)b * O + o) * D);
-    float so = 0.f, dt = 0.f;
+  // four objects per wave and trip: their rows are requested together (one object at a time was one dependent memory
+  // round trip + two wave reductions per object, 20 in a row at O = 80: 37 us for a 16 MB read)
+  for (int o0 = w; o0 < O; o0 += 4 * kWaves) {
+    const float4 *x4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x4[u] = reinterpret_cast<const float4 *>(obj + ((size_t)b * O + min(o0 + u * kWaves, O - 1)) * D);
+    float so[4] = {0.f, 0.f, 0.f, 0.f}, dt[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = lane; i < D4; i += 64) {
-      const float4 v = x4[i];
-      so += dot4(v, v);
-      dt += dot4(v, tn4[i]);
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = x4[u][i];
+      const float4 t = tn4[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { so[u] += dot4(v[u], v[u]); dt[u] += dot4(v[u], t); }
     }
-    so = wave_sum(so);
-    dt = wave_sum(dt);
-    const float io = 1.f / fmaxf(sqrtf(so), eps);
-    if (lane == 0) {
-      inv_o[(size_t)b * O + o] = io;
-      lg[o] = dt * io;
-      cosv[(size_t)b * O + o] = dt * io;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * kWaves;
+      const float s2 = wave_sum(so[u]), d2 = wave_sum(dt[u]);
+      const float io = 1.f / fmaxf(sqrtf(s2), eps);
+      if (lane == 0 && o < O) {
+        inv_o[(size_t)b * O + o] = io;
+        lg[o] = d2 * io;
+        cosv[(size_t)b * O + o] = d2 * io;
+      }
     }
   }
   __syncthreads();
@@ -114,20 +124,28 @@ __global__ __launch_bounds__(kBlock) void text_obj_fwd_kernel(int B, int O, int 
   s = wave_sum(s);
   const float lse = m + __logf(s);
   for (int o = lane; o < O; o += 64) prob[(size_t)b * O + o] = mk[o] ? __expf(lg[o] - lse) : 0.f;
-  if (lane != 0) return;
-  inv_t[b] = it;
   const long long lab = labels[b];
   const bool counted = lab != ignore_index && lab >= 0 && lab < O;
-  // a label on a masked object has logit -inf: loss +inf, as F.cross_entropy gives
-  const float mine = counted ? lse - (mk[lab] ? lg[lab] : -INFINITY) : 0.f;
-  if (publish_and_last(loss_rows, b, mine, ticket, B)) {
-    float total = 0.f;
-    int cnt = 0;
-    for (int i = 0; i < B; ++i) {
-      total += peek(loss_rows + i);
-      const long long li = labels[i];
-      cnt += (li != ignore_index && li >= 0 && li < O) ? 1 : 0;
-    }
+  int last = 0;
+  if (lane == 0) {
+    inv_t[b] = it;
+    // a label on a masked object has logit -inf: loss +inf, as F.cross_entropy gives
+    const float mine = counted ? lse - (mk[lab] ? lg[lab] : -INFINITY) : 0.f;
+    last = publish_and_last(loss_rows, b, mine, ticket, B) ? 1 : 0;
+  }
+  if (!__shfl(last, 0, 64)) return;
+  // the last scene to arrive: the mean, by the whole wave (lane-strided partial sums in a fixed order; one lane walking
+  // the B values paid a memory round trip per value: 30 us)
+  float total = 0.f;
+  int cnt = 0;
+  for (int i = lane; i < B; i += 64) {
+    total += peek(loss_rows + i);
+    const long long li = labels[i];
+    cnt += (li != ignore_index && li >= 0 && li < O) ? 1 : 0;
+  }
+  total = wave_sum(total);
+  for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  if (lane == 0) {
     scal[0] = total / (float)cnt;
     scal[1] = (float)cnt;
   }
@@ -197,10 +215,15 @@ __global__ __launch_bounds__(kBlock) void text_obj_bwd_kernel(int B, int O, int 
   for (int i = threadIdx.x; i < D4; i += kBlock) {
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     const float4 *x4 = reinterpret_cast<const float4 *>(obj + (size_t)b * O * D) + i;
-    for (int o = 0; o < O; ++o) {
-      const float4 x = x4[(size_t)o * D4];
-      const float c = co[o];
-      acc.x += c * x.x; acc.y += c * x.y; acc.z += c * x.z; acc.w += c * x.w;
+    for (int o0 = 0; o0 < O; o0 += 8) {                            // 8 rows requested together, added in object order
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = x4[(size_t)min(o0 + u, O - 1) * D4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float c = (o0 + u < O) ? co[min(o0 + u, O - 1)] : 0.f;
+        acc.x += c * x[u].x; acc.y += c * x[u].y; acc.z += c * x[u].z; acc.w += c * x[u].w;
+      }
     }
     const float4 t = tn4[i];
     float4 r;
@@ -245,20 +268,36 @@ __global__ __launch_bounds__(kBlock) void clip_fwd_kernel(int n, int D, int norm
     an4[k] = x; bn4[k] = y;
   }
   __syncthreads();
-  for (int j = w; j < n; j += kWaves) {
-    const float4 *aj4 = reinterpret_cast<const float4 *>(a + (size_t)j * D), *bj4 = reinterpret_cast<const float4 *>(bm + (size_t)j * D);
-    float d_row = 0.f, s_b = 0.f, d_col = 0.f, s_a = 0.f;
-    for (int k = lane; k < D4; k += 64) {
-      const float4 y = bj4[k], x = aj4[k];
-      d_row += dot4(an4[k], y); s_b += dot4(y, y);
-      d_col += dot4(bn4[k], x); s_a += dot4(x, x);
+  for (int j0 = w; j0 < n; j0 += 2 * kWaves) {                     // two rows of each operand per wave and trip
+    const float4 *aj4[2], *bj4[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = min(j0 + u * kWaves, n - 1);
+      aj4[u] = reinterpret_cast<const float4 *>(a + (size_t)j * D);
+      bj4[u] = reinterpret_cast<const float4 *>(bm + (size_t)j * D);
     }
-    d_row = wave_sum(d_row); s_b = wave_sum(s_b); d_col = wave_sum(d_col); s_a = wave_sum(s_a);
-    if (lane == 0) {
-      const float jb = normalize ? 1.f / fmaxf(sqrtf(s_b), eps) : 1.f, ja = normalize ? 1.f / fmaxf(sqrtf(s_a), eps) : 1.f;
-      row[j] = d_row * jb;
-      col[j] = d_col * ja;
-      M[(size_t)i * n + j] = d_row * jb;
+    float d_row[2] = {0.f, 0.f}, s_b[2] = {0.f, 0.f}, d_col[2] = {0.f, 0.f}, s_a[2] = {0.f, 0.f};
+    for (int k = lane; k < D4; k += 64) {
+      float4 x[2], y[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { y[u] = bj4[u][k]; x[u] = aj4[u][k]; }
+      const float4 an_k = an4[k], bn_k = bn4[k];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        d_row[u] += dot4(an_k, y[u]); s_b[u] += dot4(y[u], y[u]);
+        d_col[u] += dot4(bn_k, x[u]); s_a[u] += dot4(x[u], x[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = j0 + u * kWaves;
+      const float dr = wave_sum(d_row[u]), sb2 = wave_sum(s_b[u]), dc = wave_sum(d_col[u]), sa2 = wave_sum(s_a[u]);
+      if (lane == 0 && j < n) {
+        const float jb = normalize ? 1.f / fmaxf(sqrtf(sb2), eps) : 1.f, ja = normalize ? 1.f / fmaxf(sqrtf(sa2), eps) : 1.f;
+        row[j] = dr * jb;
+        col[j] = dc * ja;
+        M[(size_t)i * n + j] = dr * jb;
+      }
     }
   }
   __syncthreads();
@@ -270,18 +309,21 @@ __global__ __launch_bounds__(kBlock) void clip_fwd_kernel(int n, int D, int norm
   float er = 0.f, ec = 0.f;
   for (int j = lane; j < n; j += 64) { er += __expf(s * row[j] - mr); ec += __expf(s * col[j] - mc); }
   er = wave_sum(er); ec = wave_sum(ec);
-  if (lane != 0) return;
-  const float lr = mr + __logf(er), lc = mc + __logf(ec);
-  lse_row[i] = lr;
-  lse_col[i] = lc;
-  inv_a[i] = ia;
-  inv_b[i] = ib;
-  const float mine = (lr - s * row[i]) + (lc - s * col[i]);
-  if (publish_and_last(loss_rows, i, mine, ticket, n)) {
-    float total = 0.f;
-    for (int k = 0; k < n; ++k) total += peek(loss_rows + k);
-    loss[0] = total / (2.f * (float)n);
+  int last = 0;
+  if (lane == 0) {
+    const float lr = mr + __logf(er), lc = mc + __logf(ec);
+    lse_row[i] = lr;
+    lse_col[i] = lc;
+    inv_a[i] = ia;
+    inv_b[i] = ib;
+    const float mine = (lr - s * row[i]) + (lc - s * col[i]);
+    last = publish_and_last(loss_rows, i, mine, ticket, n) ? 1 : 0;
   }
+  if (!__shfl(last, 0, 64)) return;
+  float total = 0.f;                                              // the mean, by the whole wave of the last arrival
+  for (int k = lane; k < n; k += 64) total += peek(loss_rows + k);
+  total = wave_sum(total);
+  if (lane == 0) loss[0] = total / (2.f * (float)n);
 }
 
 // Workgroup i: dM[i][j] (row) and dM[j][i] (column) with
@@ -318,11 +360,14 @@ __global__ __launch_bounds__(kBlock) void clip_bwd_kernel(int n, int D, int norm
   }
   p_row = block_sum(p_row, red);                                  // = a_n[i] . da_n[i] / s; orders cr / cc too
   p_col = block_sum(p_col, red);
-  if (threadIdx.x == 0) {
-    if (publish_and_last(ds_rows, i, p_row, ticket, n)) {
+  if (threadIdx.x < 64) {                                          // wave 0: the last arrival sums the row partials
+    int last = 0;
+    if (threadIdx.x == 0) last = publish_and_last(ds_rows, i, p_row, ticket, n) ? 1 : 0;
+    if (__shfl(last, 0, 64)) {
       float total = 0.f;
-      for (int k = 0; k < n; ++k) total += peek(ds_rows + k);
-      dscale[0] = raw <= max_scale ? total : 0.f;                  // torch.clamp(max=): gradient where raw <= max
+      for (int k = threadIdx.x; k < n; k += 64) total += peek(ds_rows + k);
+      total = wave_sum(total);
+      if (threadIdx.x == 0) dscale[0] = raw <= max_scale ? total : 0.f;   // torch.clamp(max=): gradient where raw <= max
     }
   }
   if (!need_feats) return;
@@ -332,11 +377,21 @@ __global__ __launch_bounds__(kBlock) void clip_bwd_kernel(int n, int D, int norm
   for (int k = threadIdx.x; k < D4; k += kBlock) {
     float4 ua = {0.f, 0.f, 0.f, 0.f}, ub = {0.f, 0.f, 0.f, 0.f};
     const float4 *b4 = reinterpret_cast<const float4 *>(bm) + k, *a4 = reinterpret_cast<const float4 *>(a) + k;
-    for (int j = 0; j < n; ++j) {
-      const float4 y = b4[(size_t)j * D4], x = a4[(size_t)j * D4];
-      const float r = cr[j], c = cc[j];
-      ua.x += r * y.x; ua.y += r * y.y; ua.z += r * y.z; ua.w += r * y.w;
-      ub.x += c * x.x; ub.y += c * x.y; ub.z += c * x.z; ub.w += c * x.w;
+    for (int j0 = 0; j0 < n; j0 += 8) {                            // 8 rows of each operand requested together, added in row order
+      float4 y[8], x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t j = (size_t)min(j0 + u, n - 1);
+        y[u] = b4[j * D4];
+        x[u] = a4[j * D4];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool in = j0 + u < n;
+        const float r = in ? cr[min(j0 + u, n - 1)] : 0.f, c = in ? cc[min(j0 + u, n - 1)] : 0.f;
+        ua.x += r * y[u].x; ua.y += r * y[u].y; ua.z += r * y[u].z; ua.w += r * y[u].w;
+        ub.x += c * x[u].x; ub.y += c * x[u].y; ub.z += c * x[u].z; ub.w += c * x[u].w;
+      }
     }
     const float4 xi = a4[(size_t)i * D4], yi = b4[(size_t)i * D4];
     float4 ra, rb;

@@ -119,25 +119,26 @@ __global__ __launch_bounds__(kBlock) void masked_ce_fwd_vec_kernel(int n_rows, i
   __shared__ float s_m[kBlock / 64], s_s[kBlock / 64];
   __shared__ int s_last;
   const int row = blockIdx.x;
-  const bool dead = rows_dev && row >= *rows_dev;               // the per-row outputs of dead rows are still defined (0)
+  const int live_rows = rows_dev ? min(n_rows, *rows_dev) : n_rows;
+  const bool dead = row >= live_rows;                           // the per-row outputs of dead rows are still defined (0)
   const long long label = dead ? ignore_index : labels[row];
-  // mean over the labelled rows, taken by the LAST workgroup to arrive (row order, no float atomics): every workgroup
-  // publishes its row loss, takes a ticket; the last one adds the n_rows values (64 lanes, fixed order) and counts labels
+  // mean over the labelled rows, taken by the LAST LIVE workgroup to arrive (row order, no float atomics): every live
+  // workgroup publishes its row loss and takes a ticket; the last one adds the live values (64 lanes, fixed order) and
+  // counts labels.  Dead rows take no ticket: 3 200 workgroups incrementing one word cost 30 us of serialised atomics.
   auto finish = [&](float mine) {
     if (!mean_out) { if (threadIdx.x == 0) loss[row] = mine; return; }
     if (threadIdx.x == 0) {
       __hip_atomic_store(loss + row, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == (unsigned int)n_rows - 1u);
+      s_last = (t == (unsigned int)live_rows - 1u);
       if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last || threadIdx.x >= 64) return;
-    const int live = rows_dev ? min(n_rows, *rows_dev) : n_rows;
     float tot = 0.f;
     int cnt = 0;
-    for (int r = threadIdx.x; r < live; r += 64) {
+    for (int r = threadIdx.x; r < live_rows; r += 64) {
       tot += __hip_atomic_load(loss + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long lb = labels[r];
       cnt += (lb != ignore_index && lb >= 0 && lb < V) ? 1 : 0;
@@ -145,7 +146,15 @@ __global__ __launch_bounds__(kBlock) void masked_ce_fwd_vec_kernel(int n_rows, i
     for (int off = 32; off >= 1; off >>= 1) { tot += __shfl_xor(tot, off, 64); cnt += __shfl_xor(cnt, off, 64); }
     if (threadIdx.x == 0) { mean_out[0] = tot / (float)cnt; mean_out[1] = (float)cnt; }
   };
-  if (dead || label == ignore_index || label < 0 || label >= V) {
+  if (dead) {
+    if (threadIdx.x == 0) {
+      loss[row] = 0.f;
+      lse_out[row] = 0.f;
+      if (mean_out && live_rows == 0 && row == 0) { mean_out[0] = __int_as_float(0x7FC00000); mean_out[1] = 0.f; }   // mean of nothing
+    }
+    return;
+  }
+  if (label == ignore_index || label < 0 || label >= V) {
     if (threadIdx.x == 0) lse_out[row] = 0.f;
     finish(0.f);
     return;
