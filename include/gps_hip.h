@@ -65,6 +65,28 @@ GPS_API int gps_furthest_point_sampling(int b, int n, int m, const float *datase
 GPS_API int gps_furthest_point_sampling_xyz(int b, int n, int m, const float *dataset, int32_t *idxs,
                                             float *new_xyz, gps_stream_t stream);
 
+/* ---- distinct clouds only (frozen object encoder) ------------------------------------------------------------
+ * The reference pads a scene to its maximum object count with CONSTANT clouds (data/datasets/dataset_wrapper.py:64-65:
+ * pad_tensors(obj_fts, lens=max_obj_len, pad=1.0)) and runs PointNet++ on every slot
+ * (modules/vision/pcd_openvocab_encoder.py:156-160); every pad gets the same features.  gps_cloud_compact decides from
+ * the DATA which objects of cloud (b, n, ld) [xyz | ld - 3 feature columns] are pads -- one 32-bit word repeated over
+ * the whole cloud, the same word as the first such object of the batch -- and lays out the work list: the other
+ * objects in their order, then ONE pad representative (if any).
+ *   obj_of (b) int32      object at each work slot (slots past the extent name a valid object)
+ *   slot_of (b) int64     work slot whose result object o reads (every pad: the representative's)
+ *   scal (4) int32        [work slots, ordinary objects, first pad object or -1, work slots * rows_mult]
+ *   xyz_c (b, n, 3), feat_c (b, n, ld - 3) point-major     the clouds of the work slots (the rest is not written)
+ *   flag_scratch (2 b) int32
+ * gps_point_set_object_extent(p): while p is not NULL the per-object launches of gps_furthest_point_sampling[_xyz]
+ * (register-resident form), gps_ball_query, gps_sa_mlp_forward*, gps_split3_points process objects [0, *p) only and
+ * neither read nor write the others (p = scal of the plan; device memory; process-wide, like gps_sa_mlp_set_products:
+ * set it around the encoder's launches, reset it to NULL afterwards).  Per-object results do not depend on the other
+ * objects of the batch, so result[slot_of[o]] is bit-identical to running every object. */
+GPS_API int gps_cloud_compact(int b, int n, int ld, const float *cloud, int rows_mult, int32_t *flag_scratch,
+                              int32_t *obj_of, long long *slot_of, int32_t *scal, float *xyz_c, float *feat_c,
+                              gps_stream_t stream);
+GPS_API void gps_point_set_object_extent(const int *n_objects_dev);
+
 /* out[i,l,j] = points[i,l,idx[i,j]].  Replaces gather_points_kernel_wrapper
  * (src/sampling.cpp:4-6, kernel src/sampling_gpu.cu:8-20).
  *   points (b,c,n) f32, idx (b,npoints) i32 -> out (b,c,npoints) f32. */

@@ -84,6 +84,8 @@ SIGNATURES = {
     "gps_gemm_wgrad_grouped": [ctypes.POINTER(WgradProblem), _i, _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_furthest_point_sampling_xyz": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "gps_cloud_compact": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gps_point_set_object_extent": [_vp],
     "gps_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
@@ -182,6 +184,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_last_hip_error.restype = ctypes.c_char_p
     lib.gps_sa_mlp_wpack_floats.restype = ctypes.c_longlong
     lib.gps_embedding_grad_scratch_ints.restype = ctypes.c_longlong
+    lib.gps_point_set_object_extent.restype = None
     lib.gps_sa_mlp_wpack_floats.argtypes = [_i, _i, _i, _i]
     lib.gps_sa_mlp_layer_floats.restype = ctypes.c_longlong
     lib.gps_sa_mlp_layer_floats.argtypes = [_i, _i]

@@ -30,6 +30,8 @@
 #include "gps_gemm_layout.h"
 #include "gps_hip.h"
 
+namespace gps { const int *object_extent(); }   // gps_point_ops.hip
+
 namespace gps_gemm {
 
 using namespace gps_gemm_layout;
@@ -1323,7 +1325,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long lon
 // One workgroup per object; the (C, n) feature block is staged through LDS so that both sides are coalesced.
 __global__ __launch_bounds__(256) void split3_points_kernel(int n, int C, const float *__restrict__ xyz,
                                                             const float *__restrict__ feats, int k_pad,
-                                                            uint16_t *__restrict__ out) {
+                                                            uint16_t *__restrict__ out, const int *__restrict__ n_obj_dev) {
+  if (n_obj_dev && (int)blockIdx.x >= *n_obj_dev) return;      // object extent (gps_point_set_object_extent)
   extern __shared__ float tile[];                    // [n][3 + C + 1]
   const int b = blockIdx.x, K = 3 + C, ldt = K + 1;
   for (int e = threadIdx.x; e < n * 3; e += 256) tile[(e / 3) * ldt + (e % 3)] = xyz[(size_t)b * n * 3 + e];
@@ -1508,7 +1511,7 @@ int gps_split3_points(int b, int n, int c, const float *xyz, const float *feats,
   const size_t lds = (size_t)n * (3 + c + 1) * sizeof(float);
   if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gps_gemm::split3_points_kernel, dim3(b), dim3(256), lds, (hipStream_t)stream, n, c, xyz, feats, k_pad,
-                     (uint16_t *)out);
+                     (uint16_t *)out, gps::object_extent());
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

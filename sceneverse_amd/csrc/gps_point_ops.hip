@@ -31,6 +31,9 @@
 
 namespace gps {
 
+// Object extent of the per-object launches (gps_point_set_object_extent): a device int, or null.  Defined below.
+const int *object_extent();
+
 constexpr int kWave = 64;
 constexpr int kBlock = 256;            // 4 waves per workgroup, one per SIMD
 constexpr int kWavesPerBlock = kBlock / kWave;
@@ -111,9 +114,11 @@ template <int R>
 __global__ __launch_bounds__(kBlock) void fps_resident_kernel(int b, int n, int m, int p, int Q,
                                                                const float *__restrict__ dataset,
                                                                int32_t *__restrict__ idxs,
-                                                               float *__restrict__ centres) {
+                                                               float *__restrict__ centres,
+                                                               const int *__restrict__ n_obj_dev) {
   const int obj = blockIdx.x * kWavesPerBlock + wave_id();
   if (obj >= b) return;  // whole wave exits together
+  if (n_obj_dev && obj >= *n_obj_dev) return;   // object extent (gps_point_set_object_extent): nothing read or written
   const int L = lane_id();
   const float *ds = dataset + (size_t)obj * n * 3;
   int32_t *out = idxs + (size_t)obj * m;
@@ -327,9 +332,11 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
                                                              int nsample,
                                                              const float *__restrict__ new_xyz,
                                                              const float *__restrict__ xyz,
-                                                             int32_t *__restrict__ idx) {
+                                                             int32_t *__restrict__ idx,
+                                                             const int *__restrict__ n_obj_dev) {
   extern __shared__ int32_t bq_rows[];  // kWavesPerBlock rows of nsample ints
   const int obj = blockIdx.x;
+  if (n_obj_dev && obj >= *n_obj_dev) return;   // object extent: nothing read or written
   const int L = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
   const float *p = xyz + (size_t)obj * n * 3;
   const float *q = new_xyz + (size_t)obj * m * 3;
@@ -511,10 +518,12 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(int b, int n, int m,
 // (whose 5120 launches of 256 threads each did ~30 instructions of work per wave).
 __global__ __launch_bounds__(kBlock) void ball_query_small_kernel(int b, int n, int m, float radius, int nsample,
                                                                   const float *__restrict__ new_xyz,
-                                                                  const float *__restrict__ xyz, int32_t *__restrict__ idx) {
+                                                                  const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                                  const int *__restrict__ n_obj_dev) {
   const int L = lane_id();
   const int obj = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(wave_id());
   if (obj >= b) return;
+  if (n_obj_dev && obj >= *n_obj_dev) return;
   const float *p = xyz + (size_t)obj * n * 3;
   const float *q = new_xyz + (size_t)obj * m * 3;
   int32_t *o = idx + (size_t)obj * m * nsample;
@@ -878,6 +887,106 @@ __global__ __launch_bounds__(kBlock) void pairwise_to_planes_kernel(int L, const
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// [r5] Distinct-cloud plan of a batch of object clouds.  The reference pads a scene to its maximum object count with
+// CONSTANT clouds (data/datasets/dataset_wrapper.py:64-65: pad_tensors(obj_fts, lens=max_obj_len, pad=1.0)) and runs
+// PointNet++ on every slot (modules/vision/pcd_openvocab_encoder.py:156-160): at the bench workload 37 % of the 5 120
+// object slots are such pads, and every one of them gets the same features.  Per-object kernels are independent across
+// objects, so the encoder can run on the objects that are NOT pads plus ONE pad representative, and every pad slot
+// reads the representative's result: bit-identical outputs, a third less work in FPS / ball_query / the SA levels.
+// "Pad" is decided here from the data, never from a mask: an object whose (n, ld) cloud is ONE 32-bit word repeated,
+// with the same word as the first such object of the batch (other constant clouds are ordinary objects).
+//   flag kernel     one workgroup per object: uniform? + the word
+//   plan kernel     one workgroup: stable order [ordinary objects | first pad object], slot_of[] for the way back
+//   copy kernel     compact xyz (slot, n, 3) and point-major features (slot, n, ld - 3) of the planned objects
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void cloud_uniform_kernel(int words, const uint32_t *__restrict__ cloud,
+                                                                int32_t *__restrict__ uniform, uint32_t *__restrict__ word) {
+  const int obj = blockIdx.x;
+  const uint32_t *p = cloud + (size_t)obj * words;
+  const uint32_t w0 = p[0];
+  unsigned int diff = 0u;
+  if ((words & 3) == 0 && (reinterpret_cast<uintptr_t>(cloud) & 15) == 0) {
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
+    for (int i = threadIdx.x; i < words / 4; i += kBlock) {
+      const uint4 v = p4[i];
+      diff |= ((v.x ^ w0) | (v.y ^ w0)) | ((v.z ^ w0) | (v.w ^ w0));
+    }
+  } else {
+    for (int i = threadIdx.x; i < words; i += kBlock) diff |= p[i] ^ w0;
+  }
+  const int differs = __syncthreads_or(diff != 0u);
+  if (threadIdx.x == 0) { uniform[obj] = differs ? 0 : 1; word[obj] = w0; }
+}
+
+__global__ __launch_bounds__(1024) void cloud_plan_kernel(int b, int rows_mult, const int32_t *__restrict__ uniform,
+                                                           const uint32_t *__restrict__ word,
+                                                           int32_t *__restrict__ obj_of, int64_t *__restrict__ slot_of,
+                                                           int32_t *__restrict__ scal) {
+  __shared__ int s_cnt[2][16];
+  __shared__ int s_first_pad;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_first_pad = 0x7FFFFFFF;
+  __syncthreads();
+  for (int o = threadIdx.x; o < b; o += 1024)
+    if (uniform[o]) atomicMin(&s_first_pad, o);
+  __syncthreads();
+  const int fp = s_first_pad;
+  const bool has_pad = fp != 0x7FFFFFFF;
+  const uint32_t pad_word = has_pad ? word[fp] : 0u;
+  auto is_pad = [&](int o) { return has_pad && uniform[o] != 0 && word[o] == pad_word; };
+  int base = 0, par = 0;
+  for (int i0 = 0; i0 < b; i0 += 1024) {
+    const int o = i0 + threadIdx.x;
+    const bool work = o < b && !is_pad(o);
+    const unsigned long long mask = __ballot(work);
+    const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (lane == 0) s_cnt[par][w] = __popcll(mask);
+    __syncthreads();
+    int wave_base = 0, trip = 0;
+    for (int k = 0; k < 16; ++k) { const int c = s_cnt[par][k]; wave_base += (k < w) ? c : 0; trip += c; }
+    if (work) {
+      const int slot = base + wave_base + before;
+      obj_of[slot] = o;
+      slot_of[o] = slot;
+    }
+    base += trip;
+    par ^= 1;
+  }
+  const int n_work = base + (has_pad ? 1 : 0);          // base = number of ordinary objects (the same in every thread)
+  for (int o = threadIdx.x; o < b; o += 1024) {
+    if (is_pad(o)) slot_of[o] = base;                   // every pad reads the representative's slot
+    if (o >= n_work) obj_of[o] = has_pad ? fp : 0;      // slots past the extent name a valid object (never processed)
+  }
+  if (threadIdx.x == 0) {
+    if (has_pad) obj_of[base] = fp;
+    scal[0] = n_work;
+    scal[1] = base;
+    scal[2] = has_pad ? fp : -1;
+    scal[3] = n_work * rows_mult;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cloud_copy_kernel(int n, int ld, const float *__restrict__ cloud,
+                                                             const int32_t *__restrict__ obj_of,
+                                                             const int32_t *__restrict__ scal, float *__restrict__ xyz_c,
+                                                             float *__restrict__ feat_c) {
+  const int slot = blockIdx.x;
+  if (slot >= scal[0]) return;
+  const int c_feat = ld - 3;
+  const float *src = cloud + (size_t)obj_of[slot] * n * ld;
+  float *dx = xyz_c + (size_t)slot * n * 3, *df = feat_c + (size_t)slot * n * c_feat;
+  for (int e = threadIdx.x; e < n * ld; e += kBlock) {
+    const int pnt = e / ld, c = e - pnt * ld;
+    const float v = src[e];
+    if (c < 3) dx[pnt * 3 + c] = v;
+    else df[pnt * c_feat + (c - 3)] = v;
+  }
+}
+
+static const int *g_object_extent = nullptr;
+const int *object_extent() { return g_object_extent; }
+
 }  // namespace gps
 
 // ==========================================================================================
@@ -953,7 +1062,7 @@ static int fps_launch(int b, int n, int m, const float *dataset, float *temp, in
   const dim3 grid((b + gps::kWavesPerBlock - 1) / gps::kWavesPerBlock), block(gps::kBlock);
 #define GPS_FPS_CASE(R_)                                                                       \
   hipLaunchKernelGGL(gps::fps_resident_kernel<R_>, grid, block, 0, s, b, n, m, p, Q, dataset, \
-                     idxs, centres)
+                     idxs, centres, gps::object_extent())
   if (need <= 1) GPS_FPS_CASE(1);
   else if (need <= 2) GPS_FPS_CASE(2);
   else if (need <= 4) GPS_FPS_CASE(4);
@@ -979,6 +1088,26 @@ int gps_furthest_point_sampling_xyz(int b, int n, int m, const float *dataset, i
                                     gps_stream_t stream) {
   if (b > 0 && m > 0 && !new_xyz) return GPS_ERR_INVALID_ARGUMENT;
   return fps_launch(b, n, m, dataset, nullptr, idxs, new_xyz, stream);
+}
+
+void gps_point_set_object_extent(const int *n_objects_dev) { gps::g_object_extent = n_objects_dev; }
+
+int gps_cloud_compact(int b, int n, int ld, const float *cloud, int rows_mult, int32_t *flag_scratch, int32_t *obj_of,
+                      long long *slot_of, int32_t *scal, float *xyz_c, float *feat_c, gps_stream_t stream) {
+  if (b < 0 || n < 1 || ld < 3) return GPS_ERR_INVALID_ARGUMENT;
+  if (!scal || (b > 0 && (!cloud || !flag_scratch || !obj_of || !slot_of || !xyz_c || (ld > 3 && !feat_c))))
+    return GPS_ERR_INVALID_ARGUMENT;
+  if ((long long)n * ld > 0x7FFFFFFFll) return GPS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *word = reinterpret_cast<uint32_t *>(flag_scratch + b);
+  if (b > 0)
+    hipLaunchKernelGGL(gps::cloud_uniform_kernel, dim3(b), dim3(gps::kBlock), 0, s, n * ld, (const uint32_t *)cloud,
+                       flag_scratch, word);
+  hipLaunchKernelGGL(gps::cloud_plan_kernel, dim3(1), dim3(1024), 0, s, b, rows_mult, flag_scratch, word, obj_of,
+                     (int64_t *)slot_of, scal);
+  if (b > 0)
+    hipLaunchKernelGGL(gps::cloud_copy_kernel, dim3(b), dim3(gps::kBlock), 0, s, n, ld, cloud, obj_of, scal, xyz_c, feat_c);
+  return finish_launch();
 }
 
 int gps_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
@@ -1024,12 +1153,12 @@ int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *
   const int need = (n + gps::kWave - 1) / gps::kWave;
 #define GPS_BQ_CASE(R_)                                                                         \
   hipLaunchKernelGGL(gps::ball_query_kernel<R_>, grid, block, lds, s, b, n, m, radius, nsample, \
-                     new_xyz, xyz, idx)
+                     new_xyz, xyz, idx, gps::object_extent())
   // block schedule of the register-resident scan for 1024 / 2048-point clouds (gps::BqSched); GPS_BQ_SCHED selects one
   // of the compiled alternatives for tuning runs (tools/kernel_bench.py), the default is the measured best
 #define GPS_BQ_SCHED_CASE(R_, A_, B_, C_, REST_)                                                                          \
   hipLaunchKernelGGL((gps::ball_query_kernel<R_, gps::BqSched<A_, B_, C_, REST_>>), grid, block, lds, s, b, n, m, radius, \
-                     nsample, new_xyz, xyz, idx)
+                     nsample, new_xyz, xyz, idx, gps::object_extent())
 #define GPS_BQ_SCHEDS(R_)                                        \
   switch (sched) {                                               \
     case 1: GPS_BQ_SCHED_CASE(R_, 4, 4, 0, 8); break;            \
@@ -1046,7 +1175,7 @@ int gps_ball_query(int b, int n, int m, float radius, int nsample, const float *
   }();
   if (need <= 1) {
     hipLaunchKernelGGL(gps::ball_query_small_kernel, dim3((b + gps::kWavesPerBlock - 1) / gps::kWavesPerBlock), block, 0, s, b, n,
-                       m, radius, nsample, new_xyz, xyz, idx);
+                       m, radius, nsample, new_xyz, xyz, idx, gps::object_extent());
   } else if (need <= 2) GPS_BQ_CASE(2);
   else if (need <= 4) GPS_BQ_CASE(4);
   else if (need <= 8) GPS_BQ_CASE(8);

@@ -34,6 +34,8 @@
 
 #include "gps_hip.h"
 
+namespace gps { const int *object_extent(); }   // gps_point_ops.hip: device int or null (gps_point_set_object_extent)
+
 #ifndef GPS_SA1_WAVES
 #define GPS_SA1_WAVES 8   // weights resident in LDS: waves only share the object
 #endif
@@ -152,7 +154,8 @@ template <int CF, int C1, int C2, int C3>
 __global__ __launch_bounds__(kBlock, 2) void sa_mlp_kernel(
     int b, int n, int npoint, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ feats, const int32_t *__restrict__ idx,
-    const float *__restrict__ wpack, float *__restrict__ out) {
+    const float *__restrict__ wpack, float *__restrict__ out, const int *__restrict__ n_obj_dev) {
+  if (n_obj_dev && (int)blockIdx.x >= *n_obj_dev) return;      // object extent: nothing read or written
   constexpr int CIN = 3 + CF;
   constexpr int S1 = layer_steps(CIN), S2 = C1 / 2, S3 = C2 / 2;
   constexpr int T1 = tile_floats(CIN), T2 = tile_floats(C1), T3 = tile_floats(C2);
@@ -313,7 +316,7 @@ int launch_sa(int b, int n, int npoint, const float *xyz, const float *new_xyz, 
     attr_set = true;
   }
   hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3(b), dim3(kBlock), lds, s, b, n, npoint, xyz,
-                     new_xyz, feats, idx, wpack, out);
+                     new_xyz, feats, idx, wpack, out, gps::object_extent());
   return GPS_OK;
 }
 
@@ -456,7 +459,8 @@ template <int CF, int C1, int C2, int C3, int WAVES, bool RESIDENT, bool PM = fa
 __global__ __launch_bounds__(WAVES * 64) void sa_mlp_x3_kernel(
     int b, int n, int npoint, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ feats, const int32_t *__restrict__ idx,
-    const float *__restrict__ wpack, float *__restrict__ out, int ld_feat = 0) {
+    const float *__restrict__ wpack, float *__restrict__ out, int ld_feat, const int *__restrict__ n_obj_dev) {
+  if (n_obj_dev && (int)blockIdx.x >= *n_obj_dev) return;      // object extent: nothing read or written
   constexpr int BLOCK = WAVES * 64;
   constexpr int CIN = 3 + CF;
   constexpr int S1 = steps16(CIN), S2 = C1 / 16, S3 = C2 / 16;
@@ -656,7 +660,7 @@ int launch_sa_x3_n(int b, int n, int npoint, const float *xyz, const float *new_
     attr_lds = lds;
   }
   hipLaunchKernelGGL((sa_mlp_x3_kernel<CF, C1, C2, C3, WAVES, RESIDENT, PM, NPROD>), dim3(b), dim3(WAVES * 64), lds, s, b, n,
-                     npoint, xyz, new_xyz, feats, idx, wpack, out, ld_feat);
+                     npoint, xyz, new_xyz, feats, idx, wpack, out, ld_feat, gps::object_extent());
   return GPS_OK;
 }
 

@@ -519,10 +519,11 @@ def split3_points(xyz: torch.Tensor, feats: torch.Tensor, k_pad: int) -> torch.T
     return out
 
 
-def split3_mlp_max16(x: torch.Tensor, layers) -> torch.Tensor:
+def split3_mlp_max16(x: torch.Tensor, layers, rows_dev=None) -> torch.Tensor:
     """relu(...relu(x W1^T + s1)... Wn^T + sn) followed by the max over every 16 consecutive rows, fp32-accurate,
     as n MFMA GEMMs: x fp32 (M, K) (or the bf16 operand split3_points made), M % 16 == 0; layers = [(split3_weight(W_i, k_pad_i), shift_i fp32), ...] with
-    k_pad_1 = K rounded up to 8 and k_pad_i = N_(i-1) (multiples of 8).  -> fp32 (M / 16, N_n)."""
+    k_pad_1 = K rounded up to 8 and k_pad_i = N_(i-1) (multiples of 8).  -> fp32 (M / 16, N_n).
+    rows_dev (device int32, a multiple of 16): only the first *rows_dev rows carry work, the rest is not written."""
     if x.dtype == torch.bfloat16:           # already the [hi | lo | hi] operand of the first layer
         a, M = x, x.shape[0]
     else:
@@ -533,11 +534,11 @@ def split3_mlp_max16(x: torch.Tensor, layers) -> torch.Tensor:
         assert a.shape[1] == K3
         if li + 1 < len(layers):
             c = torch.empty((M, 3 * N), dtype=torch.bfloat16, device=x.device)
-            gemm(GEMM_NT, EPI_RELU_SPLIT, M, N, K3, a, K3, w3, K3, c, 3 * N, bias=shift)
+            gemm(GEMM_NT, EPI_RELU_SPLIT, M, N, K3, a, K3, w3, K3, c, 3 * N, bias=shift, extent_dev=rows_dev)
             a = c
         else:
             out = torch.empty((M // 16, N), dtype=torch.float32, device=x.device)
-            gemm(GEMM_NT, EPI_RELU_MAX16, M, N, K3, a, K3, w3, K3, out, N, bias=shift)
+            gemm(GEMM_NT, EPI_RELU_MAX16, M, N, K3, a, K3, w3, K3, out, N, bias=shift, extent_dev=rows_dev)
     return out
 
 

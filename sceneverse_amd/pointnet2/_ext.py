@@ -151,6 +151,48 @@ def furthest_point_sampling_xyz(points: torch.Tensor, nsamples: int):
     return out, cen
 
 
+class CloudPlan:
+    """Work list of gps_cloud_compact: the objects that are not pads (constant clouds) + one pad representative."""
+    __slots__ = ("xyz", "feats_pm", "obj_of", "slot_of", "scal", "n_work", "rows16")
+
+
+def cloud_compact(cloud: torch.Tensor, rows_mult: int = 16) -> CloudPlan:
+    """cloud (b, n, 3 + C) fp32 contiguous -> CloudPlan: xyz (b, n, 3) / feats_pm (b, n, C) of the work slots, obj_of,
+    slot_of (int64: `result.index_select(0, slot_of)` is the result of every object), n_work / rows16 device ints."""
+    _chk(cloud, "cloud", torch.float32)
+    b, n, ld = cloud.shape
+    dev = cloud.device
+    plan = CloudPlan()
+    plan.xyz = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    plan.feats_pm = torch.empty((b, n, max(ld - 3, 0)), dtype=torch.float32, device=dev)
+    plan.obj_of = torch.empty(b, dtype=torch.int32, device=dev)
+    plan.slot_of = torch.empty(b, dtype=torch.int64, device=dev)
+    plan.scal = torch.empty(4, dtype=torch.int32, device=dev)
+    flag = torch.empty(2 * b, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev), _timed(f"cloud_compact(n={n},ld={ld})", 4 * b * n * ld * 2):
+        st = _native.load().gps_cloud_compact(b, n, ld, cloud.data_ptr(), int(rows_mult), flag.data_ptr(), plan.obj_of.data_ptr(),
+                                              plan.slot_of.data_ptr(), plan.scal.data_ptr(), plan.xyz.data_ptr(),
+                                              plan.feats_pm.data_ptr() if ld > 3 else None, _stream())
+    _native.check(st, "cloud_compact")
+    plan.n_work, plan.rows16 = plan.scal[0:1], plan.scal[3:4]
+    return plan
+
+
+class object_extent:
+    """with object_extent(n_dev): the per-object launches of this module process objects [0, *n_dev) only."""
+
+    def __init__(self, n_dev):
+        self.n_dev = n_dev
+
+    def __enter__(self):
+        _native.load().gps_point_set_object_extent(self.n_dev.data_ptr() if self.n_dev is not None else None)
+        return self
+
+    def __exit__(self, *exc):
+        _native.load().gps_point_set_object_extent(None)
+        return False
+
+
 def three_nn(unknowns: torch.Tensor, knows: torch.Tensor):
     _chk(unknowns, "unknowns", torch.float32)
     _chk(knows, "knows", torch.float32)

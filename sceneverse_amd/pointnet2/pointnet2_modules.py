@@ -83,6 +83,11 @@ def fold_shared_mlp(mlp: "pt_utils.SharedMLP"):
     return ws, shifts
 
 
+# Row extent (device int32) of the group-all level's GEMMs while the object encoder runs on a distinct-cloud work list
+# (modules/layers/pointnet.py): rows = work slots x points per object.  None = every row.
+_OBJECT_ROWS = None
+
+
 def _frozen_key(mlp: nn.Module):
     return tuple((t.data_ptr(), t._version) for t in list(mlp.parameters()) + list(mlp.buffers()))
 
@@ -222,7 +227,7 @@ class _PointnetSAModuleBase(nn.Module):
                                           for w, s, kp in zip(ws, shifts, k_pads)])
                         mlp.__dict__["_gps_split3"] = cache
                     a = G.split3_points(xyz, features, cache[1][0][0].shape[1] // 3)
-                    return G.split3_mlp_max16(a, cache[1]).unsqueeze(-1)
+                    return G.split3_mlp_max16(a, cache[1], rows_dev=_OBJECT_ROWS).unsqueeze(-1)
                 for w, sft in zip(ws, shifts):
                     x = torch.relu_(torch.addmm(sft, x, w.t()))
                 return x.view(b, n, -1).amax(dim=1).unsqueeze(-1)

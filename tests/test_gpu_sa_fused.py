@@ -183,3 +183,58 @@ def test_single_product_bf16_mode_states_its_error():
     with torch.no_grad():
         again = net(pcs.to(DEV)).cpu()                      # back on the default: 1e-4 again
     _close(again, want, "PointNetPP after switching back")
+
+
+@pytest.mark.parametrize("pattern", ["mixed", "no_pads", "all_pads", "two_constants", "nearly_constant"])
+def test_distinct_clouds_only_is_bit_identical_to_every_slot(pattern):
+    """modules/layers/pointnet.py: the frozen encoder on the work list of gps_cloud_compact (ordinary objects + one pad
+    representative; a pad = a cloud that is one 32-bit word repeated, the word of the first such object -- the reference
+    pads with 1.0) against the same encoder on every slot: torch.equal, for batches with pads in the middle, without pads,
+    of pads only, with constant clouds of two different values (only the first value's are pads), and with a cloud that
+    differs from the pad in ONE word (an ordinary object)."""
+    from sceneverse_amd.modules.layers import pointnet as PN
+    from sceneverse_amd.pointnet2 import _ext
+    net = _encoder(3)
+    pcs = _clouds()[:20].clone()
+    if pattern == "mixed":
+        pcs[[0, 3, 4, 11, 19]] = 1.0
+    elif pattern == "all_pads":
+        pcs[:] = 1.0
+    elif pattern == "two_constants":
+        pcs[[2, 9]] = 0.0
+        pcs[[5, 7, 8]] = 1.0
+    elif pattern == "nearly_constant":
+        pcs[[1, 6, 12]] = 1.0
+        pcs[6, 100, 4] = 0.5
+    pcs = pcs.to(DEV)
+    plan = _ext.cloud_compact(pcs)
+    words = pcs.view(torch.int32).reshape(pcs.shape[0], -1)
+    uniform = (words == words[:, :1]).all(dim=1)
+    pad = torch.zeros_like(uniform)
+    if uniform.any():
+        first = int(torch.nonzero(uniform).flatten()[0].item())
+        pad = uniform & (words[:, 0] == words[first, 0])
+    n_ord = int((~pad).sum().item())
+    assert plan.scal.tolist()[:2] == [n_ord + int(pad.any().item()), n_ord]
+    assert plan.scal[3].item() == 16 * plan.scal[0].item()
+    ord_ids = torch.nonzero(~pad).flatten()
+    assert torch.equal(plan.obj_of[:n_ord].long(), ord_ids) and torch.equal(plan.slot_of[ord_ids], torch.arange(n_ord, device=DEV))
+    if pad.any():
+        assert plan.scal[2].item() == first and plan.obj_of[n_ord].item() == first
+        assert (plan.slot_of[pad] == n_ord).all()
+    assert torch.equal(plan.xyz[:n_ord], pcs[ord_ids][..., 0:3]) and torch.equal(plan.feats_pm[:n_ord], pcs[ord_ids][..., 3:])
+    _ext.profile_start()
+    with torch.no_grad():
+        got = net(pcs)
+    rec = _ext.profile_stop()
+    PN.set_distinct_clouds(False)
+    try:
+        with torch.no_grad():
+            want = net(pcs)
+    finally:
+        PN.set_distinct_clouds(True)
+    if M._SA_PRECISION == "bf16x3":
+        assert any(k.startswith("cloud_compact") for k in rec), rec.keys()        # the work-list path was taken
+        assert torch.equal(got, want)
+    else:
+        _close(got, want, "fp32 mode keeps every slot")                           # (no point-major first level there)

@@ -118,13 +118,18 @@ def main():
         if op is not None:
             opname = op["name"]
             shapes = str(op.get("args", {}).get("Input Dims", ""))[:80]
-        key = (name[:70], opname[:40], shapes, (py or "?")[-80:])
+        short = name
+        m = __import__("re").search(r"at::native::(?:\(anonymous namespace\)::)?([A-Za-z0-9_]+(?:<[^,>]*)?)", name.split("(")[0] if name.startswith("void at::native::vectorized") is False else name[40:])
+        if "at::native::" in name:
+            inner = name.split("at::native::")
+            short = "..." + "at::native::".join(inner[1:])[:66] if len(inner) > 2 else name[:70]
+        key = (short[:70], opname[:40], shapes, (py or "?")[-80:])
         agg[key][0] += e["dur"]
         agg[key][1] += 1
     rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
     total = sum(v[0] for v in agg.values())
     print(f"# total device time of the listed kernels: {total / 1e3 / args.steps:.3f} ms/step", file=out)
-    for (name, opname, shapes, py), (t, n) in rows[:160]:
+    for (name, opname, shapes, py), (t, n) in rows[:400]:
         print(f"{t / 1e3 / args.steps:8.4f} ms {n / args.steps:6.1f}x  {name:70s} | {opname:40s} | {shapes:80s} | {py}", file=out)
 
 
