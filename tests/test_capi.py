@@ -51,6 +51,10 @@ def test_argument_validation_without_gpu():
     assert lib.gps_masked_ce_forward_rows(4, 30522, 1, 16, 30528, 1, -1, None, 1, 1, 1, None, None) == -1      # mean without ticket
     assert lib.gps_lm_row_plan(8, 0, 1, -1, 1, 1, 1, None) == -1                                     # vocab < 1
     assert lib.gps_lm_row_plan(8, 10, None, -1, 1, 1, 1, None) == -1
+    assert lib.gps_cloud_compact(4, 0, 6, 16, 16, 1, 1, 1, 1, 16, 16, None) == -1                     # n < 1
+    assert lib.gps_cloud_compact(4, 1024, 2, 16, 16, 1, 1, 1, 1, 16, 16, None) == -1                  # ld < 3
+    assert lib.gps_cloud_compact(4, 1024, 6, None, 16, 1, 1, 1, 1, 16, 16, None) == -1                # no cloud
+    lib.gps_point_set_object_extent(None)                                                             # (a no-op reset)
     assert lib.gps_text_obj_ce_forward(0, 80, 768, None, None, None, None, 1e-12, -100, None, None, None, None, None, None,
                                        None, None) == 0
     assert lib.gps_text_obj_ce_forward(4, 80, 770, 16, 16, 1, 1, 1e-12, -100, 1, 1, 1, 1, 1, 1, 1, None) == -2   # D % 4
