@@ -57,9 +57,14 @@ class PointNetPP(nn.Module):
             return False
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return False
-        last = self.encoder[-1]
-        return (all(M._is_frozen(mlp) for sa in self.encoder for mlp in sa.mlps) and last.npoint is None
-                and len(self.encoder) >= 2 and self.encoder[-2].npoint is not None and hasattr(M.pointnet2_utils._ext, "cloud_compact"))
+        first, last, ext = self.encoder[0], self.encoder[-1], M.pointnet2_utils._ext
+        if not (all(M._is_frozen(mlp) for sa in self.encoder for mlp in sa.mlps) and last.npoint is None
+                and len(self.encoder) >= 2 and self.encoder[-2].npoint is not None and hasattr(ext, "cloud_compact")
+                and len(first.groupers) == 1 and hasattr(first.groupers[0], "nsample")):
+            return False
+        # the first level must take its point-major fused form (else the plan's three launches would be wasted work)
+        chans = [l.conv.out_channels for l in first.mlps[0].children() if hasattr(l, "conv")]
+        return bool(ext.sa_mlp_point_major_supported(pc.size(-1) - 3, chans, first.groupers[0].nsample, M._SA_PRECISION))
 
     def _forward_distinct(self, pc):
         """PointNet++ on the objects that are not pads + ONE pad representative (the reference pads scenes with constant
