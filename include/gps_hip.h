@@ -641,9 +641,10 @@ GPS_API int gps_loc_embed_backward(int n_rows, int k_in, int d, const float *dy,
  *   of GPS_GEMM_EPI_DGELU is recomputed from the same (seed, index), nothing is stored.  p_drop = 0: none.
  * splits (TN only): K is cut into `splits` ranges whose fp32 partial tiles go to `workspace`
  *   (gps_gemm_workspace_floats() floats) and are summed in split order by a second launch (deterministic);
- *   gps_gemm_pick_splits() gives the default.  variant: tile configuration 0..12 (8, 9, 10: persistent workgroups;
+ *   gps_gemm_pick_splits() gives the default.  variant: tile configuration 0..13 (8, 9, 10: persistent workgroups;
  *   11: four-wave 256 x 256 with register-staged operands; 12: eight-wave two-group 256 x 256, the default for long
- *   reductions and wide weight gradients), or -1 = chosen from the shape.
+ *   reductions and wide weight gradients; 13: its stream-K form, see gps_gemm_sk_workspace_bytes), or -1 = chosen from
+ *   the shape.
  * Requirements (else GPS_ERR_UNSUPPORTED): lda, ldb multiples of 8, K too unless form TN; N, ldc, ldaux multiples of 4; for
  *   reduction-major operands their column count (N, and M in form TN) a multiple of 8; A, B, C, bias 16-byte aligned. */
 #define GPS_GEMM_NT 0
@@ -692,6 +693,14 @@ GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
  * profile reader needs to match a launch with its rocprofv3 row */
 GPS_API int gps_gemm_pick_variant(int form, int M, int N, int K, int splits);
 GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
+/* variant 13 (forms NT / NN, bf16 epilogues): the stream-K form of variant 12 -- one resident workgroup per CU, each
+ * taking an equal share of the K tiles of ALL 256 x 256 output tiles, so that a launch is never a whole number of
+ * "rounds" of tiles; a tile cut by a share boundary is finished by the workgroup that holds its k = 0 end, which adds
+ * the other shares' fp32 accumulators (in a fixed order: deterministic for a given shape, device-side extent and CU
+ * count).  Needs `workspace` = gps_gemm_sk_workspace_bytes() bytes, 16-byte aligned, whose first 4 KiB are ZERO before
+ * the first launch (the kernel leaves them zero); without it variant 13 runs as variant 12.  One launch at a time per
+ * workspace (launches on one stream are fine).  Word 256 of the workspace is set to 1 if a bounded wait ever expired. */
+GPS_API long long gps_gemm_sk_workspace_bytes(void);
 /* Grouped weight gradients: for every problem p,  C_p (M,N) fp32 [+]= A_p (K,M)^T . B_p (K,N)  and, when colsum_p is not
  * NULL, colsum_p (M) [+]= column sums of A_p over K -- the weight and bias gradient of one nn.Linear (A = dY, B = X, bf16,
  * both reduction-major as in form GPS_GEMM_TN) -- for ALL problems in one persistent launch, each 256 x 256 output tile

@@ -82,7 +82,32 @@ struct Params {
   const int *extent_dev;   // optional device count of leading token rows that carry work (rows of M for NT / NN, of K for TN)
   int row0;                // NT / NN: this launch covers rows row0 .. row0 + M - 1 of a larger product (dropout stream index only)
   int accumulate;          // EPI_F32, splits == 1: C += acc, colsum += column sums (grouped weight gradients into live .grad buffers)
+  unsigned int *sk_flags;  // stream-K form: one arrival word per workgroup position (zero between launches) + an error word;
+                           // `partial` then holds one 256 x 256 fp32 slab per workgroup position
+#ifdef GPS_GEMM_TRACE
+  unsigned long long *trace;   // tools/probes/gemm_probe.hip: (workgroups, kTraceSlots) shader-clock stamps of wave 0
+#endif
 };
+
+// Per-workgroup time stamps for tools/probes/gemm_probe.hip (compiled out of the library): slot 0 = kernel entry,
+// 1 = first stage landed, 2 = main loop done, 3 = epilogue issued, 4 = s_memrealtime at entry, 5 = at exit, 8.. = K tiles.
+#ifdef GPS_GEMM_TRACE
+constexpr int kTraceSlots = 32;
+#define GPS_TRACE(P, slot)                                                                                    \
+  do {                                                                                                        \
+    if ((P).trace && threadIdx.x == 0 && (slot) < kTraceSlots)                                                \
+      (P).trace[(size_t)blockIdx.x * kTraceSlots + (slot)] = ((slot) == 4 || (slot) == 5) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define GPS_TRACE_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")     // slot 6: the epilogue's stores acknowledged
+#define GPS_TRACE_VAL(P, slot, v)                                                                             \
+  do {                                                                                                        \
+    if ((P).trace && threadIdx.x == 0 && (slot) < kTraceSlots) (P).trace[(size_t)blockIdx.x * kTraceSlots + (slot)] = (v); \
+  } while (0)
+#else
+#define GPS_TRACE_VAL(P, slot, v) do { } while (0)
+#define GPS_TRACE(P, slot) do { } while (0)
+#define GPS_TRACE_DRAIN() do { } while (0)
+#endif
 
 __device__ __forceinline__ uint16_t f2bf(float f) {   // round to nearest even (finite inputs)
   unsigned int u = __float_as_uint(f);
@@ -382,6 +407,91 @@ constexpr int waves_per_simd(int BM, int BN, int NW, int NBUF) {
   return w < 1 ? 1 : (w > 2 ? 2 : w);     // the accumulators never leave room for more than 2
 }
 
+// Lane (i, g) holds the packed 4-column groups o0 (fragment b) and o1 (fragment b + 1) of output row i: columns 4 g .. 4 g + 3
+// of each.  v_permlane16_swap exchanges the ODD 16-lane rows of its first operand with the EVEN rows of its second, i.e.
+// lane group g = 2 j + 1 hands its o0 to group 2 j and gets that group's o1: afterwards an even group holds 8 consecutive
+// columns of fragment b (8 j .. 8 j + 7) and an odd group 8 consecutive columns of fragment b + 1 -- one 16-byte store per
+// lane, no LDS round trip (the first version: two ds_bpermute, a wait and four selects per pair).
+__device__ __forceinline__ u32x4 pair_exchange(const u32x2 &o0, const u32x2 &o1) {
+  const auto x0 = __builtin_amdgcn_permlane16_swap(o0[0], o1[0], false, false);
+  const auto x1 = __builtin_amdgcn_permlane16_swap(o0[1], o1[1], false, false);
+  return u32x4{x0[0], x1[0], x0[1], x1[1]};
+}
+
+// bias / activation / dropout of one 4-column group of row m -> the packed bf16 result (and the packed
+// pre-activation / low halves through `pre` for the GELU and split forms); aux4 = this group's 4 saved values
+template <int EPI>
+__device__ __forceinline__ u32x2 epi_finish(const Params &P, bool dropout, unsigned long long seed, f32x4 v, int m, int n,
+                                           const f32x4 &bias, const u32x2 &aux4, u32x2 &pre) {
+  v = v + bias;
+  const unsigned long long idx = (unsigned long long)(m + P.row0) * (unsigned long long)P.N + (unsigned long long)n;
+  if (EPI == EPI_BIAS_GELU) {
+    pre = pack4(v);
+    v[0] = gelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
+    v[1] = gelu_f(bf2f((uint16_t)(pre[0] >> 16)));
+    v[2] = gelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
+    v[3] = gelu_f(bf2f((uint16_t)(pre[1] >> 16)));
+  } else if (EPI == EPI_BIAS_GELU_FACTOR) {
+    // the activation from the bf16-rounded pre-activation (as EPI_BIAS_GELU), and the backward factor beside it
+    const u32x2 pr = pack4(v);
+    f32x4 fac;
+    const float xin[4] = {bf2f((uint16_t)(pr[0] & 0xFFFFu)), bf2f((uint16_t)(pr[0] >> 16)), bf2f((uint16_t)(pr[1] & 0xFFFFu)),
+                          bf2f((uint16_t)(pr[1] >> 16))};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float gv, dgv;
+      gelu_and_dgelu(xin[r], gv, dgv);
+      v[r] = gv;
+      fac[r] = dgv;
+    }
+    if (dropout) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float k = rng_u32(seed, idx + r) >= P.drop_thr ? P.keep_scale : 0.f;
+        v[r] *= k;
+        fac[r] *= k;
+      }
+    }
+    pre = pack4(fac);
+    return pack4(v);
+  } else if (EPI == EPI_MUL_AUX) {
+    v[0] *= bf2f((uint16_t)(aux4[0] & 0xFFFFu));
+    v[1] *= __uint_as_float(aux4[0] & 0xFFFF0000u);
+    v[2] *= bf2f((uint16_t)(aux4[1] & 0xFFFFu));
+    v[3] *= __uint_as_float(aux4[1] & 0xFFFF0000u);
+  } else if (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  } else if (EPI == EPI_RELU_SPLIT) {
+    // fp32 value carried as two bf16: hi = rne(v), lo = rne(v - hi) (exact difference); `pre` takes the lo words
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    const u32x2 hi = pack4(v);
+    f32x4 rest;
+    rest[0] = v[0] - bf2f((uint16_t)(hi[0] & 0xFFFFu));
+    rest[1] = v[1] - bf2f((uint16_t)(hi[0] >> 16));
+    rest[2] = v[2] - bf2f((uint16_t)(hi[1] & 0xFFFFu));
+    rest[3] = v[3] - bf2f((uint16_t)(hi[1] >> 16));
+    pre = pack4(rest);
+    return hi;
+  } else if (EPI == EPI_DGELU) {
+    v[0] *= dgelu_f(bf2f((uint16_t)(aux4[0] & 0xFFFFu)));
+    v[1] *= dgelu_f(bf2f((uint16_t)(aux4[0] >> 16)));
+    v[2] *= dgelu_f(bf2f((uint16_t)(aux4[1] & 0xFFFFu)));
+    v[3] *= dgelu_f(bf2f((uint16_t)(aux4[1] >> 16)));
+  } else if (EPI == EPI_DRELU) {
+    v[0] = (aux4[0] & 0x7FFFu) ? v[0] * P.keep_scale : 0.f;
+    v[1] = (aux4[0] & 0x7FFF0000u) ? v[1] * P.keep_scale : 0.f;
+    v[2] = (aux4[1] & 0x7FFFu) ? v[2] * P.keep_scale : 0.f;
+    v[3] = (aux4[1] & 0x7FFF0000u) ? v[3] * P.keep_scale : 0.f;
+  }
+  if (dropout && (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_DGELU)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rng_u32(seed, idx + r) >= P.drop_thr ? v[r] * P.keep_scale : 0.f;
+  }
+  return pack4(v);
+}
+
 // ---- epilogue of one tile: lane (i, g) holds C[m0 + wm0 + 16 a + i][n0 + wn0 + 16 b + 4 g + 0..3] -----------------
 template <int TM, int TN, int EPI>
 __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN], f32x4 (&csum)[TM], bool do_colsum,
@@ -437,76 +547,8 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   }
   const bool dropout = P.drop_thr != 0u;
   const unsigned long long seed = dropout ? P.seed + (P.seed_dev ? *P.seed_dev : 0ull) : 0ull;
-  // bias / activation / dropout of one 4-column group of row m -> the packed bf16 result (and the packed
-  // pre-activation / low halves through `pre` for the GELU and split forms); aux4 = this group's 4 saved values
   auto finish = [&](f32x4 v, int m, int n, const f32x4 &bias, const u32x2 &aux4, u32x2 &pre) -> u32x2 {
-    v = v + bias;
-    const unsigned long long idx = (unsigned long long)(m + P.row0) * (unsigned long long)P.N + (unsigned long long)n;
-    if (EPI == EPI_BIAS_GELU) {
-      pre = pack4(v);
-      v[0] = gelu_f(bf2f((uint16_t)(pre[0] & 0xFFFFu)));
-      v[1] = gelu_f(bf2f((uint16_t)(pre[0] >> 16)));
-      v[2] = gelu_f(bf2f((uint16_t)(pre[1] & 0xFFFFu)));
-      v[3] = gelu_f(bf2f((uint16_t)(pre[1] >> 16)));
-    } else if (EPI == EPI_BIAS_GELU_FACTOR) {
-      // the activation from the bf16-rounded pre-activation (as EPI_BIAS_GELU), and the backward factor beside it
-      const u32x2 pr = pack4(v);
-      f32x4 fac;
-      const float xin[4] = {bf2f((uint16_t)(pr[0] & 0xFFFFu)), bf2f((uint16_t)(pr[0] >> 16)), bf2f((uint16_t)(pr[1] & 0xFFFFu)),
-                            bf2f((uint16_t)(pr[1] >> 16))};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float gv, dgv;
-        gelu_and_dgelu(xin[r], gv, dgv);
-        v[r] = gv;
-        fac[r] = dgv;
-      }
-      if (dropout) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float k = rng_u32(seed, idx + r) >= P.drop_thr ? P.keep_scale : 0.f;
-          v[r] *= k;
-          fac[r] *= k;
-        }
-      }
-      pre = pack4(fac);
-      return pack4(v);
-    } else if (EPI == EPI_MUL_AUX) {
-      v[0] *= bf2f((uint16_t)(aux4[0] & 0xFFFFu));
-      v[1] *= __uint_as_float(aux4[0] & 0xFFFF0000u);
-      v[2] *= bf2f((uint16_t)(aux4[1] & 0xFFFFu));
-      v[3] *= __uint_as_float(aux4[1] & 0xFFFF0000u);
-    } else if (EPI == EPI_BIAS_RELU) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-    } else if (EPI == EPI_RELU_SPLIT) {
-      // fp32 value carried as two bf16: hi = rne(v), lo = rne(v - hi) (exact difference); `pre` takes the lo words
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      const u32x2 hi = pack4(v);
-      f32x4 rest;
-      rest[0] = v[0] - bf2f((uint16_t)(hi[0] & 0xFFFFu));
-      rest[1] = v[1] - bf2f((uint16_t)(hi[0] >> 16));
-      rest[2] = v[2] - bf2f((uint16_t)(hi[1] & 0xFFFFu));
-      rest[3] = v[3] - bf2f((uint16_t)(hi[1] >> 16));
-      pre = pack4(rest);
-      return hi;
-    } else if (EPI == EPI_DGELU) {
-      v[0] *= dgelu_f(bf2f((uint16_t)(aux4[0] & 0xFFFFu)));
-      v[1] *= dgelu_f(bf2f((uint16_t)(aux4[0] >> 16)));
-      v[2] *= dgelu_f(bf2f((uint16_t)(aux4[1] & 0xFFFFu)));
-      v[3] *= dgelu_f(bf2f((uint16_t)(aux4[1] >> 16)));
-    } else if (EPI == EPI_DRELU) {
-      v[0] = (aux4[0] & 0x7FFFu) ? v[0] * P.keep_scale : 0.f;
-      v[1] = (aux4[0] & 0x7FFF0000u) ? v[1] * P.keep_scale : 0.f;
-      v[2] = (aux4[1] & 0x7FFFu) ? v[2] * P.keep_scale : 0.f;
-      v[3] = (aux4[1] & 0x7FFF0000u) ? v[3] * P.keep_scale : 0.f;
-    }
-    if (dropout && (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_DGELU)) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = rng_u32(seed, idx + r) >= P.drop_thr ? v[r] * P.keep_scale : 0.f;
-    }
-    return pack4(v);
+    return epi_finish<EPI>(P, dropout, seed, v, m, n, bias, aux4, pre);
   };
   constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_RELU_SPLIT || EPI == EPI_BIAS_GELU_FACTOR;
   constexpr bool HAS_AUX = EPI == EPI_DGELU || EPI == EPI_DRELU || EPI == EPI_MUL_AUX;
@@ -526,8 +568,8 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
   // Pairs of adjacent 16-column fragments leave as 16-byte stores: inside a pair, the even lane groups (g = 0, 2)
   // send their 4 columns of fragment b + 1 to the odd group next to them and receive that group's 4 columns of
   // fragment b, so every lane ends up with 8 consecutive columns of one row -- half the store instructions of the
-  // natural 8-byte form (the epilogue is store-ISSUE bound, guide T21).  Needs whole 8-column groups (N % 8 == 0)
-  // and 16-byte aligned rows; otherwise the 8-byte form below.
+  // natural 8-byte form (guide T21); the exchange is pair_exchange() = two v_permlane16_swap.  Needs whole 8-column groups
+  // (N % 8 == 0) and 16-byte aligned rows; otherwise the 8-byte form below.
   const bool wide = (TN % 2 == 0) && (P.N % 8 == 0) && (P.ldc % 8 == 0) &&
                     (!HAS_PRE || P.aux_out == nullptr || P.ldaux_out % 8 == 0);
   if (EPI == EPI_RELU_SPLIT && !wide) return;        // the C entry point only admits N % 8 == 0 == ldc % 8 for this form
@@ -560,15 +602,11 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
         u32x2 pre0 = {0u, 0u}, pre1 = {0u, 0u};
         const u32x2 o0 = finish(acc[a][b], m, nb0, bias[b], aux[a][b], pre0);
         const u32x2 o1 = finish(acc[a][b + 1], m, nb1, bias[b + 1], aux[a][b + 1], pre1);
-        const u32x2 send = odd ? o0 : o1;
-        const u32x2 recv = {(unsigned int)__shfl_xor((int)send[0], 16, 64), (unsigned int)__shfl_xor((int)send[1], 16, 64)};
-        const u32x4 out = odd ? u32x4{recv[0], recv[1], o1[0], o1[1]} : u32x4{o0[0], o0[1], recv[0], recv[1]};
+        const u32x4 out = pair_exchange(o0, o1);
         const unsigned int off = (unsigned int)(((long long)m * P.ldc + n_out) * 2) | col_ok;
         __builtin_amdgcn_raw_buffer_store_b128(out, rC, off, 0, 0);
         if (EPI == EPI_RELU_SPLIT || HAS_PRE) {
-          const u32x2 sp = odd ? pre0 : pre1;
-          const u32x2 rp = {(unsigned int)__shfl_xor((int)sp[0], 16, 64), (unsigned int)__shfl_xor((int)sp[1], 16, 64)};
-          const u32x4 po = odd ? u32x4{rp[0], rp[1], pre1[0], pre1[1]} : u32x4{pre0[0], pre0[1], rp[0], rp[1]};
+          const u32x4 po = pair_exchange(pre0, pre1);
           if (EPI == EPI_RELU_SPLIT) {
             __builtin_amdgcn_raw_buffer_store_b128(po, rC, off + 2u * P.N, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(out, rC, off + 4u * P.N, 0, 0);
@@ -592,6 +630,90 @@ __device__ __forceinline__ void store_tile(const Params &P, f32x4 (&acc)[TM][TN]
       if (HAS_PRE)
         __builtin_amdgcn_raw_buffer_store_b64(pre, rPre, (unsigned int)(((long long)m * P.ldaux_out + n) * 2) | col_ok, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b64(o, rC, (unsigned int)(((long long)m * P.ldc + n) * 2) | col_ok, 0, 0);
+    }
+  }
+#endif
+}
+
+// ---- epilogue of the two-group 256 x 256 kernels: the wave's four 64 x 32 quadrants in one pass ---------------------------
+// Four store_tile calls would each start with their own loads (bias, saved activations) and wait for them: four exposed
+// memory round trips per tile and wave (profiles/r6/gemm_probe_trace_a.jsonl: 4.4 us of epilogue per tile at EPI_BIAS
+// although the store path takes 128 KB in 1.8 us, gemm_probe storebw).  Here the bias vectors arrive as arguments (fetched by
+// load_bias_8p before the main loop: 16 registers) and the saved activations of quadrant q + 1 are requested before
+// quadrant q is finished and stored.
+template <int EPI>
+__device__ __forceinline__ void load_bias_8p(const Params &P, int n0, int wc, int lane, f32x4 (&bias4)[2][2]) {
+  constexpr bool HAS_BIAS = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_RELU_SPLIT || EPI == EPI_BIAS_GELU_FACTOR;
+  if constexpr (EPI == EPI_F32 || EPI == EPI_RELU_SPLIT || EPI == EPI_RELU_MAX16) return;      // (store_quads takes the store_tile path)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.bias), 0, (HAS_BIAS && P.bias) ? 4u * P.N : 0u, 0x00020000);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int n = n0 + 128 * qb + 32 * wc + 16 * b + 4 * g;
+      bias4[qb][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBias, n < P.N ? 4u * n : 0x80000000u, 0, 0));
+    }
+#endif
+}
+
+template <int EPI>
+__device__ __forceinline__ void store_quads(const Params &P, f32x4 (&acc)[2][2][4][2], int split, int m0, int n0, int wr, int wc,
+                                            int lane, const f32x4 (&bias4)[2][2]) {
+  constexpr bool HAS_AUX = EPI == EPI_DGELU || EPI == EPI_DRELU || EPI == EPI_MUL_AUX;
+  constexpr bool HAS_PRE = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FACTOR;
+  const bool wide = (P.N % 8 == 0) && (P.ldc % 8 == 0) && (!HAS_PRE || P.aux_out == nullptr || P.ldaux_out % 8 == 0);
+  if (EPI == EPI_F32 || EPI == EPI_RELU_SPLIT || EPI == EPI_RELU_MAX16 || !wide) {
+    f32x4 unused[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      store_tile<4, 2, EPI>(P, acc[q >> 1][q & 1], unused, false, split, m0, n0, 128 * (q >> 1) + 64 * wr, 128 * (q & 1) + 32 * wc, lane);
+    return;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int i = lane & 15, g = lane >> 4;
+  const bool odd = g & 1;
+  const bool dropout = P.drop_thr != 0u;
+  const unsigned long long seed = dropout ? P.seed + (P.seed_dev ? *P.seed_dev : 0ull) : 0ull;
+  constexpr unsigned int kOOB = 0x80000000u;
+  const auto bytes_of = [&](long long ld) { return (unsigned int)((((long long)P.M - 1) * ld + P.N) * 2); };
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, bytes_of(P.ldc), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(P.aux), 0, HAS_AUX ? bytes_of(P.ldaux) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rPre = __builtin_amdgcn_make_buffer_rsrc(P.aux_out, 0, (HAS_PRE && P.aux_out) ? bytes_of(P.ldaux_out) : 0u, 0x00020000);
+  auto row_of = [&](int q, int a) { return m0 + 128 * (q >> 1) + 64 * wr + 16 * a + i; };
+  auto col_of = [&](int q, int b) { return n0 + 128 * (q & 1) + 32 * wc + 16 * b + 4 * g; };
+  auto load_aux = [&](int q, u32x2 (&aux)[4][2]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        aux[a][b] = u32x2{0u, 0u};
+        if (HAS_AUX) {
+          const int n = col_of(q, b);
+          aux[a][b] = __builtin_amdgcn_raw_buffer_load_b64(rAux, n < P.N ? (unsigned int)(((long long)row_of(q, a) * P.ldaux + n) * 2) : kOOB, 0, 0);
+        }
+      }
+  };
+  // quadrant order C00, C01, C11, C10: the order their last MFMAs were issued in
+  constexpr int kOrder[4] = {0, 1, 3, 2};
+  u32x2 aux[2][4][2];
+  load_aux(kOrder[0], aux[0]);
+#pragma unroll
+  for (int qi = 0; qi < 4; ++qi) {
+    const int q = kOrder[qi];
+    if (HAS_AUX && qi + 1 < 4) load_aux(kOrder[qi + 1], aux[(qi + 1) & 1]);
+    const int n_out = n0 + 128 * (q & 1) + 32 * wc + 16 * (odd ? 1 : 0) + 8 * (g >> 1);     // first of the 8 columns this lane stores
+    const unsigned int col_ok = n_out < P.N ? 0u : kOOB;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int m = row_of(q, a);
+      u32x2 pre0 = {0u, 0u}, pre1 = {0u, 0u};
+      const u32x2 o0 = epi_finish<EPI>(P, dropout, seed, acc[q >> 1][q & 1][a][0], m, col_of(q, 0), bias4[q & 1][0], aux[qi & 1][a][0], pre0);
+      const u32x2 o1 = epi_finish<EPI>(P, dropout, seed, acc[q >> 1][q & 1][a][1], m, col_of(q, 1), bias4[q & 1][1], aux[qi & 1][a][1], pre1);
+      __builtin_amdgcn_raw_buffer_store_b128(pair_exchange(o0, o1), rC, (unsigned int)(((long long)m * P.ldc + n_out) * 2) | col_ok, 0, 0);
+      if (HAS_PRE)
+        __builtin_amdgcn_raw_buffer_store_b128(pair_exchange(pre0, pre1), rPre, (unsigned int)(((long long)m * P.ldaux_out + n_out) * 2) | col_ok, 0, 0);
     }
   }
 #endif
@@ -670,6 +792,8 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
     }
   }
 
+  GPS_TRACE(P, 0);
+  GPS_TRACE(P, 4);
   Stager<BM, ATR, NW> sa;
   Stager<BN, BTR, NW> sb;
   sa.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
@@ -705,6 +829,8 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
       // epilogue's stores, issued after the prefetched copies, only make the count conservative)
       wait_stages<NP, NBUF - 2>(has_next ? NBUF - 2 : min(nst - 1 - it, NBUF - 2));
       __builtin_amdgcn_s_barrier();
+      if (it == 0) GPS_TRACE(P, 1);
+      GPS_TRACE(P, 8 + it);
       {
         if (it + NBUF - 1 < nst) {
           issue_stage<BM, BN, ATR, BTR, NW>(sa, sb, smem + fill * STAGE, k_left, wave, lane);
@@ -723,7 +849,12 @@ __global__ __launch_bounds__(WGM *WGN * 64, waves_per_simd(BM, BN, WGM *WGN, NBU
       cur = (cur == NBUF - 1) ? 0 : cur + 1;
       fill = (fill == NBUF - 1) ? 0 : fill + 1;
     }
+    GPS_TRACE(P, 2);
     store_tile<TM, TN, EPI>(P, acc, csum, do_colsum, split_c, m0_c, n0_c, wm0, wn0, lane);
+    GPS_TRACE(P, 3);
+    GPS_TRACE_DRAIN();
+    GPS_TRACE(P, 6);
+    GPS_TRACE(P, 5);
     if (!has_next) break;
     vid = vnext;
   }
@@ -927,6 +1058,8 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
   constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
   constexpr bool COLSUM = EPI == EPI_F32 && ATR;
   const int wr = wave >> 2, wc = wave & 3;
+  GPS_TRACE(P, 0);
+  GPS_TRACE(P, 4);
   const int k_span = k_eff - kt0 * BK;                      // reduction indices from this workgroup's first K tile on
 
   Stager<128, ATR, 8> sa0, sa1;
@@ -954,6 +1087,8 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[q >> 1][q & 1][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bias4[2][2];                                        // the epilogue's bias vectors: their latency hides behind the main loop
+  load_bias_8p<EPI>(P, n0, wc, lane, bias4);
   // bias gradient of the TN form: column sums of A over k, on the vector ALU beside the MFMAs (tile column 0 only).
   // The four waves of a wave row hold the SAME A fragments; wave column wc sums fragment row block a = wc (rows
   // 64 wr + 16 wc + [0, 16) of each half): lane (i, g) adds the 8 k values it holds of row i with four v_dot2c against
@@ -1021,11 +1156,13 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
+    GPS_TRACE(P, 1);
     if (wr == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind
 
 #pragma clang loop unroll(disable)
     for (int t = 0; t < nst; ++t) {
       const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
+      GPS_TRACE(P, 8 + t);
       // ---- phase 1: C00 ----
       read_b(cur + OFF_B0, bq0);
       __builtin_amdgcn_sched_barrier(0);
@@ -1097,10 +1234,12 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       }
     }
   }
-  f32x4 unused[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    store_tile<4, 2, EPI>(P, acc[q >> 1][q & 1], unused, false, split, m0, n0, 128 * (q >> 1) + 64 * wr, 128 * (q & 1) + 32 * wc, lane);
+  GPS_TRACE(P, 2);
+  store_quads<EPI>(P, acc, split, m0, n0, wr, wc, lane, bias4);
+  GPS_TRACE(P, 3);
+  GPS_TRACE_DRAIN();
+  GPS_TRACE(P, 6);
+  GPS_TRACE(P, 5);
 }
 
 template <bool ATR, bool BTR, int EPI>
@@ -1119,6 +1258,299 @@ int launch_8p(Params &P, hipStream_t s) {
   const long long blocks = (long long)P.ntm * P.ntn * P.splits;
   if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS, s, P);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stream-K form of the two-group 256 x 256 kernel (forms NT / NN, every bf16 epilogue): variant 13.
+//
+// Why: one workgroup per CU and whole tiles means the launch runs in ROUNDS -- 450 tiles (12 608 x 2 304) take two
+// rounds of 256 although they are 1.76 rounds of work, 150 tiles (12 608 x 768, K = 2 304) leave 106 CUs idle for the
+// whole launch, 264 tiles (8 320 x 2 048) run a second round for 8 tiles -- and every CU of a round reaches its
+// epilogue at the same moment: 33 MB of stores hit HBM together while the matrix pipes wait
+// (profiles/r6/gemm_probe_trace_a.jsonl: main loop 16.2 us, epilogue 4.4 us, prologue 1.8 us per tile and CU).
+// Here the K tiles of ALL output tiles form one sequence (tile-major, tile_n fastest); the launch has one resident
+// workgroup per CU and workgroup position w takes the w-th equal share of that sequence, whatever tile boundaries it
+// crosses.  A share is a few SEGMENTS (K-tile runs inside one output tile):
+//   * a segment that covers its tile's whole reduction ends in the ordinary epilogue;
+//   * a segment that starts behind k = 0 (always the FIRST segment of a share) is a contribution: the fp32
+//     accumulators go to this position's slab with write-through (sc1) stores and the position's arrival word is set;
+//   * a segment that starts at k = 0 but ends early (always the LAST segment of a share) owns the tile: it adds the
+//     slabs of the following positions whose shares begin inside this tile (in position order: deterministic),
+//     then runs the epilogue.  Contributions are computed at the very start of a launch and consumed at the very
+//     end of another workgroup's share, so owners practically never wait; contributors never wait at all (no deadlock
+//     whatever the dispatch order; the spin is bounded all the same and reports through the error word).
+// Slab hand-off as the guide prescribes for large payloads: sc1 stores -> every wave s_waitcnt vmcnt(0) -> barrier ->
+// one relaxed agent-scope flag store; the owner polls relaxed from one lane, then every lane reads with sc1 loads.
+// Tile boundaries fall at different times on different CUs, so epilogue stores no longer arrive in bursts.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSkSlabFloats = 256 * 256;          // one workgroup's accumulators
+constexpr int kSkMaxGrid = 256;
+constexpr int kSkFlagBytes = 4096;                 // kSkMaxGrid arrival words + the error word, padded
+constexpr unsigned int kSkSpinLimit = 1u << 21;
+
+// K tiles kt0 .. kt0 + nst - 1 of the 256 x 256 tile at (m0, n0) into `acc` (gemm8p_tile's loop without the TN extras;
+// a ragged last K tile reads zeros past K).  On return both wave groups are aligned on the same barrier.
+template <bool BTR>
+__device__ __forceinline__ void gemm8p_segment(const Params &P, unsigned char *smem, int lane, int wave, int m0, int n0,
+                                               int kt0, int nst, f32x4 (&acc)[2][2][4][2]) {
+  constexpr int HALF = 128 * BK * 2, BUF = 4 * HALF;
+  constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int k_span = P.K - kt0 * BK;
+  Stager<128, false, 8> sa0, sa1;
+  Stager<128, BTR, 8> sb0, sb1;
+  sa0.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
+  sa1.init(P.A, P.lda, P.M, m0 + 128, kt0 * BK, wave, lane);
+  sb0.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
+  sb1.init(P.B, P.ldb, P.N, n0 + 128, kt0 * BK, wave, lane);
+  auto issue = [&](auto &st, unsigned char *dst, int tj) {
+    if (k_span - tj * BK < BK) st.issue_tail(dst, k_span - tj * BK, wave, lane);
+    else st.issue_full(dst, wave);
+  };
+  bf16x8 aq[2][4], bq0[2][2], bq1[2][2];
+  auto read_a = [&](const unsigned char *half) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) aq[ks][a] = read_frag<128, false>(half, 64 * wr + 16 * a, ks, lane);
+  };
+  auto read_b = [&](const unsigned char *half, bf16x8 (&bq)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bq[ks][b] = read_frag<128, BTR>(half, 32 * wc + 16 * b, ks, lane);
+  };
+  auto mfma16 = [&](f32x4 (&c)[4][2], const bf16x8 (&bq)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][b], aq[ks][a], c[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (nst <= 0) return;
+  unsigned char *cur = smem, *oth = smem + BUF;
+  issue(sb0, cur + OFF_B0, 0);
+  issue(sa0, cur + OFF_A0, 0);
+  issue(sb1, cur + OFF_B1, 0);
+  issue(sa1, cur + OFF_A1, 0);
+  if (nst > 1) {
+    issue(sb0, oth + OFF_B0, 1);
+    issue(sa0, oth + OFF_A0, 1);
+    issue(sb1, oth + OFF_B1, 1);
+    wait_vmcnt<6>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind
+#pragma clang loop unroll(disable)
+  for (int t = 0; t < nst; ++t) {
+    const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
+    // ---- phase 1: C00 ----
+    read_b(cur + OFF_B0, bq0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(cur + OFF_A0);
+    if (n1) issue(sa1, oth + OFF_A1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BTR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (tr reads: two per fragment; wait for all)
+    else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(acc[0][0], bq0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: C01 ----
+    read_b(cur + OFF_B1, bq1);
+    if (n2) issue(sb0, cur + OFF_B0, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(acc[0][1], bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: C11 ----
+    read_a(cur + OFF_A1);
+    if (n2) issue(sa0, cur + OFF_A0, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(acc[1][1], bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: C10 ----
+    if (n2) {
+      issue(sb1, cur + OFF_B1, t + 2);
+      wait_vmcnt<6>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    mfma16(acc[1][0], bq0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    unsigned char *tmp = cur;
+    cur = oth;
+    oth = tmp;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+}
+
+template <bool BTR, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_sk_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * BUF = 128 KB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int G = (int)gridDim.x;
+  const int w = xcd_virtual_id(blockIdx.x, G);                  // position in the K-tile sequence (contiguous per XCD)
+  int ntm = P.ntm;
+  if (P.extent_dev) ntm = min(P.ntm, max(0, (*P.extent_dev + 255) / 256));   // live tile rows only
+  const int nkt = P.nkt, ntn = P.ntn;
+  const int U = ntm * ntn * nkt;                                // K-tile units of the launch
+  const int per = U / G, rem = U - per * G;
+  auto share_begin = [&](int pos) { return pos * per + min(pos, rem); };
+  int u = share_begin(w);
+  const int u1 = share_begin(w + 1);
+  GPS_TRACE(P, 0);
+  GPS_TRACE(P, 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(P.partial, 0, (unsigned int)G * kSkSlabFloats * 4u, 0x00020000);
+#endif
+  int seg_no = 0;     // (trace builds: slots 8 + 6 * seg + {0 start, 1 accumulators ready, 2 main loop done, 3 ending issued, 4 K tiles, 5 kind})
+  while (u < u1) {
+    GPS_TRACE(P, 8 + 6 * seg_no);
+    // (integer divisions run on the vector ALU: results go back to scalar registers, the tile code branches on them)
+    const int T = __builtin_amdgcn_readfirstlane(u / nkt);
+    const int k0 = u - T * nkt;
+    const int kend = min(nkt, k0 + (u1 - u));
+    const int tm = __builtin_amdgcn_readfirstlane(T / ntn);
+    const int tn = T - tm * ntn;
+    const int m0 = tm * 256, n0 = tn * 256;
+    f32x4 acc[2][2][4][2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // everything the endings derive from the lane index is recomputed per segment: hoisted out of the share loop those
+    // values (store offsets, column tests, ...) would be live across the main loop, whose 214 registers leave no room
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const unsigned int lane_off = (unsigned int)(wave * 32 * 64 + lane_e) * 16u;   // + r * 1024: this lane's register r in a slab
+    const bool owner = k0 == 0 && kend < nkt;
+    int c_end = w + 1;                                          // contributors: positions w + 1 .. c_end - 1
+    if (owner) {
+      // ---- owner of a split tile: its accumulators START as the sum of the slabs of the positions whose shares begin
+      // inside this tile (position order: deterministic).  Those were written at the very start of the launch; this
+      // segment is the last of its share.
+      const int tile_end = (T + 1) * nkt;
+      while (c_end < G && share_begin(c_end) < tile_end && share_begin(c_end) < U) ++c_end;
+      if (threadIdx.x == 0) {
+        for (int c = w + 1; c < c_end; ++c) {
+          unsigned int spins = 0;
+          while (__hip_atomic_load(&P.sk_flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > kSkSpinLimit) {                            // never expected: report, do not hang
+              __hip_atomic_store(&P.sk_flags[kSkMaxGrid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          __hip_atomic_store(&P.sk_flags[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        }
+      }
+      __syncthreads();
+    }
+    // eight registers at a time: the runtime loop over contributors then carries 32 values, not all 128 accumulators
+    // (carried whole, the loop's entry and back-edge copies of the accumulators get different registers: 2 x 128)
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = w + 1; c < c_end; ++c) {
+        const unsigned int so = (unsigned int)c * (kSkSlabFloats * 4u);
+        f32x4 part[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          part[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rS, lane_off + (unsigned int)(r0 + r) * 1024u, so, 16));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += part[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[(r0 + r) >> 4][((r0 + r) >> 3) & 1][((r0 + r) >> 1) & 3][(r0 + r) & 1] = v[r];
+    }
+#endif
+    f32x4 bias4[2][2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (k0 == 0) load_bias_8p<EPI>(P, n0, wc, lane_e, bias4);     // this segment ends in the epilogue
+#endif
+    GPS_TRACE(P, 8 + 6 * seg_no + 1);
+    gemm8p_segment<BTR>(P, smem, lane, wave, m0, n0, k0, kend - k0, acc);
+    GPS_TRACE(P, 2);
+    GPS_TRACE(P, 8 + 6 * seg_no + 2);
+    GPS_TRACE_VAL(P, 8 + 6 * seg_no + 4, (unsigned long long)(kend - k0));
+    GPS_TRACE_VAL(P, 8 + 6 * seg_no + 5, (unsigned long long)(k0 > 0 ? 1 : kend < nkt ? 2 : 0));
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane_e));
+    if (k0 > 0) {
+      // ---- contribution: accumulators -> slab w (write-through), then the arrival word ----
+      const unsigned int so = (unsigned int)w * (kSkSlabFloats * 4u);
+#pragma unroll
+      for (int r = 0; r < 32; ++r)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r >> 4][(r >> 3) & 1][(r >> 1) & 3][r & 1]), rS,
+                                               (unsigned int)(wave * 32 * 64 + lane_e) * 16u + (unsigned int)r * 1024u, so, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&P.sk_flags[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      store_quads<EPI>(P, acc, 0, m0, n0, wr, wc, lane_e, bias4);
+    }
+#endif
+    GPS_TRACE(P, 3);
+    GPS_TRACE(P, 8 + 6 * seg_no + 3);
+    ++seg_no;
+    // the next segment's first copies overwrite stage buffers: every wave must have left the main loop (it has: the
+    // segment ends on a common barrier) -- and the epilogue must not still be reading LDS (it does not use it)
+    u += kend - k0;
+  }
+  GPS_TRACE_DRAIN();
+  GPS_TRACE(P, 6);
+  GPS_TRACE(P, 5);
+}
+
+template <bool BTR, int EPI>
+int launch_sk(Params &P, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * BK * 2;
+  P.ntm = (P.M + 255) / 256;
+  P.ntn = (P.N + 255) / 256;
+  auto kern = &gemm8p_sk_kernel<BTR, EPI>;
+  static bool attr_done = false;
+  static int n_cu = 0;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return GPS_ERR_LAUNCH;
+    attr_done = true;
+  }
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GPS_ERR_LAUNCH;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (n_cu > kSkMaxGrid) n_cu = kSkMaxGrid;
+  }
+  const long long units = (long long)P.ntm * P.ntn * P.nkt;
+  if (units <= 0 || units > 0x3FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+  static const int grid_env = [] { const char *e = getenv("GPS_GEMM_SK_GRID"); return e ? atoi(e) : 0; }();
+  static const int min_units = [] { const char *e = getenv("GPS_GEMM_SK_MIN_UNITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+  long long grid = units / min_units;                     // every share keeps >= min_units K tiles
+  if (grid > n_cu) grid = n_cu;
+  if (grid_env > 0 && grid_env < grid) grid = grid_env;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, P);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
@@ -1404,10 +1836,10 @@ int launch_cfg(Params &P, hipStream_t s) {
 //   8  = 7, persistent workgroups (stage ring runs across tiles)                  9  = 6, persistent
 //  10  = 4, persistent                                                        11  256x256  2x2 (4 waves, 512 registers), operands
 //                                                                                register-staged two stages ahead (gemm256_kernel)
-constexpr int kVariants = 13;
+constexpr int kVariants = 14;
 struct VariantShape { int bm, bn; };
 constexpr VariantShape kShapes[kVariants] = {{128, 128}, {256, 128}, {128, 128}, {128, 64}, {256, 256}, {256, 128}, {128, 64}, {128, 128},
-                                              {128, 128}, {128, 64}, {256, 256}, {256, 256}, {256, 256}};
+                                              {128, 128}, {128, 64}, {256, 256}, {256, 256}, {256, 256}, {256, 256}};
 template <bool ATR, bool BTR, int EPI>
 int launch_variant(Params &P, int variant, hipStream_t s) {
   switch (variant) {
@@ -1440,6 +1872,10 @@ int launch_variant(Params &P, int variant, hipStream_t s) {
     case 12:      // 256 x 256, eight waves in two alternating groups (gemm8p_kernel): NT / NN with whole K stages, TN
       if constexpr (ATR && BTR && EPI == EPI_F32) return launch_8p<ATR, BTR, EPI>(P, s);
       else if constexpr (ATR || EPI == EPI_F32 || EPI == EPI_RELU_SPLIT || EPI == EPI_RELU_MAX16) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else return (P.K % BK == 0 && P.K >= BK && P.splits == 1) ? launch_8p<ATR, BTR, EPI>(P, s) : launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+    case 13:      // stream-K form of 12 (gemm8p_sk_kernel): NT / NN with bf16 epilogues and a workspace; else as 12 / the 128 x 128 tiles
+      if constexpr (ATR || EPI == EPI_F32 || EPI == EPI_RELU_SPLIT || EPI == EPI_RELU_MAX16) return launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
+      else if (P.partial && P.sk_flags && P.K >= BK && P.splits == 1) return launch_sk<BTR, EPI>(P, s);
       else return (P.K % BK == 0 && P.K >= BK && P.splits == 1) ? launch_8p<ATR, BTR, EPI>(P, s) : launch_cfg<128, 128, 4, 2, ATR, BTR, EPI, 2>(P, s);
     default: return GPS_ERR_INVALID_ARGUMENT;
   }
@@ -1474,8 +1910,13 @@ inline int pick_variant(int form, int M, int N, int K, int splits) {
   return tiles >= 384 ? 7 : 6;
 }
 
+#ifdef GPS_GEMM_TRACE
+static unsigned long long *g_probe_trace = nullptr;      // set by tools/probes/gemm_probe.hip
+#endif
+
 }  // namespace gps_gemm
 
+#ifndef GPS_GEMM_NO_ENTRY      // (tools/probes/sk_regs.hip compiles single kernels of this file)
 extern "C" {
 
 int gps_gemm_pick_splits(int form, int M, int N, int K) {
@@ -1496,6 +1937,10 @@ int gps_gemm_pick_splits(int form, int M, int N, int K) {
 int gps_gemm_pick_variant(int form, int M, int N, int K, int splits) {
   if (form != GPS_GEMM_NT && form != GPS_GEMM_NN && form != GPS_GEMM_TN) return -1;
   return gps_gemm::pick_variant(form, M, N, K, splits < 1 ? gps_gemm_pick_splits(form, M, N, K) : splits);
+}
+
+long long gps_gemm_sk_workspace_bytes(void) {
+  return (long long)gps_gemm::kSkFlagBytes + (long long)gps_gemm::kSkMaxGrid * gps_gemm::kSkSlabFloats * 4;
 }
 
 long long gps_gemm_workspace_floats(int form, int M, int N, int splits) {
@@ -1710,10 +2155,19 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a->K == 0) P.nkt = 0;
 
+#ifdef GPS_GEMM_TRACE
+  P.trace = g_probe_trace;
+#endif
   int variant = a->variant;
   if (variant < 0) variant = pick_variant(a->form, a->M, a->N, a->K, P.splits);
   if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
 
+  if (variant == 13 && a->form != GPS_GEMM_TN && !f32out && a->workspace) {
+    // stream-K scratch (gps_gemm_sk_workspace_bytes()): [arrival words | one fp32 slab per workgroup position]
+    if ((uintptr_t)a->workspace & 15) return GPS_ERR_UNSUPPORTED;
+    P.sk_flags = reinterpret_cast<unsigned int *>(a->workspace);
+    P.partial = a->workspace + kSkFlagBytes / 4;
+  }
   int st;
   // ([r4] negative result: cutting the rows of a product whose 128 x 128 tiles leave a nearly empty last round -- 8 320 x
   // 2 048: 1 040 tiles = 2.03 rounds of 512 -- into whole rounds + a tail launch of 128 x 64 tiles was built, verified
@@ -1783,3 +2237,4 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
 }
 
 }  // extern "C"
+#endif  // GPS_GEMM_NO_ENTRY
