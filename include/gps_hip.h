@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 9
+#define GPS_HIP_ABI_VERSION 10
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -739,6 +739,14 @@ GPS_API int gps_gemm_wgrad_grouped_set_xcd_queues(int on);
 GPS_API int gps_split3_points(int b, int n, int c, const float *xyz, const float *feats, int k_pad, void *out,
                               gps_stream_t stream);
 GPS_API int gps_gemm_bf16(const gps_gemm_args *args, gps_stream_t stream);
+/* n (<= 4) INDEPENDENT products of ONE form (NT or NN) and ONE epilogue -- each with its own operands, shape, bias, saved
+ * activations, dropout stream and device-side row extent -- as one launch of the 256 x 256 kernel (variant 12) over the union
+ * of their output tiles: e.g. the same Linear of the text stack and of the object stack of the GPS model, which are
+ * independent until the joint layers (reference model/openvocab.py:41-63) and alone fill 23 - 59 % of the chip.  Results are
+ * those of n gps_gemm_bf16 calls with variant 12.  `variant`, `splits`, `workspace` are ignored.  GPS_ERR_UNSUPPORTED (nothing
+ * launched: the caller issues the products one by one) for fp32 / split-bf16 epilogues, K < 64, or K % 64 != 0 with an
+ * epilogue other than GPS_GEMM_EPI_BIAS; GPS_ERR_INVALID_ARGUMENT when forms or epilogues differ.  n == 1 is gps_gemm_bf16. */
+GPS_API int gps_gemm_bf16_grouped(const gps_gemm_args *args, int n, gps_stream_t stream);
 
 /* ---- optimizer step: gradient clipping + AdamW over all parameter tensors ------------------------------
  * Replaces `accelerator.clip_grad_norm_` + `optimizer.step()` of the reference's training step

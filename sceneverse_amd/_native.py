@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgps_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "gps_hip.h")
 
 GPS_OK = 0
+GPS_ERR_INVALID_ARGUMENT = -1
 GPS_ERR_UNSUPPORTED = -2
 _lib = None
 
@@ -74,6 +75,9 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_DGELU, EPI_DRELU, EPI_F32 = 0, 1, 2,
 EPI_RELU_SPLIT, EPI_RELU_MAX16 = 6, 7
 EPI_BIAS_GELU_FACTOR, EPI_MUL_AUX = 8, 9
 
+# entries of SIGNATURES whose return value is not an `int` status
+NON_STATUS_RESTYPES = {"gps_embedding_grad_scratch_ints": ctypes.c_longlong, "gps_point_set_object_extent": None}
+
 # name -> argtypes, mirroring include/gps_hip.h one to one
 SIGNATURES = {
     "gps_adamw_step": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
@@ -81,6 +85,7 @@ SIGNATURES = {
     "gps_gemm_pick_variant": [_i, _i, _i, _i, _i],
     "gps_gemm_wgrad_grouped_set_xcd_queues": [_i],
     "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
+    "gps_gemm_bf16_grouped": [ctypes.POINTER(GemmArgs), _i, _vp],
     "gps_gemm_wgrad_grouped": [ctypes.POINTER(WgradProblem), _i, _vp],
     "gps_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "gps_furthest_point_sampling_xyz": [_i, _i, _i, _vp, _vp, _vp, _vp],
@@ -183,8 +188,6 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.gps_error_string.argtypes = [_i]
     lib.gps_last_hip_error.restype = ctypes.c_char_p
     lib.gps_sa_mlp_wpack_floats.restype = ctypes.c_longlong
-    lib.gps_embedding_grad_scratch_ints.restype = ctypes.c_longlong
-    lib.gps_point_set_object_extent.restype = None
     lib.gps_sa_mlp_wpack_floats.argtypes = [_i, _i, _i, _i]
     lib.gps_sa_mlp_layer_floats.restype = ctypes.c_longlong
     lib.gps_sa_mlp_layer_floats.argtypes = [_i, _i]
@@ -206,6 +209,12 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _i
+    # the entries of SIGNATURES that do NOT return a status (set after the loop above, which would overwrite them:
+    # a 64-bit scratch size read as c_int under-allocates for large n * d)
+    for name, restype in NON_STATUS_RESTYPES.items():
+        getattr(lib, name).restype = restype
+    lib.gps_gemm_sk_workspace_bytes.restype = ctypes.c_longlong
+    lib.gps_gemm_sk_workspace_bytes.argtypes = []
     _lib = lib
     return lib
 

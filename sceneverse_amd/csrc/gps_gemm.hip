@@ -1013,7 +1013,7 @@ int launch_256(Params &P, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 // one 256 x 256 output tile at (m0, n0): K tiles kt0 .. kt0 + nst - 1 of the reduction (k_eff = reduction indices that
 // carry work), partial index `split`; tile_n == 0 computes the column sums of the TN form
-template <bool ATR, bool BTR, int EPI>
+template <bool ATR, bool BTR, int EPI, bool RAGGED = false>
 __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem, int lane, int wave, int m0, int n0,
                                             int tile_n, int split, int kt0, int nst, int k_eff);
 
@@ -1051,7 +1051,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Params P) {
   gemm8p_tile<ATR, BTR, EPI>(P, smem, lane, wave, m0, n0, tile_n, split, kt0, nst, k_eff);
 }
 
-template <bool ATR, bool BTR, int EPI>
+// RAGGED (forms NT / NN): K % 64 != 0, the last K tile reads zeros past K (as the token-row reduction of the TN form always may)
+template <bool ATR, bool BTR, int EPI, bool RAGGED>
 __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem, int lane, int wave, int m0, int n0,
                                             int tile_n, int split, int kt0, int nst, int k_eff) {
   constexpr int HALF = 128 * BK * 2, BUF = 4 * HALF;
@@ -1070,7 +1071,7 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
   sb1.init(P.B, P.ldb, P.N, n0 + 128, kt0 * BK, wave, lane);
   // half-tile of K tile `tj` (relative to kt0) into `dst`; only a reduction-major (token-row) K can be ragged
   auto issue = [&](auto &st, unsigned char *dst, int tj) {
-    if constexpr (ATR) {
+    if constexpr (ATR || RAGGED) {
       const int kl = k_span - tj * BK;
       if (kl < BK) {
         st.issue_tail(dst, kl, wave, lane);
@@ -1262,6 +1263,95 @@ int launch_8p(Params &P, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Grouped forward / input-gradient launches: up to kGroupMax INDEPENDENT products of one form and epilogue (each with its own
+// operands, shape, bias, saved activations and device-side row extent) as ONE launch of the two-group 256 x 256 kernel over
+// the union of their output tiles.
+//
+// Why: the text stack (12 608 live rows) and the object stack (5 120 rows) of the GPS model are independent until the
+// joint layers (reference model/openvocab.py:41-63) and their layers have the same op sequence; one at a time the 768-wide
+// products are 150 and 60 tiles of 256 x 256 on 256 CUs -- two launches that leave 41 % and 77 % of the chip idle -- together
+// 210 tiles, one pass.  (A second HIP stream or graph branch would also overlap them, but forked graphs are what the
+// allocator's stream-ordered reuse cannot survive on this ROCm: HISTORY 9a.)
+// Tiles are enumerated problem by problem in the order given (the host puts the longest reduction first); the blocks of an
+// XCD take a contiguous range of that list, so an XCD mostly works on ONE problem's panels.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kGroupMax = 4;
+struct GroupParams {
+  Params p[kGroupMax];
+  int n;
+};
+
+template <bool BTR, int EPI, bool RAGGED>
+__global__ __launch_bounds__(512, 2) void gemm8p_grouped_kernel(const GroupParams G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * BUF = 128 KB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // live tiles of every problem (device-side row extents) and this block's place in their concatenation
+  int ntm[kGroupMax], tiles[kGroupMax], total = 0;
+#pragma unroll
+  for (int j = 0; j < kGroupMax; ++j) {
+    ntm[j] = 0;
+    tiles[j] = 0;
+    if (j < G.n) {
+      ntm[j] = G.p[j].ntm;
+      if (G.p[j].extent_dev) ntm[j] = min(ntm[j], max(0, (*G.p[j].extent_dev + 255) / 256));
+      tiles[j] = ntm[j] * G.p[j].ntn;
+      total += tiles[j];
+    }
+  }
+  if ((int)blockIdx.x >= total) return;
+  int tile = xcd_virtual_id(blockIdx.x, total), j = 0;
+#pragma unroll
+  for (int q = 0; q < kGroupMax - 1; ++q)
+    if (j == q && tile >= tiles[q]) {
+      tile -= tiles[q];
+      j = q + 1;
+    }
+  // the problem's record, selected on the scalar unit (j is wave-uniform: pointers stay in SGPRs, no waterfall loops)
+  Params P = G.p[0];
+  int ntm_j = ntm[0];
+#pragma unroll
+  for (int q = 1; q < kGroupMax; ++q)
+    if (j == q) {
+      P = G.p[q];
+      ntm_j = ntm[q];
+    }
+  const int GM = 4;
+  const int group = tile / (GM * P.ntn), in_group = tile - group * (GM * P.ntn);
+  const int gmr = min(GM, ntm_j - group * GM);
+  const int tile_n = in_group / gmr;
+  const int m0 = (group * GM + (in_group - tile_n * gmr)) * 256, n0 = tile_n * 256;
+  gemm8p_tile<false, BTR, EPI, RAGGED>(P, smem, lane, wave, __builtin_amdgcn_readfirstlane(m0), __builtin_amdgcn_readfirstlane(n0),
+                                       __builtin_amdgcn_readfirstlane(tile_n), 0, 0, P.nkt, P.K);
+}
+
+template <bool BTR, int EPI, bool RAGGED>
+int launch_grouped(GroupParams &G, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * BK * 2;
+  auto kern = &gemm8p_grouped_kernel<BTR, EPI, RAGGED>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return GPS_ERR_LAUNCH;
+    attr_done = true;
+  }
+  long long blocks = 0;
+  for (int j = 0; j < G.n; ++j) {
+    G.p[j].ntm = (G.p[j].M + 255) / 256;
+    G.p[j].ntn = (G.p[j].N + 255) / 256;
+    G.p[j].gm = 4;
+    blocks += (long long)G.p[j].ntm * G.p[j].ntn;
+  }
+  if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS, s, G);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+template <bool BTR, int EPI>
+int launch_grouped_any(GroupParams &G, bool ragged, hipStream_t s) {
+  return ragged ? launch_grouped<BTR, EPI, true>(G, s) : launch_grouped<BTR, EPI, false>(G, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Stream-K form of the two-group 256 x 256 kernel (forms NT / NN, every bf16 epilogue): variant 13.
 //
 // Why: one workgroup per CU and whole tiles means the launch runs in ROUNDS -- 450 tiles (12 608 x 2 304) take two
@@ -1289,25 +1379,86 @@ constexpr int kSkMaxGrid = 256;
 constexpr int kSkFlagBytes = 4096;                 // kSkMaxGrid arrival words + the error word, padded
 constexpr unsigned int kSkSpinLimit = 1u << 21;
 
-// K tiles kt0 .. kt0 + nst - 1 of the 256 x 256 tile at (m0, n0) into `acc` (gemm8p_tile's loop without the TN extras;
-// a ragged last K tile reads zeros past K).  On return both wave groups are aligned on the same barrier.
-template <bool BTR>
-__device__ __forceinline__ void gemm8p_segment(const Params &P, unsigned char *smem, int lane, int wave, int m0, int n0,
-                                               int kt0, int nst, f32x4 (&acc)[2][2][4][2]) {
+// The kernel is ONE loop over the K tiles of the share.  The copies of K tile g + 1 / g + 2 are issued while K tile g is
+// computed (gemm8p_tile's schedule) -- also when those K tiles belong to the NEXT output tile: the stager of each half-tile
+// is re-aimed when the K tile it is about to copy is the first of a tile.  A segment's ending (epilogue, or the slab
+// stores of a contribution) therefore runs with the next segment's first operands already on their way: no per-tile
+// prologue after the first one.  At a segment end the two wave groups align on one barrier (group 0 waits one barrier for
+// group 1), run the ending side by side, and group 1 takes its one-barrier lag back.
+// RAGGED: K % 64 != 0 -- the last K tile of every output tile takes the zero-filling copy path; kept out of the K % 64 == 0
+// instantiations because its mere presence in the loop costs 10 % (gemm_probe trace, 36 K tiles: 61.6 vs 56.0 us).
+template <bool BTR, int EPI, bool RAGGED>
+__global__ __launch_bounds__(512, 2) void gemm8p_sk_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * BUF = 128 KB
   constexpr int HALF = 128 * BK * 2, BUF = 4 * HALF;
   constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int k_span = P.K - kt0 * BK;
+  const int G = (int)gridDim.x;
+  const int w = xcd_virtual_id(blockIdx.x, G);                  // position in the K-tile sequence (contiguous per XCD)
+  int ntm = P.ntm;
+  if (P.extent_dev) ntm = min(P.ntm, max(0, (*P.extent_dev + 255) / 256));   // live tile rows only
+  const int nkt = P.nkt, ntn = P.ntn;
+  const int U = ntm * ntn * nkt;                                // K-tile units of the launch
+  const int per = U / G, rem = U - per * G;
+  auto share_begin = [&](int pos) { return pos * per + min(pos, rem); };
+  const int u0 = share_begin(w);
+  const int n_units = share_begin(w + 1) - u0;
+  GPS_TRACE(P, 0);
+  GPS_TRACE(P, 4);
+  if (n_units <= 0) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(P.partial, 0, (unsigned int)G * kSkSlabFloats * 4u, 0x00020000);
+
+  // (tile row, tile column, K tile) of a unit; tile_n fastest, then K
+  struct Unit { int tm, tn, kt; };
+  auto next_unit = [&](const Unit &d) {
+    Unit r = d;
+    if (++r.kt == nkt) {
+      r.kt = 0;
+      if (++r.tn == ntn) { r.tn = 0; ++r.tm; }
+    }
+    return r;
+  };
+  Unit d0;                                                      // the unit being computed
+  {
+    const int T = __builtin_amdgcn_readfirstlane(u0 / nkt);
+    d0.kt = u0 - T * nkt;
+    d0.tm = __builtin_amdgcn_readfirstlane(T / ntn);
+    d0.tn = T - d0.tm * ntn;
+  }
+  const int first_kt = d0.kt;                                   // > 0: the share starts with a contribution
+  Unit d1 = next_unit(d0), d2 = next_unit(d1);                  // the units whose copies are issued during d0
+
   Stager<128, false, 8> sa0, sa1;
   Stager<128, BTR, 8> sb0, sb1;
-  sa0.init(P.A, P.lda, P.M, m0, kt0 * BK, wave, lane);
-  sa1.init(P.A, P.lda, P.M, m0 + 128, kt0 * BK, wave, lane);
-  sb0.init(P.B, P.ldb, P.N, n0, kt0 * BK, wave, lane);
-  sb1.init(P.B, P.ldb, P.N, n0 + 128, kt0 * BK, wave, lane);
-  auto issue = [&](auto &st, unsigned char *dst, int tj) {
-    if (k_span - tj * BK < BK) st.issue_tail(dst, k_span - tj * BK, wave, lane);
-    else st.issue_full(dst, wave);
+  // half-tile `half` (0 / 1) of operand A or B of unit d into dst; the stager is re-aimed at the first K tile of a tile
+  auto issue_a = [&](Stager<128, false, 8> &st, int half, unsigned char *dst, const Unit &d, bool aim) {
+    if (aim || d.kt == 0) st.init(P.A, P.lda, P.M, d.tm * 256 + 128 * half, d.kt * BK, wave, lane);
+    if constexpr (RAGGED) {
+      const int kl = P.K - d.kt * BK;
+      if (kl < BK) {
+        st.issue_tail(dst, kl, wave, lane);
+        return;
+      }
+    }
+    st.issue_full(dst, wave);
   };
+  auto issue_b = [&](Stager<128, BTR, 8> &st, int half, unsigned char *dst, const Unit &d, bool aim) {
+    if (aim || d.kt == 0) st.init(P.B, P.ldb, P.N, d.tn * 256 + 128 * half, d.kt * BK, wave, lane);
+    if constexpr (RAGGED) {
+      const int kl = P.K - d.kt * BK;
+      if (kl < BK) {
+        st.issue_tail(dst, kl, wave, lane);
+        return;
+      }
+    }
+    st.issue_full(dst, wave);
+  };
+
+  f32x4 acc[2][2][4][2];
+  f32x4 bias4[2][2];
   bf16x8 aq[2][4], bq0[2][2], bq1[2][2];
   auto read_a = [&](const unsigned char *half) {
 #pragma unroll
@@ -1331,30 +1482,48 @@ __device__ __forceinline__ void gemm8p_segment(const Params &P, unsigned char *s
         for (int b = 0; b < 2; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][b], aq[ks][a], c[a][b], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
-  if (nst <= 0) return;
+
   unsigned char *cur = smem, *oth = smem + BUF;
-  issue(sb0, cur + OFF_B0, 0);
-  issue(sa0, cur + OFF_A0, 0);
-  issue(sb1, cur + OFF_B1, 0);
-  issue(sa1, cur + OFF_A1, 0);
-  if (nst > 1) {
-    issue(sb0, oth + OFF_B0, 1);
-    issue(sa0, oth + OFF_A0, 1);
-    issue(sb1, oth + OFF_B1, 1);
+  // prologue: unit 0 complete in buffer 0, the first three halves of unit 1 in flight into buffer 1
+  issue_b(sb0, 0, cur + OFF_B0, d0, true);
+  issue_a(sa0, 0, cur + OFF_A0, d0, true);
+  issue_b(sb1, 1, cur + OFF_B1, d0, true);
+  issue_a(sa1, 1, cur + OFF_A1, d0, true);
+  if (n_units > 1) {
+    issue_b(sb0, 0, oth + OFF_B0, d1, false);
+    issue_a(sa0, 0, oth + OFF_A0, d1, false);
+    issue_b(sb1, 1, oth + OFF_B1, d1, false);
     wait_vmcnt<6>();
   } else {
     wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind
+  GPS_TRACE(P, 1);
+  if (wr == 1) __builtin_amdgcn_s_barrier();                   // group 1 runs one barrier behind
+
+  bool seg_first = true;            // d0 is the first K tile of a segment
+  bool owner_tail = false;
+  Unit d_last = d0;
+  int pending = 0;                  // 1: slab stores issued, arrival word not yet set
+  int seg_no = 0;
 #pragma clang loop unroll(disable)
-  for (int t = 0; t < nst; ++t) {
-    const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
+  for (int g = 0; g < n_units; ++g) {
+    const bool n1 = g + 1 < n_units, n2 = g + 2 < n_units;
+    if (seg_first) {
+      GPS_TRACE(P, 8 + 6 * seg_no);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[q >> 1][q & 1][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      seg_first = false;
+    }
     // ---- phase 1: C00 ----
     read_b(cur + OFF_B0, bq0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(cur + OFF_A0);
-    if (n1) issue(sa1, oth + OFF_A1, t + 1);
+    if (n1) issue_a(sa1, 1, oth + OFF_A1, d1, false);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (BTR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (tr reads: two per fragment; wait for all)
     else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -1366,7 +1535,7 @@ __device__ __forceinline__ void gemm8p_segment(const Params &P, unsigned char *s
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: C01 ----
     read_b(cur + OFF_B1, bq1);
-    if (n2) issue(sb0, cur + OFF_B0, t + 2);
+    if (n2) issue_b(sb0, 0, cur + OFF_B0, d2, false);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1376,7 +1545,7 @@ __device__ __forceinline__ void gemm8p_segment(const Params &P, unsigned char *s
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: C11 ----
     read_a(cur + OFF_A1);
-    if (n2) issue(sa0, cur + OFF_A0, t + 2);
+    if (n2) issue_a(sa0, 0, cur + OFF_A0, d2, false);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1385,87 +1554,99 @@ __device__ __forceinline__ void gemm8p_segment(const Params &P, unsigned char *s
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 4: C10 ----
-    if (n2) {
-      issue(sb1, cur + OFF_B1, t + 2);
-      wait_vmcnt<6>();
-    } else {
-      wait_vmcnt<0>();
-    }
+    if (n2) issue_b(sb1, 1, cur + OFF_B1, d2, false);
+    // a contribution's slab stores (issued at the end of the previous K tile) must be acknowledged before its arrival word
+    // is set: this one wait is a full drain, and the word is set behind the barrier after next (by then group 1's waves,
+    // one barrier behind, have drained theirs as well)
+    if (pending == 1 || !n2) wait_vmcnt<0>();
+    else wait_vmcnt<6>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     mfma16(acc[1][0], bq0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    const bool seg_last = d0.kt == nkt - 1 || !n1;
+    if (pending == 1 && !seg_last) {
+      if (threadIdx.x == 0) __hip_atomic_store(&P.sk_flags[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pending = 0;
+    }
+    if (seg_last) {
+      GPS_TRACE(P, 8 + 6 * seg_no + 2);
+      if (wr == 0) __builtin_amdgcn_s_barrier();               // both groups side by side through the ending
+      const bool contribution = seg_no == 0 && first_kt > 0;
+      const int m0 = d0.tm * 256, n0 = d0.tn * 256;
+      // (offsets derived from the lane index are recomputed here, not carried through the main loop)
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const unsigned int lane_off = (unsigned int)(wave * 32 * 64 + lane_e) * 16u;     // + r * 1024: this lane's register r in a slab
+      GPS_TRACE_VAL(P, 8 + 6 * seg_no + 5, (unsigned long long)(contribution ? 1 : d0.kt != nkt - 1 ? 2 : 0));
+      if (contribution) {
+        if (pending == 1) {          // (cannot happen: a share holds one contribution; kept for the invariant's sake)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (threadIdx.x == 0) __hip_atomic_store(&P.sk_flags[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned int so = (unsigned int)w * (kSkSlabFloats * 4u);
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r >> 4][(r >> 3) & 1][(r >> 1) & 3][r & 1]), rS,
+                                                 lane_off + (unsigned int)r * 1024u, so, 16);
+        pending = 1;
+      } else if (d0.kt == nkt - 1) {
+        // (the bias is fetched here, not ahead of the main loop as in gemm8p_tile: beside the LDS-DMA copies in flight the
+        // compiler drains vmcnt to 0 in front of any ordinary load, i.e. the whole prefetch ring once per tile: +0.6 us)
+        load_bias_8p<EPI>(P, n0, wc, lane_e, bias4);
+        store_quads<EPI>(P, acc, 0, m0, n0, wr, wc, lane_e, bias4);
+      } else {
+        owner_tail = true;          // the owner of a split tile: finished behind the loop (this is the share's last K tile)
+      }
+      GPS_TRACE(P, 8 + 6 * seg_no + 3);
+      GPS_TRACE_VAL(P, 8 + 6 * seg_no + 4, (unsigned long long)g);
+      ++seg_no;
+      seg_first = true;
+      if (wr == 1 && n1) __builtin_amdgcn_s_barrier();         // group 1 one barrier behind again
+    }
+    d_last = d0;
+    d0 = d1;
+    d1 = d2;
+    d2 = next_unit(d2);
     unsigned char *tmp = cur;
     cur = oth;
     oth = tmp;
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-}
-
-template <bool BTR, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm8p_sk_kernel(const Params P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * BUF = 128 KB
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int G = (int)gridDim.x;
-  const int w = xcd_virtual_id(blockIdx.x, G);                  // position in the K-tile sequence (contiguous per XCD)
-  int ntm = P.ntm;
-  if (P.extent_dev) ntm = min(P.ntm, max(0, (*P.extent_dev + 255) / 256));   // live tile rows only
-  const int nkt = P.nkt, ntn = P.ntn;
-  const int U = ntm * ntn * nkt;                                // K-tile units of the launch
-  const int per = U / G, rem = U - per * G;
-  auto share_begin = [&](int pos) { return pos * per + min(pos, rem); };
-  int u = share_begin(w);
-  const int u1 = share_begin(w + 1);
-  GPS_TRACE(P, 0);
-  GPS_TRACE(P, 4);
-#if defined(__HIP_DEVICE_COMPILE__)
-  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(P.partial, 0, (unsigned int)G * kSkSlabFloats * 4u, 0x00020000);
-#endif
-  int seg_no = 0;     // (trace builds: slots 8 + 6 * seg + {0 start, 1 accumulators ready, 2 main loop done, 3 ending issued, 4 K tiles, 5 kind})
-  while (u < u1) {
-    GPS_TRACE(P, 8 + 6 * seg_no);
-    // (integer divisions run on the vector ALU: results go back to scalar registers, the tile code branches on them)
-    const int T = __builtin_amdgcn_readfirstlane(u / nkt);
-    const int k0 = u - T * nkt;
-    const int kend = min(nkt, k0 + (u1 - u));
-    const int tm = __builtin_amdgcn_readfirstlane(T / ntn);
-    const int tn = T - tm * ntn;
-    const int m0 = tm * 256, n0 = tn * 256;
-    f32x4 acc[2][2][4][2];
-#if defined(__HIP_DEVICE_COMPILE__)
-    // everything the endings derive from the lane index is recomputed per segment: hoisted out of the share loop those
-    // values (store offsets, column tests, ...) would be live across the main loop, whose 214 registers leave no room
+  if (pending == 1) {                // the share ended on (or one K tile after) its contribution; set the word BEFORE
+                                     // waiting for anybody else's (no chains of owners waiting on owners)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&P.sk_flags[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (owner_tail) {
+    // ---- owner of a split tile (always the last segment of a share; outside the loop so that its registers are not
+    // live across the main loop): add the slabs of the positions whose shares begin inside this tile, in position order.
+    // Eight registers at a time: the runtime loop over contributors then carries 32 values, not the 128 accumulators
+    // (carried whole, entry and back-edge copies get different registers).
+    const Unit dl = d_last;
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
-    const unsigned int lane_off = (unsigned int)(wave * 32 * 64 + lane_e) * 16u;   // + r * 1024: this lane's register r in a slab
-    const bool owner = k0 == 0 && kend < nkt;
-    int c_end = w + 1;                                          // contributors: positions w + 1 .. c_end - 1
-    if (owner) {
-      // ---- owner of a split tile: its accumulators START as the sum of the slabs of the positions whose shares begin
-      // inside this tile (position order: deterministic).  Those were written at the very start of the launch; this
-      // segment is the last of its share.
-      const int tile_end = (T + 1) * nkt;
-      while (c_end < G && share_begin(c_end) < tile_end && share_begin(c_end) < U) ++c_end;
-      if (threadIdx.x == 0) {
-        for (int c = w + 1; c < c_end; ++c) {
-          unsigned int spins = 0;
-          while (__hip_atomic_load(&P.sk_flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > kSkSpinLimit) {                            // never expected: report, do not hang
-              __hip_atomic_store(&P.sk_flags[kSkMaxGrid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
+    const unsigned int lane_off = (unsigned int)(wave * 32 * 64 + lane_e) * 16u;
+    const int tile_end = ((dl.tm * ntn + dl.tn) + 1) * nkt;
+    int c_end = w + 1;
+    while (c_end < G && share_begin(c_end) < tile_end && share_begin(c_end) < U) ++c_end;
+    if (threadIdx.x == 0) {
+      for (int c = w + 1; c < c_end; ++c) {
+        unsigned int spins = 0;
+        while (__hip_atomic_load(&P.sk_flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > kSkSpinLimit) {                        // never expected: report, do not hang
+            __hip_atomic_store(&P.sk_flags[kSkMaxGrid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
           }
-          __hip_atomic_store(&P.sk_flags[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
         }
+        __hip_atomic_store(&P.sk_flags[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       }
-      __syncthreads();
     }
-    // eight registers at a time: the runtime loop over contributors then carries 32 values, not all 128 accumulators
-    // (carried whole, the loop's entry and back-edge copies of the accumulators get different registers: 2 x 128)
+    __syncthreads();
+    GPS_TRACE(P, 8 + 6 * (seg_no - 1) + 1);
 #pragma unroll
     for (int r0 = 0; r0 < 32; r0 += 8) {
       f32x4 v[8];
@@ -1480,54 +1661,36 @@ __global__ __launch_bounds__(512, 2) void gemm8p_sk_kernel(const Params P) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += part[r];
       }
+      // (the adds are pinned here: sunk behind the other chunks' loops, all four chunks' sums would be live at once)
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc[(r0 + r) >> 4][((r0 + r) >> 3) & 1][((r0 + r) >> 1) & 3][(r0 + r) & 1] = v[r];
+      for (int r = 0; r < 8; ++r) {
+        f32x4 &dst = acc[(r0 + r) >> 4][((r0 + r) >> 3) & 1][((r0 + r) >> 1) & 3][(r0 + r) & 1];
+        dst += v[r];
+        asm volatile("" : "+v"(dst));
+      }
     }
-#endif
-    f32x4 bias4[2][2];
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (k0 == 0) load_bias_8p<EPI>(P, n0, wc, lane_e, bias4);     // this segment ends in the epilogue
-#endif
-    GPS_TRACE(P, 8 + 6 * seg_no + 1);
-    gemm8p_segment<BTR>(P, smem, lane, wave, m0, n0, k0, kend - k0, acc);
-    GPS_TRACE(P, 2);
-    GPS_TRACE(P, 8 + 6 * seg_no + 2);
-    GPS_TRACE_VAL(P, 8 + 6 * seg_no + 4, (unsigned long long)(kend - k0));
-    GPS_TRACE_VAL(P, 8 + 6 * seg_no + 5, (unsigned long long)(k0 > 0 ? 1 : kend < nkt ? 2 : 0));
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(lane_e));
-    if (k0 > 0) {
-      // ---- contribution: accumulators -> slab w (write-through), then the arrival word ----
-      const unsigned int so = (unsigned int)w * (kSkSlabFloats * 4u);
-#pragma unroll
-      for (int r = 0; r < 32; ++r)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r >> 4][(r >> 3) & 1][(r >> 1) & 3][r & 1]), rS,
-                                               (unsigned int)(wave * 32 * 64 + lane_e) * 16u + (unsigned int)r * 1024u, so, 16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(&P.sk_flags[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      store_quads<EPI>(P, acc, 0, m0, n0, wr, wc, lane_e, bias4);
-    }
-#endif
-    GPS_TRACE(P, 3);
-    GPS_TRACE(P, 8 + 6 * seg_no + 3);
-    ++seg_no;
-    // the next segment's first copies overwrite stage buffers: every wave must have left the main loop (it has: the
-    // segment ends on a common barrier) -- and the epilogue must not still be reading LDS (it does not use it)
-    u += kend - k0;
+    load_bias_8p<EPI>(P, dl.tn * 256, wc, lane_e, bias4);
+    store_quads<EPI>(P, acc, 0, dl.tm * 256, dl.tn * 256, wr, wc, lane_e, bias4);
+    GPS_TRACE(P, 8 + 6 * (seg_no - 1) + 3);
   }
+#endif
   GPS_TRACE_DRAIN();
   GPS_TRACE(P, 6);
   GPS_TRACE(P, 5);
 }
 
+template <bool BTR, int EPI, bool RAGGED>
+int launch_sk_r(Params &P, hipStream_t s);
 template <bool BTR, int EPI>
 int launch_sk(Params &P, hipStream_t s) {
+  return (P.K % BK) ? launch_sk_r<BTR, EPI, true>(P, s) : launch_sk_r<BTR, EPI, false>(P, s);
+}
+template <bool BTR, int EPI, bool RAGGED>
+int launch_sk_r(Params &P, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * BK * 2;
   P.ntm = (P.M + 255) / 256;
   P.ntn = (P.N + 255) / 256;
-  auto kern = &gemm8p_sk_kernel<BTR, EPI>;
+  auto kern = &gemm8p_sk_kernel<BTR, EPI, RAGGED>;
   static bool attr_done = false;
   static int n_cu = 0;
   if (!attr_done) {
@@ -2091,11 +2254,16 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
   return GPS_OK;
 }
 
-int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
+// argument checks of gps_gemm_bf16 / gps_gemm_bf16_grouped and the kernel's record; *done: nothing to compute (M or N == 0)
+static int gps_gemm_fill_params(const gps_gemm_args *a, gps_gemm::Params &P, bool *done) {
   using namespace gps_gemm;
+  *done = false;
   if (!a || a->M < 0 || a->N < 0 || a->K < 0) return GPS_ERR_INVALID_ARGUMENT;
   if (a->form < 0 || a->form > 2 || a->epilogue < 0 || a->epilogue > 9) return GPS_ERR_INVALID_ARGUMENT;
-  if (a->M == 0 || a->N == 0) return GPS_OK;
+  if (a->M == 0 || a->N == 0) {
+    *done = true;
+    return GPS_OK;
+  }
   if (!a->A || !a->B || !a->C) return GPS_ERR_INVALID_ARGUMENT;
   // 16-byte global chunks and 8 / 16-byte stores: leading dimensions in multiples of 8 elements, N of 4, K of 8
   if ((a->lda & 7) || (a->ldb & 7) || (a->N & 3)) return GPS_ERR_UNSUPPORTED;
@@ -2133,7 +2301,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
     if (a->epilogue == GPS_GEMM_EPI_RELU_MAX16 && (a->M & 15)) return GPS_ERR_UNSUPPORTED;
   }
 
-  Params P = {};
+  P = Params{};
   P.M = a->M; P.N = a->N; P.K = a->K;
   P.A = (const uint16_t *)a->A; P.lda = a->lda;
   P.B = (const uint16_t *)a->B; P.ldb = a->ldb;
@@ -2152,9 +2320,72 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   P.seed = a->seed; P.seed_dev = (const unsigned long long *)a->seed_dev;
   P.extent_dev = a->extent_dev;
   P.row0 = a->form != GPS_GEMM_TN ? a->reserved2 : 0;
-  hipStream_t s = (hipStream_t)stream;
   if (a->K == 0) P.nkt = 0;
 
+  return GPS_OK;
+}
+
+int gps_gemm_bf16_grouped(const gps_gemm_args *args, int n, gps_stream_t stream) {
+  using namespace gps_gemm;
+  if (n < 0 || (n > 0 && !args)) return GPS_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GPS_OK;
+  if (n == 1) return gps_gemm_bf16(&args[0], stream);
+  if (n > kGroupMax) return GPS_ERR_UNSUPPORTED;
+  const int form = args[0].form, epi = args[0].epilogue;
+  if (form != GPS_GEMM_NT && form != GPS_GEMM_NN) return GPS_ERR_UNSUPPORTED;
+  if (epi == GPS_GEMM_EPI_F32 || epi == GPS_GEMM_EPI_RELU_SPLIT || epi == GPS_GEMM_EPI_RELU_MAX16) return GPS_ERR_UNSUPPORTED;
+  GroupParams G = {};
+  bool ragged = false;
+  for (int i = 0; i < n; ++i) {
+    const gps_gemm_args &a = args[i];
+    if (a.form != form || a.epilogue != epi) return GPS_ERR_INVALID_ARGUMENT;     // one kernel instantiation per launch
+    Params P;
+    bool done = false;
+    const int st = gps_gemm_fill_params(&a, P, &done);
+    if (st != GPS_OK) return st;
+    if (done) continue;
+    if (a.K < BK) return GPS_ERR_UNSUPPORTED;
+    ragged = ragged || (a.K % BK) != 0;
+    // longest reduction first (stable insertion): its tiles get the lowest block ids, i.e. start first
+    int at = G.n;
+    while (at > 0 && G.p[at - 1].K < P.K) {
+      G.p[at] = G.p[at - 1];
+      --at;
+    }
+    G.p[at] = P;
+    ++G.n;
+  }
+  if (G.n == 0) return GPS_OK;
+  if (ragged && epi != GPS_GEMM_EPI_BIAS) return GPS_ERR_UNSUPPORTED;           // ragged K: the plain-bias instantiations only
+  hipStream_t s = (hipStream_t)stream;
+  if (form == GPS_GEMM_NT) {
+    switch (epi) {
+      case GPS_GEMM_EPI_BIAS: return launch_grouped_any<false, EPI_BIAS>(G, ragged, s);
+      case GPS_GEMM_EPI_BIAS_GELU: return launch_grouped<false, EPI_BIAS_GELU, false>(G, s);
+      case GPS_GEMM_EPI_BIAS_RELU: return launch_grouped<false, EPI_BIAS_RELU, false>(G, s);
+      case GPS_GEMM_EPI_BIAS_GELU_FACTOR: return launch_grouped<false, EPI_BIAS_GELU_FACTOR, false>(G, s);
+      default: return GPS_ERR_UNSUPPORTED;
+    }
+  }
+  switch (epi) {
+    case GPS_GEMM_EPI_BIAS: return launch_grouped_any<true, EPI_BIAS>(G, ragged, s);
+    case GPS_GEMM_EPI_DGELU: return launch_grouped<true, EPI_DGELU, false>(G, s);
+    case GPS_GEMM_EPI_DRELU: return launch_grouped<true, EPI_DRELU, false>(G, s);
+    case GPS_GEMM_EPI_MUL_AUX: return launch_grouped<true, EPI_MUL_AUX, false>(G, s);
+    default: return GPS_ERR_UNSUPPORTED;
+  }
+}
+
+int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
+  using namespace gps_gemm;
+  Params P;
+  bool done = false;
+  {
+    const int st0 = gps_gemm_fill_params(a, P, &done);
+    if (st0 != GPS_OK || done) return st0;
+  }
+  const bool f32out = a->epilogue == GPS_GEMM_EPI_F32;
+  hipStream_t s = (hipStream_t)stream;
 #ifdef GPS_GEMM_TRACE
   P.trace = g_probe_trace;
 #endif

@@ -667,6 +667,11 @@ class GPSTrainStep:
         """One optimisation step; returns (total_loss tensor, dict of loss tensors).  No host sync."""
         self.net.train()
         self._drop_previous_graph()
+        # The text and the object stack run in lock-step with paired GEMM launches (modules/layers/gemm.py drive_pair).  The
+        # split-graph step cuts the backward pass BETWEEN the two stacks (two graphs, `_bottom_groups`): there the pairs
+        # share their forward launches only and keep one autograd node per stack.
+        from .modules.layers import gemm as _gemm_mode
+        _gemm_mode.set_twin_backward(not self.graph_dp)
         if self.graph or self.graph_dp:
             data_dict['cur_step'] = 0
             data_dict['total_steps'] = 1 << 30

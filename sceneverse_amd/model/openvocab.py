@@ -69,6 +69,26 @@ class OpenVocab(_GPSBase):
         if self.use_scene_cap:
             self.object_pool = lambda x: x.mean(dim=1)
 
+    def _twin_generators(self, data_dict):
+        """The text encoder and the object encoder as two generators of their GEMM calls (modules/layers/gemm.py
+        drive_pair), or None when either side has no generator form / the inputs are not on the GPU / pairing is off.
+        The two stacks are independent until `unified_encoder` (reference model/openvocab.py:41-63)."""
+        from ..modules.layers import gemm
+        lang, pts = self.lang_encoder, self.point_encoder
+        if not (gemm.twin_stacks() and data_dict['txt_ids'].is_cuda and torch.is_autocast_enabled("cuda")
+                and hasattr(lang, "forward_pair_gen") and hasattr(pts, "forward_gen")
+                and "Scene" not in self.cfg.model.vision.name):
+            return None
+        if self.use_scene_cap:
+            g_txt = lang.forward_pair_gen(data_dict['txt_ids'], data_dict['txt_masks'], data_dict['scene_txt_ids'],
+                                          data_dict['scene_txt_masks'], cls_second=True)
+        else:
+            g_txt = lang.forward_gen(data_dict['txt_ids'], data_dict['txt_masks'])
+        g_obj = pts.forward_gen(data_dict['obj_fts'].float(), data_dict['obj_locs'], data_dict['obj_masks'],
+                                data_dict['obj_sem_masks'], data_dict['obj_labels'], data_dict['cur_step'],
+                                data_dict['total_steps'])
+        return g_txt, g_obj
+
     def forward(self, data_dict):
         if 'cur_step' not in data_dict:
             data_dict['cur_step'] = 1
@@ -76,7 +96,17 @@ class OpenVocab(_GPSBase):
 
         scene_txt = None
         pre = self._encode_objects(data_dict) if _OBJ_FIRST else None
-        if self.use_scene_cap and hasattr(self.lang_encoder, "forward_pair"):
+        twin = self._twin_generators(data_dict) if pre is None else None
+        if twin is not None:
+            # the two bottom stacks in lock-step: their layers' GEMMs leave pairwise as single launches
+            from ..modules.layers import gemm
+            txt_out, pre = gemm.drive_pair(*twin)
+            if self.use_scene_cap:
+                txt, scene_txt = txt_out
+                data_dict['scene_text_embed'] = scene_txt[:, 0]
+            else:
+                txt = txt_out
+        elif self.use_scene_cap and hasattr(self.lang_encoder, "forward_pair"):
             # the sentence and the scene caption go through the text encoder's layers as one row batch
             txt, scene_txt = self.lang_encoder.forward_pair(data_dict['txt_ids'], data_dict['txt_masks'],
                                                             data_dict['scene_txt_ids'], data_dict['scene_txt_masks'],

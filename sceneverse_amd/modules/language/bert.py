@@ -96,6 +96,12 @@ def set_fused_embedding(flag: bool) -> None:
     _FAST_EMB = bool(flag)
 
 
+def _returning(value):
+    """A generator that yields nothing and returns `value` (a stack without GEMM calls to pair)."""
+    return value
+    yield       # noqa: unreachable -- makes this a generator function
+
+
 @LANGUAGE_REGISTRY.register()
 class BERTLanguageEncoder(nn.Module):
     def __init__(self, cfg, weights="bert-base-uncased", hidden_size=768, num_hidden_layers=4,
@@ -173,9 +179,14 @@ class BERTLanguageEncoder(nn.Module):
                                "the outputs of that forward are NaN.  Use right-padded masks or set_varlen(False).")
 
     def _fast_forward_varlen(self, texts, cls_only=()):
+        from ..layers import gemm
+        return gemm.drive(self._fast_forward_varlen_gen(texts, cls_only))
+
+    def _fast_forward_varlen_gen(self, texts, cls_only=()):
         """The encoder stack over the VALID tokens only (see _VARLEN above).  texts = [(ids (B_i, L_i), masks), ...];
         -> per text the last hidden state as (B_i, L_i, D) with zeros at padded positions, or (B_i, 1, D) = the
-        [CLS] rows for the texts listed in `cls_only`."""
+        [CLS] rows for the texts listed in `cls_only`.  A generator: the layers' GEMM calls are yielded (gemm.LinearOp /
+        gemm.FFNOp), `gemm.drive` runs them one by one, `gemm.drive_pair` beside the object encoder's."""
         from ..layers import gemm
         from ..layers.fused_attention import fused_varlen_self_attention
         from ..layers.fused_norm import add_dropout_layer_norm
@@ -245,7 +256,7 @@ class BERTLanguageEncoder(nn.Module):
         for li, layer in enumerate(m.encoder.layer):
             sa, so = layer.attention.self, layer.attention.output
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-                packed = gemm.packed_linear(x16, [sa.query, sa.key, sa.value], rows_dev=n_valid)
+                packed = yield gemm.LinearOp.of(x16, [sa.query, sa.key, sa.value], rows_dev=n_valid)
                 ctx = fused_varlen_self_attention(packed, cu, S, cap, H, dropout_p=sa.dropout.p, training=training,
                                                   order=order, q_limit=q_limit if (cls_tail and li == last) else None)
                 rows = n_valid
@@ -254,11 +265,11 @@ class BERTLanguageEncoder(nn.Module):
                     # backward: their (undefined) gradients must not be scattered back into the full row batch
                     ctx = _ZeroDeadRows.apply(ctx.index_select(0, sel), rows_tail)
                     x, rows = _ZeroDeadRows.apply(x.index_select(0, sel), rows_tail), rows_tail
-                attn_out = gemm.linear(ctx, so.dense.weight, so.dense.bias, rows_dev=rows)
+                attn_out = yield gemm.LinearOp.of(ctx, [so.dense], rows_dev=rows)
                 x, x16 = add_dropout_layer_norm(x, attn_out, so.LayerNorm, so.dropout.p, training, want_bf16=True,
                                                 rows_dev=rows)
-                ffn_out = gemm.ffn(x16, layer.intermediate.dense, layer.output.dense, "gelu", 0.0, training,
-                                   rows_dev=rows)
+                ffn_out = yield gemm.FFNOp(x16, layer.intermediate.dense, layer.output.dense, "gelu", 0.0, training,
+                                           rows_dev=rows)
                 x, x16 = add_dropout_layer_norm(x, ffn_out, layer.output.LayerNorm, layer.output.dropout.p, training,
                                                 want_bf16=True, rows_dev=rows)
         # back to the callers' layouts
@@ -285,8 +296,9 @@ class BERTLanguageEncoder(nn.Module):
             s0 += B
         return outs
 
-    def _fast_forward_multi(self, texts, cls_only=()):
-        """texts = [(ids (B_i, L_i), masks (B_i, L_i)), ...] -> [last hidden state (B_i, L_i, D), ...].
+    def _fast_forward_multi(self, texts, cls_only=(), as_gen: bool = False):
+        """texts = [(ids (B_i, L_i), masks (B_i, L_i)), ...] -> [last hidden state (B_i, L_i, D), ...]
+        (as_gen: a generator of the stack's GEMM calls that returns them, see _fast_forward_varlen_gen).
         Every row-wise operation of a layer (QKV / output / FFN GEMMs, residual + LayerNorm) runs ONCE over the
         token rows of all texts together -- the weights are the same, the rows independent -- and only the attention
         core runs per text (its own length and padding mask).  One text: the reference's call.  Two (the sentence
@@ -300,7 +312,10 @@ class BERTLanguageEncoder(nn.Module):
         m, H = self.model, self.bert_config.num_attention_heads
         if _VARLEN and self._varlen_ok(texts) and self._masks_are_prefixes(texts):
             self.last_path = "varlen"
-            return self._fast_forward_varlen(texts, cls_only)
+            g = self._fast_forward_varlen_gen(texts, cls_only)
+            return g if as_gen else gemm.drive(g)
+        if as_gen:
+            return _returning(self._fast_forward_multi(texts, cls_only))
         self.last_path = "padded"
         xs, shapes, pads = [], [], []
         fused_emb = _FAST_EMB and all(fused_embedding.supported(m.embeddings, ids) for ids, _ in texts)
@@ -373,3 +388,16 @@ class BERTLanguageEncoder(nn.Module):
             return self._fast_forward(txt_ids, txt_masks)
         self.last_path = "hf"
         return self.model(txt_ids, txt_masks).last_hidden_state
+
+    # ---- generator forms (the model runs this stack in lock-step with the object encoder's: gemm.drive_pair) ----
+    def forward_gen(self, txt_ids, txt_masks):
+        if self._fast_ok(txt_ids):
+            return (yield from self._fast_forward_multi([(txt_ids, txt_masks)], as_gen=True))[0]
+        return self.forward(txt_ids, txt_masks)
+
+    def forward_pair_gen(self, ids_a, masks_a, ids_b, masks_b, cls_second: bool = False):
+        if self._fast_ok(ids_a) and self._fast_ok(ids_b):
+            a, b = yield from self._fast_forward_multi([(ids_a, masks_a), (ids_b, masks_b)], cls_only=(1,) if cls_second else (),
+                                                       as_gen=True)
+            return a, b
+        return self.forward_pair(ids_a, masks_a, ids_b, masks_b, cls_second)

@@ -71,13 +71,18 @@ def _stream() -> int:
 _FORM_NAME = {GEMM_NT: "nt", GEMM_NN: "nn", GEMM_TN: "tn"}
 
 
-def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int,
-         C: torch.Tensor, ldc: int, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
-         ldaux: int = 0, aux_out: Optional[torch.Tensor] = None, ldaux_out: int = 0,
-         workspace: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, p_drop: float = 0.0,
-         seed_dev: Optional[torch.Tensor] = None, splits: int = 1, variant: Optional[int] = None,
-         extent_dev: Optional[torch.Tensor] = None) -> None:
-    """Thin checked call of gps_gemm_bf16 on the current stream (shapes in the header's convention)."""
+class _Product:
+    """One NT / NN / TN product ready to launch: the C argument record + what bench.py's per-launch accounting needs.
+    `keep` pins the tensors whose addresses the record holds."""
+    __slots__ = ("args", "name", "nbytes", "flops", "work_fraction", "device", "keep", "form", "epilogue")
+
+
+def _product(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int,
+             C: torch.Tensor, ldc: int, bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
+             ldaux: int = 0, aux_out: Optional[torch.Tensor] = None, ldaux_out: int = 0,
+             workspace: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, p_drop: float = 0.0,
+             seed_dev: Optional[torch.Tensor] = None, splits: int = 1, variant: Optional[int] = None,
+             extent_dev: Optional[torch.Tensor] = None) -> _Product:
     a = GemmArgs()
     a.form, a.epilogue, a.M, a.N, a.K = form, epilogue, M, N, K
     a.splits = splits
@@ -89,7 +94,7 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
     a.workspace, a.colsum, a.seed_dev = _ptr(workspace), _ptr(colsum), _ptr(seed_dev)
     a.extent_dev = _ptr(extent_dev)
     a.seed, a.p_drop = 0, float(p_drop)
-    from ...pointnet2._ext import _timed, profiling
+    from ...pointnet2._ext import profiling
     nbytes = 2 * (M * K + N * K) + {EPI_F32: 4 * M * N, EPI_RELU_SPLIT: 6 * M * N, EPI_RELU_MAX16: M * N // 4}.get(epilogue, 2 * M * N)
     work_fraction = None
     if extent_dev is not None and profiling():
@@ -103,13 +108,95 @@ def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda:
             nbytes = lambda f: int(2 * f * K * (M + N)) + out_b * M * N  # noqa: E731
         else:                    # A and C lose rows, the weight operand is read whole
             nbytes = lambda f: int(f * M * (2 * K + out_b * N)) + 2 * N * K  # noqa: E731
-    with torch.cuda.device(A.device), _timed(f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K},epi={epilogue})", nbytes,
-                                             2 * M * N * K, "bf16", work_fraction):
-        st = _native.load().gps_gemm_bf16(ctypes.byref(a), _stream())
-    _native.check(st, f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K})")
+    q = _Product()
+    q.args, q.form, q.epilogue, q.device = a, form, epilogue, A.device
+    q.name = f"gemm_{_FORM_NAME[form]}(M={M},N={N},K={K},epi={epilogue})"
+    q.nbytes, q.flops, q.work_fraction = nbytes, 2 * M * N * K, work_fraction
+    q.keep = (A, B, C, bias, aux, aux_out, workspace, colsum, seed_dev, extent_dev)
+    return q
+
+
+def _launch(q: _Product) -> None:
+    from ...pointnet2._ext import _timed
+    with torch.cuda.device(q.device), _timed(q.name, q.nbytes, q.flops, "bf16", q.work_fraction):
+        st = _native.load().gps_gemm_bf16(ctypes.byref(q.args), _stream())
+    _native.check(st, q.name)
+
+
+_GROUPED = True          # False: the products of a twin call leave one by one (A/B, tests)
+
+
+def set_grouped_launches(flag: bool) -> None:
+    global _GROUPED
+    _GROUPED = bool(flag)
+
+
+def _launch_together(products: Sequence[_Product]) -> None:
+    """Independent products: those that share form and epilogue leave as ONE launch over the union of their output tiles
+    (gps_gemm_bf16_grouped -- e.g. the same Linear of the text stack and of the object stack, which alone fill 23 - 59 %
+    of the chip); whatever the library declines (GPS_ERR_UNSUPPORTED) leaves one by one."""
+    products = [q for q in products if q is not None]
+    if len(products) < 2 or not _GROUPED:
+        for q in products:
+            _launch(q)
+        return
+    lib = _native.load()
+    pending = list(products)
+    while pending:
+        head = pending[0]
+        same = [q for q in pending if q.form == head.form and q.epilogue == head.epilogue and q.device == head.device
+                and head.form != GEMM_TN][:4]
+        pending = [q for q in pending if all(q is not t for t in same)] if len(same) > 1 else pending[1:]
+        if len(same) < 2:
+            _launch(head)
+            continue
+        arr = (GemmArgs * len(same))(*[q.args for q in same])
+        from ...pointnet2._ext import _timed, profiling
+        args = [q.args for q in same]
+        name = (f"gemm_{_FORM_NAME[head.form]}_grouped(M={'+'.join(str(a.M) for a in args)},N={'+'.join(str(a.N) for a in args)},"
+                f"K={'+'.join(str(a.K) for a in args)},epi={head.epilogue})")
+        flops = sum(q.flops for q in same)
+        work_fraction, nbytes = None, None
+        if profiling():
+            fr = [q.work_fraction for q in same]
+            live = lambda: [f() if f is not None else 1.0 for f in fr]  # noqa: E731
+            work_fraction = lambda: sum(q.flops * f for q, f in zip(same, live())) / max(1, flops)  # noqa: E731
+            nbytes = lambda _f: sum((q.nbytes(f) if callable(q.nbytes) else q.nbytes) for q, f in zip(same, live()))  # noqa: E731
+        else:
+            nbytes = 0
+        with torch.cuda.device(head.device), _timed(name, nbytes, flops, "bf16", work_fraction):
+            st = lib.gps_gemm_bf16_grouped(arr, len(same), _stream())
+        if st == _native.GPS_ERR_UNSUPPORTED:
+            for q in same:
+                _launch(q)
+        else:
+            _native.check(st, name)
+
+
+def gemm(form: int, epilogue: int, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int,
+         C: torch.Tensor, ldc: int, **kw) -> None:
+    """Thin checked call of gps_gemm_bf16 on the current stream (shapes in the header's convention; keyword arguments
+    as `_product`)."""
+    _launch(_product(form, epilogue, M, N, K, A, lda, B, ldb, C, ldc, **kw))
 
 
 # ---- the three contractions of a Linear -------------------------------------------------------------------
+def _forward_product(x16: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str] = None,
+                     p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None, want_pre=False,
+                     rows_dev: Optional[torch.Tensor] = None):
+    """-> (product, y, pre or None): the forward GEMM of `linear_forward`, not yet launched."""
+    T, K = x16.shape
+    N = w16.shape[0]
+    y = torch.empty((T, N), dtype=torch.bfloat16, device=x16.device)
+    pre = torch.empty_like(y) if (want_pre and act == "gelu") else None
+    epi = {None: EPI_BIAS, "gelu": EPI_BIAS_GELU, "relu": EPI_BIAS_RELU}[act]
+    if want_pre == "factor" and act == "gelu":
+        epi = EPI_BIAS_GELU_FACTOR
+    q = _product(GEMM_NT, epi, T, N, K, x16, x16.stride(0), w16, w16.stride(0), y, N, bias=bias, aux_out=pre, ldaux_out=N,
+                 p_drop=p_drop if act else 0.0, seed_dev=seed_dev, extent_dev=rows_dev)
+    return q, y, pre
+
+
 def linear_forward(x16: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], act: Optional[str] = None,
                    p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None, want_pre: bool = False,
                    rows_dev: Optional[torch.Tensor] = None):
@@ -118,16 +205,23 @@ def linear_forward(x16: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Te
     pass multiplies by (`linear_dgrad(act="factor")`), from the erf terms the activation computes anyway.
     rows_dev (all three contractions): int32 device word, the number of leading token rows that carry work; tiles of
     rows past it are skipped (their output rows stay unwritten), the weight gradient sums the live rows only."""
-    T, K = x16.shape
-    N = w16.shape[0]
-    y = torch.empty((T, N), dtype=torch.bfloat16, device=x16.device)
-    pre = torch.empty_like(y) if (want_pre and act == "gelu") else None
-    epi = {None: EPI_BIAS, "gelu": EPI_BIAS_GELU, "relu": EPI_BIAS_RELU}[act]
-    if want_pre == "factor" and act == "gelu":
-        epi = EPI_BIAS_GELU_FACTOR
-    gemm(GEMM_NT, epi, T, N, K, x16, x16.stride(0), w16, w16.stride(0), y, N, bias=bias, aux_out=pre, ldaux_out=N,
-         p_drop=p_drop if act else 0.0, seed_dev=seed_dev, extent_dev=rows_dev)
+    q, y, pre = _forward_product(x16, w16, bias, act, p_drop, seed_dev, want_pre, rows_dev)
+    _launch(q)
     return (y, pre) if want_pre else y
+
+
+def _dgrad_product(dy16: torch.Tensor, w16: torch.Tensor, act: Optional[str] = None, aux: Optional[torch.Tensor] = None,
+                   p_drop: float = 0.0, seed_dev: Optional[torch.Tensor] = None,
+                   rows_dev: Optional[torch.Tensor] = None):
+    """-> (product, dx): the input-gradient GEMM of `linear_dgrad`, not yet launched."""
+    T, N = dy16.shape
+    K = w16.shape[1]
+    dx = torch.empty((T, K), dtype=torch.bfloat16, device=dy16.device)
+    epi = {None: EPI_BIAS, "gelu": EPI_DGELU, "relu": EPI_DRELU, "factor": EPI_MUL_AUX}[act]
+    q = _product(GEMM_NN, epi, T, K, N, dy16, dy16.stride(0), w16, w16.stride(0), dx, K, aux=aux,
+                 ldaux=aux.stride(0) if aux is not None else 0, p_drop=p_drop if act in ("gelu", "relu") else 0.0,
+                 seed_dev=seed_dev, extent_dev=rows_dev)
+    return q, dx
 
 
 def linear_dgrad(dy16: torch.Tensor, w16: torch.Tensor, act: Optional[str] = None, aux: Optional[torch.Tensor] = None,
@@ -136,13 +230,8 @@ def linear_dgrad(dy16: torch.Tensor, w16: torch.Tensor, act: Optional[str] = Non
     """dy16 (T, N) bf16, w16 (N, K) bf16 -> dx (T, K) bf16 = dy W, optionally times the derivative of the
     activation that PRODUCED this layer's input (aux = its saved pre-activation (gelu) / output (relu)), or -- act
     "factor" -- times aux itself (the factor `linear_forward(want_pre="factor")` saved: derivative x dropout mask)."""
-    T, N = dy16.shape
-    K = w16.shape[1]
-    dx = torch.empty((T, K), dtype=torch.bfloat16, device=dy16.device)
-    epi = {None: EPI_BIAS, "gelu": EPI_DGELU, "relu": EPI_DRELU, "factor": EPI_MUL_AUX}[act]
-    gemm(GEMM_NN, epi, T, K, N, dy16, dy16.stride(0), w16, w16.stride(0), dx, K, aux=aux,
-         ldaux=aux.stride(0) if aux is not None else 0, p_drop=p_drop if act in ("gelu", "relu") else 0.0, seed_dev=seed_dev,
-         extent_dev=rows_dev)
+    q, dx = _dgrad_product(dy16, w16, act, aux, p_drop, seed_dev, rows_dev)
+    _launch(q)
     return dx
 
 
@@ -691,6 +780,11 @@ def _as_rows16(x: torch.Tensor) -> torch.Tensor:
     return x2
 
 
+# forward results computed ahead of the autograd node that owns them (`_twin_*_forward_only`: the two stacks' forward
+# products leave paired, their backward passes stay separate nodes): id(input tensor) -> what the node's forward would compute
+_PRECOMPUTED = {}
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b over the concatenation of n weight blocks (n = 1: a plain Linear)."""
 
@@ -700,9 +794,13 @@ class _LinearFn(torch.autograd.Function):
         if len(wb) == 2 * n + 1:                             # optional trailing device-side row count
             rows_dev, wb = wb[-1], wb[:-1]
         weights, biases = wb[:n], wb[n:]
-        w16, b32 = shadow_of(weights, biases)
-        x16 = _as_rows16(x)
-        y = linear_forward(x16, w16, b32, rows_dev=rows_dev)
+        ahead = _PRECOMPUTED.pop(id(x), None)
+        if ahead is not None:
+            x16, w16, y = ahead
+        else:
+            w16, b32 = shadow_of(weights, biases)
+            x16 = _as_rows16(x)
+            y = linear_forward(x16, w16, b32, rows_dev=rows_dev)
         ctx.rows_dev = rows_dev
         ctx.save_for_backward(x16, w16)
         ctx.meta = (x.shape, x.dtype, n, [w.shape[0] for w in weights], [b is not None for b in biases])
@@ -714,12 +812,6 @@ class _LinearFn(torch.autograd.Function):
         x16, w16 = ctx.saved_tensors
         x_shape, x_dtype, n, rows, has_b = ctx.meta
         dy16 = _as_rows16(dy)
-        from ... import _debug
-        if _debug.ENABLED:
-            tag = f"lin{w16.shape[0]}x{w16.shape[1]}r{x16.shape[0]}"
-            _debug.tap(tag + ".dy16", dy16)
-            _debug.tap(tag + ".x16", x16)
-            _debug.tap(tag + ".rows", ctx.rows_dev)
         need_w = any(ctx.needs_input_grad[2:2 + n])
         need_b = any(ctx.needs_input_grad[2 + n:])
         dws, dbs = [None] * n, [None] * n
@@ -808,15 +900,19 @@ class _FFNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act, p_drop, seed_dev, rows_dev=None):
-        w1_16, b1_32 = shadow_of((w1,), (b1,))
-        w2_16, b2_32 = shadow_of((w2,), (b2,))
-        x16 = _as_rows16(x)
-        # gelu: the forward epilogue saves gelu'(pre) x dropout-mask / (1 - p) (one multiply per element in the backward
-        # epilogue instead of the erf terms and the mask hash: gps_gemm.hip EPI_BIAS_GELU_FACTOR / EPI_MUL_AUX)
-        h, pre = linear_forward(x16, w1_16, b1_32, act=act, p_drop=p_drop, seed_dev=seed_dev,
-                                want_pre="factor" if (act == "gelu" and _GELU_FACTOR) else True, rows_dev=rows_dev)
+        ahead = _PRECOMPUTED.pop(id(x), None)
         ctx.gelu_factor = act == "gelu" and _GELU_FACTOR
-        y = linear_forward(h, w2_16, b2_32, rows_dev=rows_dev)
+        if ahead is not None:
+            x16, w1_16, w2_16, h, pre, y = ahead
+        else:
+            w1_16, b1_32 = shadow_of((w1,), (b1,))
+            w2_16, b2_32 = shadow_of((w2,), (b2,))
+            x16 = _as_rows16(x)
+            # gelu: the forward epilogue saves gelu'(pre) x dropout-mask / (1 - p) (one multiply per element in the backward
+            # epilogue instead of the erf terms and the mask hash: gps_gemm.hip EPI_BIAS_GELU_FACTOR / EPI_MUL_AUX)
+            h, pre = linear_forward(x16, w1_16, b1_32, act=act, p_drop=p_drop, seed_dev=seed_dev,
+                                    want_pre="factor" if ctx.gelu_factor else True, rows_dev=rows_dev)
+            y = linear_forward(h, w2_16, b2_32, rows_dev=rows_dev)
         ctx.rows_dev = rows_dev
         ctx.save_for_backward(x16, w1_16, w2_16, h, pre, seed_dev)
         ctx.meta = (x.shape, x.dtype, act, float(p_drop), b1 is not None, b2 is not None)
@@ -856,6 +952,321 @@ def ffn(x: torch.Tensor, linear1: torch.nn.Linear, linear2: torch.nn.Linear, act
         from .fused_attention import _next_device_seed
         seed_dev = _next_device_seed(x.device)
     return _FFNFn.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, act, p, seed_dev, rows_dev)
+
+
+# ---- two independent stacks in lock-step: paired products --------------------------------------------------------------------
+# The text encoder and the object encoder of the GPS model do not see each other until the joint layers (reference
+# model/openvocab.py:41-63) and their layers run the same op sequence: packed projection -> attention core -> output
+# projection -> residual LayerNorm -> FFN -> residual LayerNorm.  Launched one stack after the other their 768-wide GEMMs
+# are 150 (text, 12 608 live rows) and 60 (objects) tiles of 256 x 256 on 256 CUs.  Here the layer code of either stack is a
+# GENERATOR that yields its GEMM calls (`LinearOp`, `FFNOp`) instead of making them; `drive(gen)` executes them one by one
+# (the ordinary forward), `drive_pair(gen_a, gen_b)` advances both stacks in step and issues the two products of a pair as
+# one launch (`_TwinLinearFn`, `_TwinFFNFn`: ONE autograd node per pair, so that the backward pass pairs the input-gradient
+# GEMMs the same way; weight gradients already leave grouped -- `grouped_wgrads`).  tools/probes/gemm_probe group: the
+# eight forward / input-gradient launches of one layer pair 849 -> 616 us.
+class LinearOp:
+    """y = x [W_0; W_1; ...]^T + [b_0; ...] (`packed_linear`; one Linear: `linear`)."""
+    __slots__ = ("x", "weights", "biases", "rows_dev")
+
+    def __init__(self, x, weights, biases, rows_dev=None):
+        self.x, self.weights, self.biases, self.rows_dev = x, tuple(weights), tuple(biases), rows_dev
+
+    @staticmethod
+    def of(x, layers: Sequence[torch.nn.Linear], rows_dev=None) -> "LinearOp":
+        return LinearOp(x, [m.weight for m in layers], [m.bias for m in layers], rows_dev)
+
+    def run(self):
+        extra = (self.rows_dev,) if self.rows_dev is not None else ()
+        return _LinearFn.apply(self.x, len(self.weights), *self.weights, *self.biases, *extra)
+
+
+class FFNOp:
+    """y = dropout(act(x W1^T + b1)) W2^T + b2 (`ffn`)."""
+    __slots__ = ("x", "linear1", "linear2", "act", "p_drop", "training", "rows_dev")
+
+    def __init__(self, x, linear1, linear2, act, p_drop, training, rows_dev=None):
+        self.x, self.linear1, self.linear2, self.act = x, linear1, linear2, act
+        self.p_drop, self.training, self.rows_dev = float(p_drop), bool(training), rows_dev
+
+    def run(self):
+        return ffn(self.x, self.linear1, self.linear2, self.act, self.p_drop, self.training, rows_dev=self.rows_dev)
+
+
+def _step(gen, value, first):
+    """Advance a layer generator: -> (op, None) when it yields its next GEMM call, (None, result) when it returns."""
+    try:
+        return (next(gen) if first else gen.send(value)), None
+    except StopIteration as stop:
+        return None, (stop.value,)
+
+
+def drive(gen):
+    """Run a layer generator alone: every yielded op is executed on the spot."""
+    op, done = _step(gen, None, True)
+    while done is None:
+        op, done = _step(gen, op.run(), False)
+    return done[0]
+
+
+_TWIN = True             # False: `drive_pair` runs its two generators one after the other (A/B, tests)
+
+
+def set_twin_stacks(flag: bool) -> None:
+    global _TWIN
+    _TWIN = bool(flag)
+
+
+def twin_stacks() -> bool:
+    return _TWIN and _ENABLED and _GROUPED
+
+
+def drive_pair(gen_a, gen_b):
+    """Run two INDEPENDENT layer generators in lock-step; ops of the same kind that both have pending go out paired.
+    -> (result_a, result_b).  Results equal `drive(gen_a), drive(gen_b)` (the products are the same, tile for tile)."""
+    if not twin_stacks():
+        return drive(gen_a), drive(gen_b)
+    op_a, done_a = _step(gen_a, None, True)
+    op_b, done_b = _step(gen_b, None, True)
+    while done_a is None or done_b is None:
+        if done_a is not None:
+            op_b, done_b = _step(gen_b, op_b.run(), False)
+        elif done_b is not None:
+            op_a, done_a = _step(gen_a, op_a.run(), False)
+        elif isinstance(op_a, LinearOp) and isinstance(op_b, LinearOp):
+            ya, yb = _twin_linear(op_a, op_b)
+            op_a, done_a = _step(gen_a, ya, False)
+            op_b, done_b = _step(gen_b, yb, False)
+        elif isinstance(op_a, FFNOp) and isinstance(op_b, FFNOp) and op_a.act == op_b.act:
+            ya, yb = _twin_ffn(op_a, op_b)
+            op_a, done_a = _step(gen_a, ya, False)
+            op_b, done_b = _step(gen_b, yb, False)
+        else:
+            # different kinds: the FFN waits (it is the longer op); the sequences re-align at the next matching pair
+            if isinstance(op_a, LinearOp):
+                op_a, done_a = _step(gen_a, op_a.run(), False)
+            else:
+                op_b, done_b = _step(gen_b, op_b.run(), False)
+    return done_a[0], done_b[0]
+
+
+def _dx_out(dx, shape, dtype):
+    dx = dx.view(shape)
+    return dx if dx.dtype == dtype else dx.to(dtype)
+
+
+class _TwinLinearFn(torch.autograd.Function):
+    """(y_a, y_b) = (`_LinearFn` of side a, `_LinearFn` of side b) with the two forward products -- and, when both output
+    gradients arrive together, the two input-gradient products -- issued as one launch each.  A backward call that brings
+    only one side's gradient (the split-graph data-parallel step runs the text and the object encoder's backward as two
+    graphs) computes that side alone."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, na, nb, rows_a, rows_b, *wb):
+        ctx.set_materialize_grads(False)
+        sides, at = [], 0
+        for x, n, rows_dev in ((xa, na, rows_a), (xb, nb, rows_b)):
+            weights, biases = wb[at:at + n], wb[at + n:at + 2 * n]
+            at += 2 * n
+            w16, b32 = shadow_of(weights, biases)
+            x16 = _as_rows16(x)
+            q, y, _ = _forward_product(x16, w16, b32, rows_dev=rows_dev)
+            sides.append((q, y, x16, w16, x.shape, x.dtype, weights, biases, rows_dev))
+        _launch_together([sd[0] for sd in sides])
+        ctx.save_for_backward(sides[0][2], sides[0][3], sides[1][2], sides[1][3])
+        ctx.meta = [(sd[4], sd[5], [w.shape[0] for w in sd[6]], [b is not None for b in sd[7]]) for sd in sides]
+        ctx.params = [(sd[6], sd[7]) for sd in sides]
+        ctx.rows_dev = [sd[8] for sd in sides]
+        ctx.n = (na, nb)
+        return tuple(sd[1].view(*sd[4][:-1], sd[3].shape[0]) for sd in sides)
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        saved = ctx.saved_tensors
+        na, nb = ctx.n
+        need = ctx.needs_input_grad
+        grads_x, grads_wb, products, finish = [None, None], [], [], []
+        at = 6
+        for side, (dy, n) in enumerate(((dya, na), (dyb, nb))):
+            x16, w16 = saved[2 * side], saved[2 * side + 1]
+            x_shape, x_dtype, rows, has_b = ctx.meta[side]
+            need_ws, need_bs = need[at:at + n], need[at + n:at + 2 * n]
+            at += 2 * n
+            dws, dbs = [None] * n, [None] * n
+            if dy is not None:
+                dy16 = _as_rows16(dy)
+                rd = ctx.rows_dev[side]
+                deferred = False
+                if any(need_ws) and all(need_ws) and all((not hb) or g for hb, g in zip(has_b, need_bs)):
+                    deferred = _wgrad_to_params(dy16, x16, ctx.params[side][0], ctx.params[side][1], rows, rd)
+                if need[side]:
+                    q, dx = _dgrad_product(dy16, w16, rows_dev=rd)
+                    products.append(q)
+                    finish.append((side, dx, x_shape, x_dtype))
+                if (any(need_ws) or any(need_bs)) and not deferred:
+                    dw, db = linear_wgrad(dy16, x16, want_bias=any(need_bs), rows_dev=rd)
+                    r = 0
+                    for i in range(n):
+                        if need_ws[i]:
+                            dws[i] = dw[r:r + rows[i]]
+                        if has_b[i] and need_bs[i]:
+                            dbs[i] = db[r:r + rows[i]]
+                        r += rows[i]
+            grads_wb += dws + dbs
+        _launch_together(products)
+        for side, dx, x_shape, x_dtype in finish:
+            grads_x[side] = _dx_out(dx, x_shape, x_dtype)
+        return (grads_x[0], grads_x[1], None, None, None, None, *grads_wb)
+
+
+_TWIN_BACKWARD = True    # False: paired forward products, SEPARATE autograd nodes (a backward pass that is cut between the
+#                          two stacks -- the split-graph data-parallel step runs them as two graphs -- must not meet a node
+#                          that belongs to both: it would run twice and drag the other stack's nodes along with undefined
+#                          gradients)
+
+
+def set_twin_backward(flag: bool) -> None:
+    global _TWIN_BACKWARD
+    _TWIN_BACKWARD = bool(flag)
+
+
+def _twin_linear_forward_only(op_a: LinearOp, op_b: LinearOp):
+    ahead = []
+    with torch.no_grad():
+        for op in (op_a, op_b):
+            w16, b32 = shadow_of(op.weights, op.biases)
+            x16 = _as_rows16(op.x)
+            q, y, _ = _forward_product(x16, w16, b32, rows_dev=op.rows_dev)
+            ahead.append((q, (x16, w16, y)))
+        _launch_together([q for q, _ in ahead])
+    outs = []
+    for op, (_, res) in zip((op_a, op_b), ahead):
+        _PRECOMPUTED[id(op.x)] = res
+        try:
+            outs.append(op.run())
+        finally:
+            _PRECOMPUTED.pop(id(op.x), None)
+    return tuple(outs)
+
+
+def _twin_ffn_forward_only(op_a: FFNOp, op_b: FFNOp):
+    from .fused_attention import _next_device_seed
+    factor = op_a.act == "gelu" and _GELU_FACTOR
+    st = []
+    with torch.no_grad():
+        for op in (op_a, op_b):
+            p = op.p_drop if op.training else 0.0
+            seed = _next_device_seed(op.x.device) if p > 0.0 else None
+            w1_16, b1_32 = shadow_of((op.linear1.weight,), (op.linear1.bias,))
+            w2_16, b2_32 = shadow_of((op.linear2.weight,), (op.linear2.bias,))
+            x16 = _as_rows16(op.x)
+            q1, h, pre = _forward_product(x16, w1_16, b1_32, act=op.act, p_drop=p, seed_dev=seed,
+                                          want_pre="factor" if factor else True, rows_dev=op.rows_dev)
+            st.append(dict(op=op, p=p, seed=seed, x16=x16, w1_16=w1_16, w2_16=w2_16, b2_32=b2_32, q1=q1, h=h, pre=pre))
+        _launch_together([d["q1"] for d in st])
+        for d in st:
+            d["q2"], d["y"], _ = _forward_product(d["h"], d["w2_16"], d["b2_32"], rows_dev=d["op"].rows_dev)
+        _launch_together([d["q2"] for d in st])
+    outs = []
+    for d in st:
+        op = d["op"]
+        _PRECOMPUTED[id(op.x)] = (d["x16"], d["w1_16"], d["w2_16"], d["h"], d["pre"], d["y"])
+        try:
+            outs.append(_FFNFn.apply(op.x, op.linear1.weight, op.linear1.bias, op.linear2.weight, op.linear2.bias, op.act,
+                                     d["p"], d["seed"], op.rows_dev))
+        finally:
+            _PRECOMPUTED.pop(id(op.x), None)
+    return tuple(outs)
+
+
+def _twin_linear(op_a: LinearOp, op_b: LinearOp):
+    if not _TWIN_BACKWARD:
+        return _twin_linear_forward_only(op_a, op_b)
+    return _TwinLinearFn.apply(op_a.x, op_b.x, len(op_a.weights), len(op_b.weights), op_a.rows_dev, op_b.rows_dev,
+                               *op_a.weights, *op_a.biases, *op_b.weights, *op_b.biases)
+
+
+class _TwinFFNFn(torch.autograd.Function):
+    """(y_a, y_b) = (`_FFNFn` of side a, `_FFNFn` of side b): both first GEMMs as one launch, both second GEMMs as one
+    launch; backward likewise when both gradients arrive (else the side that did alone)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, act, pa, pb, seed_a, seed_b, rows_a, rows_b, w1a, b1a, w2a, b2a, w1b, b1b, w2b, b2b):
+        ctx.set_materialize_grads(False)
+        factor = act == "gelu" and _GELU_FACTOR
+        st = []
+        for x, p, seed, rd, w1, b1, w2, b2 in ((xa, pa, seed_a, rows_a, w1a, b1a, w2a, b2a), (xb, pb, seed_b, rows_b, w1b, b1b, w2b, b2b)):
+            w1_16, b1_32 = shadow_of((w1,), (b1,))
+            w2_16, b2_32 = shadow_of((w2,), (b2,))
+            x16 = _as_rows16(x)
+            q1, h, pre = _forward_product(x16, w1_16, b1_32, act=act, p_drop=p, seed_dev=seed,
+                                          want_pre="factor" if factor else True, rows_dev=rd)
+            st.append(dict(x=x, x16=x16, w1_16=w1_16, w2_16=w2_16, b2_32=b2_32, q1=q1, h=h, pre=pre, p=p, seed=seed, rd=rd,
+                           params=(w1, b1, w2, b2)))
+        _launch_together([d["q1"] for d in st])
+        ys = []
+        for d in st:
+            d["q2"], y, _ = _forward_product(d["h"], d["w2_16"], d["b2_32"], rows_dev=d["rd"])
+            ys.append(y)
+        _launch_together([d["q2"] for d in st])
+        ctx.save_for_backward(*[t for d in st for t in (d["x16"], d["w1_16"], d["w2_16"], d["h"], d["pre"], d["seed"])])
+        ctx.meta = [(d["x"].shape, d["x"].dtype, float(d["p"]), d["params"][1] is not None, d["params"][3] is not None) for d in st]
+        ctx.params = [d["params"] for d in st]
+        ctx.rows_dev = [d["rd"] for d in st]
+        ctx.act, ctx.gelu_factor = act, factor
+        return tuple(y.view(*d["x"].shape[:-1], d["w2_16"].shape[0]) for y, d in zip(ys, st))
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        saved, need, act = ctx.saved_tensors, ctx.needs_input_grad, ctx.act
+        live = []
+        grads = {}
+        for side, dy in enumerate((dya, dyb)):
+            if dy is None:
+                continue
+            x16, w1_16, w2_16, h, pre, seed = saved[6 * side:6 * side + 6]
+            x_shape, x_dtype, p, has_b1, has_b2 = ctx.meta[side]
+            w1, b1, w2, b2 = ctx.params[side]
+            nw = need[9 + 4 * side:13 + 4 * side]
+            all_w = nw[0] and nw[2] and (not has_b1 or nw[1]) and (not has_b2 or nw[3])
+            live.append(dict(side=side, dy16=_as_rows16(dy), x16=x16, w1_16=w1_16, w2_16=w2_16, h=h, pre=pre, seed=seed,
+                             x_shape=x_shape, x_dtype=x_dtype, p=p, has_b1=has_b1, has_b2=has_b2, w1=w1, b1=b1, w2=w2, b2=b2,
+                             all_w=all_w, rd=ctx.rows_dev[side], dw1=None, db1=None, dw2=None, db2=None))
+        for d in live:
+            if not (d["all_w"] and _wgrad_to_params(d["dy16"], d["h"], (d["w2"],), (d["b2"],), (d["w2"].shape[0],), d["rd"])):
+                d["dw2"], d["db2"] = linear_wgrad(d["dy16"], d["h"], want_bias=d["has_b2"], rows_dev=d["rd"])
+            d["q"], d["dpre"] = _dgrad_product(d["dy16"], d["w2_16"], act="factor" if ctx.gelu_factor else act,
+                                               aux=d["pre"] if act == "gelu" else d["h"], p_drop=d["p"], seed_dev=d["seed"],
+                                               rows_dev=d["rd"])
+        _launch_together([d["q"] for d in live])
+        products = []
+        for d in live:
+            if not (d["all_w"] and _wgrad_to_params(d["dpre"], d["x16"], (d["w1"],), (d["b1"],), (d["w1"].shape[0],), d["rd"])):
+                d["dw1"], d["db1"] = linear_wgrad(d["dpre"], d["x16"], want_bias=d["has_b1"], rows_dev=d["rd"])
+            d["dx"] = None
+            if need[d["side"]]:
+                q, d["dx"] = _dgrad_product(d["dpre"], d["w1_16"], rows_dev=d["rd"])
+                products.append(q)
+        _launch_together(products)
+        out = [None] * 17
+        for d in live:
+            if d["dx"] is not None:
+                out[d["side"]] = _dx_out(d["dx"], d["x_shape"], d["x_dtype"])
+            out[9 + 4 * d["side"]:13 + 4 * d["side"]] = [d["dw1"], d["db1"], d["dw2"], d["db2"]]
+        return tuple(out)
+
+
+def _twin_ffn(op_a: FFNOp, op_b: FFNOp):
+    from .fused_attention import _next_device_seed
+    if not _TWIN_BACKWARD:
+        return _twin_ffn_forward_only(op_a, op_b)
+    ps, seeds = [], []
+    for op in (op_a, op_b):
+        p = op.p_drop if op.training else 0.0
+        ps.append(p)
+        seeds.append(_next_device_seed(op.x.device) if p > 0.0 else None)
+    return _TwinFFNFn.apply(op_a.x, op_b.x, op_a.act, ps[0], ps[1], seeds[0], seeds[1], op_a.rows_dev, op_b.rows_dev,
+                            op_a.linear1.weight, op_a.linear1.bias, op_a.linear2.weight, op_a.linear2.bias,
+                            op_b.linear1.weight, op_b.linear1.bias, op_b.linear2.weight, op_b.linear2.bias)
 
 
 def activation_name(fn) -> Optional[str]:

@@ -178,16 +178,17 @@ class MultiHeadAttentionSpatial(nn.Module):
             return torch.log(torch.clamp(loc, min=1e-6))
         return loc
 
-    def _forward_fused(self, x, pairwise_locs, key_padding_mask):
+    def _forward_fused_gen(self, x, pairwise_locs, key_padding_mask):
         """fusion 'cond', self-attention, bf16 on the GPU: ONE projection GEMM producing
         [q | k | v | per-head (bias, w_1..w_5)] (libgps_hip.so's MFMA GEMM on a persistent packed bf16
-        copy of the four weights) and one fused attention launch."""
+        copy of the four weights) and one fused attention launch.  A generator: the two GEMMs are YIELDED
+        (gemm.LinearOp) so that a caller may pair them with another stack's (gemm.drive / gemm.drive_pair)."""
         from . import gemm
         from .fused_attention import fused_self_attention
         if _bf16_mode(x) and gemm.usable(x, self.d_model, self.d_model):
-            packed = gemm.packed_linear(_gemm_input(x), [self.w_qs, self.w_ks, self.w_vs, self.lang_cond_fc])
+            packed = yield gemm.LinearOp.of(_gemm_input(x), [self.w_qs, self.w_ks, self.w_vs, self.lang_cond_fc])
             out = fused_self_attention(packed, self.n_head, pairwise_locs, key_padding_mask)
-            return gemm.linear(out, self.fc.weight, self.fc.bias), None
+            return (yield gemm.LinearOp.of(out, [self.fc])), None
         # fp32 operands (the fp32 master path: fp32 MFMA core) or bf16 without the native GEMMs (A/B runs)
         w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.lang_cond_fc.weight], 0)
         bias = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias, self.lang_cond_fc.bias], 0)
@@ -198,10 +199,14 @@ class MultiHeadAttentionSpatial(nn.Module):
             return self.fc(out), None
 
     def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, txt_embeds=None):
+        from . import gemm
+        return gemm.drive(self.forward_gen(q, k, v, pairwise_locs, key_padding_mask, txt_embeds))
+
+    def forward_gen(self, q, k, v, pairwise_locs, key_padding_mask=None, txt_embeds=None):
         if (self.spatial_attn_fusion == 'cond' and k is q and v is q and not self.need_weights
                 and self.spatial_n_head == self.n_head and self.spatial_dim == 5
                 and _use_hip(q, self.d_model, self.n_head)):
-            return self._forward_fused(q, pairwise_locs, key_padding_mask)
+            return (yield from self._forward_fused_gen(q, pairwise_locs, key_padding_mask))
         x_in = q
         qh = _split_heads(self.w_qs(q), self.n_head)
         kh = _split_heads(self.w_ks(k), self.n_head)
@@ -335,16 +340,22 @@ class MultiheadSelfAttention(nn.Module):
         return out, (probs.mean(dim=1) if probs is not None else None)
 
 
-def _ffn(layer, x):
+def _ffn_gen(layer, x):
     """linear2(dropout(activation(linear1(x)))) -- on the GPU in bf16: two MFMA GEMMs with the bias, activation
-    and dropout in their epilogues (libgps_hip.so), backward likewise (modules/layers/gemm.py)."""
+    and dropout in their epilogues (libgps_hip.so), backward likewise (modules/layers/gemm.py).  Generator: the native
+    form is yielded as one gemm.FFNOp."""
     from . import gemm
     if x.is_cuda:
         act = gemm.activation_name(layer.activation)
         if act is not None and gemm.usable(x, layer.linear1.in_features, layer.linear1.out_features) \
                 and layer.linear2.out_features % 8 == 0:
-            return gemm.ffn(x, layer.linear1, layer.linear2, act, layer.dropout.p, layer.training)
+            return (yield gemm.FFNOp(x, layer.linear1, layer.linear2, act, layer.dropout.p, layer.training))
     return layer.linear2(layer.dropout(layer.activation(layer.linear1(x))))
+
+
+def _ffn(layer, x):
+    from . import gemm
+    return gemm.drive(_ffn_gen(layer, x))
 
 
 def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout, want_bf16: bool = False, post=None):
@@ -376,18 +387,24 @@ def _gemm_input(x: Tensor) -> Tensor:
     return alt if (alt is not None and alt.shape == x.shape) else x
 
 
-def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add):
+def _layer_output_gen(layer, tgt: Tensor, ffn_in: Tensor, post_add):
     """Last step of a post-norm layer: norm2(tgt + dropout2(ffn)) [+ post_add].  With `post_add` (the addend the next
     layer would apply to its input: the re-added location / type embeddings) on the bf16 GPU path, the sum and its bf16
     copy leave the same launch; the copy travels as an attribute of the fp32 result for the next layer's `_gemm_input`."""
+    h = yield from _ffn_gen(layer, ffn_in)
     if post_add is None:
-        return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2)
+        return _res_norm(layer.norm2, tgt, h, layer.dropout2)
     if _FUSE_POST_ADD and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
-        y, y16 = _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2, want_bf16=True, post=post_add)
+        y, y16 = _res_norm(layer.norm2, tgt, h, layer.dropout2, want_bf16=True, post=post_add)
         if y16 is not y:
             y._gps_bf16 = y16
         return y
-    return _res_norm(layer.norm2, tgt, _ffn(layer, ffn_in), layer.dropout2) + post_add
+    return _res_norm(layer.norm2, tgt, h, layer.dropout2) + post_add
+
+
+def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add):
+    from . import gemm
+    return gemm.drive(_layer_output_gen(layer, tgt, ffn_in, post_add))
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -440,12 +457,18 @@ class TransformerSpatialEncoderLayer(TransformerEncoderLayer):
 
     def forward(self, tgt, tgt_pairwise_locs, tgt_mask: Optional[Tensor] = None,
                 tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None):
-        h, attn = self.self_attn(tgt, tgt, tgt, tgt_pairwise_locs,
-                                 key_padding_mask=tgt_key_padding_mask)
+        from . import gemm
+        return gemm.drive(self.forward_gen(tgt, tgt_pairwise_locs, tgt_mask, tgt_key_padding_mask, post_add))
+
+    def forward_gen(self, tgt, tgt_pairwise_locs, tgt_mask: Optional[Tensor] = None,
+                    tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None):
+        """The layer as a generator of its GEMM calls (gemm.drive runs it alone, gemm.drive_pair beside another stack)."""
+        h, attn = yield from self.self_attn.forward_gen(tgt, tgt, tgt, tgt_pairwise_locs,
+                                                        key_padding_mask=tgt_key_padding_mask)
         b16 = _bf16_mode(tgt) and tgt.dtype == torch.float32
         tgt, ffn_in = _res_norm(self.norm1, tgt, h, self.dropout1, want_bf16=True) if b16 else \
             (lambda t: (t, t))(_res_norm(self.norm1, tgt, h, self.dropout1))
-        return _layer_output(self, tgt, ffn_in, post_add), attn
+        return (yield from _layer_output_gen(self, tgt, ffn_in, post_add)), attn
 
 
 class TransformerDecoderLayer(nn.Module):

@@ -96,6 +96,13 @@ class PointOpenVocabEncoder(nn.Module):
                 max_steps=None, **kwargs):
         """obj_pcds (B,O,P,6), obj_locs (B,O,6), obj_masks (B,O) bool ->
         (obj_embeds (B,O,768) after spatial layers, obj_embeds_pre (B,O,768), obj_sem_cls (B,O,607))."""
+        from ..layers import gemm
+        return gemm.drive(self.forward_gen(obj_pcds, obj_locs, obj_masks, obj_sem_masks, obj_labels, cur_step, max_steps))
+
+    def forward_gen(self, obj_pcds, obj_locs, obj_masks, obj_sem_masks, obj_labels=None, cur_step=None,
+                    max_steps=None, **kwargs):
+        """`forward` as a generator that yields the GEMM calls of its spatial layers (modules/layers/gemm.py drive /
+        drive_pair: the model runs this stack in lock-step with the text encoder's)."""
         if self.freeze:
             self.freeze_bn(self.point_feature_extractor)
         B, O = obj_pcds.shape[:2]
@@ -120,6 +127,6 @@ class PointOpenVocabEncoder(nn.Module):
             obj_embeds = obj_embeds + loc_embeds
             n_layers = len(self.spatial_encoder)
             for li, layer in enumerate(self.spatial_encoder):     # later re-adds ride on the previous layer's last LayerNorm
-                obj_embeds, _ = layer(obj_embeds, pairwise_locs, tgt_key_padding_mask=pad,
-                                      post_add=loc_embeds if li + 1 < n_layers else None)
+                obj_embeds, _ = yield from layer.forward_gen(obj_embeds, pairwise_locs, tgt_key_padding_mask=pad,
+                                                             post_add=loc_embeds if li + 1 < n_layers else None)
         return obj_embeds, obj_embeds_pre, obj_sem_cls

@@ -379,6 +379,104 @@ static void cmd_loop(int argc, char **argv) {
   release(b);
 }
 
+// ---- grouped launches: the same Linear of the text stack and of the object stack as one launch vs two -------------------
+static void fill_args(gps_gemm_args &a, const Shape &s, const Buffers &b, int set, int variant) {
+  memset(&a, 0, sizeof(a));
+  a.form = s.form; a.epilogue = s.epi; a.M = s.M; a.N = s.N; a.K = s.K; a.splits = 1; a.variant = variant;
+  a.A = b.A[set]; a.lda = s.K;
+  a.B = b.B; a.ldb = s.form == 0 ? s.K : s.N;
+  a.C = b.C[set]; a.ldc = s.N;
+  a.bias = (s.epi == 0 || s.epi == 1 || s.epi == 2 || s.epi == 8) ? b.bias : nullptr;
+  a.aux = b.aux[set]; a.ldaux = s.N;
+  a.aux_out = b.aux_out[set]; a.ldaux_out = s.N;
+  a.p_drop = (s.epi == 8 || s.epi == 2 || s.epi == 4 || s.epi == 1 || s.epi == 3) ? 0.1f : 0.f;
+  a.seed = 42;
+}
+static void cmd_group(int argc, char **argv) {
+  struct Pair { Shape a, b; };
+  static const Pair pairs[] = {
+      {{0, 0, 12608, 2304, 768, "text qkv fwd"}, {0, 0, 5120, 2376, 768, "obj qkv fwd"}},
+      {{0, 0, 12608, 768, 768, "text out fwd"}, {0, 0, 5120, 768, 768, "obj out fwd"}},
+      {{0, 8, 12608, 3072, 768, "text ffn1 fwd"}, {0, 8, 5120, 2048, 768, "obj ffn1 fwd"}},
+      {{0, 0, 12608, 768, 3072, "text ffn2 fwd"}, {0, 0, 5120, 768, 2048, "obj ffn2 fwd"}},
+      {{1, 9, 12608, 3072, 768, "text ffn1 dgrad"}, {1, 9, 5120, 2048, 768, "obj ffn1 dgrad"}},
+      {{1, 0, 12608, 768, 3072, "text ffn2 dgrad"}, {1, 0, 5120, 768, 2048, "obj ffn2 dgrad"}},
+      {{1, 0, 12608, 768, 768, "text out dgrad"}, {1, 0, 5120, 768, 768, "obj out dgrad"}},
+      {{1, 0, 12608, 768, 2304, "text qkv dgrad"}, {1, 0, 5120, 768, 2376, "obj qkv dgrad"}},
+  };
+  const int rounds = 7, inner = 6, sets = 3;
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  unsigned long long *cnt;
+  float *maxd;
+  CK(hipMalloc(&cnt, 8));
+  CK(hipMalloc(&maxd, 4));
+  double sum_sep = 0, sum_best = 0, sum_grp = 0;
+  printf("%-34s %10s %10s %10s   %s\n", "pair", "separate", "best 7/12", "grouped", "grouped == variant 12 (words differing)");
+  for (const Pair &pr : pairs) {
+    Buffers ba = make(pr.a, sets), bb = make(pr.b, sets);
+    auto time_it = [&](auto &&body) {
+      std::vector<double> t;
+      int set = 0;
+      for (int r = 0; r < rounds + 1; ++r) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < inner; ++i) { body(set); set = (set + 1) % sets; }
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) t.push_back(1e3 * ms / inner);
+      }
+      std::sort(t.begin(), t.end());
+      return t[t.size() / 2];
+    };
+    const double sep = time_it([&](int set) { launch(pr.a, ba, set, -1, st); launch(pr.b, bb, set, -1, st); });
+    double best = 1e30;
+    for (int va : {7, 12})
+      for (int vb : {6, 7, 12})
+        best = std::min(best, time_it([&](int set) { launch(pr.a, ba, set, va, st); launch(pr.b, bb, set, vb, st); }));
+    int status = 0;
+    const double grp = time_it([&](int set) {
+      gps_gemm_args a[2];
+      fill_args(a[0], pr.a, ba, set, -1);
+      fill_args(a[1], pr.b, bb, set, -1);
+      status |= gps_gemm_bf16_grouped(a, 2, (gps_stream_t)st);
+    });
+    // correctness: grouped outputs against variant 12 of each product (same kernel body: bit-equal)
+    unsigned long long diff = 0;
+    for (int which = 0; which < 2; ++which) {
+      const Shape &s = which ? pr.b : pr.a;
+      Buffers &b = which ? bb : ba;
+      uint16_t *ref;
+      CK(hipMalloc(&ref, b.c_elems * 2));
+      launch(s, b, 0, 12, st);
+      CK(hipMemcpyAsync(ref, b.C[0], b.c_elems * 2, hipMemcpyDeviceToDevice, st));
+      CK(hipMemsetAsync(b.C[0], 0xFF, b.c_elems * 2, st));
+      gps_gemm_args a[2];
+      fill_args(a[0], pr.a, ba, 0, -1);
+      fill_args(a[1], pr.b, bb, 0, -1);
+      status |= gps_gemm_bf16_grouped(a, 2, (gps_stream_t)st);
+      CK(hipMemsetAsync(cnt, 0, 8, st));
+      CK(hipMemsetAsync(maxd, 0, 4, st));
+      diff_bf16<<<1024, 256, 0, st>>>(ref, b.C[0], b.c_elems, cnt, maxd);
+      unsigned long long hc = 0;
+      CK(hipMemcpyAsync(&hc, cnt, 8, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      diff += hc;
+      CK(hipFree(ref));
+    }
+    printf("%-16s + %-15s %10.1f %10.1f %10.1f   status %d, %llu\n", pr.a.what, pr.b.what, sep, best, grp, status, diff);
+    fflush(stdout);
+    sum_sep += sep; sum_best += best; sum_grp += grp;
+    release(ba);
+    release(bb);
+  }
+  printf("%-34s %10.1f %10.1f %10.1f\n", "sum (one layer, fwd + dgrad)", sum_sep, sum_best, sum_grp);
+}
+
 // ---- store-path microbenchmark: what one CU's 8 waves can push per clock, by access pattern ---------------------------
 // pattern 0: 1 KiB contiguous per wave-instruction; 1: 16 rows x 64 B (the GEMM epilogue's 16-byte stores today);
 // 2: 64 rows x 16 B (row per lane); 3: 8 rows x 128 B; 4: 4 rows x 256 B; 5: 2 rows x 512 B.  Row pitch 512 B... `pitch`.
@@ -493,6 +591,7 @@ int main(int argc, char **argv) {
   else if (!strcmp(argv[1], "trace")) cmd_trace(argc, argv);
   else if (!strcmp(argv[1], "loop")) cmd_loop(argc, argv);
   else if (!strcmp(argv[1], "storebw")) cmd_storebw(argc, argv);
+  else if (!strcmp(argv[1], "group")) cmd_group(argc, argv);
   else { fprintf(stderr, "unknown mode %s\n", argv[1]); return 1; }
   return 0;
 }

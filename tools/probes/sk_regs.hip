@@ -9,5 +9,8 @@ namespace gps_gemm {
 #ifndef SK_BTR
 #define SK_BTR false
 #endif
-template __global__ void gemm8p_sk_kernel<SK_BTR, SK_EPI>(const Params);
+#ifndef SK_RAGGED
+#define SK_RAGGED false
+#endif
+template __global__ void gemm8p_sk_kernel<SK_BTR, SK_EPI, SK_RAGGED>(const Params);
 }

@@ -7,8 +7,14 @@ from collections import defaultdict
 
 SLOTS = 32
 raw = open(sys.argv[1], "rb").read()
-mhz = float(sys.argv[2]) if len(sys.argv) > 2 else 2000.0
 n = len(raw) // (8 * SLOTS)
+# shader clock from the two stamp kinds (s_memtime cycles against s_memrealtime's 100 MHz)
+_r = []
+for w in range(n):
+    t = struct.unpack_from(f"{SLOTS}Q", raw, w * 8 * SLOTS)
+    if t[0] and t[5] > t[4] + 500:
+        _r.append((t[6] - t[0]) / ((t[5] - t[4]) / 100.0))
+mhz = sorted(_r)[len(_r) // 2] if _r else (float(sys.argv[2]) if len(sys.argv) > 2 else 2000.0)
 acc = defaultdict(lambda: defaultdict(list))
 tot = []
 for w in range(n):
@@ -21,13 +27,13 @@ for w in range(n):
         if t[b] == 0 or t[b + 3] == 0:
             continue
         kind, nst = t[b + 5], t[b + 4]
-        acc[kind]["ready"].append((t[b + 1] - t[b]) / mhz)
-        acc[kind]["loop"].append((t[b + 2] - t[b + 1]) / mhz)
-        acc[kind]["per_kt"].append((t[b + 2] - t[b + 1]) / mhz / max(nst, 1))
+        acc[kind]["ready"].append((t[b + 1] - t[b + 2]) / mhz if t[b + 1] else 0.0)     # owner: flags seen, measured from main loop done
+        acc[kind]["loop"].append((t[b + 2] - t[b]) / mhz)
+        acc[kind]["per_kt"].append((t[b + 2] - t[b]) / mhz / max(nst, 1))
         acc[kind]["ending"].append((t[b + 3] - t[b + 2]) / mhz)
         acc[kind]["nst"].append(nst)
 med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
-print(f"workgroups {len(tot)}  total us median {med(tot):.1f} max {max(tot):.1f}")
+print(f"workgroups {len(tot)}  total us median {med(tot):.1f} max {max(tot):.1f}  ({mhz:.0f} MHz)")
 for kind, name in ((1, "contribution"), (0, "whole tile"), (2, "owner")):
     a = acc[kind]
     if not a:
