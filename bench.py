@@ -449,6 +449,11 @@ def main() -> None:
                          "split-graph data-parallel step")
     ap.add_argument("--all-object-slots", action="store_true",
                     help="frozen object encoder on every object slot, pad clouds included (off: distinct clouds only)")
+    ap.add_argument("--text-lengths", choices=["uniform", "full"], default="uniform",
+                    help="length law of the synthetic texts.  uniform (default, builder-chosen): sentence U{6..50}, scene caption "
+                         "U{30..300} valid tokens, right-padded -- real captions vary in length, the reference pads them to "
+                         "max_length (configs/final/all_pretrain.yaml:35-36,46) and runs every padded row; full: every text at "
+                         "its maximum length (no padded rows to skip: what `value_full_length_text` reports beside `value`)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the reporting-only passes after the timed region (profiler, unfused point-op timing)")
     args = ap.parse_args()
@@ -566,6 +571,24 @@ def main() -> None:
     if not preset["scene_cap"]:
         batch.pop("scene_txt_ids"), batch.pop("scene_txt_masks")
 
+    def full_length_texts(src, seed):
+        """{ids / masks} of `src` with every padding position turned into an ordinary token ([SEP] last): all rows valid."""
+        out = {}
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for ids_k, mask_k in (("txt_ids", "txt_masks"), ("scene_txt_ids", "scene_txt_masks")):
+            if ids_k not in src:
+                continue
+            ids = src[ids_k].clone()
+            mk = src[mask_k]
+            fill = torch.randint(1000, 30522, ids.shape, generator=g).to(ids.device)
+            ids = torch.where(mk != 0, ids, fill)
+            ids[:, -1] = 102
+            out[ids_k], out[mask_k] = ids, torch.ones_like(mk)
+        return out
+
+    if args.text_lengths == "full":
+        batch.update(full_length_texts(batch, 4242 + rank))
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
@@ -610,18 +633,11 @@ def main() -> None:
     # so the fully-populated figure is measured beside `value`, same process, same graphs (the row counts live on the
     # device), W warm-up + K timed steps.
     dt_full = None
-    if preset["scene_cap"] and not args.no_extras:
+    full = None
+    if preset["scene_cap"] and not args.no_extras and args.text_lengths != "full":
         # (`batch` may alias the graph's static input buffers: keep the measured texts aside and put them back after)
         saved_text = {k: batch[k].clone() for k in ("txt_ids", "txt_masks", "scene_txt_ids", "scene_txt_masks")}
-        full = dict(batch)
-        g = torch.Generator(device="cpu").manual_seed(4242 + rank)
-        for ids_k, mask_k in (("txt_ids", "txt_masks"), ("scene_txt_ids", "scene_txt_masks")):
-            ids = batch[ids_k].clone()
-            mk = batch[mask_k]
-            fill = torch.randint(1000, 30522, ids.shape, generator=g).to(ids.device)
-            ids = torch.where(mk != 0, ids, fill)                # padding positions become ordinary tokens
-            ids[:, -1] = 102                                     # [SEP]
-            full[ids_k], full[mask_k] = ids, torch.ones_like(mk)
+        full = {**batch, **full_length_texts(batch, 4242 + rank)}
         for _ in range(max(1, args.warmup)):
             step.step(dict(full))
         barrier()
@@ -638,6 +654,7 @@ def main() -> None:
     # the batch (builder-chosen: n_real ~ U{20..79} of 80), so the same graph is also timed on a batch WITHOUT pad clouds:
     # every pad slot gets the cloud of its scene's first object (obj_masks unchanged: only the encoder's work changes).
     dt_nopad = None
+    dt_cons = None
     pad_frac = None
     if "obj_fts" in batch and "obj_masks" in batch and not args.no_extras and not args.all_object_slots:
         pads = batch["obj_masks"].logical_not()
@@ -653,6 +670,21 @@ def main() -> None:
             step.step(dict(batch))
         barrier()
         dt_nopad = time.perf_counter() - t1
+        # ... and with BOTH builder-chosen savings off at once (no pad clouds to skip, no padded text rows to skip): the
+        # jointly conservative figure
+        if full is not None:
+            saved_text = {k: batch[k].clone() for k in ("txt_ids", "txt_masks", "scene_txt_ids", "scene_txt_masks")}
+            cons = {**batch, **{k: full[k] for k in saved_text}}
+            for _ in range(max(1, args.warmup)):
+                step.step(dict(cons))
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step.step(dict(cons))
+            barrier()
+            dt_cons = time.perf_counter() - t1
+            for k, v in saved_text.items():
+                batch[k].copy_(v)
         batch["obj_fts"].copy_(saved_obj)
         del saved_obj
         step.step(dict(batch))
@@ -686,6 +718,35 @@ def main() -> None:
             step.step(dict(batch))
         barrier()
         dt_samp = time.perf_counter() - t2
+    # [r6] The same step with the two set-abstraction levels of the frozen point encoder in their single-product mode
+    # (`--sa-bf16`: one bf16 product per multiply-accumulate instead of the fp32-accurate split-bf16 three; opt-in, features
+    # within 5.8e-3 max of the fp32 path): the product count is baked into the captured launches, so this is a second engine
+    # (same configuration and seed), W warm-up + K timed steps.
+    dt_sa16 = None
+    if (args.config == "pretrain" and not args.no_extras and not args.sa_bf16 and not args.fp32 and world == 1 and step.graph
+            and not args.all_object_slots):
+        from sceneverse_amd.pointnet2 import pointnet2_modules as _sam
+        _sam.set_sa_precision("bf16")
+        try:
+            step2 = GPSTrainStep(cfg, device=dev, amp_dtype=torch.bfloat16, graph=True, native_gemm=not args.no_native_gemm,
+                                 wgrad_group=not args.no_wgrad_group)
+            b2 = synth_batch(args.batch, n_obj=args.n_obj, n_pts=args.n_pts, txt_len=preset["txt_len"], seed=42 + rank, device=dev)
+            if not preset["scene_cap"]:
+                b2.pop("scene_txt_ids"), b2.pop("scene_txt_masks")
+            if args.text_lengths == "full":
+                b2.update(full_length_texts(b2, 4242 + rank))
+            for _ in range(step2.graph_warmup + 1 + max(1, args.warmup)):
+                step2.step(dict(b2))
+            barrier()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                step2.step(dict(b2))
+            barrier()
+            dt_sa16 = time.perf_counter() - t3
+            del step2, b2
+            torch.cuda.empty_cache()
+        finally:
+            _sam.set_sa_precision("bf16x3")
     # Per-launch durations (HIP events around every native call) are taken from three EXTRA eager steps of the same
     # workload right after the timed region, on every rank (the steps contain the data-parallel collectives): a
     # replayed graph cannot host event pairs, and in the eager modes the ~1 200 event records per step would sit on
@@ -773,7 +834,8 @@ def main() -> None:
                 # the tile configuration the library picks for the shape = the kernel symbol rocprofv3 lists the launch
                 # under (gemm8p_kernel / gemm_kernel<128,128,..> / gemm_kernel<128,64,..>, each x form x epilogue)
                 from sceneverse_amd import _native as _nat
-                v = _nat.load().gps_gemm_pick_variant(_FORM.get(mm.group(1), -1), int(mm.group(2)), int(mm.group(3)), int(mm.group(4)), 0)
+                v = _nat.load().gps_gemm_pick_variant_ex(_FORM.get(mm.group(1), -1), int(mm.group(2)), int(mm.group(3)), int(mm.group(4)), 0,
+                                                         int(mm.group(5)))
                 return f"gemm_{mm.group(1)}(epi={mm.group(5)},tile={_TILE.get(v, v)})"
             mm = _re.match(r"(attn_\w+)\(L=\d+,spatial=(\d)\)(\[\w+\])?", name)
             if mm:
@@ -781,6 +843,9 @@ def main() -> None:
             mm = _re.match(r"(gemm_tn_grouped)\(", name)
             if mm:
                 return mm.group(1)
+            mm = _re.match(r"(gemm_n[nt]_grouped)\(.*epi=(\d+)\)", name)      # paired text / object products: gemm8p_grouped_kernel<form, epi>
+            if mm:
+                return f"{mm.group(1)}(epi={mm.group(2)},tile=8p256x256)"
             mm = _re.match(r"(add_dropout_layernorm_\w+)\(", name)
             if mm:
                 return mm.group(1)
@@ -873,6 +938,9 @@ def main() -> None:
         gemm_rows = [r for r in kernels if r["kernel"].startswith("gemm_")]
         gemm_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in gemm_rows)
         gemm_sec = sum(r["avg_us"] * 1e-6 * r["launches_per_step"] for r in gemm_rows)
+        # every native launch's algorithmic (live-row) FLOPs of one step against the whole step's time and the bf16 MFMA peak
+        all_flops = sum(r.get("algorithmic_flops", 0) * r["launches_per_step"] for r in kernels)
+        whole_step_frac = round(all_flops / (dt / args.steps) / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4) if all_flops else None
         in_scope_tf = IN_SCOPE_TRANSFORMER_GFLOP_PER_PAIR * pairs_per_s / 1e3
         headline_full = {
             "ball_query_group_unfused": bqg,
@@ -922,6 +990,11 @@ def main() -> None:
             **({"value_with_device_sampler": round(args.batch * world * args.steps / dt_samp, 2)} if dt_samp else {}),
             **({"value_no_pad_objects": round(args.batch * world * args.steps / dt_nopad, 2),
                 "ms_per_step_no_pad_objects": round(1e3 * dt_nopad / args.steps, 3)} if dt_nopad else {}),
+            **({"value_conservative": round(args.batch * world * args.steps / dt_cons, 2),
+                "ms_per_step_conservative": round(1e3 * dt_cons / args.steps, 3)} if dt_cons else {}),
+            **({"value_sa_bf16": round(args.batch * world * args.steps / dt_sa16, 2),
+                "ms_per_step_sa_bf16": round(1e3 * dt_sa16 / args.steps, 3)} if dt_sa16 else {}),
+            **({"whole_step_frac_bf16_mfma": whole_step_frac} if whole_step_frac is not None else {}),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -942,6 +1015,9 @@ def main() -> None:
                                         "distinct clouds only: the pad slots (constant clouds) are encoded once; "
                                         "compare with value_no_pad_objects"),
                        **({"pad_object_fraction": round(pad_frac, 4)} if pad_frac is not None else {}),
+                       "text_lengths": ("uniform: builder-chosen law (--text-lengths); the reference pads every text to max_length "
+                                        "(configs/final/all_pretrain.yaml:35-36,46): see value_full_length_text / value_conservative"
+                                        if args.text_lengths == "uniform" else "full: every text at max_length (no padded rows)"),
                        **({"sentence_len": f"U{{6..{preset['txt_len']}}}", "caption_len": "U{30..300}" if preset["scene_cap"] else None,
                            "text_live_row_fraction": round(float(sum(batch[k].float().sum().item() for k in batch if k.endswith("txt_masks")))
                                                            / max(1.0, float(sum(batch[k].numel() for k in batch if k.endswith("txt_masks")))), 4)}),

@@ -79,8 +79,9 @@ GPS_API int gps_furthest_point_sampling_xyz(int b, int n, int m, const float *da
  *   flag_scratch (2 b) int32
  * gps_point_set_object_extent(p): while p is not NULL the per-object launches of gps_furthest_point_sampling[_xyz]
  * (register-resident form), gps_ball_query, gps_sa_mlp_forward*, gps_split3_points process objects [0, *p) only and
- * neither read nor write the others (p = scal of the plan; device memory; process-wide, like gps_sa_mlp_set_products:
- * set it around the encoder's launches, reset it to NULL afterwards).  Per-object results do not depend on the other
+ * neither read nor write the others (p = scal of the plan; device memory; a setting of the CALLING HOST THREAD -- launches
+ * issued by other threads never see it; gps_sa_mlp_set_products is process-wide -- set it around the encoder's launches,
+ * reset it to NULL afterwards).  Per-object results do not depend on the other
  * objects of the batch, so result[slot_of[o]] is bit-identical to running every object. */
 GPS_API int gps_cloud_compact(int b, int n, int ld, const float *cloud, int rows_mult, int32_t *flag_scratch,
                               int32_t *obj_of, long long *slot_of, int32_t *scal, float *xyz_c, float *feat_c,
@@ -692,6 +693,8 @@ GPS_API int gps_gemm_pick_splits(int form, int M, int N, int K);
  * 256 x 256 kernel (gemm8p_kernel), 7 / 2 = 128 x 128 tiles, 6 = 128 x 64 tiles (gemm_kernel instantiations) -- what a
  * profile reader needs to match a launch with its rocprofv3 row */
 GPS_API int gps_gemm_pick_variant(int form, int M, int N, int K, int splits);
+/* the same for a given epilogue (the split-bf16 epilogues 6 / 7 keep the 128 x 128 tiles at short reductions) */
+GPS_API int gps_gemm_pick_variant_ex(int form, int M, int N, int K, int splits, int epilogue);
 GPS_API long long gps_gemm_workspace_floats(int form, int M, int N, int splits);
 /* variant 13 (forms NT / NN, bf16 epilogues): the stream-K form of variant 12 -- one resident workgroup per CU, each
  * taking an equal share of the K tiles of ALL 256 x 256 output tiles, so that a launch is never a whole number of

@@ -83,6 +83,7 @@ SIGNATURES = {
     "gps_adamw_step": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "gps_gemm_pick_splits": [_i, _i, _i, _i],
     "gps_gemm_pick_variant": [_i, _i, _i, _i, _i],
+    "gps_gemm_pick_variant_ex": [_i, _i, _i, _i, _i, _i],
     "gps_gemm_wgrad_grouped_set_xcd_queues": [_i],
     "gps_gemm_bf16": [ctypes.POINTER(GemmArgs), _vp],
     "gps_gemm_bf16_grouped": [ctypes.POINTER(GemmArgs), _i, _vp],

@@ -615,11 +615,15 @@ int launch(const Params &P, bool backward, hipStream_t s) {
   const size_t lds = backward ? bwd_lds<NT>() : fwd_lds<NT>();
   constexpr int kOccBig = NT <= 5 ? 4 : 2;
   const bool alt = backward && NT <= 5 && bwd_occ() == 3;
-  static bool granted[2] = {false, false};
-  if (lds > 64 * 1024 && !granted[backward ? 1 : 0]) {
-    const void *fn = backward ? (const void *)&bwd_kernel<NT, kOccBig> : (const void *)&fwd_kernel<NT>;
+  // one flag per INSTANTIATION that can be launched below (forward | backward | backward at the alternative occupancy)
+  static bool granted[3] = {false, false, false};
+  const int which = !backward ? 0 : (alt ? 2 : 1);
+  if (lds > 64 * 1024 && !granted[which]) {
+    const void *fn = !backward ? (const void *)&fwd_kernel<NT>
+                     : alt     ? (const void *)&bwd_kernel<NT, (NT <= 5 ? 3 : kOccBig)>
+                               : (const void *)&bwd_kernel<NT, kOccBig>;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPS_ERR_LAUNCH;
-    granted[backward ? 1 : 0] = true;
+    granted[which] = true;
   }
   if (!backward) hipLaunchKernelGGL((fwd_kernel<NT>), grid, block, lds, s, P);
   else if (alt) hipLaunchKernelGGL((bwd_kernel<NT, (NT <= 5 ? 3 : kOccBig)>), grid, block, lds, s, P);

@@ -422,6 +422,7 @@ int gps_text_obj_ce_forward(int B, int O, int D, const float *obj, const float *
     return GPS_ERR_INVALID_ARGUMENT;
   if ((D & 3) || D > 8192 || O > 4096 || !aligned16(obj) || !aligned16(text)) return GPS_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(D + O + gps_contra::kWaves) * sizeof(float);
+  if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;      // (no MaxDynamicSharedMemorySize grant: the default limit; callers fall back)
   hipLaunchKernelGGL(gps_contra::text_obj_fwd_kernel, dim3(B), dim3(gps_contra::kBlock), lds, (hipStream_t)stream, B, O, D,
                      obj, text, (const int64_t *)labels, masks, eps, ignore_index, cosv, prob, inv_o, inv_t, loss_rows, scal,
                      ticket);
@@ -440,6 +441,7 @@ int gps_text_obj_ce_backward(int B, int O, int D, const float *obj, const float 
     return GPS_ERR_UNSUPPORTED;
   const int G = dobj ? (O + 15) / 16 : 0;
   const size_t lds = (size_t)(D + O + gps_contra::kWaves) * sizeof(float);
+  if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;      // (no MaxDynamicSharedMemorySize grant: the default limit; callers fall back)
   hipLaunchKernelGGL(gps_contra::text_obj_bwd_kernel, dim3(G + 1, B), dim3(gps_contra::kBlock), lds, (hipStream_t)stream, B,
                      O, D, G, obj, text, (const int64_t *)labels, eps, ignore_index, cosv, prob, inv_o, inv_t, scal, grad_out,
                      dobj, dtext);
@@ -454,6 +456,7 @@ int gps_clip_loss_forward(int n, int D, int normalize, const float *a, const flo
     return GPS_ERR_INVALID_ARGUMENT;
   if ((D & 3) || D > 8192 || n > 8192 || !aligned16(a) || !aligned16(b)) return GPS_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(2 * D + 2 * n + gps_contra::kWaves) * sizeof(float);
+  if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;      // (no MaxDynamicSharedMemorySize grant: the default limit; callers fall back)
   hipLaunchKernelGGL(gps_contra::clip_fwd_kernel, dim3(n), dim3(gps_contra::kBlock), lds, (hipStream_t)stream, n, D, normalize,
                      a, b, scale, max_scale, eps, M, lse_row, lse_col, inv_a, inv_b, loss_rows, loss, ticket);
   return launch_status();
@@ -470,6 +473,7 @@ int gps_clip_loss_backward(int n, int D, int normalize, const float *a, const fl
   if ((D & 3) || D > 8192 || n > 8192 || !aligned16(a) || !aligned16(b) || (da && (!aligned16(da) || !aligned16(db))))
     return GPS_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(2 * n + gps_contra::kWaves) * sizeof(float);
+  if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;      // (no MaxDynamicSharedMemorySize grant: the default limit; callers fall back)
   hipLaunchKernelGGL(gps_contra::clip_bwd_kernel, dim3(n), dim3(gps_contra::kBlock), lds, (hipStream_t)stream, n, D, normalize,
                      da ? 1 : 0, a, b, scale, max_scale, eps, M, lse_row, lse_col, inv_a, inv_b, grad_out, da, db, dscale,
                      ds_rows, ticket);

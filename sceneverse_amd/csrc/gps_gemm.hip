@@ -44,6 +44,38 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __attribute__((aligned(64))) const unsigned int g_zero_block[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+// Host-side state that belongs to a DEVICE (attributes granted to a kernel, CU counts, occupancy answers) is kept per
+// device ordinal: one process may drive several GPUs (the usual deployment is one process per GPU, where index 0 is all
+// that is ever used).
+constexpr int kMaxDevices = 32;
+inline int current_device() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : -1;
+}
+struct PerDeviceFlag { bool done[kMaxDevices] = {}; };
+// dynamic LDS above 64 KB must be granted to a kernel once per device
+template <typename K>
+inline bool grant_dynamic_lds(K kern, int bytes, PerDeviceFlag &f) {
+  const int d = current_device();
+  if (d < 0) return false;
+  if (f.done[d]) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  f.done[d] = true;
+  return true;
+}
+// CUs of the current device (0 on failure)
+inline int device_cu_count() {
+  static int n_cu[kMaxDevices] = {};
+  const int d = current_device();
+  if (d < 0) return 0;
+  if (n_cu[d] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 0;
+    n_cu[d] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n_cu[d];
+}
+
 enum Epi : int {
   EPI_BIAS = 0,        // C bf16 = acc + bias
   EPI_BIAS_GELU = 1,   // aux_out bf16 = pre = acc + bias; C bf16 = dropout(gelu(bf16(pre)))
@@ -267,7 +299,11 @@ struct Stager {
 // ---------------------------------------------------------------------------------------------------------
 template <int ROWS, bool RM>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char *tile, int r0, int ks, int lane) {
+#if defined(GPS_PROBE_ABL) && GPS_PROBE_ABL == 1        // timing ablation (wrong results): every fragment as one 16-byte read
+  if (false) {
+#else
   if (RM) {
+#endif
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) s16x4 *)(tile + rm_frag<ROWS>(r0, ks, lane, 0)));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -975,12 +1011,8 @@ int launch_256(Params &P, hipStream_t s) {
   P.ntn = (P.N + 255) / 256;
   P.gm = 4;
   auto kern = &gemm256_kernel<BTR, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return GPS_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static PerDeviceFlag granted;
+  if (!grant_dynamic_lds(kern, LDS, granted)) return GPS_ERR_LAUNCH;
   const long long blocks = (long long)P.ntm * P.ntn;
   if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, s, P);
@@ -1071,7 +1103,11 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
   sb1.init(P.B, P.ldb, P.N, n0 + 128, kt0 * BK, wave, lane);
   // half-tile of K tile `tj` (relative to kt0) into `dst`; only a reduction-major (token-row) K can be ragged
   auto issue = [&](auto &st, unsigned char *dst, int tj) {
+#ifndef GPS_PROBE_NO_TAIL
     if constexpr (ATR || RAGGED) {
+#else
+    if constexpr (false) {
+#endif
       const int kl = k_span - tj * BK;
       if (kl < BK) {
         st.issue_tail(dst, kl, wave, lane);
@@ -1095,7 +1131,11 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
   // 64 wr + 16 wc + [0, 16) of each half): lane (i, g) adds the 8 k values it holds of row i with four v_dot2c against
   // bf16 ones (exact products, fp32 sums) -- two registers per wave and 8 instead of 32 dot instructions per phase and
   // wave (all of them on wave column 0 stretched phases 1 and 3 of every tile of column 0 by half).
+#if defined(GPS_PROBE_ABL) && GPS_PROBE_ABL == 2        // timing ablation: no column sums
+  const bool do_colsum = false;
+#else
   const bool do_colsum = COLSUM && P.colsum != nullptr && tile_n == 0;
+#endif
   float csum[2] = {0.f, 0.f};
   bf16x8 aq[2][4], bq0[2][2], bq1[2][2];
 
@@ -1171,8 +1211,12 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       if (n1) issue(sa1, oth + OFF_A1, t + 1);
       __builtin_amdgcn_sched_barrier(0);
       // the B reads (issued first) are done: B0 may be refilled one phase from now
+#if defined(GPS_PROBE_ABL) && GPS_PROBE_ABL == 3        // timing ablation (WAR-unsafe): no wait in front of the barrier
+      if constexpr (!ATR) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+#else
       if constexpr (ATR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (tr reads: two per fragment; wait for all)
       else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -1250,12 +1294,8 @@ int launch_8p(Params &P, hipStream_t s) {
   P.ntn = (P.N + 255) / 256;
   P.gm = 4;
   auto kern = &gemm8p_kernel<ATR, BTR, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return GPS_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static PerDeviceFlag granted;
+  if (!grant_dynamic_lds(kern, LDS, granted)) return GPS_ERR_LAUNCH;
   const long long blocks = (long long)P.ntm * P.ntn * P.splits;
   if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS, s, P);
@@ -1329,12 +1369,8 @@ template <bool BTR, int EPI, bool RAGGED>
 int launch_grouped(GroupParams &G, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * BK * 2;
   auto kern = &gemm8p_grouped_kernel<BTR, EPI, RAGGED>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return GPS_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static PerDeviceFlag granted;
+  if (!grant_dynamic_lds(kern, LDS, granted)) return GPS_ERR_LAUNCH;
   long long blocks = 0;
   for (int j = 0; j < G.n; ++j) {
     G.p[j].ntm = (G.p[j].M + 255) / 256;
@@ -1691,20 +1727,11 @@ int launch_sk_r(Params &P, hipStream_t s) {
   P.ntm = (P.M + 255) / 256;
   P.ntn = (P.N + 255) / 256;
   auto kern = &gemm8p_sk_kernel<BTR, EPI, RAGGED>;
-  static bool attr_done = false;
-  static int n_cu = 0;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return GPS_ERR_LAUNCH;
-    attr_done = true;
-  }
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GPS_ERR_LAUNCH;
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (n_cu > kSkMaxGrid) n_cu = kSkMaxGrid;
-  }
+  static PerDeviceFlag granted;
+  if (!grant_dynamic_lds(kern, LDS, granted)) return GPS_ERR_LAUNCH;
+  int n_cu = device_cu_count();
+  if (n_cu <= 0) return GPS_ERR_LAUNCH;
+  if (n_cu > kSkMaxGrid) n_cu = kSkMaxGrid;
   const long long units = (long long)P.ntm * P.ntn * P.nkt;
   if (units <= 0 || units > 0x3FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   static const int grid_env = [] { const char *e = getenv("GPS_GEMM_SK_GRID"); return e ? atoi(e) : 0; }();
@@ -1778,7 +1805,14 @@ __global__ __launch_bounds__(64) void wgrad_table_write_kernel(const WgradChunkA
   }
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_problems, int total_tiles, int xcd_queues) {
+#ifdef GPS_GEMM_TRACE
+#define GPS_WGRAD_TRACE_PARAM , unsigned long long *trace
+#define GPS_WGRAD_TRACE_ARG , g_probe_trace
+#else
+#define GPS_WGRAD_TRACE_PARAM
+#define GPS_WGRAD_TRACE_ARG
+#endif
+__global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_problems, int total_tiles, int xcd_queues GPS_WGRAD_TRACE_PARAM) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 128 KB (gemm8p_tile)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1808,6 +1842,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_p
     s_next = total_tiles;
     s_queue = 0;
   };
+#ifdef GPS_GEMM_TRACE
+  unsigned long long tr_kt = 0, tr_tiles = 0;
+  if (trace && threadIdx.x == 0) { trace[(size_t)blockIdx.x * kTraceSlots + 0] = __builtin_amdgcn_s_memtime(); trace[(size_t)blockIdx.x * kTraceSlots + 4] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   int t, queue = 0, p = 0;
   if (!xcd_queues) {
     t = xcd_virtual_id(blockIdx.x, G);
@@ -1868,6 +1906,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_p
     // ever see its own LDS traffic
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     gemm8p_tile<true, true, EPI_F32>(P, smem, lane, wave, tile_m * 256, tile_n * 256, tile_n, 0, 0, nst, k_eff);
+#ifdef GPS_GEMM_TRACE
+    tr_kt += (unsigned long long)nst;
+    ++tr_tiles;
+    if (trace && threadIdx.x == 0) {
+      unsigned long long *tw = trace + (size_t)blockIdx.x * kTraceSlots;
+      tw[6] = __builtin_amdgcn_s_memtime(); tw[5] = __builtin_amdgcn_s_memrealtime(); tw[7] = tr_kt; tw[8] = tr_tiles;
+    }
+#endif
     if (threadIdx.x == 0) take();
     __syncthreads();                                        // s_next visible; the next tile's first copies overwrite the stage buffers
     t = __builtin_amdgcn_readfirstlane(s_next);
@@ -1963,25 +2009,23 @@ int launch_cfg(Params &P, hipStream_t s) {
   P.gm = BM >= 256 ? 4 : 8;           // ~16 (128-row) panels of K = 768 bf16 stay under the 4 MiB L2 of an XCD
   auto kern = &gemm_kernel<BM, BN, WGM, WGN, ATR, BTR, EPI, NBUF, PF, PERSIST>;
   constexpr int THREADS = WGM * WGN * 64;
-  static bool attr_done = false;
-  if (LDS > 64 * 1024 && !attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-        hipSuccess)
-      return GPS_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static PerDeviceFlag granted;
+  if (LDS > 64 * 1024 && !grant_dynamic_lds(kern, LDS, granted)) return GPS_ERR_LAUNCH;
   long long blocks = (long long)P.ntm * P.ntn * P.splits;
   if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return GPS_ERR_UNSUPPORTED;
   if (PERSIST) {
     // as many workgroups as the chip holds at once (a multiple of 8: the same number on every XCD)
-    static int slots = 0;
+    static int slots_of[kMaxDevices] = {};
+    const int dev = current_device();
+    if (dev < 0) return GPS_ERR_LAUNCH;
+    int &slots = slots_of[dev];
     if (slots == 0) {
-      int per_cu = 0, dev = 0;
-      hipDeviceProp_t prop;
+      int per_cu = 0;
+      const int n_cu = device_cu_count();
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), THREADS, LDS) != hipSuccess ||
-          hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1)
+          n_cu <= 0 || per_cu < 1)
         return GPS_ERR_LAUNCH;
-      slots = per_cu * prop.multiProcessorCount / 8 * 8;
+      slots = per_cu * n_cu / 8 * 8;
       if (slots < 8) slots = 8;
     }
     const long long want = (blocks + 7) / 8 * 8;
@@ -2057,7 +2101,7 @@ inline int tn_8p_splits(int M, int N, int K) {
   if (s > nkt / 24) s = nkt / 24;        // >= 24 K tiles per workgroup: below that the fp32 partial tiles and the prologue dominate
   return tiles * s >= 160 ? (int)s : 0;
 }
-inline int pick_variant(int form, int M, int N, int K, int splits) {
+inline int pick_variant(int form, int M, int N, int K, int splits, int epilogue = EPI_BIAS) {
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
   if (form == GPS_GEMM_TN) return (tiles256 >= 18 && tiles256 * splits >= 160 && tiles256 * splits <= 256) ? 12 : 2;
   // long reductions over >= 140 tiles of 256 x 256 (more than half the CUs busy in the last round): the two-group kernel
@@ -2069,6 +2113,11 @@ inline int pick_variant(int form, int M, int N, int K, int splits) {
     return v > 0 ? v : 1536;
   }();
   if (K % 64 == 0 && K >= min_k_8p && tiles256 >= 140) return 12;
+  // [r6] with the four-quadrant epilogue (store_quads: 4.4 -> 2.2 us per tile at EPI_BIAS) the two-group kernel also wins at
+  // K = 768 once the launch is several rounds of tiles (12 608 x 2 304 x 768: 52.4 vs 66.8 us, x 3 072 with the GELU epilogues
+  // 111 vs 124 / 106 vs 122; profiles/r6/gemm_probe_table_h_streamk.txt); the 264 / 297-tile products of the joint layers
+  // (1.03 / 1.16 rounds) stay on the 128 x 128 tiles
+  if (K % 64 == 0 && K >= 768 && tiles256 >= 400 && epilogue != EPI_RELU_SPLIT && epilogue != EPI_RELU_MAX16) return 12;
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * splits;
   return tiles >= 384 ? 7 : 6;
 }
@@ -2098,8 +2147,12 @@ int gps_gemm_pick_splits(int form, int M, int N, int K) {
 }
 
 int gps_gemm_pick_variant(int form, int M, int N, int K, int splits) {
+  return gps_gemm_pick_variant_ex(form, M, N, K, splits, GPS_GEMM_EPI_BIAS);
+}
+
+int gps_gemm_pick_variant_ex(int form, int M, int N, int K, int splits, int epilogue) {
   if (form != GPS_GEMM_NT && form != GPS_GEMM_NN && form != GPS_GEMM_TN) return -1;
-  return gps_gemm::pick_variant(form, M, N, K, splits < 1 ? gps_gemm_pick_splits(form, M, N, K) : splits);
+  return gps_gemm::pick_variant(form, M, N, K, splits < 1 ? gps_gemm_pick_splits(form, M, N, K) : splits, epilogue);
 }
 
 long long gps_gemm_sk_workspace_bytes(void) {
@@ -2135,17 +2188,10 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
   if (n_problems < 0 || (n_problems > 0 && !problems)) return GPS_ERR_INVALID_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
   constexpr int LDS = 2 * 4 * 128 * BK * 2;
-  static bool attr_done = false;
-  static int n_cu = 0;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return GPS_ERR_LAUNCH;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GPS_ERR_LAUNCH;
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    attr_done = true;
-  }
+  static PerDeviceFlag granted;
+  if (!grant_dynamic_lds(&wgrad_grouped_kernel, LDS, granted)) return GPS_ERR_LAUNCH;
+  const int n_cu = device_cu_count();
+  if (n_cu <= 0) return GPS_ERR_LAUNCH;
   // validate everything before the first launch (requirements of the TN form of gps_gemm_bf16)
   int live = 0;
   for (int i = 0; i < n_problems; ++i) {
@@ -2162,7 +2208,10 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
   if (live == 0) return GPS_OK;
   // longest reductions first (stable): with the snake deal of wgrad_grouped_kernel every workgroup gets one tile of each cost class
   int order[kWgradMaxProblems];
-  static unsigned int slot_counter = 0;
+  static unsigned int slot_counters[kMaxDevices] = {};       // (the tables are __device__ globals: one set per device)
+  const int dev_now = current_device();
+  if (dev_now < 0) return GPS_ERR_LAUNCH;
+  unsigned int &slot_counter = slot_counters[dev_now];
   for (int base = 0; base < n_problems;) {
     int cnt = 0, end = base;
     while (end < n_problems && cnt < kWgradMaxProblems) {
@@ -2248,7 +2297,7 @@ int gps_gemm_wgrad_grouped(const gps_wgrad_problem *problems, int n_problems, gp
       if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
     }
     const int total = (int)tile0;
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)grid), dim3(512), LDS, s, slot, cnt, total, queues ? 1 : 0);
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((unsigned)grid), dim3(512), LDS, s, slot, cnt, total, queues ? 1 : 0 GPS_WGRAD_TRACE_ARG);
     if (hipGetLastError() != hipSuccess) return GPS_ERR_LAUNCH;
   }
   return GPS_OK;
@@ -2390,7 +2439,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
   P.trace = g_probe_trace;
 #endif
   int variant = a->variant;
-  if (variant < 0) variant = pick_variant(a->form, a->M, a->N, a->K, P.splits);
+  if (variant < 0) variant = pick_variant(a->form, a->M, a->N, a->K, P.splits, a->epilogue);
   if (variant >= kVariants) return GPS_ERR_INVALID_ARGUMENT;
 
   if (variant == 13 && a->form != GPS_GEMM_TN && !f32out && a->workspace) {

@@ -984,7 +984,8 @@ __global__ __launch_bounds__(kBlock) void cloud_copy_kernel(int n, int ld, const
   }
 }
 
-static const int *g_object_extent = nullptr;
+static thread_local const int *g_object_extent = nullptr;      // per host thread: a launch issued from another thread (a loader
+//                                                                  thread's point ops) must not inherit an extent it did not set
 const int *object_extent() { return g_object_extent; }
 
 }  // namespace gps

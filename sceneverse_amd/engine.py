@@ -677,7 +677,9 @@ class GPSTrainStep:
             data_dict['total_steps'] = 1 << 30
             if self._graph is None:
                 self._rebind_lr()
-            with self._strict_accumulate_grad():
+            # (pure replays run no autograd: the warning filter -- process-global state -- is only touched by the eager
+            # warm-up steps and the capture)
+            with (self._strict_accumulate_grad() if self._graph is None else contextlib.nullcontext()):
                 total, losses = self._graph_dp_step(data_dict) if self.graph_dp else self._graph_step(data_dict)
             self._sched_step()
             self.global_step += 1

@@ -281,11 +281,6 @@ class _FusedVarlenSelfAttention(torch.autograd.Function):
         dpacked = torch.empty_like(packed)
         base, esz, gbase = packed.data_ptr(), packed.element_size(), dpacked.data_ptr()
         frac = _varlen_fraction(cu_rows, n_seq, cap)
-        from ... import _debug
-        if _debug.ENABLED:
-            for nm, t in (("vattn.dout", dout), ("vattn.packed", packed), ("vattn.out", out), ("vattn.lse", lse),
-                          ("vattn.cu", cu_rows), ("vattn.qlimit", q_limit)):
-                _debug.tap(nm, t)
         with torch.cuda.device(packed.device):
             _call(True, f"attn_backward(L<={cap},varlen,seqs={n_seq})", esz * n_seq * cap * 8 * D,
                   10 * n_seq * n_head * cap * cap * HEAD_DIM, work_fraction=frac,
@@ -294,8 +289,6 @@ class _FusedVarlenSelfAttention(torch.autograd.Function):
                   p_drop=p_drop, seed=0, seed_dev=_ptr(seed_dev), out=out, ld_o=D, lse=lse, dout=dout,
                   dq=gbase, ld_dq=W, dk=gbase + D * esz, dv=gbase + 2 * D * esz, ld_dkv=W, cu_rows=cu_rows,
                   seq_order=_ptr(order), q_limit=_ptr(q_limit), delta_ws=_delta_ws(n_seq, n_head, cap, packed.device))
-        if _debug.ENABLED:
-            _debug.tap("vattn.dpacked", dpacked)
         return dpacked, None, None, None, None, None, None, None, None
 
 

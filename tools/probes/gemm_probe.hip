@@ -135,7 +135,7 @@ static Buffers make(const Shape &s, int sets) {
   for (int i = 0; i < sets; ++i) {
     uint16_t *a, *c, *x = nullptr, *y = nullptr;
     CK(hipMalloc(&a, b.a_elems * 2));
-    CK(hipMalloc(&c, b.c_elems * 2));
+    CK(hipMalloc(&c, b.c_elems * 4));      // (fp32 results of form TN fit as well)
     fill_bf16<<<2048, 256>>>(a, b.a_elems, 0x9000u + i, 1.f);
     if (has_aux(s.epi)) {
       CK(hipMalloc(&x, b.c_elems * 2));
@@ -175,8 +175,14 @@ static int launch(const Shape &s, const Buffers &b, int set, int variant, hipStr
   memset(&a, 0, sizeof(a));
   if (variant == 13) a.workspace = sk_workspace();
   a.form = s.form; a.epilogue = s.epi; a.M = s.M; a.N = s.N; a.K = s.K; a.splits = 1; a.variant = variant;
-  a.A = b.A[set]; a.lda = s.K;
-  a.B = b.B; a.ldb = s.form == 0 ? s.K : s.N;      // NT: W (N, K); NN: W (K, N)
+  a.A = b.A[set]; a.lda = s.form == 2 ? s.M : s.K;  // TN: dY (K, M)
+  a.B = b.B; a.ldb = s.form == 0 ? s.K : s.N;      // NT: W (N, K); NN: W (K, N); TN: X (K, N)
+  if (s.form == 2) {
+    a.splits = gps_gemm_pick_splits(2, s.M, s.N, s.K);
+    static float *ws = nullptr;
+    if (!ws) CK(hipMalloc(&ws, (size_t)512 << 20));
+    a.workspace = ws;
+  }
   a.C = b.C[set]; a.ldc = s.N;
   a.bias = (s.epi == 0 || s.epi == 1 || s.epi == 2 || s.epi == 8) ? b.bias : nullptr;
   a.aux = b.aux[set]; a.ldaux = s.N;
@@ -477,6 +483,83 @@ static void cmd_group(int argc, char **argv) {
   printf("%-34s %10.1f %10.1f %10.1f\n", "sum (one layer, fwd + dgrad)", sum_sep, sum_best, sum_grp);
 }
 
+// ---- the grouped weight-gradient launch of one step (48 of its 69 problems): per-workgroup K-tile rate and finish times -------
+static void cmd_wgrad(int argc, char **argv) {
+  struct W { int M, N, K; };
+  std::vector<W> ws;
+  for (int l = 0; l < 4; ++l) {
+    for (W w : {W{2304, 768, 12608}, W{768, 768, 12608}, W{3072, 768, 12608}, W{768, 3072, 12608}}) ws.push_back(w);
+    for (W w : {W{2376, 768, 5120}, W{768, 768, 5120}, W{2048, 768, 5120}, W{768, 2048, 5120}}) ws.push_back(w);
+    for (W w : {W{2304, 768, 8320}, W{768, 768, 8320}, W{2048, 768, 8320}, W{768, 2048, 8320}}) ws.push_back(w);
+  }
+  // operands: dY (K, M), X (K, N) per problem, shared buffers per (K, width) class to bound memory
+  auto alloc_bf16 = [&](size_t elems, unsigned seed) {
+    uint16_t *p;
+    CK(hipMalloc(&p, elems * 2));
+    fill_bf16<<<2048, 256>>>(p, elems, seed, 1.f);
+    return p;
+  };
+  std::vector<gps_wgrad_problem> probs;
+  std::vector<void *> keep;
+  double flops = 0;
+  for (size_t i = 0; i < ws.size(); ++i) {
+    const W &w = ws[i];
+    uint16_t *A = alloc_bf16((size_t)w.K * w.M, 100 + (unsigned)i), *B = alloc_bf16((size_t)w.K * w.N, 300 + (unsigned)i);
+    float *C, *cs;
+    CK(hipMalloc(&C, (size_t)w.M * w.N * 4));
+    CK(hipMalloc(&cs, (size_t)w.M * 4));
+    gps_wgrad_problem q;
+    memset(&q, 0, sizeof(q));
+    q.M = w.M; q.N = w.N; q.K = w.K; q.accumulate = 0;
+    q.A = A; q.lda = w.M; q.B = B; q.ldb = w.N; q.C = C; q.ldc = w.N; q.colsum = cs;
+    probs.push_back(q);
+    flops += 2.0 * w.M * w.N * w.K;
+  }
+  CK(hipDeviceSynchronize());
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  const int max_wgs = 512;
+  unsigned long long *tr;
+  CK(hipMalloc(&tr, (size_t)max_wgs * gps_gemm::kTraceSlots * 8));
+  for (int mode = 1; mode >= 0; --mode) {
+    gps_gemm_wgrad_grouped_set_xcd_queues(mode);
+    for (int i = 0; i < 2; ++i) gps_gemm_wgrad_grouped(probs.data(), (int)probs.size(), (gps_stream_t)st);
+    CK(hipStreamSynchronize(st));
+    CK(hipMemset(tr, 0, (size_t)max_wgs * gps_gemm::kTraceSlots * 8));
+    gps_gemm::g_probe_trace = tr;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    gps_gemm_wgrad_grouped(probs.data(), (int)probs.size(), (gps_stream_t)st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    gps_gemm::g_probe_trace = nullptr;
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h((size_t)max_wgs * gps_gemm::kTraceSlots);
+    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> per_kt, busy, endt;
+    unsigned long long rt0 = ~0ull, kts = 0, tiles = 0;
+    for (int w = 0; w < max_wgs; ++w) if (h[(size_t)w * 32]) rt0 = std::min(rt0, h[(size_t)w * 32 + 4]);
+    for (int w = 0; w < max_wgs; ++w) {
+      const unsigned long long *t = &h[(size_t)w * 32];
+      if (!t[0] || !t[6]) continue;
+      const double us = (double)(t[5] - t[4]) / 100.0;
+      per_kt.push_back(us / (double)t[7]);
+      busy.push_back(us);
+      endt.push_back((double)(t[5] - rt0) / 100.0);
+      kts += t[7]; tiles += t[8];
+    }
+    std::sort(per_kt.begin(), per_kt.end()); std::sort(busy.begin(), busy.end()); std::sort(endt.begin(), endt.end());
+    const size_t n = per_kt.size();
+    printf("xcd_queues %d: wall %.1f us (%.0f TFLOP/s), %zu workgroups, %llu tiles, %llu K tiles; per K tile us p10 %.3f p50 %.3f p90 %.3f; "
+           "workgroup finish us p10 %.1f p50 %.1f p90 %.1f max %.1f; ideal at p50 rate %.1f us\n",
+           mode, 1e3 * ms, flops / (1e3 * ms) * 1e-6, n, tiles, kts, per_kt[n / 10], per_kt[n / 2], per_kt[n * 9 / 10], endt[n / 10], endt[n / 2],
+           endt[n * 9 / 10], endt[n - 1], (double)kts * per_kt[n / 2] / (double)n);
+  }
+}
+
 // ---- store-path microbenchmark: what one CU's 8 waves can push per clock, by access pattern ---------------------------
 // pattern 0: 1 KiB contiguous per wave-instruction; 1: 16 rows x 64 B (the GEMM epilogue's 16-byte stores today);
 // 2: 64 rows x 16 B (row per lane); 3: 8 rows x 128 B; 4: 4 rows x 256 B; 5: 2 rows x 512 B.  Row pitch 512 B... `pitch`.
@@ -592,6 +675,7 @@ int main(int argc, char **argv) {
   else if (!strcmp(argv[1], "loop")) cmd_loop(argc, argv);
   else if (!strcmp(argv[1], "storebw")) cmd_storebw(argc, argv);
   else if (!strcmp(argv[1], "group")) cmd_group(argc, argv);
+  else if (!strcmp(argv[1], "wgrad")) cmd_wgrad(argc, argv);
   else { fprintf(stderr, "unknown mode %s\n", argv[1]); return 1; }
   return 0;
 }
