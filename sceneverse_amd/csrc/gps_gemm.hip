@@ -124,18 +124,24 @@ struct Params {
 // Per-workgroup time stamps for tools/probes/gemm_probe.hip (compiled out of the library): slot 0 = kernel entry,
 // 1 = first stage landed, 2 = main loop done, 3 = epilogue issued, 4 = s_memrealtime at entry, 5 = at exit, 8.. = K tiles.
 #ifdef GPS_GEMM_TRACE
-constexpr int kTraceSlots = 32;
+constexpr int kTraceSlots = 96;     // 0..31 workgroup stamps; 32..63 / 64..95: the phases of ONE K tile (the 9th) as seen by wave 0 / wave 4
 #define GPS_TRACE(P, slot)                                                                                    \
   do {                                                                                                        \
     if ((P).trace && threadIdx.x == 0 && (slot) < kTraceSlots)                                                \
       (P).trace[(size_t)blockIdx.x * kTraceSlots + (slot)] = ((slot) == 4 || (slot) == 5) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
   } while (0)
 #define GPS_TRACE_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")     // slot 6: the epilogue's stores acknowledged
+#define GPS_PTRACE(P, t, idx)                                                                                 \
+  do {                                                                                                        \
+    if ((P).trace && (t) == 8 && (threadIdx.x == 0 || threadIdx.x == 256))                                    \
+      (P).trace[(size_t)blockIdx.x * kTraceSlots + (threadIdx.x ? 64 : 32) + (idx)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #define GPS_TRACE_VAL(P, slot, v)                                                                             \
   do {                                                                                                        \
     if ((P).trace && threadIdx.x == 0 && (slot) < kTraceSlots) (P).trace[(size_t)blockIdx.x * kTraceSlots + (slot)] = (v); \
   } while (0)
 #else
+#define GPS_PTRACE(P, t, idx) do { } while (0)
 #define GPS_TRACE_VAL(P, slot, v) do { } while (0)
 #define GPS_TRACE(P, slot) do { } while (0)
 #define GPS_TRACE_DRAIN() do { } while (0)
@@ -299,11 +305,7 @@ struct Stager {
 // ---------------------------------------------------------------------------------------------------------
 template <int ROWS, bool RM>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char *tile, int r0, int ks, int lane) {
-#if defined(GPS_PROBE_ABL) && GPS_PROBE_ABL == 1        // timing ablation (wrong results): every fragment as one 16-byte read
-  if (false) {
-#else
   if (RM) {
-#endif
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) s16x4 *)(tile + rm_frag<ROWS>(r0, ks, lane, 0)));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -1103,11 +1105,7 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
   sb1.init(P.B, P.ldb, P.N, n0 + 128, kt0 * BK, wave, lane);
   // half-tile of K tile `tj` (relative to kt0) into `dst`; only a reduction-major (token-row) K can be ragged
   auto issue = [&](auto &st, unsigned char *dst, int tj) {
-#ifndef GPS_PROBE_NO_TAIL
     if constexpr (ATR || RAGGED) {
-#else
-    if constexpr (false) {
-#endif
       const int kl = k_span - tj * BK;
       if (kl < BK) {
         st.issue_tail(dst, kl, wave, lane);
@@ -1131,11 +1129,7 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
   // 64 wr + 16 wc + [0, 16) of each half): lane (i, g) adds the 8 k values it holds of row i with four v_dot2c against
   // bf16 ones (exact products, fp32 sums) -- two registers per wave and 8 instead of 32 dot instructions per phase and
   // wave (all of them on wave column 0 stretched phases 1 and 3 of every tile of column 0 by half).
-#if defined(GPS_PROBE_ABL) && GPS_PROBE_ABL == 2        // timing ablation: no column sums
-  const bool do_colsum = false;
-#else
   const bool do_colsum = COLSUM && P.colsum != nullptr && tile_n == 0;
-#endif
   float csum[2] = {0.f, 0.f};
   bf16x8 aq[2][4], bq0[2][2], bq1[2][2];
 
@@ -1205,47 +1199,56 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
       GPS_TRACE(P, 8 + t);
       // ---- phase 1: C00 ----
+      GPS_PTRACE(P, t, 0);
       read_b(cur + OFF_B0, bq0);
       __builtin_amdgcn_sched_barrier(0);
       read_a(cur + OFF_A0);
       if (n1) issue(sa1, oth + OFF_A1, t + 1);
       __builtin_amdgcn_sched_barrier(0);
       // the B reads (issued first) are done: B0 may be refilled one phase from now
-#if defined(GPS_PROBE_ABL) && GPS_PROBE_ABL == 3        // timing ablation (WAR-unsafe): no wait in front of the barrier
-      if constexpr (!ATR) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-#else
       if constexpr (ATR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (tr reads: two per fragment; wait for all)
       else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-#endif
+      GPS_PTRACE(P, t, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 2);
       mfma16(acc[0][0], bq0);
       colsum8(csum[0]);
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 3);
       __builtin_amdgcn_s_barrier();
       // ---- phase 2: C01 ----
+      GPS_PTRACE(P, t, 4);
       read_b(cur + OFF_B1, bq1);
       if (n2) issue(sb0, cur + OFF_B0, t + 2);
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 5);
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 6);
       mfma16(acc[0][1], bq1);
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 7);
       __builtin_amdgcn_s_barrier();
       // ---- phase 3: C11 ----
+      GPS_PTRACE(P, t, 8);
       read_a(cur + OFF_A1);
       if (n2) issue(sa0, cur + OFF_A0, t + 2);
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 9);
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 10);
       mfma16(acc[1][1], bq1);
       colsum8(csum[1]);
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 11);
       __builtin_amdgcn_s_barrier();
       // ---- phase 4: C10 ----
+      GPS_PTRACE(P, t, 12);
       if (n2) {
         issue(sb1, cur + OFF_B1, t + 2);
         wait_vmcnt<6>();
@@ -1253,10 +1256,14 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
         wait_vmcnt<0>();
       }
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 13);
       __builtin_amdgcn_s_barrier();
+      GPS_PTRACE(P, t, 14);
       mfma16(acc[1][0], bq0);
       __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 15);
       __builtin_amdgcn_s_barrier();
+      GPS_PTRACE(P, t, 16);
       unsigned char *tmp = cur;
       cur = oth;
       oth = tmp;

@@ -332,6 +332,19 @@ static void summarize_trace(const std::vector<unsigned long long> &tr, int wgs, 
   printf("{\"workgroups_traced\": %zu, \"wall_us\": %.2f, \"shader_MHz\": %.0f,\n", total.size(), wall_us, f);
   printf(" \"us\": {\"prologue\": %.2f, \"main_loop\": %.2f, \"per_k_tile\": %.3f, \"per_k_tile_p90\": %.3f, \"epilogue_issue\": %.2f, \"epilogue_drain\": %.2f, \"workgroup\": %.2f, \"workgroup_p90\": %.2f},\n",
          med(pro) / f, med(loop) / f, med(ktile) / f, pct(ktile, 0.9) / f, med(epi_issue) / f, med(epi_drain) / f, med(total) / f, pct(total, 0.9) / f);
+  // phase stamps of K tile 8 (waves 0 and 4): medians of the 16 intervals, in shader cycles
+  for (int wv = 0; wv < 2; ++wv) {
+    printf(" \"phase_cycles_wave%d\": [", wv ? 4 : 0);
+    for (int i = 0; i < 16; ++i) {
+      std::vector<double> d;
+      for (int w = 0; w < wgs; ++w) {
+        const unsigned long long *t = &tr[(size_t)w * kTraceSlots + 32 + 32 * wv];
+        if (t[i] && t[i + 1] && t[i + 1] > t[i]) d.push_back((double)(t[i + 1] - t[i]));
+      }
+      printf("%s%.0f", i ? ", " : "", med(d));
+    }
+    printf("],\n");
+  }
   printf(" \"start_us\": {\"p10\": %.2f, \"p50\": %.2f, \"p90\": %.2f, \"max\": %.2f}, \"end_us\": {\"p10\": %.2f, \"p50\": %.2f, \"p90\": %.2f, \"max\": %.2f}}\n",
          pct(start_rt, 0.1), pct(start_rt, 0.5), pct(start_rt, 0.9), pct(start_rt, 1.0), pct(end_rt, 0.1), pct(end_rt, 0.5), pct(end_rt, 0.9), pct(end_rt, 1.0));
 }
@@ -541,9 +554,9 @@ static void cmd_wgrad(int argc, char **argv) {
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     std::vector<double> per_kt, busy, endt;
     unsigned long long rt0 = ~0ull, kts = 0, tiles = 0;
-    for (int w = 0; w < max_wgs; ++w) if (h[(size_t)w * 32]) rt0 = std::min(rt0, h[(size_t)w * 32 + 4]);
+    for (int w = 0; w < max_wgs; ++w) if (h[(size_t)w * gps_gemm::kTraceSlots]) rt0 = std::min(rt0, h[(size_t)w * gps_gemm::kTraceSlots + 4]);
     for (int w = 0; w < max_wgs; ++w) {
-      const unsigned long long *t = &h[(size_t)w * 32];
+      const unsigned long long *t = &h[(size_t)w * gps_gemm::kTraceSlots];
       if (!t[0] || !t[6]) continue;
       const double us = (double)(t[5] - t[4]) / 100.0;
       per_kt.push_back(us / (double)t[7]);

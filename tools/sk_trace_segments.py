@@ -5,7 +5,7 @@ import struct
 import sys
 from collections import defaultdict
 
-SLOTS = 32
+SLOTS = 96
 raw = open(sys.argv[1], "rb").read()
 n = len(raw) // (8 * SLOTS)
 # shader clock from the two stamp kinds (s_memtime cycles against s_memrealtime's 100 MHz)
