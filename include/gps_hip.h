@@ -593,6 +593,14 @@ typedef struct gps_varlen_text {
 } gps_varlen_text;
 GPS_API int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq_full, int *i32_out, long long *i64_out,
                             unsigned char *valid_out, gps_stream_t stream);
+/* Row-compaction plan of n_seq sequences of seq_len rows each with an ARBITRARY validity mask (valid: (n_seq * seq_len)
+ * bytes, non-zero = valid) -- the joint text + object sequences of the unified encoder (reference
+ * modules/grounding/unified_encoder.py:147-177), whose padded rows are masked as attention keys and ignored as outputs:
+ *   perm (n) int64: compact row r <- flat row perm[r] (the valid rows in their order, then the invalid ones);
+ *   inv (n) int64: flat row -> compact row;  cu (n_seq + 1) int32: first compact row of every sequence, cu[n_seq] = n_live;
+ *   n_live (1) int32.  n_seq * seq_len <= 2^22.  One launch. */
+GPS_API int gps_rows_plan(int n_seq, int seq_len, const unsigned char *valid, long long *perm, long long *inv, int *cu, int *n_live,
+                          gps_stream_t stream);
 
 /* ---- box-location embedding  y = LayerNorm(x W^T + b)  (tiny reduction length) ---------------------------------
  * Replaces `loc_layers = nn.Sequential(nn.Linear(dim_loc, hidden), nn.LayerNorm(hidden))` of the object encoder and the

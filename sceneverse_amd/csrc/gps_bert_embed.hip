@@ -394,6 +394,63 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
 
 }  // namespace gps_bert_embed
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-compaction plan of a batch of fixed-length sequences with an arbitrary validity mask (the joint text + object
+// sequences of the unified encoder: [valid text tokens | text padding | valid objects | padded object slots], reference
+// modules/grounding/unified_encoder.py:147-177 runs every padded row through its four layers; only the valid rows are ever
+// read: as attention keys the padded ones are masked, as outputs they are ignored by every head and loss).
+//   perm (n) int64   compact row r <- flat row perm[r]: the valid rows in their order, then the invalid ones
+//   inv  (n) int64   flat row e -> its compact row
+//   cu (n_seq + 1) int32   first compact row of every sequence (its valid rows are contiguous), cu[n_seq] = n_live
+//   n_live (1) int32
+// One workgroup; two passes over the mask around one block-wide exclusive scan.
+// ---------------------------------------------------------------------------------------------------------
+namespace gps_rowplan {
+constexpr int kThreads = 1024;
+__global__ __launch_bounds__(kThreads) void plan_kernel(int n_seq, int seq_len, const unsigned char *__restrict__ valid,
+                                                        long long *__restrict__ perm, long long *__restrict__ inv,
+                                                        int *__restrict__ cu, int *__restrict__ n_live) {
+  __shared__ int part[kThreads];
+  __shared__ int wave_tot[kThreads / 64];
+  const int n = n_seq * seq_len;
+  const int per = (n + kThreads - 1) / kThreads;
+  const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+  int cnt = 0;
+  for (int e = lo; e < hi; ++e) cnt += valid[e] ? 1 : 0;
+  // exclusive scan of the per-thread counts: inside each wave by shuffles, across the 16 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < kThreads / 64; ++w) {
+    const int t = wave_tot[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  int before = base + incl - cnt;                 // valid rows in front of this thread's chunk
+  (void)part;
+  for (int e = lo; e < hi; ++e) {
+    if (e % seq_len == 0) cu[e / seq_len] = before;
+    const bool v = valid[e] != 0;
+    const int r = v ? before : total + (e - before);      // invalid rows follow the valid ones, in their order
+    perm[r] = e;
+    inv[e] = r;
+    before += v ? 1 : 0;
+  }
+  if (threadIdx.x == 0) {
+    cu[n_seq] = total;
+    n_live[0] = total;
+  }
+}
+}  // namespace gps_rowplan
+
+
 extern "C" {
 
 int gps_bert_embed_partial_rows(int n_rows) { return gps_bert_embed::grid_rows(n_rows); }
@@ -515,6 +572,16 @@ int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq_full, i
   const size_t lds = sizeof(int) * (2 * (size_t)seq + 1);
   hipLaunchKernelGGL(varlen_plan_kernel, dim3(1), dim3(kPlanThreads), lds, (hipStream_t)stream, A, (int32_t *)i32_out,
                      (int64_t *)i64_out, (uint8_t *)valid_out);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+
+int gps_rows_plan(int n_seq, int seq_len, const unsigned char *valid, long long *perm, long long *inv, int *cu, int *n_live,
+                  gps_stream_t stream) {
+  if (n_seq < 1 || seq_len < 1 || !valid || !perm || !inv || !cu || !n_live) return GPS_ERR_INVALID_ARGUMENT;
+  if ((long long)n_seq * seq_len > (1 << 22)) return GPS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gps_rowplan::plan_kernel, dim3(1), dim3(gps_rowplan::kThreads), 0, (hipStream_t)stream, n_seq, seq_len,
+                     valid, perm, inv, cu, n_live);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

@@ -62,7 +62,14 @@ def test_gps_pretrain_bf16_autocast(golden_cpu):
     diff = (out["og3d_logits"].float().cpu()[masks] - ref).abs().max().item()
     assert diff < 1e-2 * ref.abs().max().item(), (diff, ref.abs().max().item())
     for k in ("intra_text_embed", "intra_obj_embeds", "inter_obj_embeds", "scene_embed"):
-        d = (out[k].float().cpu() - g[k]).abs().max().item()
+        got, want = out[k].float().cpu(), g[k]
+        if k == "intra_obj_embeds":
+            # outputs of the JOINT layers: the bf16 fast path runs them on the valid rows only and returns zeros at the
+            # padded object slots, where the reference leaves the results of its masked-out rows (no head or loss reads
+            # them: tests/test_gpu_joint_compact.py)
+            assert float(got[~masks].abs().max() if (~masks).any() else 0.0) == 0.0
+            got, want = got[masks], want[masks]
+        d = (got - want).abs().max().item()
         assert d < 0.08, (k, d)
     for k, v in g["losses"].items():
         assert abs(losses[k].item() - v) < 3e-2 * max(1.0, abs(v)), (k, losses[k].item(), v)
