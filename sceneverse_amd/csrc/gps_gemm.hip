@@ -1202,11 +1202,19 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       GPS_PTRACE(P, t, 0);
       read_b(cur + OFF_B0, bq0);
       __builtin_amdgcn_sched_barrier(0);
+      // transposing B reads (NN, TN): a read segment that holds any of them costs ~450 - 600 cycles whether it holds 8 or
+      // 32 (profiles/r6/gemm_sched_ab.txt), one without ~230: B1 (phase 2's operand; its registers are free since phase 3
+      // of the previous tile, its half-tile landed with that tile's phase-4 wait) is read HERE, phase 2 reads nothing
+      if constexpr (BTR) {
+        read_b(cur + OFF_B1, bq1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       read_a(cur + OFF_A0);
       if (n1) issue(sa1, oth + OFF_A1, t + 1);
       __builtin_amdgcn_sched_barrier(0);
-      // the B reads (issued first) are done: B0 may be refilled one phase from now
+      // the B0 reads (issued first) are done: B0 may be refilled one phase from now
       if constexpr (ATR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (tr reads: two per fragment; wait for all)
+      else if constexpr (BTR) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // 8 + 8 tr reads of B0, B1, then 8 of A0: >= 9 retired
       else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
       GPS_PTRACE(P, t, 1);
       __builtin_amdgcn_s_barrier();
@@ -1220,7 +1228,7 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       __builtin_amdgcn_s_barrier();
       // ---- phase 2: C01 ----
       GPS_PTRACE(P, t, 4);
-      read_b(cur + OFF_B1, bq1);
+      if constexpr (!BTR) read_b(cur + OFF_B1, bq1);
       if (n2) issue(sb0, cur + OFF_B0, t + 2);
       __builtin_amdgcn_sched_barrier(0);
       GPS_PTRACE(P, t, 5);

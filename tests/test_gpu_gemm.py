@@ -382,6 +382,43 @@ def test_device_side_row_extent_forward_and_input_gradient(form, variant):
         assert torch.isnan(y[first_dead:].float()).all(), (form, variant, ext)
 
 
+@pytest.mark.parametrize("form", ["nt", "nn"])
+@pytest.mark.parametrize("M,N,K", [(12608, 768, 3072), (5120, 2376, 768), (8320, 768, 776), (5000, 520, 1536)])
+def test_stream_k_variant(form, M, N, K):
+    """Variant 13 (gemm8p_sk_kernel: equal K-tile shares per CU, partial tiles through fp32 slabs + arrival flags) against
+    fp32 torch.mm and against the default variant; the arrival words are back at zero after every launch, so the same
+    workspace serves consecutive launches; ragged K tail (776) and a device-side row extent included.  Not selected by
+    pick_variant: this test keeps the explicit variant honest."""
+    lib = _native.load()
+    ws = torch.zeros(int(lib.gps_gemm_sk_workspace_bytes()) // 4, device=DEV)
+    x = _rand16(M, K, seed=51)
+    b = torch.randn(N, device=DEV)
+    if form == "nt":
+        w = _rand16(N, K, scale=0.05, seed=52)
+        ref = x.float() @ w.float().t() + b
+        call = lambda y, v, **kw: G.gemm(_native.GEMM_NT, _native.EPI_BIAS, M, N, K, x, K, w, K, y, N, bias=b, variant=v, **kw)  # noqa: E731
+    else:
+        w = _rand16(K, N, scale=0.05, seed=53)
+        ref = x.float() @ w.float() + b
+        call = lambda y, v, **kw: G.gemm(_native.GEMM_NN, _native.EPI_BIAS, M, N, K, x, K, w, N, y, N, bias=b, variant=v, **kw)  # noqa: E731
+    y7 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    call(y7, 7)
+    for rep in range(2):
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        call(y, 13, workspace=ws)
+        _close16(y, ref, f"stream-K {form} {M}x{N}x{K} launch {rep}")
+        # different summation order of the K shares: one bf16 rounding step apart from the default variant at most
+        assert (y.float() - y7.float()).abs().max().item() <= TOL16 * ref.abs().max().item()
+    flags = ws[:1024].view(torch.int32)
+    assert int(flags.abs().sum()) == 0, "arrival / error words not reset"
+    ext = M - 300
+    rows = torch.tensor([ext], dtype=torch.int32, device=DEV)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call(y, 13, workspace=ws, extent_dev=rows)
+    _close16(y[:ext], ref[:ext], f"stream-K {form} extent")
+    assert torch.isnan(y[-(-ext // 256) * 256:].float()).all()
+
+
 def _grouped(probs):
     """probs: list of dicts(dy (T, M) bf16, x (T, N) bf16, C fp32 (M, N), colsum or None, accumulate, extent or None)."""
     import ctypes

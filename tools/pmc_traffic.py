@@ -24,7 +24,7 @@ NAMES = [
     (r"fps_resident_kernel<1>", "furthest_point_sampling(n=32,m=16)"),
     (r"ball_query_kernel<16", "ball_query(n=1024,m=32,ns=32)"),
     (r"ball_query_kernel<1,", "ball_query(n=32,m=16,ns=32)"),
-    (r"wgrad_grouped_kernel", "gemm_tn_grouped(problems=68)"),
+    (r"wgrad_grouped_kernel", "gemm_tn_grouped(problems=69)"),
     (r"ball_query_small_kernel", "ball_query(n=32,m=16,ns=32)"),
     (r"add_dropout_ln_bwd_kernel", "add_dropout_layernorm_backward"),
     (r"add_dropout_ln_fwd_kernel", "add_dropout_layernorm_forward"),

@@ -99,8 +99,10 @@ def main():
         GM.linear_wgrad(dyb, x, rows_dev=n_valid)
     print("valid text rows", int(n_valid), "of", rows_all, flush=True)
     # [r4] the grouped weight-gradient launch of the step: the 69 problems of one backward pass (4 text layers over the
-    # live text rows, 4 object layers over 5 120 rows, 4 joint layers over 8 320 rows), written into fresh buffers
+    # live text rows, 4 object layers over 5 120 rows, 4 joint layers over the live joint rows [r6: sentence tokens +
+    # real objects of the bench batch, the device-side extent of the compacted unified encoder]), written into fresh buffers
     probs, keep = [], []
+    n_joint = (d["txt_masks"].sum() + d["obj_masks"].sum()).to(torch.int32).reshape(1).to(dev)
 
     def add(T, parts, K_in, ext=None):
         dy = (0.1 * torch.randn(T, sum(parts), device=dev)).to(torch.bfloat16)
@@ -120,14 +122,14 @@ def main():
         add(rows_all, [768, 768, 768], 768, n_valid), add(rows_all, [768], 768, n_valid)
         add(rows_all, [3072], 768, n_valid), add(rows_all, [768], 3072, n_valid)
         add(5120, [768, 768, 768, 72], 768), add(5120, [768], 768), add(5120, [2048], 768), add(5120, [768], 2048)
-        add(8320, [2304], 768), add(8320, [768], 768), add(8320, [2048], 768), add(8320, [768], 2048)
+        add(8320, [2304], 768, n_joint), add(8320, [768], 768, n_joint), add(8320, [2048], 768, n_joint), add(8320, [768], 2048, n_joint)
     # [r5] + the masked-LM head's transform (dense 768 -> 768 over the labelled rows only, modules/heads/pretrain_head.py)
     n_lm = torch.tensor([480], dtype=torch.int32, device=dev)
     add(3200, [768], 768, n_lm)
     arr = (_native.WgradProblem * len(probs))(*probs)
     for _ in range(3):
         _native.check(_native.load().gps_gemm_wgrad_grouped(arr, len(probs), torch.cuda.current_stream().cuda_stream), "wgrad_grouped")
-    print("grouped weight gradients:", len(probs), "problems", flush=True)
+    print("grouped weight gradients:", len(probs), "problems; live joint rows", int(n_joint), flush=True)
     ps = [torch.nn.Parameter(torch.randn(4096, 768, device=dev)) for _ in range(8)]
     from sceneverse_amd.optim.fused_adamw import GpsAdamW
     opt = GpsAdamW(ps, lr=1e-3)
