@@ -1197,7 +1197,7 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
 #pragma clang loop unroll(disable)
     for (int t = 0; t < nst; ++t) {
       const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
-      GPS_TRACE(P, 8 + t);
+      if (t < 24) GPS_TRACE(P, 8 + t);            // slots 8..31; 32.. hold the phase stamps of K tile 8
       // ---- phase 1: C00 ----
       GPS_PTRACE(P, t, 0);
       read_b(cur + OFF_B0, bq0);
@@ -1920,6 +1920,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_p
     // every scalar load of the record has landed before the tile starts: the tile's counted lgkmcnt waits must only
     // ever see its own LDS traffic
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef GPS_GEMM_TRACE
+    P.trace = trace ? trace + (size_t)512 * kTraceSlots : nullptr;   // the tile's own stamps (phases of its 9th K tile): second region of the probe's buffer
+#endif
     gemm8p_tile<true, true, EPI_F32>(P, smem, lane, wave, tile_m * 256, tile_n * 256, tile_n, 0, 0, nst, k_eff);
 #ifdef GPS_GEMM_TRACE
     tr_kt += (unsigned long long)nst;

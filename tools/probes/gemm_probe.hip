@@ -323,7 +323,7 @@ static void summarize_trace(const std::vector<unsigned long long> &tr, int wgs, 
     total.push_back(cyc);
     start_rt.push_back((double)(t[4] - rt0) / 100.0);
     end_rt.push_back((double)(t[5] - rt0) / 100.0);
-    for (int k = 9; k < kTraceSlots; ++k)
+    for (int k = 9; k < 32; ++k)
       if (t[k] && t[k - 1]) ktile.push_back((double)(t[k] - t[k - 1]));
   }
   auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
@@ -533,12 +533,12 @@ static void cmd_wgrad(int argc, char **argv) {
   CK(hipStreamCreate(&st));
   const int max_wgs = 512;
   unsigned long long *tr;
-  CK(hipMalloc(&tr, (size_t)max_wgs * gps_gemm::kTraceSlots * 8));
+  CK(hipMalloc(&tr, (size_t)2 * max_wgs * gps_gemm::kTraceSlots * 8));      // [the launch's stamps | the tile function's own]
   for (int mode = 1; mode >= 0; --mode) {
     gps_gemm_wgrad_grouped_set_xcd_queues(mode);
     for (int i = 0; i < 2; ++i) gps_gemm_wgrad_grouped(probs.data(), (int)probs.size(), (gps_stream_t)st);
     CK(hipStreamSynchronize(st));
-    CK(hipMemset(tr, 0, (size_t)max_wgs * gps_gemm::kTraceSlots * 8));
+    CK(hipMemset(tr, 0, (size_t)2 * max_wgs * gps_gemm::kTraceSlots * 8));
     gps_gemm::g_probe_trace = tr;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -550,7 +550,7 @@ static void cmd_wgrad(int argc, char **argv) {
     gps_gemm::g_probe_trace = nullptr;
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> h((size_t)max_wgs * gps_gemm::kTraceSlots);
+    std::vector<unsigned long long> h((size_t)2 * max_wgs * gps_gemm::kTraceSlots);
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     std::vector<double> per_kt, busy, endt;
     unsigned long long rt0 = ~0ull, kts = 0, tiles = 0;
@@ -570,6 +570,21 @@ static void cmd_wgrad(int argc, char **argv) {
            "workgroup finish us p10 %.1f p50 %.1f p90 %.1f max %.1f; ideal at p50 rate %.1f us\n",
            mode, 1e3 * ms, flops / (1e3 * ms) * 1e-6, n, tiles, kts, per_kt[n / 10], per_kt[n / 2], per_kt[n * 9 / 10], endt[n / 10], endt[n / 2],
            endt[n * 9 / 10], endt[n - 1], (double)kts * per_kt[n / 2] / (double)n);
+    // phases of the 9th K tile of each workgroup's LAST tile (waves 0 / 4), medians over the workgroups, shader cycles
+    // incl. ~170 per stamp: [reads, barrier + lgkm, mfma, barrier] x 4
+    for (int wv = 0; wv < 2; ++wv) {
+      printf("  phase cycles wave %d:", wv ? 4 : 0);
+      for (int i = 0; i < 16; ++i) {
+        std::vector<double> d;
+        for (int w = 0; w < max_wgs; ++w) {
+          const unsigned long long *t = &h[(size_t)(max_wgs + w) * gps_gemm::kTraceSlots + 32 + 32 * wv];
+          if (t[i] && t[i + 1] && t[i + 1] > t[i]) d.push_back((double)(t[i + 1] - t[i]));
+        }
+        std::sort(d.begin(), d.end());
+        printf("%s%.0f", (i % 4) ? " " : " | ", d.empty() ? 0.0 : d[d.size() / 2]);
+      }
+      printf("\n");
+    }
   }
 }
 
