@@ -602,6 +602,14 @@ GPS_API int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq
 GPS_API int gps_rows_plan(int n_seq, int seq_len, const unsigned char *valid, long long *perm, long long *inv, int *cu, int *n_live,
                           gps_stream_t stream);
 
+/* Masked row gather: out[i] (d fp32) = src[idx[i]] when row i is ON -- i < *n_live (n_live non-NULL), valid[i] != 0 (valid
+ * non-NULL), 0 <= idx[i] < n_src -- else zeros; out16 (optional) the same rows rounded to bf16.  d % 4 == 0.  With perm / inv
+ * of gps_rows_plan it is the pack of the joint rows (idx = perm, n_live), the unpack into the padded layout (idx = inv,
+ * valid) and the gradient of either (the other call): replaces index_select + where and, in backward, the zero-fill +
+ * atomic index_add_ autograd derives (reference: the padded layout of modules/grounding/unified_encoder.py:147-177). */
+GPS_API int gps_rows_gather(int n_out, int n_src, int d, const float *src, const long long *idx, const unsigned char *valid,
+                            const int *n_live, float *out, unsigned short *out16, gps_stream_t stream);
+
 /* ---- box-location embedding  y = LayerNorm(x W^T + b)  (tiny reduction length) ---------------------------------
  * Replaces `loc_layers = nn.Sequential(nn.Linear(dim_loc, hidden), nn.LayerNorm(hidden))` of the object encoder and the
  * unified encoder (modules/vision/pcd_openvocab_encoder.py:64-66, :177; modules/grounding/unified_encoder.py:28-30, :158).

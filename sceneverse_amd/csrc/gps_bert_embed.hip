@@ -448,6 +448,32 @@ __global__ __launch_bounds__(kThreads) void plan_kernel(int n_seq, int seq_len, 
     n_live[0] = total;
   }
 }
+// out[i] = src[idx[i]] for the rows that are ON -- i < *n_live (when given) and valid[i] != 0 (when given) and idx[i] inside
+// the source -- else zeros; optionally also as bf16.  One wave per row, 16 bytes per lane and step.  With a row permutation
+// and its inverse (gps_rows_plan) this one kernel is the pack (idx = perm, n_live), the unpack (idx = inv, valid) and both of
+// their gradients (the same two calls with the roles of the index tensors swapped): no zero-fill + atomic index_add_.
+__global__ __launch_bounds__(256) void rows_gather_kernel(int n_out, int n_src, int d4, const float4 *__restrict__ src,
+                                                          const long long *__restrict__ idx, const unsigned char *__restrict__ valid,
+                                                          const int *__restrict__ n_live, float4 *__restrict__ out,
+                                                          uint2 *__restrict__ out16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int live = n_live ? min(n_out, max(*n_live, 0)) : n_out;
+  for (int r = blockIdx.x * 4 + wave; r < n_out; r += gridDim.x * 4) {
+    bool on = r < live && (!valid || valid[r] != 0);
+    long long s = on ? idx[r] : 0;
+    on = on && s >= 0 && s < (long long)n_src;
+    for (int c = lane; c < d4; c += 64) {
+      const float4 v = on ? src[(size_t)s * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      out[(size_t)r * d4 + c] = v;
+      if (out16) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+        const bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        out16[(size_t)r * d4 + c] = __builtin_bit_cast(uint2, h);
+      }
+    }
+  }
+}
+
 }  // namespace gps_rowplan
 
 
@@ -575,6 +601,18 @@ int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq_full, i
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 
+
+int gps_rows_gather(int n_out, int n_src, int d, const float *src, const long long *idx, const unsigned char *valid,
+                    const int *n_live, float *out, unsigned short *out16, gps_stream_t stream) {
+  if (n_out < 0 || n_src < 1 || d < 4 || !src || !idx || !out) return GPS_ERR_INVALID_ARGUMENT;
+  if (d % 4) return GPS_ERR_UNSUPPORTED;
+  if (n_out == 0) return GPS_OK;
+  const int blocks = (n_out + 3) / 4 < 4096 ? (n_out + 3) / 4 : 4096;
+  hipLaunchKernelGGL(gps_rowplan::rows_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_out, n_src, d / 4,
+                     reinterpret_cast<const float4 *>(src), idx, valid, n_live, reinterpret_cast<float4 *>(out),
+                     reinterpret_cast<uint2 *>(out16));
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
 
 int gps_rows_plan(int n_seq, int seq_len, const unsigned char *valid, long long *perm, long long *inv, int *cu, int *n_live,
                   gps_stream_t stream) {

@@ -32,6 +32,10 @@
 
 namespace gps { const int *object_extent(); }   // gps_point_ops.hip
 
+#ifndef GPS_GEMM_8P_PHASES
+#define GPS_GEMM_8P_PHASES 2      // phases per K tile of the two-group 256 x 256 kernel (4 = the walk of rounds 3 - 6a; A/B builds)
+#endif
+
 namespace gps_gemm {
 
 using namespace gps_gemm_layout;
@@ -1194,6 +1198,67 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
     GPS_TRACE(P, 1);
     if (wr == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind
 
+#if GPS_GEMM_8P_PHASES == 2
+    // TWO phases of 32 MFMAs per K tile: [B0 B1 A0 reads | copies] barrier [C00 C01] barrier, [A1 reads | copies | vmcnt]
+    // barrier [C11 C10] barrier.  A read segment with transposing reads costs 450 - 600 cycles whatever it holds
+    // (profiles/r6/gemm_sched_ab.txt): behind a 16-MFMA segment of the other group (290 cycles) it is exposed, behind a
+    // 32-MFMA one (580) it is not -- and a K tile takes 4 barriers instead of 8.  Same half-tile protocol as the
+    // four-phase walk with phases (1, 2) -> A and (3, 4) -> B: A1(t + 1) is requested in phase A, B0 A0 B1 of tile t + 2 in
+    // phase B (all three halves were last read in phase A); every wave retires its fragment reads BEFORE the first
+    // barrier of a phase (group 1's first barrier is group 0's second: what group 0 overwrites after it must have been
+    // read by group 1 before it).
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < nst; ++t) {
+      const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
+      if (t < 24) GPS_TRACE(P, 8 + t);            // slots 8..31; 32.. hold the phase stamps of K tile 8
+      // ---- phase A: C00, C01 ----
+      GPS_PTRACE(P, t, 0);
+      read_b(cur + OFF_B0, bq0);
+      read_b(cur + OFF_B1, bq1);
+      read_a(cur + OFF_A0);
+      if (n1) issue(sa1, oth + OFF_A1, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      GPS_PTRACE(P, t, 1);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 2);
+      mfma16(acc[0][0], bq0);
+      mfma16(acc[0][1], bq1);
+      colsum8(csum[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 3);
+      __builtin_amdgcn_s_barrier();
+      GPS_PTRACE(P, t, 4); GPS_PTRACE(P, t, 5); GPS_PTRACE(P, t, 6); GPS_PTRACE(P, t, 7);
+      // ---- phase B: C11, C10 ----
+      GPS_PTRACE(P, t, 8);
+      read_a(cur + OFF_A1);
+      if (n2) {
+        issue(sb0, cur + OFF_B0, t + 2);
+        issue(sa0, cur + OFF_A0, t + 2);
+        issue(sb1, cur + OFF_B1, t + 2);
+        wait_vmcnt<6>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      GPS_PTRACE(P, t, 9);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 10);
+      mfma16(acc[1][1], bq1);
+      mfma16(acc[1][0], bq0);
+      colsum8(csum[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      GPS_PTRACE(P, t, 11);
+      __builtin_amdgcn_s_barrier();
+      GPS_PTRACE(P, t, 12); GPS_PTRACE(P, t, 13); GPS_PTRACE(P, t, 14); GPS_PTRACE(P, t, 15); GPS_PTRACE(P, t, 16);
+      unsigned char *tmp = cur;
+      cur = oth;
+      oth = tmp;
+    }
+#else
 #pragma clang loop unroll(disable)
     for (int t = 0; t < nst; ++t) {
       const bool n1 = t + 1 < nst, n2 = t + 2 < nst;
@@ -1276,6 +1341,7 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       cur = oth;
       oth = tmp;
     }
+#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();
   }
 

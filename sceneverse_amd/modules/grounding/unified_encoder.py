@@ -130,7 +130,7 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         back into the (B, T, D) layout with ZEROS at the padded positions (the reference leaves unspecified values there).
         At the bench workload 60 % of the 8 320 joint rows are valid."""
         from ... import _native
-        from ..language.bert import _UnpadRows, _ZeroDeadRows
+        from ..language.bert import _GatherRows
         from ..layers import gemm
         from ..layers.fused_attention import fused_varlen_self_attention
         from ..layers.fused_norm import add_dropout_layer_norm
@@ -149,8 +149,10 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         joint = torch.cat((txt_embeds, obj_embeds), dim=1) + extra
         # rows past n_live of the compact buffers are never written by the extent-aware kernels: their (undefined)
         # gradients must not flow back
-        x = _ZeroDeadRows.apply(joint.reshape(n, D).index_select(0, perm), n_live)
-        extra_c = _ZeroDeadRows.apply(extra.reshape(n, D).index_select(0, perm), n_live)
+        # (one launch each, forward and backward: gps_rows_gather with perm / inv; zeros in the dead rows)
+        valid8 = valid.view(torch.uint8)
+        x = _GatherRows.apply(joint.reshape(n, D), perm, None, n_live, inv, valid8, None)
+        extra_c = _GatherRows.apply(extra.reshape(n, D), perm, None, n_live, inv, valid8, None)
         x16 = x
         n_layers = len(self.unified_encoder)
         for li, layer in enumerate(self.unified_encoder):
@@ -164,7 +166,7 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
                                training, rows_dev=n_live)
             x, x16 = add_dropout_layer_norm(x, ffn_out, layer.norm2, layer.dropout2.p, training, want_bf16=True, rows_dev=n_live,
                                             post=extra_c if li + 1 < n_layers else None)
-        out = _UnpadRows.apply(x, inv, valid[:, None]).view(B, T, D)
+        out = _GatherRows.apply(x, inv, valid8, None, perm, None, n_live).view(B, T, D)
         return torch.split(out, [Lt, T - Lt], dim=1)
 
     def forward(self, txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks,

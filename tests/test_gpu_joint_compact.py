@@ -36,6 +36,73 @@ def test_rows_plan_matches_a_stable_sort():
         assert int(n_live.item()) == int(valid.sum())
 
 
+def _plan(valid):
+    from sceneverse_amd import _native
+    n_seq, L = valid.shape
+    n = n_seq * L
+    v = valid.to(DEV).reshape(-1)
+    perm = torch.empty(n, dtype=torch.int64, device=DEV)
+    inv = torch.empty(n, dtype=torch.int64, device=DEV)
+    cu = torch.empty(n_seq + 1, dtype=torch.int32, device=DEV)
+    n_live = torch.empty(1, dtype=torch.int32, device=DEV)
+    _native.check(_native.load().gps_rows_plan(n_seq, L, v.view(torch.uint8).data_ptr(), perm.data_ptr(), inv.data_ptr(),
+                                              cu.data_ptr(), n_live.data_ptr(), torch.cuda.current_stream().cuda_stream), "rows_plan")
+    return v, perm, inv, n_live
+
+
+@pytest.mark.parametrize("n_seq,L,D", [(7, 13, 768), (64, 130, 768), (3, 5, 8), (1, 1, 4)])
+def test_rows_gather_packs_and_unpacks_with_exact_gradients(n_seq, L, D):
+    """gps_rows_gather through _GatherRows: pack (perm, n_live) == index_select with zeros in the dead rows, unpack (inv,
+    valid) == the padded layout with zeros at invalid positions; both are copies, so values AND gradients are bit-equal to
+    the torch formulation (index_select / where; gradient = zero-fill + index_add_ of distinct rows)."""
+    from sceneverse_amd.modules.language.bert import _GatherRows
+    g = torch.Generator().manual_seed(11)
+    valid = torch.rand(n_seq, L, generator=g) < 0.6
+    if n_seq > 2:
+        valid[0] = False
+        valid[2] = True
+    v, perm, inv, n_live = _plan(valid)
+    n, live = n_seq * L, int(valid.sum())
+    v8 = v.view(torch.uint8)
+    x = torch.randn(n, D, generator=g).to(DEV).requires_grad_(True)
+    # pack
+    packed = _GatherRows.apply(x, perm, None, n_live, inv, v8, None)
+    ref = x.detach().index_select(0, perm)
+    ref[live:] = 0
+    assert torch.equal(packed.detach(), ref)
+    w = torch.randn(n, D, generator=g).to(DEV)
+    w_nan = w.clone()
+    w_nan[live:] = float("nan")                       # gradients of dead packed rows are undefined memory in the step
+    (gx,) = torch.autograd.grad(packed, x, w_nan)
+    ref_g = torch.zeros(n, D, device=DEV)
+    ref_g[perm[:live]] = w[:live]
+    assert torch.equal(gx, ref_g)
+    # unpack
+    y = torch.randn(n, D, generator=g).to(DEV)
+    y[live:] = float("nan")                           # rows no kernel wrote
+    y.requires_grad_(True)
+    out = _GatherRows.apply(y, inv, v8, None, perm, None, n_live)
+    ref = torch.where(v[:, None], y.detach().nan_to_num(0.0).index_select(0, inv), torch.zeros((), device=DEV))
+    assert torch.equal(out.detach(), ref)
+    (gy,) = torch.autograd.grad(out, y, w)
+    ref_g = torch.zeros(n, D, device=DEV)
+    ref_g[:live] = w.index_select(0, perm[:live])
+    assert torch.equal(gy, ref_g)
+    # bf16 copy and argument checks of the C entry
+    from sceneverse_amd import _native
+    o32, o16 = _GatherRows._run(x.detach(), perm, None, n_live, want16=True)
+    assert torch.equal(o16, o32.to(torch.bfloat16))
+    lib = _native.load()
+    s = torch.cuda.current_stream().cuda_stream
+    xd = x.detach()
+    assert lib.gps_rows_gather(n, n, 6, xd.data_ptr(), perm.data_ptr(), None, None, o32.data_ptr(), None, s) == _native.GPS_ERR_UNSUPPORTED
+    assert lib.gps_rows_gather(n, n, D, None, perm.data_ptr(), None, None, o32.data_ptr(), None, s) == _native.GPS_ERR_INVALID_ARGUMENT
+    bad = perm.clone()
+    bad[0] = n + 5                                     # an index outside the source reads zeros, never memory
+    o, _ = _GatherRows._run(xd, bad, None, None)
+    assert torch.equal(o[0], torch.zeros(D, device=DEV)) and torch.equal(o[1:], xd.index_select(0, perm)[1:])
+
+
 def test_gps_model_compact_joint_rows_equal_padded_rows(golden_cpu):
     from oracle.param_fill import fill_params
     from sceneverse_amd.model.build import build_model
