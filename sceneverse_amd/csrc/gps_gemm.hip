@@ -1204,7 +1204,9 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
     // (profiles/r6/gemm_sched_ab.txt): behind a 16-MFMA segment of the other group (290 cycles) it is exposed, behind a
     // 32-MFMA one (580) it is not -- and a K tile takes 4 barriers instead of 8.  Same half-tile protocol as the
     // four-phase walk with phases (1, 2) -> A and (3, 4) -> B: A1(t + 1) is requested in phase A, B0 A0 B1 of tile t + 2 in
-    // phase B (all three halves were last read in phase A); every wave retires its fragment reads BEFORE the first
+    // phase B (all three halves were last read in phase A), and each phase waits only for the halves the NEXT phase
+    // reads (a wait for "all of tile t + 1" in phase B gave A1(t + 1) one phase to arrive: the single-problem TN loop
+    // stalled 700 cycles per K tile there); every wave retires its fragment reads BEFORE the first
     // barrier of a phase (group 1's first barrier is group 0's second: what group 0 overwrites after it must have been
     // read by group 1 before it).
 #pragma clang loop unroll(disable)
@@ -1216,7 +1218,15 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
       read_b(cur + OFF_B0, bq0);
       read_b(cur + OFF_B1, bq1);
       read_a(cur + OFF_A0);
-      if (n1) issue(sa1, oth + OFF_A1, t + 1);
+      // copies in flight, oldest first: A1(t) | B0 A0 B1 (t + 1) | A1(t + 1) | B0 A0 B1 (t + 2) | ...  Each wait lets the four
+      // newest halves (8 instructions) stay in flight, so every half has a whole K tile to land: here A1(t), read in
+      // phase B, must be in; in phase B the three halves of tile t + 1
+      if (n1) {
+        issue(sa1, oth + OFF_A1, t + 1);
+        wait_vmcnt<8>();
+      } else {
+        wait_vmcnt<0>();
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       GPS_PTRACE(P, t, 1);
@@ -1237,7 +1247,9 @@ __device__ __forceinline__ void gemm8p_tile(const Params &P, unsigned char *smem
         issue(sb0, cur + OFF_B0, t + 2);
         issue(sa0, cur + OFF_A0, t + 2);
         issue(sb1, cur + OFF_B1, t + 2);
-        wait_vmcnt<6>();
+        wait_vmcnt<8>();
+      } else if (n1) {
+        wait_vmcnt<2>();                                      // only A1(t + 1) is newer than the halves phase A reads next
       } else {
         wait_vmcnt<0>();
       }

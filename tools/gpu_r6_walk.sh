@@ -10,4 +10,4 @@ done
 for b in gemm_probe_e1 gemm_probe; do
   echo "== $b"; PROBE=tools/probes/$b bash tools/gpu_r6_trace.sh r6_walk_trace_$b '2 5 3072 768 12608 12' '1 0 12608 768 3072 12' | grep -v "start "
 done
-timeout 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_twin.py -m gpu -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_twin.py tests/test_gpu_joint_compact.py -m gpu -x -q 2>&1 | tail -5
