@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPS_HIP_ABI_VERSION 10
+#define GPS_HIP_ABI_VERSION 11
 
 #define GPS_OK 0
 #define GPS_ERR_INVALID_ARGUMENT (-1) /* negative size, NULL pointer with non-empty tensor ...   */
@@ -487,6 +487,16 @@ GPS_API int gps_add_dropout_layernorm_backward_post(int n_rows, int d, int x_bf1
                                                     unsigned long long seed, const void *seed_dev, void *dx, void *dh,
                                                     float *dgamma_part, float *dbeta_part, const int *rows_dev,
                                                     float *dpost, gps_stream_t stream);
+/* ... with dpost_accumulate != 0 the launch ADDS its gradient of the addend to dpost (rows below the device count): the
+ * SAME addend enters every layer (the reference re-adds the location / type embeddings per layer), so the layers'
+ * backward launches, which run last layer first, build its gradient in one buffer -- the first of them stores, the
+ * others add -- instead of one buffer each + an elementwise add per layer. */
+GPS_API int gps_add_dropout_layernorm_backward_post_acc(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                                        const void *dy_bf16, const void *x, const void *h, const float *gamma,
+                                                        const float *mean, const float *rstd, float p_drop,
+                                                        unsigned long long seed, const void *seed_dev, void *dx, void *dh,
+                                                        float *dgamma_part, float *dbeta_part, const int *rows_dev,
+                                                        float *dpost, int dpost_accumulate, gps_stream_t stream);
 
 /* ---- per-object input processing of the data loader ------------------------------------------------
  * Replaces ScanBase._obj_processing_post (data/datasets/base.py:697-740: optional rotation, centre/size

@@ -148,6 +148,7 @@ SIGNATURES = {
     "gps_add_dropout_layernorm_backward_rows": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 7,
     "gps_add_dropout_layernorm_forward_post": [_i] * 4 + [_vp] * 4 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 8,
     "gps_add_dropout_layernorm_backward_post": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 8,
+    "gps_add_dropout_layernorm_backward_post_acc": [_i] * 4 + [_vp] * 7 + [_f, ctypes.c_ulonglong] + [_vp] * 7 + [_i, _vp],
     "gps_attn_forward": [_i] * 4 + [_vp] * 3 + [_i] + [_vp] * 3 + [_f, ctypes.c_ulonglong, _vp, _vp, _i, _vp, _vp],
     "gps_attn_set_plain_blocks": [_i],
     "gps_sa_mlp_set_products": [_i],

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd
     const float *__restrict__ rstd_in, float p_drop, unsigned int thr, unsigned long long seed,
     const unsigned long long *__restrict__ seed_dev, TX *__restrict__ dx, TH *__restrict__ dh,
     float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, const int *__restrict__ rows_dev,
-    float *__restrict__ g_out) {
+    float *__restrict__ g_out, int g_acc) {
   extern __shared__ float red[];      // [kWaves][d] reused for dgamma then dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (rows_dev) n_rows = min(n_rows, *rows_dev);        // rows past it contribute nothing to dgamma / dbeta either
@@ -233,7 +233,15 @@ __global__ __launch_bounds__(kBlock, ITERS <= 3 ? 4 : 1) void add_dropout_ln_bwd
         const float4 g2 = to_f4(g2r[i]);
         g = make_float4(g.x + g2.x, g.y + g2.y, g.z + g2.z, g.w + g2.w);
       }
-      if (g_out) *reinterpret_cast<float4 *>(g_out + e0) = g;      // gradient of the output = gradient of a post-addend
+      if (g_out) {                                                 // gradient of the output = gradient of a post-addend
+        float4 go = g;
+        if (g_acc) {    // the post-addend's gradient so far (the later layers' launches stored / added theirs); read here, not with
+                        // the row's other loads: 12 more live registers there spill at 4 waves per SIMD (tests/test_asm_audit.py)
+          const float4 o = *reinterpret_cast<const float4 *>(g_out + e0);
+          go = make_float4(g.x + o.x, g.y + o.y, g.z + o.z, g.w + o.w);
+        }
+        *reinterpret_cast<float4 *>(g_out + e0) = go;
+      }
       const float4 xv = to_f4(xr[i]);
       float4 hv = to_f4(hr[i]);
       const unsigned int m = keep4(dr, e0);
@@ -637,7 +645,18 @@ int gps_add_dropout_layernorm_backward_post(int n_rows, int d, int x_bf16, int h
                                             unsigned long long seed, const void *seed_dev, void *dx, void *dh,
                                             float *dgamma_part, float *dbeta_part, const int *rows_dev, float *dpost,
                                             gps_stream_t stream) {
+  return gps_add_dropout_layernorm_backward_post_acc(n_rows, d, x_bf16, h_bf16, dy, dy_bf16, x, h, gamma, mean, rstd, p_drop, seed,
+                                                     seed_dev, dx, dh, dgamma_part, dbeta_part, rows_dev, dpost, 0, stream);
+}
+
+int gps_add_dropout_layernorm_backward_post_acc(int n_rows, int d, int x_bf16, int h_bf16, const void *dy,
+                                                const void *dy_bf16, const void *x, const void *h, const float *gamma,
+                                                const float *mean, const float *rstd, float p_drop,
+                                                unsigned long long seed, const void *seed_dev, void *dx, void *dh,
+                                                float *dgamma_part, float *dbeta_part, const int *rows_dev, float *dpost,
+                                                int dpost_accumulate, gps_stream_t stream) {
   if (dpost && (x_bf16 || ((uintptr_t)dpost & 15))) return GPS_ERR_UNSUPPORTED;
+  if (dpost_accumulate && !dpost) return GPS_ERR_INVALID_ARGUMENT;
   if (n_rows < 0 || d < 1 || p_drop < 0.f || p_drop >= 1.f) return GPS_ERR_INVALID_ARGUMENT;
   if ((d & 255) || d > 256 * gps_ln::kMaxIter || ((d >> 8) > 4 && (d >> 8) != 8)) return GPS_ERR_UNSUPPORTED;
   if (n_rows == 0) return GPS_OK;
@@ -651,7 +670,7 @@ int gps_add_dropout_layernorm_backward_post(int n_rows, int d, int x_bf16, int h
 #define GPS_LN_BWD_I(TX, TH, IT)                                                                                    \
   hipLaunchKernelGGL((gps_ln::add_dropout_ln_bwd_kernel<TX, TH, IT>), grid, block, lds, s, n_rows, d, (const TX *)dy, \
                      (const uint16_t *)dy_bf16, (const TX *)x, (const TH *)h, gamma, mean, rstd, p_drop, thr,       \
-                     seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part, rows_dev, dpost)
+                     seed, sd, (TX *)dx, (TH *)dh, dgamma_part, dbeta_part, rows_dev, dpost, dpost_accumulate ? 1 : 0)
 #define GPS_LN_BWD(TX, TH)                          \
   do { switch (d >> 8) {                            \
     case 1: GPS_LN_BWD_I(TX, TH, 1); break;         \

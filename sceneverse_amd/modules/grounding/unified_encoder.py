@@ -155,6 +155,8 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         extra_c = _GatherRows.apply(extra.reshape(n, D), perm, None, n_live, inv, valid8, None)
         x16 = x
         n_layers = len(self.unified_encoder)
+        from ..layers.fused_norm import SharedPostGrad
+        share = SharedPostGrad()         # gradient of extra_c: one buffer for the layers' backward launches
         for li, layer in enumerate(self.unified_encoder):
             sa = layer.self_attn
             training = layer.training
@@ -165,7 +167,7 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
             ffn_out = gemm.ffn(x16, layer.linear1, layer.linear2, gemm.activation_name(layer.activation), layer.dropout.p,
                                training, rows_dev=n_live)
             x, x16 = add_dropout_layer_norm(x, ffn_out, layer.norm2, layer.dropout2.p, training, want_bf16=True, rows_dev=n_live,
-                                            post=extra_c if li + 1 < n_layers else None)
+                                            post=extra_c if li + 1 < n_layers else None, post_share=(share, li == 0))
         out = _GatherRows.apply(x, inv, valid8, None, perm, None, n_live).view(B, T, D)
         return torch.split(out, [Lt, T - Lt], dim=1)
 
@@ -189,7 +191,10 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         # LayerNorm launch together with its bf16 copy (post_add)
         joint = joint + extra
         n_layers = len(self.unified_encoder)
+        from ..layers.fused_norm import SharedPostGrad
+        share = SharedPostGrad()
         for li, layer in enumerate(self.unified_encoder):
-            joint, _ = layer(joint, tgt_key_padding_mask=joint_pad, post_add=extra if li + 1 < n_layers else None)
+            joint, _ = layer(joint, tgt_key_padding_mask=joint_pad, post_add=extra if li + 1 < n_layers else None,
+                             post_share=(share, li == 0))
         txt_embeds, obj_embeds = torch.split(joint, [txt_len, obj_len], dim=1)
         return txt_embeds, obj_embeds

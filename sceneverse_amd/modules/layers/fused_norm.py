@@ -47,9 +47,23 @@ def _row_fraction(rows_dev: Optional[torch.Tensor], n: int):
     return lambda: min(1.0, max(0.0, float(snap.item()) / n))
 
 
+class SharedPostGrad:
+    """Gradient of an addend that enters SEVERAL layers' LayerNorm launches as `post` (the reference re-adds the location /
+    type embeddings in front of every layer): the layers' backward launches -- which run last layer first -- build it in ONE
+    buffer (the first to run stores, the others add, gps_add_dropout_layernorm_backward_post_acc) and only the launch
+    marked `final` (the FIRST layer in forward order: its backward runs after all the others') hands the buffer to autograd;
+    the others report no gradient for the addend.  Replaces one buffer + zero-fill per layer and autograd's adds."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
 class _AddDropoutLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev, want_bf16: bool, rows_dev=None, post=None):
+    def forward(ctx, x, h, gamma, beta, eps: float, p_drop: float, seed_dev, want_bf16: bool, rows_dev=None, post=None,
+                post_share=None):
+        ctx.post_share = post_share                         # (SharedPostGrad, final: bool) or None
         d = x.shape[-1]
         x2 = x.reshape(-1, d).contiguous()
         h2 = h.reshape(-1, d).contiguous()
@@ -90,9 +104,16 @@ class _AddDropoutLN(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dh = torch.empty_like(h2)
         want_dpost = ctx.post is not None and ctx.needs_input_grad[9]
-        dpost = torch.empty((n, d), dtype=torch.float32, device=x2.device) if want_dpost else None
-        if dpost is not None and rows_dev is not None:
-            dpost.zero_()                                      # rows past the device count are not written
+        share, final = ctx.post_share if (ctx.post_share is not None and want_dpost) else (None, True)
+        acc = 0
+        if share is not None and share.buf is not None:
+            dpost, acc = share.buf, 1                          # a later layer's launch started it
+        else:
+            dpost = torch.empty((n, d), dtype=torch.float32, device=x2.device) if want_dpost else None
+            if dpost is not None and rows_dev is not None:
+                dpost.zero_()                                  # rows past the device count are not written
+            if share is not None:
+                share.buf = dpost
         lib = _native.load()
         parts = int(lib.gps_ln_partial_rows(n))
         part = torch.empty((2, parts, d), dtype=torch.float32, device=x2.device)
@@ -100,12 +121,17 @@ class _AddDropoutLN(torch.autograd.Function):
         nbytes = n * d * (3 * x2.element_size() + 2 * h2.element_size())
         with torch.cuda.device(x2.device), _timed(f"add_dropout_layernorm_backward(rows={n},d={d})", nbytes,
                                                   work_fraction=_row_fraction(rows_dev, n)):
-            st = lib.gps_add_dropout_layernorm_backward_post(
+            st = lib.gps_add_dropout_layernorm_backward_post_acc(
                 n, d, int(x2.dtype == torch.bfloat16), int(h2.dtype == torch.bfloat16), dy2.data_ptr(),
                 _ptr(dy16_2), x2.data_ptr(), h2.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, 0,
                 _ptr(seed_dev), dx.data_ptr(), dh.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), _ptr(rows_dev),
-                _ptr(dpost), torch.cuda.current_stream().cuda_stream)
+                _ptr(dpost), acc, torch.cuda.current_stream().cuda_stream)
         _native.check(st, "add_dropout_layernorm_backward")
+        if share is not None:
+            if final:
+                share.buf = None                               # handed to autograd below; the next pass starts afresh
+            else:
+                dpost = None                                   # the final launch reports the sum
         if dpost is not None:
             dpost = dpost.view(ctx.post[0]).to(ctx.post[1])
         # dgamma / dbeta = column sums of the per-workgroup partial rows.  Inside gemm.grouped_wgrads() they are not
@@ -113,7 +139,7 @@ class _AddDropoutLN(torch.autograd.Function):
         # (gps_ln_reduce_partials_grouped writes gamma.grad / beta.grad); otherwise one reduce launch per LayerNorm.
         from . import gemm
         if gemm.defer_ln_param_grads(part, parts, d, *ctx.ln_params, needs=(ctx.needs_input_grad[2], ctx.needs_input_grad[3])):
-            return (dx.view(x_shape), dh.view(h_shape), None, None, None, None, None, None, None, dpost)
+            return (dx.view(x_shape), dh.view(h_shape), None, None, None, None, None, None, None, dpost, None)
         sums = torch.empty((2, d), dtype=torch.float32, device=x2.device)
         with torch.cuda.device(x2.device):
             st = lib.gps_ln_reduce_partials(parts, d, part.data_ptr(), sums.data_ptr(),
@@ -121,7 +147,7 @@ class _AddDropoutLN(torch.autograd.Function):
                                             torch.cuda.current_stream().cuda_stream)
         _native.check(st, "ln_reduce_partials")
         return (dx.view(x_shape), dh.view(h_shape), sums[0].to(g_dtype), sums[1].to(b_dtype),
-                None, None, None, None, None, dpost)
+                None, None, None, None, None, dpost, None)
 
 
 def supported(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm) -> bool:
@@ -134,12 +160,14 @@ def supported(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm) -> bool:
 
 def add_dropout_layer_norm(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm, p_drop: float = 0.0,
                            training: bool = False, want_bf16: bool = False, rows_dev: Optional[torch.Tensor] = None,
-                           post: Optional[torch.Tensor] = None):
+                           post: Optional[torch.Tensor] = None, post_share=None):
     """norm(x + dropout(h, p_drop, training)); y has x's dtype on the fused path.
     want_bf16: also return a bf16 copy of y written by the same launch (what the next GEMM reads
     under autocast; its gradient is added inside the fused backward) -> (y, y_bf16).
     post: optional addend of x's shape applied BEHIND the normalisation, y = norm(...) + post (and y_bf16 = bf16 of that
     sum): the per-layer `x + loc_embeds` / `joint + extra` of the NEXT encoder layer folded into this launch.
+    post_share: (SharedPostGrad, final) when the SAME `post` tensor enters several layers: see SharedPostGrad (final = this is
+    the first of those layers in forward order).
     rows_dev: int32 device word = number of leading rows (of the flattened (rows, d) view) that carry work; the other
     rows are neither read nor written (their content is undefined) and do not enter the dgamma / dbeta sums."""
     p = float(p_drop) if training else 0.0
@@ -156,7 +184,8 @@ def add_dropout_layer_norm(x: torch.Tensor, h: torch.Tensor, norm: nn.LayerNorm,
     if p > 0.0:
         from .fused_attention import _next_device_seed
         seed_dev = _next_device_seed(x.device)
-    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev, bool(want_bf16), rows_dev, post)
+    return _AddDropoutLN.apply(x, h, norm.weight, norm.bias, norm.eps, p, seed_dev, bool(want_bf16), rows_dev, post,
+                               post_share if post is not None else None)
 
 
 class _L2Normalize(torch.autograd.Function):

@@ -358,11 +358,11 @@ def _ffn(layer, x):
     return gemm.drive(_ffn_gen(layer, x))
 
 
-def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout, want_bf16: bool = False, post=None):
+def _res_norm(norm: nn.LayerNorm, x: Tensor, h: Tensor, drop: nn.Dropout, want_bf16: bool = False, post=None, post_share=None):
     """norm(x + drop(h)) [+ post]: one fused launch on the GPU (fused_norm), the plain ops elsewhere.
     want_bf16 (only meaningful under bf16 autocast): -> (y, bf16 copy of y for the next GEMM)."""
     from .fused_norm import add_dropout_layer_norm
-    return add_dropout_layer_norm(x, h, norm, drop.p, drop.training, want_bf16=want_bf16, post=post)
+    return add_dropout_layer_norm(x, h, norm, drop.p, drop.training, want_bf16=want_bf16, post=post, post_share=post_share)
 
 
 # Folding the next layer's `x + embedding` into this layer's last LayerNorm launch (fused_norm `post`): the sum and its
@@ -387,7 +387,7 @@ def _gemm_input(x: Tensor) -> Tensor:
     return alt if (alt is not None and alt.shape == x.shape) else x
 
 
-def _layer_output_gen(layer, tgt: Tensor, ffn_in: Tensor, post_add):
+def _layer_output_gen(layer, tgt: Tensor, ffn_in: Tensor, post_add, post_share=None):
     """Last step of a post-norm layer: norm2(tgt + dropout2(ffn)) [+ post_add].  With `post_add` (the addend the next
     layer would apply to its input: the re-added location / type embeddings) on the bf16 GPU path, the sum and its bf16
     copy leave the same launch; the copy travels as an attribute of the fp32 result for the next layer's `_gemm_input`."""
@@ -395,16 +395,17 @@ def _layer_output_gen(layer, tgt: Tensor, ffn_in: Tensor, post_add):
     if post_add is None:
         return _res_norm(layer.norm2, tgt, h, layer.dropout2)
     if _FUSE_POST_ADD and _bf16_mode(tgt) and tgt.dtype == torch.float32 and tgt.is_cuda:
-        y, y16 = _res_norm(layer.norm2, tgt, h, layer.dropout2, want_bf16=True, post=post_add)
+        # post_share: (fused_norm.SharedPostGrad, final) when the caller passes the SAME addend to several layers
+        y, y16 = _res_norm(layer.norm2, tgt, h, layer.dropout2, want_bf16=True, post=post_add, post_share=post_share)
         if y16 is not y:
             y._gps_bf16 = y16
         return y
     return _res_norm(layer.norm2, tgt, h, layer.dropout2) + post_add
 
 
-def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add):
+def _layer_output(layer, tgt: Tensor, ffn_in: Tensor, post_add, post_share=None):
     from . import gemm
-    return gemm.drive(_layer_output_gen(layer, tgt, ffn_in, post_add))
+    return gemm.drive(_layer_output_gen(layer, tgt, ffn_in, post_add, post_share))
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -425,7 +426,7 @@ class TransformerEncoderLayer(nn.Module):
         self.prenorm = prenorm
 
     def forward(self, tgt, tgt_mask: Optional[Tensor] = None,
-                tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None):
+                tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None, post_share=None):
         """post_add: optional tensor of tgt's shape added to the layer's OUTPUT (callers that re-add an embedding to
         every layer's input pass it to the previous layer instead: same sums, one launch less per layer)."""
         h = self.norm1(tgt) if self.prenorm else tgt
@@ -435,7 +436,7 @@ class TransformerEncoderLayer(nn.Module):
             b16 = _bf16_mode(tgt) and tgt.dtype == torch.float32
             tgt, ffn_in = _res_norm(self.norm1, tgt, h, self.dropout1, want_bf16=True) if b16 else \
                 (lambda t: (t, t))(_res_norm(self.norm1, tgt, h, self.dropout1))
-            return _layer_output(self, tgt, ffn_in, post_add), attn
+            return _layer_output(self, tgt, ffn_in, post_add, post_share), attn
         tgt = tgt + self.dropout1(h)
         # ref :147-153: the pre-norm variant normalises the residual stream itself before the FFN
         tgt = self.norm2(tgt)
@@ -456,19 +457,19 @@ class TransformerSpatialEncoderLayer(TransformerEncoderLayer):
             spatial_dim=spatial_dim, spatial_attn_fusion=spatial_attn_fusion)
 
     def forward(self, tgt, tgt_pairwise_locs, tgt_mask: Optional[Tensor] = None,
-                tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None):
+                tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None, post_share=None):
         from . import gemm
-        return gemm.drive(self.forward_gen(tgt, tgt_pairwise_locs, tgt_mask, tgt_key_padding_mask, post_add))
+        return gemm.drive(self.forward_gen(tgt, tgt_pairwise_locs, tgt_mask, tgt_key_padding_mask, post_add, post_share))
 
     def forward_gen(self, tgt, tgt_pairwise_locs, tgt_mask: Optional[Tensor] = None,
-                    tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None):
+                    tgt_key_padding_mask: Optional[Tensor] = None, post_add: Optional[Tensor] = None, post_share=None):
         """The layer as a generator of its GEMM calls (gemm.drive runs it alone, gemm.drive_pair beside another stack)."""
         h, attn = yield from self.self_attn.forward_gen(tgt, tgt, tgt, tgt_pairwise_locs,
                                                         key_padding_mask=tgt_key_padding_mask)
         b16 = _bf16_mode(tgt) and tgt.dtype == torch.float32
         tgt, ffn_in = _res_norm(self.norm1, tgt, h, self.dropout1, want_bf16=True) if b16 else \
             (lambda t: (t, t))(_res_norm(self.norm1, tgt, h, self.dropout1))
-        return (yield from _layer_output_gen(self, tgt, ffn_in, post_add)), attn
+        return (yield from _layer_output_gen(self, tgt, ffn_in, post_add, post_share)), attn
 
 
 class TransformerDecoderLayer(nn.Module):

@@ -126,7 +126,10 @@ class PointOpenVocabEncoder(nn.Module):
             loc_embeds = loc_embed(self.loc_layers[0], obj_locs)      # re-added every layer (ref :176-178); evaluated once
             obj_embeds = obj_embeds + loc_embeds
             n_layers = len(self.spatial_encoder)
+            from ..layers.fused_norm import SharedPostGrad
+            share = SharedPostGrad()     # the addend's gradient: one buffer for all layers' launches (layer 0's runs last)
             for li, layer in enumerate(self.spatial_encoder):     # later re-adds ride on the previous layer's last LayerNorm
                 obj_embeds, _ = yield from layer.forward_gen(obj_embeds, pairwise_locs, tgt_key_padding_mask=pad,
-                                                             post_add=loc_embeds if li + 1 < n_layers else None)
+                                                             post_add=loc_embeds if li + 1 < n_layers else None,
+                                                             post_share=(share, li == 0))
         return obj_embeds, obj_embeds_pre, obj_sem_cls

@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gps_hip.h but not exported"
     assert set(_native.SIGNATURES) <= set(declared)
-    assert lib.gps_abi_version() == 10
+    assert lib.gps_abi_version() == 11
     assert lib.gps_error_string(0) == b"ok"
     assert b"not supported" in lib.gps_error_string(-2)
 

@@ -202,6 +202,46 @@ def test_post_addend_rides_on_the_layernorm_launch(want_bf16, p):
             assert (a.float() - b.float()).abs().max().item() <= 2e-2 * scale      # h's gradient is bf16
 
 
+@pytest.mark.parametrize("rows", [None, 700])
+def test_shared_post_addend_gradient_is_built_in_one_buffer(rows):
+    """Three chained LayerNorm steps that add the SAME `post` (the per-layer re-added embeddings): with SharedPostGrad the
+    backward launches accumulate its gradient in one buffer and only the first layer's node reports it -- equal to
+    autograd's sum of three separate gradients (same addends; fp32 sums in another order: 1e-6 relative), all other
+    gradients bit-equal; a second backward pass through a fresh graph starts from an empty buffer."""
+    from sceneverse_amd.modules.layers.fused_norm import SharedPostGrad
+    n, d = 1000, 768
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(n, d, generator=g).to(DEV)
+    hs = [(0.5 * torch.randn(n, d, generator=g)).to(torch.bfloat16).to(DEV) for _ in range(3)]
+    post0 = torch.randn(n, d, generator=g).to(DEV)
+    norms = [nn.LayerNorm(d).to(DEV) for _ in range(3)]
+    w = torch.randn(n, d, generator=g).to(DEV)
+    rows_dev = torch.tensor([rows], dtype=torch.int32, device=DEV) if rows else None
+    live = rows or n
+
+    def run(shared):
+        x, post = x0.clone().requires_grad_(True), post0.clone().requires_grad_(True)
+        h_in = [h.clone().requires_grad_(True) for h in hs]
+        for p_ in (q for m in norms for q in m.parameters()):
+            p_.grad = None
+        share = SharedPostGrad() if shared else None
+        y = x
+        for li in range(3):
+            y = add_dropout_layer_norm(y, h_in[li], norms[li], 0.0, True, rows_dev=rows_dev, post=post,
+                                       post_share=(share, li == 0) if shared else None)
+        (y[:live] * w[:live]).sum().backward()
+        assert share is None or share.buf is None
+        return [x.grad[:live], post.grad[:live]] + [h.grad[:live] for h in h_in] + [q.grad for m in norms for q in m.parameters()]
+
+    ref, got, again = run(False), run(True), run(True)
+    for i, (a, b, c) in enumerate(zip(ref, got, again)):
+        assert torch.equal(b, c), i
+        if i == 1:
+            assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item() + 1e-7
+        else:
+            assert torch.equal(a.float(), b.float()), i
+
+
 def test_deferred_parameter_gradients_equal_the_autograd_ones():
     """Inside gemm.grouped_wgrads() the dgamma / dbeta of every fused residual-LayerNorm of a pass are reduced by ONE
     launch into gamma.grad / beta.grad (gps_ln_reduce_partials_grouped) instead of one reduce launch each: same values

@@ -20,7 +20,7 @@ def _mismatch(a, b):
 
 def test_library_is_the_hip_one():
     from sceneverse_amd import _native
-    assert _native.load().gps_abi_version() == 10
+    assert _native.load().gps_abi_version() == 11
 
 
 def test_fps_sa1_adversarial_and_synthetic():
