@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "gps_hip.h"
+#include "gps_device_flags.h"
 #include "gps_attention_ex.h"
 
 namespace gps_attn {
@@ -1263,7 +1264,8 @@ int launch_stream(const Params &P, bool backward, hipStream_t s) {
   if (lds > 160 * 1024) return GPS_ERR_UNSUPPORTED;
   const void *fn = backward ? (spatial ? (const void *)&attn_bwd_stream_kernel<true> : (const void *)&attn_bwd_stream_kernel<false>)
                             : (spatial ? (const void *)&attn_fwd_stream_kernel<true> : (const void *)&attn_fwd_stream_kernel<false>);
-  static size_t granted[4] = {0, 0, 0, 0};
+  static gps_dev::PerDevice<size_t, 4> granted_dev;
+  size_t *granted = granted_dev.row();
   const int slot = (backward ? 2 : 0) + (spatial ? 1 : 0);
   if (lds > 64 * 1024 && lds > granted[slot]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GPS_ERR_LAUNCH;
@@ -1309,7 +1311,8 @@ int launch(const Params &P, bool backward, hipStream_t s) {
   const bool resident = bwd_lds<NT>() <= kLdsMax;     // P^T / dS^T fit LDS
   const size_t lds = backward ? (resident ? bwd_lds<NT>() : bwd_recompute_lds<NT>()) : fwd_lds<NT>();
   if (lds > 64 * 1024) {
-    static bool done[4] = {false, false, false, false};
+    static gps_dev::PerDevice<bool, 4> done_dev;
+    bool *done = done_dev.row();
     const int slot = (backward ? 2 : 0) + (spatial ? 1 : 0);
     if (!done[slot]) {
       const void *fn =

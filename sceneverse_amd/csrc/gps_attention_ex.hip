@@ -20,6 +20,7 @@
 
 #include "gps_attention_ex.h"
 #include "gps_hip.h"
+#include "gps_device_flags.h"
 
 namespace gps_attn {
 namespace x {
@@ -690,7 +691,8 @@ int run_f32(const gps_attn_args *a, bool backward, hipStream_t s) {
   const int nw = pick_waves(backward ? (P.ntk > P.ntq ? P.ntk : P.ntq) : P.ntq);
   const dim3 grid(P.B * P.H), block(64 * nw);
   const bool spatial = P.sw != nullptr;
-  static size_t granted[4] = {0, 0, 0, 0};
+  static gps_dev::PerDevice<size_t, 4> granted_dev;
+  size_t *granted = granted_dev.row();
   int st;
   if (backward) {
     if (spatial) {
@@ -720,7 +722,8 @@ int run_fp8_forward(const gps_attn_args *a, hipStream_t s) {
   const size_t lds = rows * KS8 + 64 * (rows + 8) + 4 * rows + 4 * 32;
   const int nw = pick_waves(P.ntq);
   const dim3 grid(P.B * P.H), block(64 * nw);
-  static size_t granted[2] = {0, 0};
+  static gps_dev::PerDevice<size_t, 2> granted_dev;
+  size_t *granted = granted_dev.row();
   int st;
   if (P.sw != nullptr) {
     if ((st = set_lds(&attn_fp8_fwd_kernel<true>, lds, granted[1])) != GPS_OK) return st;

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "gps_hip.h"
+#include "gps_device_flags.h"
 #include "gps_attention_ex.h"
 
 namespace gps_attn_sp {
@@ -616,7 +617,8 @@ int launch(const Params &P, bool backward, hipStream_t s) {
   constexpr int kOccBig = NT <= 5 ? 4 : 2;
   const bool alt = backward && NT <= 5 && bwd_occ() == 3;
   // one flag per INSTANTIATION that can be launched below (forward | backward | backward at the alternative occupancy)
-  static bool granted[3] = {false, false, false};
+  static gps_dev::PerDevice<bool, 3> granted_dev;
+  bool *granted = granted_dev.row();
   const int which = !backward ? 0 : (alt ? 2 : 1);
   if (lds > 64 * 1024 && !granted[which]) {
     const void *fn = !backward ? (const void *)&fwd_kernel<NT>
@@ -923,7 +925,8 @@ template <int NT>
 int launch_plain(const Params &P, bool backward, hipStream_t s) {
   const dim3 grid(P.B * P.H), block(64 * NT);
   const size_t lds = backward ? bwd_lds<NT>() : fwd_lds<NT>();
-  static bool granted[2] = {false, false};
+  static gps_dev::PerDevice<bool, 2> granted_dev;
+  bool *granted = granted_dev.row();
   if (lds > 64 * 1024 && !granted[backward ? 1 : 0]) {
     const void *fn = backward ? (const void *)&pbwd_kernel<NT> : (const void *)&pfwd_kernel<NT>;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GPS_ERR_LAUNCH;

@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include "gps_hip.h"
+#include "gps_device_flags.h"
 
 namespace gps { const int *object_extent(); }   // gps_point_ops.hip: device int or null (gps_point_set_object_extent)
 
@@ -308,7 +309,8 @@ int launch_sa(int b, int n, int npoint, const float *xyz, const float *new_xyz, 
               const int32_t *idx, const float *wpack, float *out, hipStream_t s) {
   const size_t lds = sa_lds_bytes<CF, C1, C2, C3>(n, npoint);
   if (lds > 80 * 1024) return GPS_ERR_UNSUPPORTED;   // keep two workgroups per CU
-  static bool attr_set = false;                      // dynamic LDS above 64 KiB needs opting in
+  static gps_dev::PerDevice<bool, 1> attr_dev;          // dynamic LDS above 64 KiB needs opting in, per device
+  bool &attr_set = attr_dev.row()[0];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mlp_kernel<CF, C1, C2, C3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
