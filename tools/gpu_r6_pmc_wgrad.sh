@@ -5,7 +5,7 @@ set -u
 ulimit -c 0
 OUT=$PWD/gpurun_out/${1:-r6_pmc_wgrad}; mkdir -p $OUT
 export TMPDIR=/tmp
-P=$PWD/tools/probes/gemm_probe
+P=$PWD/${PROBE:-tools/probes/gemm_probe}
 : > $OUT/pmc_wgrad.txt
 g=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU"; do
