@@ -2026,10 +2026,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_grouped_kernel(int slot, int n_p
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int splits, long long elems, const float *__restrict__ partial,
                                                            float *__restrict__ out, long long ldo, int ncols,
                                                            int m_rows, const float *__restrict__ colsum_partial,
-                                                           float *__restrict__ colsum_out, int main_blocks) {
+                                                           float *__restrict__ colsum_out, int main_blocks,
+                                                           const int *__restrict__ row_extent) {
   if ((int)blockIdx.x < main_blocks) {
     const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= elems) return;
+    // NN form with a device-side row extent: rows past it were never computed (their partial tiles hold anything) and
+    // nobody reads them -- the masked-LM decoder's input gradient has 3 200 rows of which ~ 480 are labelled
+    if (row_extent && e >= (long long)max(*row_extent, 0) * ncols) return;
     // the partial tiles of up to 16 splits are requested together (independent loads in flight, not one memory round
     // trip per split) and then added in split order
     f32x4 v[16];
@@ -2584,7 +2588,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
           const long long elems = (long long)a->M * a->N;
           const int main_blocks = (int)((elems / 4 + 255) / 256);
           hipLaunchKernelGGL(splitk_reduce_kernel, dim3(main_blocks), dim3(256), 0, s, P.splits, elems, P.partial,
-                             reinterpret_cast<float *>(a->C), a->ldc, a->N, a->M, nullptr, nullptr, main_blocks);
+                             reinterpret_cast<float *>(a->C), a->ldc, a->N, a->M, nullptr, nullptr, main_blocks, a->extent_dev);
           st = hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
         }
         break;
@@ -2605,7 +2609,7 @@ int gps_gemm_bf16(const gps_gemm_args *a, gps_stream_t stream) {
       const int main_blocks = (int)((elems / 4 + 255) / 256);
       const int cs_blocks = a->colsum ? (a->M + 255) / 256 : 0;
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(main_blocks + cs_blocks), dim3(256), 0, s, P.splits, elems, P.partial,
-                         reinterpret_cast<float *>(a->C), a->ldc, a->N, a->M, P.colsum, a->colsum, main_blocks);
+                         reinterpret_cast<float *>(a->C), a->ldc, a->N, a->M, P.colsum, a->colsum, main_blocks, nullptr);
       st = hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
     }
   }

@@ -419,6 +419,24 @@ def test_stream_k_variant(form, M, N, K):
     assert torch.isnan(y[-(-ext // 256) * 256:].float()).all()
 
 
+@pytest.mark.parametrize("ext", [0, 1, 480, 3000, 3200])
+def test_split_k_input_gradient_stops_at_the_row_extent(ext):
+    """NN form, fp32 output, reduction split over K (the masked-LM decoder's input gradient: 3 200 token rows of which the
+    labelled ones come first, K = the vocabulary): rows below the device-side extent equal the full product, rows at or
+    past it are never written -- neither by the partial-tile launch nor by the split reduction (NaN prefill survives)."""
+    lib = _native.load()
+    M, N, K, splits = 3200, 768, 4096, 8
+    dy, w = _rand16(M, K, seed=61), _rand16(K, N, scale=0.05, seed=62)
+    ws = torch.empty(int(lib.gps_gemm_workspace_floats(_native.GEMM_NN, M, N, splits)), device=DEV)
+    rows = torch.tensor([ext], dtype=torch.int32, device=DEV)
+    dx = torch.full((M, N), float("nan"), device=DEV)
+    G.gemm(_native.GEMM_NN, _native.EPI_F32, M, N, K, dy, K, w, N, dx, N, workspace=ws, splits=splits, extent_dev=rows)
+    ref = dy.float() @ w.float()
+    if ext:
+        assert (dx[:ext] - ref[:ext]).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert torch.isnan(dx[ext:]).all()
+
+
 def _grouped(probs):
     """probs: list of dicts(dy (T, M) bf16, x (T, N) bf16, C fp32 (M, N), colsum or None, accumulate, extent or None)."""
     import ctypes
