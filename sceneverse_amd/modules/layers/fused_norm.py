@@ -52,7 +52,11 @@ class SharedPostGrad:
     type embeddings in front of every layer): the layers' backward launches -- which run last layer first -- build it in ONE
     buffer (the first to run stores, the others add, gps_add_dropout_layernorm_backward_post_acc) and only the launch
     marked `final` (the FIRST layer in forward order: its backward runs after all the others') hands the buffer to autograd;
-    the others report no gradient for the addend.  Replaces one buffer + zero-fill per layer and autograd's adds."""
+    the others report no gradient for the addend.  Replaces one buffer + zero-fill per layer and autograd's adds.
+    One object per forward call of the encoder (a fresh one every call: nothing survives a failed or partial pass).  A backward
+    pass must run ALL the sharing layers' nodes, the final one last -- true whenever the gradient is taken with respect to
+    anything at or below the first layer (every training step); a pass cut ABOVE the first layer (torch.autograd.grad
+    towards an intermediate activation only) would leave the sum unreported, so such callers pass no `post_share`."""
     __slots__ = ("buf",)
 
     def __init__(self):
