@@ -612,6 +612,16 @@ GPS_API int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq
 GPS_API int gps_rows_plan(int n_seq, int seq_len, const unsigned char *valid, long long *perm, long long *inv, int *cu, int *n_live,
                           gps_stream_t stream);
 
+/* Row mover for rows of ANY element type (row_bytes a multiple of 16, both arrays 16-byte aligned): launch row r < n moves
+ * source row (src_idx ? src_idx[r] : r) to destination row (dst_idx ? dst_idx[r] : r) when r < *n_live (n_live optional);
+ * rows whose source index is outside [0, n_src_rows) arrive as zeros, rows whose destination index is outside are dropped.
+ * Gather form (src_idx, dst_idx NULL): with zero_dead != 0 the destination rows at or past *n_live are zeroed.  Scatter form
+ * (dst_idx): only addressed rows are written -- the caller zero-fills dst; the live destination indices must be distinct.
+ * Replaces index_select + the dead-row mask and, in backward, the atomic index_add_ of the [CLS]-tail selection of the
+ * variable-length text path (no counterpart in the reference, which runs the padded batch: modules/language/bert.py:26-30). */
+GPS_API int gps_rows_move(int n, long long n_src_rows, long long n_dst_rows, int row_bytes, const void *src, const long long *src_idx,
+                          void *dst, const long long *dst_idx, const int *n_live, int zero_dead, gps_stream_t stream);
+
 /* Masked row gather: out[i] (d fp32) = src[idx[i]] when row i is ON -- i < *n_live (n_live non-NULL), valid[i] != 0 (valid
  * non-NULL), 0 <= idx[i] < n_src -- else zeros; out16 (optional) the same rows rounded to bf16.  d % 4 == 0.  With perm / inv
  * of gps_rows_plan it is the pack of the joint rows (idx = perm, n_live), the unpack into the padded layout (idx = inv,

@@ -474,6 +474,29 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(int n_out, int n_src, 
   }
 }
 
+// rows of `q` 16-byte words moved between two row arrays of any element type: row r of the launch reads source row
+// (src_idx ? src_idx[r] : r) and writes destination row (dst_idx ? dst_idx[r] : r) when r < *n_live (n_live optional) and both
+// rows exist; with zero_dead the identity-addressed destination rows at or past *n_live are zeroed instead.  One wave per row.
+__global__ __launch_bounds__(256) void rows_move_kernel(int n, long long n_src, long long n_dst, int q, const uint4 *__restrict__ src,
+                                                        const long long *__restrict__ src_idx, uint4 *__restrict__ dst,
+                                                        const long long *__restrict__ dst_idx, const int *__restrict__ n_live,
+                                                        int zero_dead) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int live = n_live ? min(n, max(*n_live, 0)) : n;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    if (r >= live) {
+      if (zero_dead && !dst_idx && r < n_dst)
+        for (int c = lane; c < q; c += 64) dst[(size_t)r * q + c] = make_uint4(0u, 0u, 0u, 0u);
+      continue;
+    }
+    const long long s = src_idx ? src_idx[r] : (long long)r;
+    const long long d = dst_idx ? dst_idx[r] : (long long)r;
+    if (d < 0 || d >= n_dst) continue;
+    const bool ok = s >= 0 && s < n_src;
+    for (int c = lane; c < q; c += 64) dst[(size_t)d * q + c] = ok ? src[(size_t)s * q + c] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 }  // namespace gps_rowplan
 
 
@@ -611,6 +634,18 @@ int gps_rows_gather(int n_out, int n_src, int d, const float *src, const long lo
   hipLaunchKernelGGL(gps_rowplan::rows_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_out, n_src, d / 4,
                      reinterpret_cast<const float4 *>(src), idx, valid, n_live, reinterpret_cast<float4 *>(out),
                      reinterpret_cast<uint2 *>(out16));
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_rows_move(int n, long long n_src_rows, long long n_dst_rows, int row_bytes, const void *src, const long long *src_idx,
+                  void *dst, const long long *dst_idx, const int *n_live, int zero_dead, gps_stream_t stream) {
+  if (n < 0 || n_src_rows < 1 || n_dst_rows < 1 || row_bytes < 16 || !src || !dst) return GPS_ERR_INVALID_ARGUMENT;
+  if ((row_bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return GPS_ERR_UNSUPPORTED;
+  if (n == 0) return GPS_OK;
+  const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  hipLaunchKernelGGL(gps_rowplan::rows_move_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, n_src_rows, n_dst_rows,
+                     row_bytes / 16, reinterpret_cast<const uint4 *>(src), src_idx, reinterpret_cast<uint4 *>(dst), dst_idx, n_live,
+                     zero_dead);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

@@ -129,6 +129,47 @@ class _GatherRows(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
+class _SelectRows(torch.autograd.Function):
+    """out[r] = x[sel[r]] for r < *rows_live, zeros past it (rows of any dtype; gps_rows_move); the live entries of `sel` are
+    distinct, so the gradient is a zero-filled buffer + a row SCATTER of the live rows -- instead of index_select + a
+    dead-row mask whose autograd gradient is where + zero-fill + atomic index_add_ (the [CLS]-tail selection: two
+    tensors, ~ 75 us per step)."""
+
+    @staticmethod
+    def _move(n, src, src_idx, dst, dst_idx, rows_live, zero_dead):
+        from ... import _native
+        with torch.cuda.device(src.device):
+            st = _native.load().gps_rows_move(n, src.shape[0], dst.shape[0], src.shape[1] * src.element_size(), src.data_ptr(),
+                                              None if src_idx is None else src_idx.data_ptr(), dst.data_ptr(),
+                                              None if dst_idx is None else dst_idx.data_ptr(), rows_live.data_ptr(),
+                                              int(zero_dead), torch.cuda.current_stream().cuda_stream)
+        _native.check(st, "rows_move")
+
+    @staticmethod
+    def forward(ctx, x, sel, rows_live):
+        x = x.contiguous()
+        out = torch.empty((sel.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+        _SelectRows._move(sel.shape[0], x, sel, out, None, rows_live, True)
+        ctx.save_for_backward(sel, rows_live)
+        ctx.rows = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sel, rows_live = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.zeros((ctx.rows, dout.shape[1]), dtype=dout.dtype, device=dout.device)
+        _SelectRows._move(sel.shape[0], dout, None, dx, sel, rows_live, False)
+        return dx, None, None
+
+
+def select_rows(x: torch.Tensor, sel: torch.Tensor, rows_live: torch.Tensor) -> torch.Tensor:
+    """x.index_select(0, sel) with the rows at or past *rows_live zeroed (forward) and ignored (backward)."""
+    if x.is_cuda and x.dim() == 2 and (x.shape[1] * x.element_size()) % 16 == 0 and sel.dtype == torch.int64:
+        return _SelectRows.apply(x, sel.contiguous(), rows_live)
+    return _ZeroDeadRows.apply(x.index_select(0, sel), rows_live)
+
+
 def gather_rows_supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0
 
@@ -306,8 +347,8 @@ class BERTLanguageEncoder(nn.Module):
                 if cls_tail and li == last:
                     # rows past `rows_tail` of the tail batch are never written by the extent-aware kernels, forward or
                     # backward: their (undefined) gradients must not be scattered back into the full row batch
-                    ctx = _ZeroDeadRows.apply(ctx.index_select(0, sel), rows_tail)
-                    x, rows = _ZeroDeadRows.apply(x.index_select(0, sel), rows_tail), rows_tail
+                    ctx = select_rows(ctx, sel, rows_tail)
+                    x, rows = select_rows(x, sel, rows_tail), rows_tail
                 attn_out = yield gemm.LinearOp.of(ctx, [so.dense], rows_dev=rows)
                 x, x16 = add_dropout_layer_norm(x, attn_out, so.LayerNorm, so.dropout.p, training, want_bf16=True,
                                                 rows_dev=rows)

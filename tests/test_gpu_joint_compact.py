@@ -103,6 +103,38 @@ def test_rows_gather_packs_and_unpacks_with_exact_gradients(n_seq, L, D):
     assert torch.equal(o[0], torch.zeros(D, device=DEV)) and torch.equal(o[1:], xd.index_select(0, perm)[1:])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_select_rows_equals_index_select_with_a_dead_row_mask(dtype):
+    """gps_rows_move through select_rows (the [CLS]-tail selection of the variable-length text path): values and gradients
+    bit-equal to index_select + _ZeroDeadRows on the live rows; dead rows zero; dead entries of `sel` may alias live ones."""
+    from sceneverse_amd.modules.language.bert import _ZeroDeadRows, select_rows
+    g = torch.Generator().manual_seed(23)
+    T, D, n_first, n_full = 900, 768, 40, 500
+    x0 = torch.randn(T, D, generator=g).to(dtype).to(DEV)
+    firsts = torch.randperm(T - n_full, generator=g)[:n_first] + n_full          # "first tokens" past the fully read rows
+    sel = torch.cat([firsts, torch.arange(n_full + 100)]).to(DEV)                 # the last 100 entries are dead (and alias)
+    live = n_first + n_full
+    rows_live = torch.tensor([live], dtype=torch.int32, device=DEV)
+    w = torch.randn(sel.shape[0], D, generator=g).to(dtype).to(DEV)
+    w_nan = w.clone()
+    w_nan[live:] = float("nan")
+    xa = x0.clone().requires_grad_(True)
+    ya = select_rows(xa, sel, rows_live)
+    (ga,) = torch.autograd.grad(ya, xa, w_nan)
+    xb = x0.clone().requires_grad_(True)
+    yb = _ZeroDeadRows.apply(xb.index_select(0, sel), rows_live)
+    (gb,) = torch.autograd.grad(yb, xb, w)
+    assert torch.equal(ya[:live], yb[:live]) and torch.equal(ya[live:], torch.zeros_like(ya[live:]))
+    assert torch.equal(ga, gb)
+    # argument checks of the C entry
+    from sceneverse_amd import _native
+    lib, s = _native.load(), torch.cuda.current_stream().cuda_stream
+    out = torch.empty(4, 8, device=DEV)
+    src = torch.zeros(4, 8, device=DEV)
+    assert lib.gps_rows_move(4, 4, 4, 24, src.data_ptr(), None, out.data_ptr(), None, None, 0, s) == _native.GPS_ERR_UNSUPPORTED
+    assert lib.gps_rows_move(4, 4, 4, 32, None, None, out.data_ptr(), None, None, 0, s) == _native.GPS_ERR_INVALID_ARGUMENT
+
+
 def test_gps_model_compact_joint_rows_equal_padded_rows(golden_cpu):
     from oracle.param_fill import fill_params
     from sceneverse_amd.model.build import build_model
