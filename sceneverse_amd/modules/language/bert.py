@@ -75,13 +75,28 @@ class _UnpadRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, src, live):
-        ctx.save_for_backward(src, live)
         ctx.rows = x.shape[0]
+        ctx.native = (x.is_cuda and x.dim() == 2 and (x.shape[1] * x.element_size()) % 16 == 0 and src.dtype == torch.int64)
+        if ctx.native:
+            # dead positions address row -1: gps_rows_move writes zeros for them (forward) and drops them (backward)
+            idx = torch.where(live[:, 0], src, torch.full((), -1, dtype=src.dtype, device=src.device))
+            ctx.save_for_backward(idx)
+            x = x.contiguous()
+            out = torch.empty((src.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+            _SelectRows._move(src.shape[0], x, idx, out, None, None, False)
+            return out
+        ctx.save_for_backward(src, live)
         rows = x.index_select(0, src)
         return torch.where(live, rows, torch.zeros((), dtype=rows.dtype, device=rows.device))
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.native:
+            (idx,) = ctx.saved_tensors
+            dout = dout.contiguous()
+            dx = torch.zeros((ctx.rows, dout.shape[1]), dtype=dout.dtype, device=dout.device)
+            _SelectRows._move(idx.shape[0], dout, None, dx, idx, None, False)
+            return dx, None, None
         src, live = ctx.saved_tensors
         n = ctx.rows
         dx = torch.zeros((n + 1, dout.shape[1]), dtype=dout.dtype, device=dout.device)     # row n: dump
@@ -141,7 +156,8 @@ class _SelectRows(torch.autograd.Function):
         with torch.cuda.device(src.device):
             st = _native.load().gps_rows_move(n, src.shape[0], dst.shape[0], src.shape[1] * src.element_size(), src.data_ptr(),
                                               None if src_idx is None else src_idx.data_ptr(), dst.data_ptr(),
-                                              None if dst_idx is None else dst_idx.data_ptr(), rows_live.data_ptr(),
+                                              None if dst_idx is None else dst_idx.data_ptr(),
+                                              None if rows_live is None else rows_live.data_ptr(),
                                               int(zero_dead), torch.cuda.current_stream().cuda_stream)
         _native.check(st, "rows_move")
 
