@@ -612,6 +612,17 @@ GPS_API int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq
 GPS_API int gps_rows_plan(int n_seq, int seq_len, const unsigned char *valid, long long *perm, long long *inv, int *cu, int *n_live,
                           gps_stream_t stream);
 
+/* Pack / unpack of the JOINT rows without a concatenated tensor: the padded side is the text rows a (n_seq, len_a, d) and the
+ * object rows b (n_seq, len_b, d), fp32, which the reference joins along the sequence axis (modules/grounding/unified_encoder.py:
+ * 147-177); flat row e = (sequence, position in [0, len_a + len_b)); perm / inv / valid / n_live as gps_rows_plan writes them.
+ *   pack2:   out[r] = flat[perm[r]] for r < *n_live, zeros past it; out16 (optional) = the same rows as bf16;
+ *   unpack2: flat[e] = valid[e] ? packed[inv[e]] : 0, written into out_a / out_b (both contiguous).
+ * Each is the gradient of the other.  d % 4 == 0, n_seq * (len_a + len_b) <= 2^22. */
+GPS_API int gps_rows_pack2(int n_seq, int len_a, int len_b, int d, const float *a, const float *b, const long long *perm,
+                           const int *n_live, float *out, unsigned short *out16, gps_stream_t stream);
+GPS_API int gps_rows_unpack2(int n_seq, int len_a, int len_b, int d, const float *packed, const long long *inv,
+                             const unsigned char *valid, float *out_a, float *out_b, gps_stream_t stream);
+
 /* Row mover for rows of ANY element type (row_bytes a multiple of 16, both arrays 16-byte aligned): launch row r < n moves
  * source row (src_idx ? src_idx[r] : r) to destination row (dst_idx ? dst_idx[r] : r) when r < *n_live (n_live optional);
  * rows whose source index is outside [0, n_src_rows) arrive as zeros, rows whose destination index is outside are dropped.
@@ -621,14 +632,6 @@ GPS_API int gps_rows_plan(int n_seq, int seq_len, const unsigned char *valid, lo
  * variable-length text path (no counterpart in the reference, which runs the padded batch: modules/language/bert.py:26-30). */
 GPS_API int gps_rows_move(int n, long long n_src_rows, long long n_dst_rows, int row_bytes, const void *src, const long long *src_idx,
                           void *dst, const long long *dst_idx, const int *n_live, int zero_dead, gps_stream_t stream);
-
-/* Masked row gather: out[i] (d fp32) = src[idx[i]] when row i is ON -- i < *n_live (n_live non-NULL), valid[i] != 0 (valid
- * non-NULL), 0 <= idx[i] < n_src -- else zeros; out16 (optional) the same rows rounded to bf16.  d % 4 == 0.  With perm / inv
- * of gps_rows_plan it is the pack of the joint rows (idx = perm, n_live), the unpack into the padded layout (idx = inv,
- * valid) and the gradient of either (the other call): replaces index_select + where and, in backward, the zero-fill +
- * atomic index_add_ autograd derives (reference: the padded layout of modules/grounding/unified_encoder.py:147-177). */
-GPS_API int gps_rows_gather(int n_out, int n_src, int d, const float *src, const long long *idx, const unsigned char *valid,
-                            const int *n_live, float *out, unsigned short *out16, gps_stream_t stream);
 
 /* ---- box-location embedding  y = LayerNorm(x W^T + b)  (tiny reduction length) ---------------------------------
  * Replaces `loc_layers = nn.Sequential(nn.Linear(dim_loc, hidden), nn.LayerNorm(hidden))` of the object encoder and the

@@ -448,32 +448,6 @@ __global__ __launch_bounds__(kThreads) void plan_kernel(int n_seq, int seq_len, 
     n_live[0] = total;
   }
 }
-// out[i] = src[idx[i]] for the rows that are ON -- i < *n_live (when given) and valid[i] != 0 (when given) and idx[i] inside
-// the source -- else zeros; optionally also as bf16.  One wave per row, 16 bytes per lane and step.  With a row permutation
-// and its inverse (gps_rows_plan) this one kernel is the pack (idx = perm, n_live), the unpack (idx = inv, valid) and both of
-// their gradients (the same two calls with the roles of the index tensors swapped): no zero-fill + atomic index_add_.
-__global__ __launch_bounds__(256) void rows_gather_kernel(int n_out, int n_src, int d4, const float4 *__restrict__ src,
-                                                          const long long *__restrict__ idx, const unsigned char *__restrict__ valid,
-                                                          const int *__restrict__ n_live, float4 *__restrict__ out,
-                                                          uint2 *__restrict__ out16) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int live = n_live ? min(n_out, max(*n_live, 0)) : n_out;
-  for (int r = blockIdx.x * 4 + wave; r < n_out; r += gridDim.x * 4) {
-    bool on = r < live && (!valid || valid[r] != 0);
-    long long s = on ? idx[r] : 0;
-    on = on && s >= 0 && s < (long long)n_src;
-    for (int c = lane; c < d4; c += 64) {
-      const float4 v = on ? src[(size_t)s * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      out[(size_t)r * d4 + c] = v;
-      if (out16) {
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-        const bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        out16[(size_t)r * d4 + c] = __builtin_bit_cast(uint2, h);
-      }
-    }
-  }
-}
-
 // rows of `q` 16-byte words moved between two row arrays of any element type: row r of the launch reads source row
 // (src_idx ? src_idx[r] : r) and writes destination row (dst_idx ? dst_idx[r] : r) when r < *n_live (n_live optional) and both
 // rows exist; with zero_dead the identity-addressed destination rows at or past *n_live are zeroed instead.  One wave per row.
@@ -494,6 +468,56 @@ __global__ __launch_bounds__(256) void rows_move_kernel(int n, long long n_src, 
     if (d < 0 || d >= n_dst) continue;
     const bool ok = s >= 0 && s < n_src;
     for (int c = lane; c < q; c += 64) dst[(size_t)d * q + c] = ok ? src[(size_t)s * q + c] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+// The padded side of the joint sequences is TWO arrays -- text rows (B, La, d) and object rows (B, Lb, d) -- that the reference
+// concatenates along the sequence axis (modules/grounding/unified_encoder.py:147-177); flat row e = (b, t), t in [0, La + Lb),
+// lives in the first array for t < La, in the second otherwise.  pack2: out[r] = flat[perm[r]] for r < *n_live, zeros past it
+// (+ the bf16 copy); unpack2: flat[e] = valid[e] ? packed[inv[e]] : 0, written straight into the two arrays.  Each is the other's
+// gradient.  No concatenated (B, La + Lb, d) tensor exists on either side, and the halves come out contiguous.
+__device__ __forceinline__ size_t flat_row_offset(long long e, int T, int La, int d4, bool &second) {
+  const long long b = e / T;
+  const int t = (int)(e - b * T);
+  second = t >= La;
+  return second ? (size_t)(b * (T - La) + (t - La)) * d4 : (size_t)(b * La + t) * d4;
+}
+__global__ __launch_bounds__(256) void rows_pack2_kernel(int n, int d4, int T, int La, const float4 *__restrict__ a,
+                                                         const float4 *__restrict__ b, const long long *__restrict__ perm,
+                                                         const int *__restrict__ n_live, float4 *__restrict__ out,
+                                                         uint2 *__restrict__ out16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int live = n_live ? min(n, max(*n_live, 0)) : n;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    bool on = r < live;
+    const long long e = on ? perm[r] : 0;
+    on = on && e >= 0 && e < (long long)n;
+    bool second = false;
+    const size_t off = on ? flat_row_offset(e, T, La, d4, second) : 0;
+    const float4 *src = second ? b : a;
+    for (int c = lane; c < d4; c += 64) {
+      const float4 v = on ? src[off + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      out[(size_t)r * d4 + c] = v;
+      if (out16) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+        const bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        out16[(size_t)r * d4 + c] = __builtin_bit_cast(uint2, h);
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void rows_unpack2_kernel(int n, int d4, int T, int La, const float4 *__restrict__ packed,
+                                                           const long long *__restrict__ inv, const unsigned char *__restrict__ valid,
+                                                           float4 *__restrict__ out_a, float4 *__restrict__ out_b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = blockIdx.x * 4 + wave; e < n; e += gridDim.x * 4) {
+    bool on = valid[e] != 0;
+    const long long r = on ? inv[e] : 0;
+    on = on && r >= 0 && r < (long long)n;
+    bool second = false;
+    const size_t off = flat_row_offset(e, T, La, d4, second);
+    float4 *dst = second ? out_b : out_a;
+    for (int c = lane; c < d4; c += 64) dst[off + c] = on ? packed[(size_t)r * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -625,18 +649,6 @@ int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq_full, i
 }
 
 
-int gps_rows_gather(int n_out, int n_src, int d, const float *src, const long long *idx, const unsigned char *valid,
-                    const int *n_live, float *out, unsigned short *out16, gps_stream_t stream) {
-  if (n_out < 0 || n_src < 1 || d < 4 || !src || !idx || !out) return GPS_ERR_INVALID_ARGUMENT;
-  if (d % 4) return GPS_ERR_UNSUPPORTED;
-  if (n_out == 0) return GPS_OK;
-  const int blocks = (n_out + 3) / 4 < 4096 ? (n_out + 3) / 4 : 4096;
-  hipLaunchKernelGGL(gps_rowplan::rows_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_out, n_src, d / 4,
-                     reinterpret_cast<const float4 *>(src), idx, valid, n_live, reinterpret_cast<float4 *>(out),
-                     reinterpret_cast<uint2 *>(out16));
-  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
-}
-
 int gps_rows_move(int n, long long n_src_rows, long long n_dst_rows, int row_bytes, const void *src, const long long *src_idx,
                   void *dst, const long long *dst_idx, const int *n_live, int zero_dead, gps_stream_t stream) {
   if (n < 0 || n_src_rows < 1 || n_dst_rows < 1 || row_bytes < 16 || !src || !dst) return GPS_ERR_INVALID_ARGUMENT;
@@ -646,6 +658,30 @@ int gps_rows_move(int n, long long n_src_rows, long long n_dst_rows, int row_byt
   hipLaunchKernelGGL(gps_rowplan::rows_move_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, n_src_rows, n_dst_rows,
                      row_bytes / 16, reinterpret_cast<const uint4 *>(src), src_idx, reinterpret_cast<uint4 *>(dst), dst_idx, n_live,
                      zero_dead);
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_rows_pack2(int n_seq, int len_a, int len_b, int d, const float *a, const float *b, const long long *perm, const int *n_live,
+                   float *out, unsigned short *out16, gps_stream_t stream) {
+  if (n_seq < 1 || len_a < 1 || len_b < 1 || d < 4 || !a || !b || !perm || !out) return GPS_ERR_INVALID_ARGUMENT;
+  if (d % 4 || (long long)n_seq * (len_a + len_b) > (1 << 22)) return GPS_ERR_UNSUPPORTED;
+  const int n = n_seq * (len_a + len_b);
+  const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  hipLaunchKernelGGL(gps_rowplan::rows_pack2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, d / 4, len_a + len_b, len_a,
+                     reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b), perm, n_live,
+                     reinterpret_cast<float4 *>(out), reinterpret_cast<uint2 *>(out16));
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_rows_unpack2(int n_seq, int len_a, int len_b, int d, const float *packed, const long long *inv, const unsigned char *valid,
+                     float *out_a, float *out_b, gps_stream_t stream) {
+  if (n_seq < 1 || len_a < 1 || len_b < 1 || d < 4 || !packed || !inv || !valid || !out_a || !out_b) return GPS_ERR_INVALID_ARGUMENT;
+  if (d % 4 || (long long)n_seq * (len_a + len_b) > (1 << 22)) return GPS_ERR_UNSUPPORTED;
+  const int n = n_seq * (len_a + len_b);
+  const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  hipLaunchKernelGGL(gps_rowplan::rows_unpack2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, d / 4, len_a + len_b, len_a,
+                     reinterpret_cast<const float4 *>(packed), inv, valid, reinterpret_cast<float4 *>(out_a),
+                     reinterpret_cast<float4 *>(out_b));
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

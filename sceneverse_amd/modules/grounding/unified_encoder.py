@@ -94,6 +94,73 @@ class UnifiedSpatialCrossEncoderV1(nn.Module):
         return txt_embeds, obj_embeds
 
 
+def _rows_call(name, *args):
+    from ... import _native
+    st = getattr(_native.load(), name)(*args, torch.cuda.current_stream().cuda_stream)
+    _native.check(st, name)
+
+
+class _PackJoint(torch.autograd.Function):
+    """Packed joint rows straight from the text rows a (B, La, D) and the object rows b (B, Lb, D): out[r] = flat[perm[r]] for
+    r < *n_live (zeros past it), flat = the (B, La + Lb) joint layout that is never materialised (gps_rows_pack2).  The gradient
+    is gps_rows_unpack2 into two contiguous tensors (zeros at invalid positions)."""
+
+    @staticmethod
+    def forward(ctx, a, b, perm, inv, valid8, n_live):
+        B, La, D = a.shape
+        Lb = b.shape[1]
+        a, b = a.float().contiguous(), b.float().contiguous()
+        out = torch.empty((B * (La + Lb), D), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _rows_call("gps_rows_pack2", B, La, Lb, D, a.data_ptr(), b.data_ptr(), perm.data_ptr(), n_live.data_ptr(),
+                       out.data_ptr(), None)
+        ctx.save_for_backward(inv, valid8)
+        ctx.dims = (B, La, Lb, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inv, valid8 = ctx.saved_tensors
+        B, La, Lb, D = ctx.dims
+        dout = dout.float().contiguous()
+        da = torch.empty((B, La, D), dtype=torch.float32, device=dout.device)
+        db = torch.empty((B, Lb, D), dtype=torch.float32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            _rows_call("gps_rows_unpack2", B, La, Lb, D, dout.data_ptr(), inv.data_ptr(), valid8.data_ptr(), da.data_ptr(),
+                       db.data_ptr())
+        return da, db, None, None, None, None
+
+
+class _UnpackJoint(torch.autograd.Function):
+    """The packed rows back as the text part (B, La, D) and the object part (B, Lb, D), both contiguous, zeros at invalid
+    positions (gps_rows_unpack2); gradient = gps_rows_pack2 of the two parts' gradients."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv, valid8, n_live, B, La, Lb):
+        D = x.shape[1]
+        x = x.float().contiguous()
+        a = torch.empty((B, La, D), dtype=torch.float32, device=x.device)
+        b = torch.empty((B, Lb, D), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _rows_call("gps_rows_unpack2", B, La, Lb, D, x.data_ptr(), inv.data_ptr(), valid8.data_ptr(), a.data_ptr(), b.data_ptr())
+        ctx.save_for_backward(perm, n_live)
+        ctx.dims = (B, La, Lb, D)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        perm, n_live = ctx.saved_tensors
+        B, La, Lb, D = ctx.dims
+        dev = perm.device
+        da = torch.zeros((B, La, D), dtype=torch.float32, device=dev) if da is None else da.float().contiguous()
+        db = torch.zeros((B, Lb, D), dtype=torch.float32, device=dev) if db is None else db.float().contiguous()
+        dx = torch.empty((B * (La + Lb), D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _rows_call("gps_rows_pack2", B, La, Lb, D, da.data_ptr(), db.data_ptr(), perm.data_ptr(), n_live.data_ptr(),
+                       dx.data_ptr(), None)
+        return dx, None, None, None, None, None, None, None
+
+
 @GROUNDING_REGISTRY.register()
 class UnifiedSpatialCrossEncoderV2(nn.Module):
     def __init__(self, cfg, hidden_size=768, dim_feedforward=2048, num_attention_heads=12,
@@ -121,7 +188,7 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
                 and gemm.activation_name(layer.activation) is not None and layer.linear1.out_features % 8 == 0
                 and attn_supported(D, H, T) and norm_supported(probe, probe.to(torch.bfloat16), layer.norm1))
 
-    def _forward_compact(self, txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks, extra):
+    def _forward_compact(self, txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks, txt_extra, obj_extra):
         """The four layers over the VALID rows only.  The reference runs every padded text position and every padded
         object slot of the joint (B, T, D) sequence through its layers (ref :147-177); padded rows are masked as attention
         keys and no head or loss reads them as outputs, so the valid rows' results do not depend on them.  Here the joint
@@ -130,7 +197,6 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         back into the (B, T, D) layout with ZEROS at the padded positions (the reference leaves unspecified values there).
         At the bench workload 60 % of the 8 320 joint rows are valid."""
         from ... import _native
-        from ..language.bert import _GatherRows
         from ..layers import gemm
         from ..layers.fused_attention import fused_varlen_self_attention
         from ..layers.fused_norm import add_dropout_layer_norm
@@ -146,13 +212,11 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
             st = _native.load().gps_rows_plan(B, T, valid.view(torch.uint8).data_ptr(), perm.data_ptr(), inv.data_ptr(),
                                               cu.data_ptr(), n_live.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _native.check(st, "rows_plan")
-        joint = torch.cat((txt_embeds, obj_embeds), dim=1) + extra
-        # rows past n_live of the compact buffers are never written by the extent-aware kernels: their (undefined)
-        # gradients must not flow back
-        # (one launch each, forward and backward: gps_rows_gather with perm / inv; zeros in the dead rows)
+        # packed rows straight from the two parts (no concatenated (B, T, D) tensor, no gather of one): zeros in the dead rows,
+        # whose (undefined) gradients the reverse launch never reads
         valid8 = valid.view(torch.uint8)
-        x = _GatherRows.apply(joint.reshape(n, D), perm, None, n_live, inv, valid8, None)
-        extra_c = _GatherRows.apply(extra.reshape(n, D), perm, None, n_live, inv, valid8, None)
+        extra_c = _PackJoint.apply(txt_extra, obj_extra, perm, inv, valid8, n_live)
+        x = _PackJoint.apply(txt_embeds, obj_embeds, perm, inv, valid8, n_live) + extra_c
         x16 = x
         n_layers = len(self.unified_encoder)
         from ..layers.fused_norm import SharedPostGrad
@@ -168,8 +232,7 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
                                training, rows_dev=n_live)
             x, x16 = add_dropout_layer_norm(x, ffn_out, layer.norm2, layer.dropout2.p, training, want_bf16=True, rows_dev=n_live,
                                             post=extra_c if li + 1 < n_layers else None, post_share=(share, li == 0))
-        out = _GatherRows.apply(x, inv, valid8, None, perm, None, n_live).view(B, T, D)
-        return torch.split(out, [Lt, T - Lt], dim=1)
+        return _UnpackJoint.apply(x, perm, inv, valid8, n_live, B, Lt, T - Lt)      # (text part, object part), contiguous
 
     def forward(self, txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks,
                 output_attentions=False, output_hidden_states=False, **kwargs):
@@ -183,9 +246,9 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         # generic reduction takes 45 - 60 us for)
         obj_extra = add_row(loc_embed(self.loc_layers[0], obj_locs), self.token_type_embeddings.weight[1])
         txt_extra = add_row(obj_extra.new_zeros((txt_embeds.shape[0], txt_len, obj_extra.shape[-1])), type_txt.to(obj_extra.dtype))
-        extra = torch.cat((txt_extra, obj_extra), dim=1)
         if self._compact_ok(txt_embeds, obj_embeds):
-            return self._forward_compact(txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks, extra)
+            return self._forward_compact(txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks, txt_extra, obj_extra)
+        extra = torch.cat((txt_extra, obj_extra), dim=1)
         joint = torch.cat((txt_embeds, obj_embeds), dim=1)
         # layer l reads joint_l + extra: the first sum is explicit, every later one leaves the previous layer's last
         # LayerNorm launch together with its bf16 copy (post_add)

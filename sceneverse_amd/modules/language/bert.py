@@ -105,45 +105,6 @@ class _UnpadRows(torch.autograd.Function):
         return dx[:n], None, None
 
 
-class _GatherRows(torch.autograd.Function):
-    """out[i] = x[idx[i]] where row i is on (i < *n_live when given, valid[i] when given), else 0 -- one launch of
-    gps_rows_gather; `back = (ridx, rvalid, rn_live)` is the same description of the REVERSE map (the forward map is
-    injective on its on-rows), so the gradient is the same launch with the roles swapped: pack (idx = perm, n_live;
-    back = (inv, valid, None)) and unpack (idx = inv, valid; back = (perm, None, n_live)) of gps_rows_plan's permutation.
-    Replaces index_select + _ZeroDeadRows / _UnpadRows on fp32 CUDA rows (their backward: zero-fill + index_add_ / index_copy_,
-    where, arange: ~10 launches, ~130 us per step for the joint rows)."""
-
-    @staticmethod
-    def _run(x, idx, valid, n_live, want16=False):
-        from ... import _native
-        n_out, d = idx.shape[0], x.shape[1]
-        x = x.contiguous()
-        out = torch.empty((n_out, d), dtype=torch.float32, device=x.device)
-        out16 = torch.empty((n_out, d), dtype=torch.bfloat16, device=x.device) if want16 else None
-        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        with torch.cuda.device(x.device):
-            st = _native.load().gps_rows_gather(n_out, x.shape[0], d, x.data_ptr(), idx.data_ptr(), ptr(valid), ptr(n_live),
-                                                out.data_ptr(), ptr(out16), torch.cuda.current_stream().cuda_stream)
-        _native.check(st, "rows_gather")
-        return out, out16
-
-    @staticmethod
-    def forward(ctx, x, idx, valid, n_live, ridx, rvalid, rn_live):
-        ctx.save_for_backward(*(t for t in (ridx, rvalid, rn_live) if t is not None))
-        ctx.have = (rvalid is not None, rn_live is not None)
-        out, _ = _GatherRows._run(x, idx, valid, n_live)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        saved = list(ctx.saved_tensors)
-        ridx = saved.pop(0)
-        rvalid = saved.pop(0) if ctx.have[0] else None
-        rn_live = saved.pop(0) if ctx.have[1] else None
-        dx, _ = _GatherRows._run(dout.float(), ridx, rvalid, rn_live)
-        return dx, None, None, None, None, None, None
-
-
 class _SelectRows(torch.autograd.Function):
     """out[r] = x[sel[r]] for r < *rows_live, zeros past it (rows of any dtype; gps_rows_move); the live entries of `sel` are
     distinct, so the gradient is a zero-filled buffer + a row SCATTER of the live rows -- instead of index_select + a
@@ -184,10 +145,6 @@ def select_rows(x: torch.Tensor, sel: torch.Tensor, rows_live: torch.Tensor) -> 
     if x.is_cuda and x.dim() == 2 and (x.shape[1] * x.element_size()) % 16 == 0 and sel.dtype == torch.int64:
         return _SelectRows.apply(x, sel.contiguous(), rows_live)
     return _ZeroDeadRows.apply(x.index_select(0, sel), rows_live)
-
-
-def gather_rows_supported(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0
 
 
 def set_fused_embedding(flag: bool) -> None:

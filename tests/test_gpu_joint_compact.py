@@ -50,57 +50,52 @@ def _plan(valid):
     return v, perm, inv, n_live
 
 
-@pytest.mark.parametrize("n_seq,L,D", [(7, 13, 768), (64, 130, 768), (3, 5, 8), (1, 1, 4)])
-def test_rows_gather_packs_and_unpacks_with_exact_gradients(n_seq, L, D):
-    """gps_rows_gather through _GatherRows: pack (perm, n_live) == index_select with zeros in the dead rows, unpack (inv,
-    valid) == the padded layout with zeros at invalid positions; both are copies, so values AND gradients are bit-equal to
-    the torch formulation (index_select / where; gradient = zero-fill + index_add_ of distinct rows)."""
-    from sceneverse_amd.modules.language.bert import _GatherRows
-    g = torch.Generator().manual_seed(11)
-    valid = torch.rand(n_seq, L, generator=g) < 0.6
-    if n_seq > 2:
-        valid[0] = False
-        valid[2] = True
+@pytest.mark.parametrize("n_seq,La,Lb,D", [(7, 5, 8, 768), (64, 50, 80, 768), (3, 1, 4, 8)])
+def test_pack2_unpack2_equal_cat_gather_and_split(n_seq, La, Lb, D):
+    """gps_rows_pack2 / gps_rows_unpack2 through _PackJoint / _UnpackJoint against cat + index_select (zeros in the dead rows)
+    and against gather + where + split: copies, so values and gradients are bit-equal."""
+    from sceneverse_amd.modules.grounding.unified_encoder import _PackJoint, _UnpackJoint
+    g = torch.Generator().manual_seed(31)
+    T = La + Lb
+    valid = torch.rand(n_seq, T, generator=g) < 0.6
+    valid[0] = False
+    valid[-1] = True
     v, perm, inv, n_live = _plan(valid)
-    n, live = n_seq * L, int(valid.sum())
+    n, live = n_seq * T, int(valid.sum())
     v8 = v.view(torch.uint8)
-    x = torch.randn(n, D, generator=g).to(DEV).requires_grad_(True)
-    # pack
-    packed = _GatherRows.apply(x, perm, None, n_live, inv, v8, None)
-    ref = x.detach().index_select(0, perm)
+    a = torch.randn(n_seq, La, D, generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn(n_seq, Lb, D, generator=g).to(DEV).requires_grad_(True)
+    packed = _PackJoint.apply(a, b, perm, inv, v8, n_live)
+    flat = torch.cat((a.detach(), b.detach()), dim=1).reshape(n, D)
+    ref = flat.index_select(0, perm)
     ref[live:] = 0
     assert torch.equal(packed.detach(), ref)
     w = torch.randn(n, D, generator=g).to(DEV)
     w_nan = w.clone()
-    w_nan[live:] = float("nan")                       # gradients of dead packed rows are undefined memory in the step
-    (gx,) = torch.autograd.grad(packed, x, w_nan)
+    w_nan[live:] = float("nan")
+    ga, gb = torch.autograd.grad(packed, (a, b), w_nan)
     ref_g = torch.zeros(n, D, device=DEV)
     ref_g[perm[:live]] = w[:live]
-    assert torch.equal(gx, ref_g)
-    # unpack
+    ref_g = ref_g.view(n_seq, T, D)
+    assert torch.equal(ga, ref_g[:, :La]) and torch.equal(gb, ref_g[:, La:])
     y = torch.randn(n, D, generator=g).to(DEV)
-    y[live:] = float("nan")                           # rows no kernel wrote
+    y[live:] = float("nan")
     y.requires_grad_(True)
-    out = _GatherRows.apply(y, inv, v8, None, perm, None, n_live)
-    ref = torch.where(v[:, None], y.detach().nan_to_num(0.0).index_select(0, inv), torch.zeros((), device=DEV))
-    assert torch.equal(out.detach(), ref)
-    (gy,) = torch.autograd.grad(out, y, w)
+    oa, ob = _UnpackJoint.apply(y, perm, inv, v8, n_live, n_seq, La, Lb)
+    assert oa.is_contiguous() and ob.is_contiguous()
+    ref = torch.where(v[:, None], y.detach().nan_to_num(0.0).index_select(0, inv), torch.zeros((), device=DEV)).view(n_seq, T, D)
+    assert torch.equal(oa.detach(), ref[:, :La]) and torch.equal(ob.detach(), ref[:, La:])
+    wa, wb = torch.randn(n_seq, La, D, generator=g).to(DEV), torch.randn(n_seq, Lb, D, generator=g).to(DEV)
+    (gy,) = torch.autograd.grad((oa, ob), y, (wa, wb))
+    wf = torch.cat((wa, wb), dim=1).reshape(n, D)
     ref_g = torch.zeros(n, D, device=DEV)
-    ref_g[:live] = w.index_select(0, perm[:live])
+    ref_g[:live] = wf.index_select(0, perm[:live])
     assert torch.equal(gy, ref_g)
-    # bf16 copy and argument checks of the C entry
-    from sceneverse_amd import _native
-    o32, o16 = _GatherRows._run(x.detach(), perm, None, n_live, want16=True)
-    assert torch.equal(o16, o32.to(torch.bfloat16))
-    lib = _native.load()
-    s = torch.cuda.current_stream().cuda_stream
-    xd = x.detach()
-    assert lib.gps_rows_gather(n, n, 6, xd.data_ptr(), perm.data_ptr(), None, None, o32.data_ptr(), None, s) == _native.GPS_ERR_UNSUPPORTED
-    assert lib.gps_rows_gather(n, n, D, None, perm.data_ptr(), None, None, o32.data_ptr(), None, s) == _native.GPS_ERR_INVALID_ARGUMENT
-    bad = perm.clone()
-    bad[0] = n + 5                                     # an index outside the source reads zeros, never memory
-    o, _ = _GatherRows._run(xd, bad, None, None)
-    assert torch.equal(o[0], torch.zeros(D, device=DEV)) and torch.equal(o[1:], xd.index_select(0, perm)[1:])
+    (gy1,) = torch.autograd.grad(_UnpackJoint.apply(y, perm, inv, v8, n_live, n_seq, La, Lb)[1], y, wb)     # one part unused
+    wf1 = torch.cat((torch.zeros_like(wa), wb), dim=1).reshape(n, D)
+    ref_g1 = torch.zeros(n, D, device=DEV)
+    ref_g1[:live] = wf1.index_select(0, perm[:live])
+    assert torch.equal(gy1, ref_g1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
