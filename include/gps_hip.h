@@ -623,6 +623,18 @@ GPS_API int gps_rows_pack2(int n_seq, int len_a, int len_b, int d, const float *
 GPS_API int gps_rows_unpack2(int n_seq, int len_a, int len_b, int d, const float *packed, const long long *inv,
                              const unsigned char *valid, float *out_a, float *out_b, gps_stream_t stream);
 
+/* First-layer input of the unified encoder in one launch (reference modules/grounding/unified_encoder.py:147-164: the text and
+ * object embeddings concatenated, the token-type / location embeddings added): with joint = (a | b), extra = (ea | eb) in the
+ * flat order of gps_rows_pack2,  x[r] = joint[perm[r]] + extra[perm[r]],  e[r] = extra[perm[r]],  x16 = bf16(x)  for
+ * r < *n_live, zeros past it.  backward: g = dx + dx16 (each optional: NULL = zero; dx16 bf16),  d(a | b)[f] = valid[f] ?
+ * g[inv[f]] : 0,  d(ea | eb)[f] = valid[f] ? g[inv[f]] + de[inv[f]] : 0  (de optional), all four outputs contiguous fp32. */
+GPS_API int gps_joint_embed_forward(int n_seq, int len_a, int len_b, int d, const float *a, const float *b, const float *ea,
+                                    const float *eb, const long long *perm, const int *n_live, float *x, float *e,
+                                    unsigned short *x16, gps_stream_t stream);
+GPS_API int gps_joint_embed_backward(int n_seq, int len_a, int len_b, int d, const float *dx, const unsigned short *dx16,
+                                     const float *de, const long long *inv, const unsigned char *valid, float *da, float *db,
+                                     float *dea, float *deb, gps_stream_t stream);
+
 /* Row mover for rows of ANY element type (row_bytes a multiple of 16, both arrays 16-byte aligned): launch row r < n moves
  * source row (src_idx ? src_idx[r] : r) to destination row (dst_idx ? dst_idx[r] : r) when r < *n_live (n_live optional);
  * rows whose source index is outside [0, n_src_rows) arrive as zeros, rows whose destination index is outside are dropped.

@@ -122,6 +122,8 @@ SIGNATURES = {
     "gps_rows_move": [_i, ctypes.c_longlong, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "gps_rows_pack2": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gps_rows_unpack2": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gps_joint_embed_forward": [_i, _i, _i, _i] + [_vp] * 10,
+    "gps_joint_embed_backward": [_i, _i, _i, _i] + [_vp] * 10,
     "gps_bert_embed_forward": [_i, _i] + [_vp] * 7 + [_f, _f, ctypes.c_ulonglong] + [_vp] * 8,
     "gps_bert_embed_backward": [_i, _i] + [_vp] * 10 + [_f, ctypes.c_ulonglong] + [_vp] * 6,
     "gps_colsum_parts": [_i, _i],

@@ -521,6 +521,72 @@ __global__ __launch_bounds__(256) void rows_unpack2_kernel(int n, int d4, int T,
   }
 }
 
+// The input of the unified encoder's first layer in one launch: packed rows x = joint + extra, e = extra (the addend the later
+// layers re-add), x16 = bf16(x), where joint = (a | b) and extra = (ea | eb) in the flat (sequence, position) order and row r of
+// the outputs is flat row perm[r] (zeros for r >= *n_live) -- replaces cat + cat + add + two gathers + the bf16 cast in front of
+// the first projection.  Its gradient launch takes dx, the bf16 gradient that came back through x16 and de, and writes the four
+// flat-side gradients (zeros at invalid positions): d(a | b) = g, d(ea | eb) = g + de with g = dx + dx16.
+__global__ __launch_bounds__(256) void joint_embed_fwd_kernel(int n, int d4, int T, int La, const float4 *__restrict__ a,
+                                                              const float4 *__restrict__ b, const float4 *__restrict__ ea,
+                                                              const float4 *__restrict__ eb, const long long *__restrict__ perm,
+                                                              const int *__restrict__ n_live, float4 *__restrict__ x,
+                                                              float4 *__restrict__ e_out, uint2 *__restrict__ x16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int live = n_live ? min(n, max(*n_live, 0)) : n;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    bool on = r < live;
+    const long long fe = on ? perm[r] : 0;
+    on = on && fe >= 0 && fe < (long long)n;
+    bool second = false;
+    const size_t off = on ? flat_row_offset(fe, T, La, d4, second) : 0;
+    const float4 *sj = second ? b : a, *se = second ? eb : ea;
+    for (int c = lane; c < d4; c += 64) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+      if (on) {
+        const float4 j = sj[off + c];
+        w = se[off + c];
+        v = make_float4(j.x + w.x, j.y + w.y, j.z + w.z, j.w + w.w);
+      }
+      x[(size_t)r * d4 + c] = v;
+      e_out[(size_t)r * d4 + c] = w;
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+      const bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      x16[(size_t)r * d4 + c] = __builtin_bit_cast(uint2, h);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void joint_embed_bwd_kernel(int n, int d4, int T, int La, const float4 *__restrict__ dx,
+                                                              const uint2 *__restrict__ dx16, const float4 *__restrict__ de,
+                                                              const long long *__restrict__ inv, const unsigned char *__restrict__ valid,
+                                                              float4 *__restrict__ da, float4 *__restrict__ db,
+                                                              float4 *__restrict__ dea, float4 *__restrict__ deb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int fe = blockIdx.x * 4 + wave; fe < n; fe += gridDim.x * 4) {
+    bool on = valid[fe] != 0;
+    const long long r = on ? inv[fe] : 0;
+    on = on && r >= 0 && r < (long long)n;
+    bool second = false;
+    const size_t off = flat_row_offset(fe, T, La, d4, second);
+    float4 *oj = second ? db : da, *oe = second ? deb : dea;
+    for (int c = lane; c < d4; c += 64) {
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), ge = g;
+      if (on) {
+        const size_t p = (size_t)r * d4 + c;
+        if (dx) g = dx[p];
+        if (dx16) {
+          const uint2 h = dx16[p];
+          g.x += __uint_as_float(h.x << 16); g.y += __uint_as_float(h.x & 0xFFFF0000u);
+          g.z += __uint_as_float(h.y << 16); g.w += __uint_as_float(h.y & 0xFFFF0000u);
+        }
+        ge = g;
+        if (de) { const float4 t = de[p]; ge = make_float4(g.x + t.x, g.y + t.y, g.z + t.z, g.w + t.w); }
+      }
+      oj[off + c] = g;
+      oe[off + c] = ge;
+    }
+  }
+}
+
 }  // namespace gps_rowplan
 
 
@@ -682,6 +748,33 @@ int gps_rows_unpack2(int n_seq, int len_a, int len_b, int d, const float *packed
   hipLaunchKernelGGL(gps_rowplan::rows_unpack2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, d / 4, len_a + len_b, len_a,
                      reinterpret_cast<const float4 *>(packed), inv, valid, reinterpret_cast<float4 *>(out_a),
                      reinterpret_cast<float4 *>(out_b));
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_joint_embed_forward(int n_seq, int len_a, int len_b, int d, const float *a, const float *b, const float *ea, const float *eb,
+                            const long long *perm, const int *n_live, float *x, float *e, unsigned short *x16, gps_stream_t stream) {
+  if (n_seq < 1 || len_a < 1 || len_b < 1 || d < 4 || !a || !b || !ea || !eb || !perm || !x || !e || !x16) return GPS_ERR_INVALID_ARGUMENT;
+  if (d % 4 || (long long)n_seq * (len_a + len_b) > (1 << 22)) return GPS_ERR_UNSUPPORTED;
+  const int n = n_seq * (len_a + len_b);
+  const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  hipLaunchKernelGGL(gps_rowplan::joint_embed_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, d / 4, len_a + len_b,
+                     len_a, reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
+                     reinterpret_cast<const float4 *>(ea), reinterpret_cast<const float4 *>(eb), perm, n_live,
+                     reinterpret_cast<float4 *>(x), reinterpret_cast<float4 *>(e), reinterpret_cast<uint2 *>(x16));
+  return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
+}
+
+int gps_joint_embed_backward(int n_seq, int len_a, int len_b, int d, const float *dx, const unsigned short *dx16, const float *de,
+                             const long long *inv, const unsigned char *valid, float *da, float *db, float *dea, float *deb,
+                             gps_stream_t stream) {
+  if (n_seq < 1 || len_a < 1 || len_b < 1 || d < 4 || !inv || !valid || !da || !db || !dea || !deb) return GPS_ERR_INVALID_ARGUMENT;
+  if (d % 4 || (long long)n_seq * (len_a + len_b) > (1 << 22)) return GPS_ERR_UNSUPPORTED;
+  const int n = n_seq * (len_a + len_b);
+  const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+  hipLaunchKernelGGL(gps_rowplan::joint_embed_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, d / 4, len_a + len_b,
+                     len_a, reinterpret_cast<const float4 *>(dx), reinterpret_cast<const uint2 *>(dx16),
+                     reinterpret_cast<const float4 *>(de), inv, valid, reinterpret_cast<float4 *>(da), reinterpret_cast<float4 *>(db),
+                     reinterpret_cast<float4 *>(dea), reinterpret_cast<float4 *>(deb));
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
 

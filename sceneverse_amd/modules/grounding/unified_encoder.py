@@ -100,35 +100,43 @@ def _rows_call(name, *args):
     _native.check(st, name)
 
 
-class _PackJoint(torch.autograd.Function):
-    """Packed joint rows straight from the text rows a (B, La, D) and the object rows b (B, Lb, D): out[r] = flat[perm[r]] for
-    r < *n_live (zeros past it), flat = the (B, La + Lb) joint layout that is never materialised (gps_rows_pack2).  The gradient
-    is gps_rows_unpack2 into two contiguous tensors (zeros at invalid positions)."""
+class _JointEmbed(torch.autograd.Function):
+    """The packed input of the first joint layer from the text rows a (B, La, D), the object rows b (B, Lb, D) and their
+    per-layer addends ea, eb (token-type / location embeddings): x = joint + extra, e = extra, x16 = bf16(x), row r = flat row
+    perm[r] of the (B, La + Lb) layout that is never materialised, zeros for r >= *n_live (gps_joint_embed_forward: replaces two
+    cats, the add, two gathers and the bf16 cast in front of the first projection).  One gradient launch turns dx, the bf16
+    gradient that comes back through x16 and de into the four flat-side gradients (gps_joint_embed_backward)."""
 
     @staticmethod
-    def forward(ctx, a, b, perm, inv, valid8, n_live):
+    def forward(ctx, a, b, ea, eb, perm, inv, valid8, n_live):
         B, La, D = a.shape
         Lb = b.shape[1]
-        a, b = a.float().contiguous(), b.float().contiguous()
-        out = torch.empty((B * (La + Lb), D), dtype=torch.float32, device=a.device)
+        a, b, ea, eb = (t.float().contiguous() for t in (a, b, ea, eb))
+        n = B * (La + Lb)
+        x = torch.empty((n, D), dtype=torch.float32, device=a.device)
+        e = torch.empty((n, D), dtype=torch.float32, device=a.device)
+        x16 = torch.empty((n, D), dtype=torch.bfloat16, device=a.device)
         with torch.cuda.device(a.device):
-            _rows_call("gps_rows_pack2", B, La, Lb, D, a.data_ptr(), b.data_ptr(), perm.data_ptr(), n_live.data_ptr(),
-                       out.data_ptr(), None)
+            _rows_call("gps_joint_embed_forward", B, La, Lb, D, a.data_ptr(), b.data_ptr(), ea.data_ptr(), eb.data_ptr(),
+                       perm.data_ptr(), n_live.data_ptr(), x.data_ptr(), e.data_ptr(), x16.data_ptr())
         ctx.save_for_backward(inv, valid8)
         ctx.dims = (B, La, Lb, D)
-        return out
+        return x, e, x16
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dx, de, dx16):
         inv, valid8 = ctx.saved_tensors
         B, La, Lb, D = ctx.dims
-        dout = dout.float().contiguous()
-        da = torch.empty((B, La, D), dtype=torch.float32, device=dout.device)
-        db = torch.empty((B, Lb, D), dtype=torch.float32, device=dout.device)
-        with torch.cuda.device(dout.device):
-            _rows_call("gps_rows_unpack2", B, La, Lb, D, dout.data_ptr(), inv.data_ptr(), valid8.data_ptr(), da.data_ptr(),
-                       db.data_ptr())
-        return da, db, None, None, None, None
+        dev = inv.device
+        dx = None if dx is None else dx.float().contiguous()
+        de = None if de is None else de.float().contiguous()
+        dx16 = None if dx16 is None else dx16.to(torch.bfloat16).contiguous()
+        outs = [torch.empty((B, L, D), dtype=torch.float32, device=dev) for L in (La, Lb, La, Lb)]
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        with torch.cuda.device(dev):
+            _rows_call("gps_joint_embed_backward", B, La, Lb, D, ptr(dx), ptr(dx16), ptr(de), inv.data_ptr(), valid8.data_ptr(),
+                       *(t.data_ptr() for t in outs))
+        return outs[0], outs[1], outs[2], outs[3], None, None, None, None
 
 
 class _UnpackJoint(torch.autograd.Function):
@@ -215,9 +223,7 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         # packed rows straight from the two parts (no concatenated (B, T, D) tensor, no gather of one): zeros in the dead rows,
         # whose (undefined) gradients the reverse launch never reads
         valid8 = valid.view(torch.uint8)
-        extra_c = _PackJoint.apply(txt_extra, obj_extra, perm, inv, valid8, n_live)
-        x = _PackJoint.apply(txt_embeds, obj_embeds, perm, inv, valid8, n_live) + extra_c
-        x16 = x
+        x, extra_c, x16 = _JointEmbed.apply(txt_embeds, obj_embeds, txt_extra, obj_extra, perm, inv, valid8, n_live)
         n_layers = len(self.unified_encoder)
         from ..layers.fused_norm import SharedPostGrad
         share = SharedPostGrad()         # gradient of extra_c: one buffer for the layers' backward launches

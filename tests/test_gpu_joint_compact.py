@@ -52,9 +52,10 @@ def _plan(valid):
 
 @pytest.mark.parametrize("n_seq,La,Lb,D", [(7, 5, 8, 768), (64, 50, 80, 768), (3, 1, 4, 8)])
 def test_pack2_unpack2_equal_cat_gather_and_split(n_seq, La, Lb, D):
-    """gps_rows_pack2 / gps_rows_unpack2 through _PackJoint / _UnpackJoint against cat + index_select (zeros in the dead rows)
-    and against gather + where + split: copies, so values and gradients are bit-equal."""
-    from sceneverse_amd.modules.grounding.unified_encoder import _PackJoint, _UnpackJoint
+    """gps_joint_embed_* through _JointEmbed and gps_rows_unpack2 / gps_rows_pack2 through _UnpackJoint against cat + add +
+    index_select (zeros in the dead rows) and gather + where + split: copies and single fp32 adds in the same order, so values and
+    gradients are bit-equal."""
+    from sceneverse_amd.modules.grounding.unified_encoder import _JointEmbed, _UnpackJoint
     g = torch.Generator().manual_seed(31)
     T = La + Lb
     valid = torch.rand(n_seq, T, generator=g) < 0.6
@@ -65,19 +66,29 @@ def test_pack2_unpack2_equal_cat_gather_and_split(n_seq, La, Lb, D):
     v8 = v.view(torch.uint8)
     a = torch.randn(n_seq, La, D, generator=g).to(DEV).requires_grad_(True)
     b = torch.randn(n_seq, Lb, D, generator=g).to(DEV).requires_grad_(True)
-    packed = _PackJoint.apply(a, b, perm, inv, v8, n_live)
+    ea = torch.randn(n_seq, La, D, generator=g).to(DEV).requires_grad_(True)
+    eb = torch.randn(n_seq, Lb, D, generator=g).to(DEV).requires_grad_(True)
+    x, e, x16 = _JointEmbed.apply(a, b, ea, eb, perm, inv, v8, n_live)
     flat = torch.cat((a.detach(), b.detach()), dim=1).reshape(n, D)
-    ref = flat.index_select(0, perm)
-    ref[live:] = 0
-    assert torch.equal(packed.detach(), ref)
-    w = torch.randn(n, D, generator=g).to(DEV)
-    w_nan = w.clone()
-    w_nan[live:] = float("nan")
-    ga, gb = torch.autograd.grad(packed, (a, b), w_nan)
-    ref_g = torch.zeros(n, D, device=DEV)
-    ref_g[perm[:live]] = w[:live]
-    ref_g = ref_g.view(n_seq, T, D)
-    assert torch.equal(ga, ref_g[:, :La]) and torch.equal(gb, ref_g[:, La:])
+    flat_e = torch.cat((ea.detach(), eb.detach()), dim=1).reshape(n, D)
+    ref_x, ref_e = (flat + flat_e).index_select(0, perm), flat_e.index_select(0, perm)
+    ref_x[live:] = 0
+    ref_e[live:] = 0
+    assert torch.equal(x.detach(), ref_x) and torch.equal(e.detach(), ref_e) and torch.equal(x16.detach(), ref_x.to(torch.bfloat16))
+    w, we = torch.randn(n, D, generator=g).to(DEV), torch.randn(n, D, generator=g).to(DEV)
+    w16 = torch.randn(n, D, generator=g).to(torch.bfloat16).to(DEV)
+    nanify = lambda t: torch.cat((t[:live], torch.full_like(t[live:], float("nan"))))  # noqa: E731
+    ga, gb, gea, geb = torch.autograd.grad((x, e, x16), (a, b, ea, eb), (nanify(w), nanify(we), nanify(w16)))
+
+    def flat_grad(rows):
+        out = torch.zeros(n, D, device=DEV)
+        out[perm[:live]] = rows[:live]
+        return out.view(n_seq, T, D)
+    gj, gje = flat_grad(w + w16.float()), flat_grad((w + w16.float()) + we)
+    assert torch.equal(ga, gj[:, :La]) and torch.equal(gb, gj[:, La:])
+    assert torch.equal(gea, gje[:, :La]) and torch.equal(geb, gje[:, La:])
+    ga2, gea2 = torch.autograd.grad(_JointEmbed.apply(a, b, ea, eb, perm, inv, v8, n_live)[0], (a, ea), nanify(w))   # x alone
+    assert torch.equal(ga2, flat_grad(w)[:, :La]) and torch.equal(gea2, ga2)
     y = torch.randn(n, D, generator=g).to(DEV)
     y[live:] = float("nan")
     y.requires_grad_(True)
