@@ -580,7 +580,7 @@ GPS_API int gps_bert_embed_backward(int n_rows, int d, const float *dy, const vo
 /* index plan of the variable-length text path (modules/language/bert.py::_fast_forward_varlen; the reference runs the
  * padded batch, modules/language/bert.py:26-30 -- this is what lets the encoder stack skip padded rows): from the
  * attention masks of n_texts texts (text i = n_seq x len ids + mask, masks NON-EMPTY PREFIXES of their rows -- the
- * caller's promise), S = sum n_seq sequences and T = sum n_seq * len token positions, ONE launch writes
+ * caller's promise), S = sum n_seq sequences and T = sum n_seq * len token positions, two launches (lengths; rows) write
  *   i32_out [4 S + 5]: lens[S] | cu_rows[S + 1] (row offsets of the compacted sequences) | order[S] (sequence indices,
  *            longest first, ties by index) | q_limit[S] (lens for the first n_seq_full sequences, 1 behind them) |
  *            n_valid | live rows of the first n_seq_full sequences | that + (S - n_seq_full) | violation (1 when some

@@ -249,11 +249,10 @@ inline int grid_rows(int n_rows) {
 
 
 // ---- index plan of the variable-length text path: everything the host derived from the attention masks with ~30 tiny
-// torch launches (cat / sum / stable argsort / cumsum / argsort / index_select / scatter / arange ...), in ONE launch.
+// torch launches (cat / sum / stable argsort / cumsum / argsort / index_select / scatter / arange ...), in two launches.
 // Masks are non-empty PREFIXES of their rows (the caller checked, see modules/language/bert.py::_masks_are_prefixes), so
 // the stable "valid rows first" permutation has a closed form: token j < len_s of sequence s is compact row cu[s] + j,
 // a padded position with flat index e is compact row n_valid + e - cu[s + 1] (the padded positions in flat order).
-constexpr int kPlanThreads = 1024;
 constexpr int kPlanMaxSeq = 8192;
 
 struct PlanText {
@@ -279,38 +278,59 @@ __device__ __forceinline__ bool mask_set(const void *m, size_t i, int eb, int is
   }
 }
 
-__global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArgs A, int32_t *__restrict__ i32_out,
+// [r6] Two launches instead of one 1 024-thread workgroup (45 us of serial memory round trips: 16 waves x 8 sequences x
+// two passes): (1) one WAVE per sequence counts its mask, (2) one WORKGROUP per sequence scans the S lengths again (S ints
+// from L2), ranks its sequence for the dispatch order and writes its rows of the plan.
+constexpr int kLensWaves = 4;
+__device__ __forceinline__ int plan_text_of(const PlanArgs &A, int s) {      // text holding global sequence s
+  int ti = 0;
+  while (ti + 1 < A.n_texts && s >= A.t[ti + 1].seq0) ++ti;
+  return ti;
+}
+
+// (a) sequence lengths: lens[s] = set elements; flag[s] = 1 when the mask is not a non-empty prefix of its row
+__global__ __launch_bounds__(64 * kLensWaves) void varlen_lens_kernel(const PlanArgs A, int32_t *__restrict__ o_lens,
+                                                                      int32_t *__restrict__ o_flag) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * kLensWaves + (threadIdx.x >> 6);
+  if (s >= A.n_seq) return;
+  const PlanText &T = A.t[plan_text_of(A, s)];
+  const int b = s - T.seq0;
+  int cnt = 0, end = 0;                                    // set elements | one past the last set element
+  for (int j0 = 0; j0 < T.len; j0 += 256) {               // four independent mask loads per trip
+    bool set[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      set[u] = mask_set(T.mask, (size_t)b * T.len + min(j0 + 64 * u + lane, T.len - 1), T.elem_bytes, T.is_float);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long bits = __ballot(j0 + 64 * u + lane < T.len && set[u]);
+      cnt += __popcll(bits);
+      if (bits) end = j0 + 64 * u + 64 - __clzll(bits);
+    }
+  }
+  if (lane == 0) {
+    o_lens[s] = cnt;
+    o_flag[s] = (cnt == 0 || cnt != end) ? 1 : 0;          // empty row, a hole, or left padding
+  }
+}
+
+constexpr int kRowsThreads = 256;
+__global__ __launch_bounds__(kRowsThreads) void varlen_plan_kernel(const PlanArgs A, int32_t *__restrict__ i32_out,
                                                                    int64_t *__restrict__ i64_out,
                                                                    uint8_t *__restrict__ valid_out) {
   extern __shared__ int plan_lds[];            // lens[S] | cu[S + 1]
   int *lens = plan_lds, *cu = plan_lds + A.n_seq;
-  __shared__ int violation;                    // some mask is not a non-empty prefix of its row
-  const int S = A.n_seq, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kPlanThreads / 64;
-  if (tid == 0) violation = 0;
-  __syncthreads();
-  // (a) sequence lengths: one wave per sequence, 64 mask elements per step
-  for (int ti = 0; ti < A.n_texts; ++ti) {
-    const PlanText &T = A.t[ti];
-    for (int b = wave; b < T.n_seq; b += n_waves) {
-      int cnt = 0, end = 0;                                  // set elements | one past the last set element
-      for (int j0 = 0; j0 < T.len; j0 += 256) {             // four independent mask loads per trip
-        bool set[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          set[u] = mask_set(T.mask, (size_t)b * T.len + min(j0 + 64 * u + lane, T.len - 1), T.elem_bytes, T.is_float);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned long long bits = __ballot(j0 + 64 * u + lane < T.len && set[u]);
-          cnt += __popcll(bits);
-          if (bits) end = j0 + 64 * u + 64 - __clzll(bits);
-        }
-      }
-      if (lane == 0) {
-        lens[T.seq0 + b] = cnt;
-        if (cnt == 0 || cnt != end) violation = 1;          // empty row, a hole, or left padding (benign race: all write 1)
-      }
-    }
-  }
+  __shared__ int red[kRowsThreads / 64];
+  const int S = A.n_seq, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S_full = A.n_seq_full;
+  int32_t *o_lens = i32_out, *o_cu = i32_out + S, *o_order = i32_out + 2 * S + 1, *o_qlim = i32_out + 3 * S + 1,
+          *o_scal = i32_out + 4 * S + 1;
+  for (int s = tid; s < S; s += kRowsThreads) lens[s] = o_lens[s];
+  // workgroup 0 alone reads the flags varlen_lens_kernel left in the q_limit slots, and alone overwrites those slots
+  int viol = 0;
+  if (blockIdx.x == 0)
+    for (int s = tid; s < S; s += kRowsThreads) viol |= o_qlim[s];
   __syncthreads();
   // (b) row offsets of the compacted sequences (wave 0, 64 sequences per step)
   if (wave == 0) {
@@ -331,55 +351,67 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
   }
   __syncthreads();
   const int n_valid = cu[S];
-  const int S_full = A.n_seq_full;
-  int32_t *o_lens = i32_out, *o_cu = i32_out + S, *o_order = i32_out + 2 * S + 1, *o_qlim = i32_out + 3 * S + 1,
-          *o_scal = i32_out + 4 * S + 1;
-  // (c) dispatch order: longest sequence first (ties by index), by counting -- S is a few hundred
-  for (int s = tid; s < S; s += kPlanThreads) {
-    const int l = lens[s];
+  // (c) dispatch order: longest sequence first (ties by index), by counting; every workgroup ranks its own sequence
+  const int s = blockIdx.x, l = lens[s];
+  {
     int rank = 0;
-    for (int q = 0; q < S; ++q) {
+    for (int q = tid; q < S; q += kRowsThreads) {
       const int lq = lens[q];
       rank += (lq > l || (lq == l && q < s)) ? 1 : 0;
     }
-    o_order[rank] = s;
-    o_lens[s] = l;
-    o_cu[s] = cu[s];
-    o_qlim[s] = s < S_full ? l : 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 64);
+    if (lane == 0) red[wave] = rank;
+    __syncthreads();
+    if (tid == 0) {
+      int r = 0;
+#pragma unroll
+      for (int w = 0; w < kRowsThreads / 64; ++w) r += red[w];
+      o_order[r] = s;
+      o_cu[s] = cu[s];
+    }
   }
-  if (tid == 0) {
-    o_cu[S] = n_valid;
-    o_scal[0] = n_valid;
-    o_scal[1] = cu[S_full];                        // live rows of the fully-read texts
-    o_scal[2] = cu[S_full] + (S - S_full);         // rows of the last layer's tail batch
-    o_scal[3] = violation;                         // != 0: the plan is NOT what the torch formulation would give
+  if (blockIdx.x == 0) {
+    __syncthreads();                               // red[] is reused
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) viol |= __shfl_xor(viol, off, 64);
+    if (lane == 0) red[wave] = viol;
+    __syncthreads();
+    for (int q = tid; q < S; q += kRowsThreads) o_qlim[q] = q < S_full ? lens[q] : 1;
+    if (tid == 0) {
+      int v = 0;
+#pragma unroll
+      for (int w = 0; w < kRowsThreads / 64; ++w) v |= red[w];
+      o_cu[S] = n_valid;
+      o_scal[0] = n_valid;
+      o_scal[1] = cu[S_full];                        // live rows of the fully-read texts
+      o_scal[2] = cu[S_full] + (S - S_full);         // rows of the last layer's tail batch
+      o_scal[3] = v;                                 // != 0: the plan is NOT what the torch formulation would give
+    }
   }
-  // (d) the compaction itself: one wave per sequence, 64 consecutive positions per step (coalesced, no divisions)
+  // (d) the compaction itself: this workgroup's sequence, 256 consecutive positions per step (coalesced, no divisions)
   int64_t *o_ids = i64_out, *o_pos = i64_out + A.n_tok, *o_inv = i64_out + 2 * A.n_tok, *o_sel = i64_out + 3 * A.n_tok;
-  for (int ti = 0; ti < A.n_texts; ++ti) {
-    const PlanText &T = A.t[ti];
-    for (int b = wave; b < T.n_seq; b += n_waves) {
-      const int s = T.seq0 + b, len_s = lens[s];
-      const long long c_valid = cu[s];                                   // compact row of the sequence's first token
-      const long long row0 = (long long)b * T.len, e0 = T.tok0 + row0;   // first position: inside the text / flat
-      const long long c_pad = (long long)n_valid + e0 - cu[s + 1];       // compact row of flat position e0 if it were padding
-      // four steps per trip, their id loads first (clamped, unconditional): the stores below may alias the ids as far
-      // as the compiler knows, so a load placed behind them would wait for its own round trip every 64 positions
-      for (int j0 = lane; j0 < T.len + lane; j0 += 256) {
-        int64_t idv[4];
+  {
+    const PlanText &T = A.t[plan_text_of(A, s)];
+    const int b = s - T.seq0;
+    const long long c_valid = cu[s];                                   // compact row of the sequence's first token
+    const long long row0 = (long long)b * T.len, e0 = T.tok0 + row0;   // first position: inside the text / flat
+    const long long c_pad = (long long)n_valid + e0 - cu[s + 1];       // compact row of flat position e0 if it were padding
+    // two steps per trip, their id loads first: the stores below may alias the ids as far as the compiler knows
+    for (int j0 = tid; j0 < T.len + tid; j0 += 2 * kRowsThreads) {
+      int64_t idv[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) idv[u] = T.ids[row0 + min(j0 + 64 * u, T.len - 1)];
+      for (int u = 0; u < 2; ++u) idv[u] = T.ids[row0 + min(j0 + kRowsThreads * u, T.len - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = j0 + 64 * u;
-          if (j < T.len) {
-            const bool ok = j < len_s;
-            const long long c = (ok ? c_valid : c_pad) + j;
-            o_ids[c] = idv[u];
-            o_pos[c] = j;
-            o_inv[e0 + j] = c;
-            valid_out[e0 + j] = ok ? 1 : 0;
-          }
+      for (int u = 0; u < 2; ++u) {
+        const int j = j0 + kRowsThreads * u;
+        if (j < T.len) {
+          const bool ok = j < l;
+          const long long c = (ok ? c_valid : c_pad) + j;
+          o_ids[c] = idv[u];
+          o_pos[c] = j;
+          o_inv[e0 + j] = c;
+          valid_out[e0 + j] = ok ? 1 : 0;
         }
       }
     }
@@ -387,7 +419,7 @@ __global__ __launch_bounds__(kPlanThreads) void varlen_plan_kernel(const PlanArg
   // (e) row selection of the last layer's tail batch: first row of every [CLS]-only sequence, then the fully-read rows
   if (S_full > 0 && S_full < S) {
     const int n_cls = S - S_full;
-    for (long long i = tid; i < n_cls + A.n_tok_full; i += kPlanThreads)
+    for (long long i = (long long)blockIdx.x * kRowsThreads + tid; i < n_cls + A.n_tok_full; i += (long long)gridDim.x * kRowsThreads)
       o_sel[i] = i < n_cls ? (long long)cu[S_full + (int)i] : i - n_cls;
   }
 }
@@ -709,7 +741,10 @@ int gps_varlen_plan(const gps_varlen_text *texts, int n_texts, int n_seq_full, i
   A.n_seq_full = n_seq_full;
   A.n_tok = tok;
   const size_t lds = sizeof(int) * (2 * (size_t)seq + 1);
-  hipLaunchKernelGGL(varlen_plan_kernel, dim3(1), dim3(kPlanThreads), lds, (hipStream_t)stream, A, (int32_t *)i32_out,
+  // lengths (+ the violation flags, parked in the q_limit slots), then one workgroup per sequence
+  hipLaunchKernelGGL(varlen_lens_kernel, dim3((seq + kLensWaves - 1) / kLensWaves), dim3(64 * kLensWaves), 0, (hipStream_t)stream, A,
+                     (int32_t *)i32_out, (int32_t *)i32_out + 3 * seq + 1);
+  hipLaunchKernelGGL(varlen_plan_kernel, dim3(seq), dim3(kRowsThreads), lds, (hipStream_t)stream, A, (int32_t *)i32_out,
                      (int64_t *)i64_out, (uint8_t *)valid_out);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;
 }
