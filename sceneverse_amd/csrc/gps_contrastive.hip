@@ -39,6 +39,21 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
   __syncthreads();
   return r;
 }
+// the same for a workgroup of NW waves (`red` = NW floats), partial sums added in wave order
+template <int NW>
+__device__ __forceinline__ float block_sum_n(float v, float *red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) r += red[w];
+  __syncthreads();
+  return r;
+}
+// [r6] the two forward kernels run 16 waves per workgroup: a wave's trips over the other rows are dependent memory round
+// trips (4 waves: 5 / 8 of them in a row, 21.5 / 24.5 us per launch for a few MB)
+constexpr int kFwdWaves = 16;
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
 // publish `mine` as row `idx` of `rows`, take a ticket; the last of `count` arrivals returns true (thread 0 only) after
@@ -58,7 +73,8 @@ __device__ __forceinline__ float peek(const float *p) { return __hip_atomic_load
 //   cosv[b][o] = <obj_n[b][o], text_n[b]>     prob[b][o] = softmax over the unmasked objects    inv_o, inv_t: 1 / max(norm, eps)
 //   loss = mean over the scenes whose label != ignore_index of (lse_b - cosv[b][label_b])       scal[0] = loss, scal[1] = count
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void text_obj_fwd_kernel(int B, int O, int D, const float *__restrict__ obj,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void text_obj_fwd_kernel(int B, int O, int D, const float *__restrict__ obj,
                                                                const float *__restrict__ text,
                                                                const int64_t *__restrict__ labels,
                                                                const uint8_t *__restrict__ masks, float eps,
@@ -66,21 +82,21 @@ __global__ __launch_bounds__(kBlock) void text_obj_fwd_kernel(int B, int O, int 
                                                                float *__restrict__ prob, float *__restrict__ inv_o,
                                                                float *__restrict__ inv_t, float *__restrict__ loss_rows,
                                                                float *__restrict__ scal, unsigned int *__restrict__ ticket) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];          // D floats: text_n | O floats: logits | kWaves
+  extern __shared__ __attribute__((aligned(16))) float sm[];          // D floats: text_n | O floats: logits | NW
   float *tn = sm, *lg = sm + D, *red = sm + D + O;
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int D4 = D >> 2;
   const float4 *t4 = reinterpret_cast<const float4 *>(text + (size_t)b * D);
   float4 *tn4 = reinterpret_cast<float4 *>(tn);
   float ss = 0.f;
-  for (int i = threadIdx.x; i < D4; i += kBlock) {
+  for (int i = threadIdx.x; i < D4; i += 64 * NW) {
     const float4 v = t4[i];
     tn4[i] = v;
     ss += dot4(v, v);
   }
-  ss = block_sum(ss, red);
+  ss = block_sum_n<NW>(ss, red);
   const float it = 1.f / fmaxf(sqrtf(ss), eps);
-  for (int i = threadIdx.x; i < D4; i += kBlock) {
+  for (int i = threadIdx.x; i < D4; i += 64 * NW) {
     float4 v = tn4[i];
     v.x *= it; v.y *= it; v.z *= it; v.w *= it;
     tn4[i] = v;
@@ -88,10 +104,10 @@ __global__ __launch_bounds__(kBlock) void text_obj_fwd_kernel(int B, int O, int 
   __syncthreads();
   // four objects per wave and trip: their rows are requested together (one object at a time was one dependent memory
   // round trip + two wave reductions per object, 20 in a row at O = 80: 37 us for a 16 MB read)
-  for (int o0 = w; o0 < O; o0 += 4 * kWaves) {
+  for (int o0 = w; o0 < O; o0 += 4 * NW) {
     const float4 *x4[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x4[u] = reinterpret_cast<const float4 *>(obj + ((size_t)b * O + min(o0 + u * kWaves, O - 1)) * D);
+    for (int u = 0; u < 4; ++u) x4[u] = reinterpret_cast<const float4 *>(obj + ((size_t)b * O + min(o0 + u * NW, O - 1)) * D);
     float so[4] = {0.f, 0.f, 0.f, 0.f}, dt[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = lane; i < D4; i += 64) {
       float4 v[4];
@@ -103,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void text_obj_fwd_kernel(int B, int O, int 
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int o = o0 + u * kWaves;
+      const int o = o0 + u * NW;
       const float s2 = wave_sum(so[u]), d2 = wave_sum(dt[u]);
       const float io = 1.f / fmaxf(sqrtf(s2), eps);
       if (lane == 0 && o < O) {
@@ -239,40 +255,41 @@ __global__ __launch_bounds__(kBlock) void text_obj_bwd_kernel(int B, int O, int 
 // Workgroup i computes row i of M (saved: the backward pass reads it) and column i (its own dots: a_n[j] . b_n[i]).
 // normalize = 0: the rows are taken as they are (inv = 1; data-parallel runs hand over gathered, already normalised rows).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void clip_fwd_kernel(int n, int D, int normalize, const float *__restrict__ a,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void clip_fwd_kernel(int n, int D, int normalize, const float *__restrict__ a,
                                                            const float *__restrict__ bm, const float *__restrict__ scale,
                                                            float max_scale, float eps, float *__restrict__ M,
                                                            float *__restrict__ lse_row, float *__restrict__ lse_col,
                                                            float *__restrict__ inv_a, float *__restrict__ inv_b,
                                                            float *__restrict__ loss_rows, float *__restrict__ loss,
                                                            unsigned int *__restrict__ ticket) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];          // D: a_n[i] | D: b_n[i] | n: row | n: col | kWaves
+  extern __shared__ __attribute__((aligned(16))) float sm[];          // D: a_n[i] | D: b_n[i] | n: row | n: col | NW
   float *an = sm, *bn = sm + D, *row = sm + 2 * D, *col = row + n, *red = col + n;
   const int i = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int D4 = D >> 2;
   float4 *an4 = reinterpret_cast<float4 *>(an), *bn4 = reinterpret_cast<float4 *>(bn);
   const float4 *ai4 = reinterpret_cast<const float4 *>(a + (size_t)i * D), *bi4 = reinterpret_cast<const float4 *>(bm + (size_t)i * D);
   float sa = 0.f, sb = 0.f;
-  for (int k = threadIdx.x; k < D4; k += kBlock) {
+  for (int k = threadIdx.x; k < D4; k += 64 * NW) {
     const float4 x = ai4[k], y = bi4[k];
     an4[k] = x; bn4[k] = y;
     sa += dot4(x, x); sb += dot4(y, y);
   }
-  sa = block_sum(sa, red);
-  sb = block_sum(sb, red);
+  sa = block_sum_n<NW>(sa, red);
+  sb = block_sum_n<NW>(sb, red);
   const float ia = normalize ? 1.f / fmaxf(sqrtf(sa), eps) : 1.f, ib = normalize ? 1.f / fmaxf(sqrtf(sb), eps) : 1.f;
-  for (int k = threadIdx.x; k < D4; k += kBlock) {
+  for (int k = threadIdx.x; k < D4; k += 64 * NW) {
     float4 x = an4[k], y = bn4[k];
     x.x *= ia; x.y *= ia; x.z *= ia; x.w *= ia;
     y.x *= ib; y.y *= ib; y.z *= ib; y.w *= ib;
     an4[k] = x; bn4[k] = y;
   }
   __syncthreads();
-  for (int j0 = w; j0 < n; j0 += 2 * kWaves) {                     // two rows of each operand per wave and trip
+  for (int j0 = w; j0 < n; j0 += 2 * NW) {                     // two rows of each operand per wave and trip
     const float4 *aj4[2], *bj4[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = min(j0 + u * kWaves, n - 1);
+      const int j = min(j0 + u * NW, n - 1);
       aj4[u] = reinterpret_cast<const float4 *>(a + (size_t)j * D);
       bj4[u] = reinterpret_cast<const float4 *>(bm + (size_t)j * D);
     }
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void clip_fwd_kernel(int n, int D, int norm
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = j0 + u * kWaves;
+      const int j = j0 + u * NW;
       const float dr = wave_sum(d_row[u]), sb2 = wave_sum(s_b[u]), dc = wave_sum(d_col[u]), sa2 = wave_sum(s_a[u]);
       if (lane == 0 && j < n) {
         const float jb = normalize ? 1.f / fmaxf(sqrtf(sb2), eps) : 1.f, ja = normalize ? 1.f / fmaxf(sqrtf(sa2), eps) : 1.f;
@@ -421,9 +438,9 @@ int gps_text_obj_ce_forward(int B, int O, int D, const float *obj, const float *
   if (!obj || !text || !labels || !masks || !cosv || !prob || !inv_o || !inv_t || !loss_rows || !scal || !ticket)
     return GPS_ERR_INVALID_ARGUMENT;
   if ((D & 3) || D > 8192 || O > 4096 || !aligned16(obj) || !aligned16(text)) return GPS_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)(D + O + gps_contra::kWaves) * sizeof(float);
+  const size_t lds = (size_t)(D + O + gps_contra::kFwdWaves) * sizeof(float);
   if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;      // (no MaxDynamicSharedMemorySize grant: the default limit; callers fall back)
-  hipLaunchKernelGGL(gps_contra::text_obj_fwd_kernel, dim3(B), dim3(gps_contra::kBlock), lds, (hipStream_t)stream, B, O, D,
+  hipLaunchKernelGGL(gps_contra::text_obj_fwd_kernel<gps_contra::kFwdWaves>, dim3(B), dim3(64 * gps_contra::kFwdWaves), lds, (hipStream_t)stream, B, O, D,
                      obj, text, (const int64_t *)labels, masks, eps, ignore_index, cosv, prob, inv_o, inv_t, loss_rows, scal,
                      ticket);
   return launch_status();
@@ -455,9 +472,9 @@ int gps_clip_loss_forward(int n, int D, int normalize, const float *a, const flo
   if (!a || !b || !scale || !M || !lse_row || !lse_col || !inv_a || !inv_b || !loss_rows || !loss || !ticket)
     return GPS_ERR_INVALID_ARGUMENT;
   if ((D & 3) || D > 8192 || n > 8192 || !aligned16(a) || !aligned16(b)) return GPS_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)(2 * D + 2 * n + gps_contra::kWaves) * sizeof(float);
+  const size_t lds = (size_t)(2 * D + 2 * n + gps_contra::kFwdWaves) * sizeof(float);
   if (lds > 64 * 1024) return GPS_ERR_UNSUPPORTED;      // (no MaxDynamicSharedMemorySize grant: the default limit; callers fall back)
-  hipLaunchKernelGGL(gps_contra::clip_fwd_kernel, dim3(n), dim3(gps_contra::kBlock), lds, (hipStream_t)stream, n, D, normalize,
+  hipLaunchKernelGGL(gps_contra::clip_fwd_kernel<gps_contra::kFwdWaves>, dim3(n), dim3(64 * gps_contra::kFwdWaves), lds, (hipStream_t)stream, n, D, normalize,
                      a, b, scale, max_scale, eps, M, lse_row, lse_col, inv_a, inv_b, loss_rows, loss, ticket);
   return launch_status();
 }

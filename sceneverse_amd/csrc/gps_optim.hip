@@ -62,16 +62,27 @@ __global__ __launch_bounds__(kThreads) void sumsq_kernel(const gps_adamw_tensor 
 
 // scal[0] = clip coefficient, scal[1] = total gradient norm; steps[slot] += 1 for every tensor updated by this call
 // (torch.optim.AdamW counts steps PER PARAMETER: one that had no gradient in some iterations lags behind)
-__global__ __launch_bounds__(kThreads) void finish_norm_kernel(int n_partial, const float *__restrict__ partial, float max_norm,
-                                                                float *__restrict__ scal, int n_tensors,
-                                                                const gps_adamw_tensor *__restrict__ tensors,
-                                                                float *__restrict__ steps) {
-  __shared__ double red[kThreads];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n_partial; i += kThreads) s += (double)partial[i];
-  red[threadIdx.x] = s;
+// (1 024 threads, four loads in flight per thread: the ~15 k partials of the bench model took 58 dependent trips of one
+// 256-thread workgroup, 18 us; the sum is fp64, its order fixed)
+constexpr int kFinishThreads = 1024;
+__global__ __launch_bounds__(kFinishThreads) void finish_norm_kernel(int n_partial, const float *__restrict__ partial, float max_norm,
+                                                                      float *__restrict__ scal, int n_tensors,
+                                                                      const gps_adamw_tensor *__restrict__ tensors,
+                                                                      float *__restrict__ steps) {
+  __shared__ double red[kFinishThreads];
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  int i = threadIdx.x;
+  for (; i + 3 * kFinishThreads < n_partial; i += 4 * kFinishThreads) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = partial[i + u * kFinishThreads];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s4[u] += (double)v[u];
+  }
+  for (; i < n_partial; i += kFinishThreads) s4[0] += (double)partial[i];
+  red[threadIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   __syncthreads();
-  for (int o = kThreads / 2; o > 0; o >>= 1) {
+  for (int o = kFinishThreads / 2; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void finish_norm_kernel(int n_partial, co
     scal[0] = coef;
     scal[1] = norm;
   }
-  for (int i = threadIdx.x; i < n_tensors; i += kThreads) steps[tensors[i].step_slot] += 1.f;
+  for (int t = threadIdx.x; t < n_tensors; t += kFinishThreads) steps[tensors[t].step_slot] += 1.f;
 }
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float coef, float lr, float b1, float b2, float eps,
@@ -160,7 +171,7 @@ int gps_adamw_step(int n_tensors, int n_chunks, const gps_adamw_tensor *tensors,
   hipStream_t s = (hipStream_t)stream;
   const int2 *ch = reinterpret_cast<const int2 *>(chunks);
   if (max_grad_norm > 0.f) hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(kThreads), 0, s, tensors, ch, partial);
-  hipLaunchKernelGGL(finish_norm_kernel, dim3(1), dim3(kThreads), 0, s, max_grad_norm > 0.f ? n_chunks : 0, partial, max_grad_norm,
+  hipLaunchKernelGGL(finish_norm_kernel, dim3(1), dim3(kFinishThreads), 0, s, max_grad_norm > 0.f ? n_chunks : 0, partial, max_grad_norm,
                      scalars, n_tensors, tensors, steps);
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(kThreads), 0, s, tensors, groups, ch, scalars, steps);
   return hipGetLastError() == hipSuccess ? GPS_OK : GPS_ERR_LAUNCH;

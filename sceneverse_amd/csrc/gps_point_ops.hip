@@ -848,7 +848,9 @@ __global__ __launch_bounds__(kBlock) void pairwise_locs_kernel(int L, const floa
   // same fp32 values; the pad columns L .. ld_pl - 1 are zero
   _Float16 *pp = planes ? planes + (size_t)scene * 5 * L * ld_pl : nullptr;
   const int cols = planes ? ld_pl : L;
-  for (int e = threadIdx.x; e < L * cols; e += kBlock) {
+  // [r6] gridDim.y workgroups share a scene's output (each found d_max over ALL pairs above: a maximum, so every slice
+  // holds the same value): one workgroup per scene left 3/4 of the CUs idle at B = 64 (24 us -> 8)
+  for (int e = blockIdx.y * kBlock + threadIdx.x; e < L * cols; e += gridDim.y * kBlock) {
     const int l = e / cols, t = e - l * cols;
     if (t >= L) {
 #pragma unroll
@@ -871,6 +873,14 @@ __global__ __launch_bounds__(kBlock) void pairwise_locs_kernel(int L, const floa
       for (int d5 = 0; d5 < 5; ++d5) pp[((size_t)d5 * L + l) * ld_pl + t] = (_Float16)f[d5];
     }
   }
+}
+
+// slices of one scene's pairs: enough workgroups for ~4 per CU, each with >= 2 trips of output work
+inline int pairwise_slices(int b, int L) {
+  const long long trips = ((long long)L * L + kBlock - 1) / kBlock;
+  long long s = (1024 + b - 1) / b;
+  if (s > trips / 2) s = trips / 2;
+  return s < 1 ? 1 : (s > 16 ? 16 : (int)s);
 }
 
 // planes from an existing (B, L, L, 5) fp32 tensor (callers that built the pairwise tensor themselves)
@@ -928,30 +938,48 @@ __global__ __launch_bounds__(1024) void cloud_plan_kernel(int b, int rows_mult, 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_first_pad = 0x7FFFFFFF;
   __syncthreads();
-  for (int o = threadIdx.x; o < b; o += 1024)
-    if (uniform[o]) atomicMin(&s_first_pad, o);
+  // one LDS atomic per wave and trip (a third of the bench batch's objects are pads: an atomic per pad lane was ~1 900
+  // serialised updates of one word)
+  for (int i0 = 0; i0 < b; i0 += 1024) {
+    const int o = i0 + (int)threadIdx.x;
+    const unsigned long long um = __ballot(o < b && uniform[o] != 0);
+    if (um && lane == 0) atomicMin(&s_first_pad, i0 + w * 64 + (__ffsll((long long)um) - 1));
+  }
   __syncthreads();
   const int fp = s_first_pad;
   const bool has_pad = fp != 0x7FFFFFFF;
   const uint32_t pad_word = has_pad ? word[fp] : 0u;
   auto is_pad = [&](int o) { return has_pad && uniform[o] != 0 && word[o] == pad_word; };
   int base = 0, par = 0;
-  for (int i0 = 0; i0 < b; i0 += 1024) {
-    const int o = i0 + threadIdx.x;
-    const bool work = o < b && !is_pad(o);
-    const unsigned long long mask = __ballot(work);
-    const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-    if (lane == 0) s_cnt[par][w] = __popcll(mask);
-    __syncthreads();
-    int wave_base = 0, trip = 0;
-    for (int k = 0; k < 16; ++k) { const int c = s_cnt[par][k]; wave_base += (k < w) ? c : 0; trip += c; }
-    if (work) {
-      const int slot = base + wave_base + before;
-      obj_of[slot] = o;
-      slot_of[o] = slot;
+  // [r6] the flags of eight trips are requested together: one trip at a time was a memory round trip in front of every
+  // scan step (5 at b = 5 120: 16.5 us for 40 KB)
+  for (int i00 = 0; i00 < b; i00 += 8 * 1024) {
+    bool wk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int o = i00 + u * 1024 + (int)threadIdx.x;
+      wk[u] = o < b && !is_pad(o);
     }
-    base += trip;
-    par ^= 1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i0 = i00 + u * 1024;
+      if (i0 >= b) break;                                // uniform
+      const int o = i0 + threadIdx.x;
+      const bool work = wk[u];
+      const unsigned long long mask = __ballot(work);
+      const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      if (lane == 0) s_cnt[par][w] = __popcll(mask);
+      __syncthreads();
+      int wave_base = 0, trip = 0;
+      for (int k = 0; k < 16; ++k) { const int c = s_cnt[par][k]; wave_base += (k < w) ? c : 0; trip += c; }
+      if (work) {
+        const int slot = base + wave_base + before;
+        obj_of[slot] = o;
+        slot_of[o] = slot;
+      }
+      base += trip;
+      par ^= 1;
+    }
   }
   const int n_work = base + (has_pad ? 1 : 0);          // base = number of ordinary objects (the same in every thread)
   for (int o = threadIdx.x; o < b; o += 1024) {
@@ -1290,8 +1318,8 @@ int gps_pairwise_locs(int b, int l, const float *centers, float eps, float *out,
   if (!centers || !out) return GPS_ERR_INVALID_ARGUMENT;
   if (l > 2048) return GPS_ERR_UNSUPPORTED;
   const size_t lds = ((size_t)l * 3 + gps::kWavesPerBlock) * sizeof(float);
-  hipLaunchKernelGGL(gps::pairwise_locs_kernel, dim3(b), dim3(gps::kBlock), lds, (hipStream_t)stream, l, centers,
-                     eps, out, (_Float16 *)nullptr, 0);
+  hipLaunchKernelGGL(gps::pairwise_locs_kernel, dim3(b, gps::pairwise_slices(b, l)), dim3(gps::kBlock), lds, (hipStream_t)stream, l,
+                     centers, eps, out, (_Float16 *)nullptr, 0);
   return finish_launch();
 }
 
@@ -1302,8 +1330,8 @@ int gps_pairwise_locs_planes(int b, int l, const float *centers, float eps, floa
   if (!centers || !planes || ld_pl < l || (ld_pl & 3)) return GPS_ERR_INVALID_ARGUMENT;
   if (l > 2048) return GPS_ERR_UNSUPPORTED;
   const size_t lds = ((size_t)l * 3 + gps::kWavesPerBlock) * sizeof(float);
-  hipLaunchKernelGGL(gps::pairwise_locs_kernel, dim3(b), dim3(gps::kBlock), lds, (hipStream_t)stream, l, centers,
-                     eps, out, (_Float16 *)planes, ld_pl);
+  hipLaunchKernelGGL(gps::pairwise_locs_kernel, dim3(b, gps::pairwise_slices(b, l)), dim3(gps::kBlock), lds, (hipStream_t)stream, l,
+                     centers, eps, out, (_Float16 *)planes, ld_pl);
   return finish_launch();
 }
 

@@ -70,7 +70,7 @@ _LDS_LIMIT = 64 * 1024          # the launches request dynamic LDS without a Max
 
 def text_obj_ce_usable(obj, text, labels, masks) -> bool:
     return (obj.dim() == 3 and text.dim() == 2 and _rows_ok(obj, text) and obj.shape[1] <= 4096
-            and 4 * (obj.shape[2] + obj.shape[1] + 8) <= _LDS_LIMIT
+            and 4 * (obj.shape[2] + obj.shape[1] + 16) <= _LDS_LIMIT
             and labels.numel() == obj.shape[0] and masks.shape == obj.shape[:2] and obj.shape[0] > 0)
 
 
@@ -124,7 +124,7 @@ class _ClipLoss(torch.autograd.Function):
 
 def clip_loss_usable(a, b, scale) -> bool:
     return (a.dim() == 2 and a.shape == b.shape and _rows_ok(a, b) and 0 < a.shape[0] <= 8192 and torch.is_tensor(scale)
-            and 4 * (2 * a.shape[1] + 2 * a.shape[0] + 8) <= _LDS_LIMIT
+            and 4 * (2 * a.shape[1] + 2 * a.shape[0] + 16) <= _LDS_LIMIT
             and scale.is_cuda and scale.numel() == 1)
 
 
