@@ -826,23 +826,28 @@ __global__ __launch_bounds__(kBlock) void pairwise_locs_kernel(int L, const floa
   for (int e = threadIdx.x; e < L * 3; e += kBlock) pw_c[e] = c[e];
   __syncthreads();
   const int pairs = L * L;
-  float mx = 0.f;                                  // d >= sqrt(eps) > 0
-  for (int e = threadIdx.x; e < pairs; e += kBlock) {
-    const int l = e / L, t = e - l * L;
-    const float dx = pw_c[l * 3 + 0] - pw_c[t * 3 + 0], dy = pw_c[l * 3 + 1] - pw_c[t * 3 + 1],
-                dz = pw_c[l * 3 + 2] - pw_c[t * 3 + 2];
-    const float d = sqrtf(((dx * dx + dy * dy) + dz * dz) + eps);
-    mx = d > mx ? d : mx;
+  // d_max = max sqrt(q) = sqrt(max q) exactly (IEEE sqrt is monotonic): the maximum runs over the squared distances, one
+  // square root at the end; rows by wave, columns by lane (no integer division).  [r6] every slice workgroup of a scene
+  // repeats this pass, so its cost is the kernel's: ~50 instructions per pair (division, IEEE sqrt) -> ~12
+  float mq = 0.f;
+  for (int l = wave_id(); l < L; l += kWavesPerBlock) {
+    const float lx = pw_c[l * 3 + 0], ly = pw_c[l * 3 + 1], lz = pw_c[l * 3 + 2];
+    for (int t = lane_id(); t < L; t += kWave) {
+      const float dx = lx - pw_c[t * 3 + 0], dy = ly - pw_c[t * 3 + 1], dz = lz - pw_c[t * 3 + 2];
+      const float q = ((dx * dx + dy * dy) + dz * dz) + eps;
+      mq = q > mq ? q : mq;
+    }
   }
   for (int off = 32; off >= 1; off >>= 1) {
-    const float o = __shfl_xor(mx, off, kWave);
-    mx = o > mx ? o : mx;
+    const float o = __shfl_xor(mq, off, kWave);
+    mq = o > mq ? o : mq;
   }
-  if (lane_id() == 0) pw_red[wave_id()] = mx;
+  if (lane_id() == 0) pw_red[wave_id()] = mq;
   __syncthreads();
-  float dmax = pw_red[0];
+  float qmax = pw_red[0];
 #pragma unroll
-  for (int w = 1; w < kWavesPerBlock; ++w) dmax = pw_red[w] > dmax ? pw_red[w] : dmax;
+  for (int w = 1; w < kWavesPerBlock; ++w) qmax = pw_red[w] > qmax ? pw_red[w] : qmax;
+  const float dmax = sqrtf(qmax);                  // d >= sqrt(eps) > 0
   float *o = out ? out + (size_t)scene * pairs * 5 : nullptr;
   // plane form (gps_attn_args.pl_planes): planes[scene][d][l][t], t contiguous (pitch ld_pl), fp16 round-to-nearest of the
   // same fp32 values; the pad columns L .. ld_pl - 1 are zero
