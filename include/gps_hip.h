@@ -638,8 +638,9 @@ GPS_API int gps_joint_embed_backward(int n_seq, int len_a, int len_b, int d, con
 /* Row mover for rows of ANY element type (row_bytes a multiple of 16, both arrays 16-byte aligned): launch row r < n moves
  * source row (src_idx ? src_idx[r] : r) to destination row (dst_idx ? dst_idx[r] : r) when r < *n_live (n_live optional);
  * rows whose source index is outside [0, n_src_rows) arrive as zeros, rows whose destination index is outside are dropped.
- * Gather form (src_idx, dst_idx NULL): with zero_dead != 0 the destination rows at or past *n_live are zeroed.  Scatter form
- * (dst_idx): only addressed rows are written -- the caller zero-fills dst; the live destination indices must be distinct.
+ * With zero_dead != 0 the destination rows of the launch rows at or past *n_live are zeroed (rows r in the gather form, rows
+ * dst_idx[r] in the scatter form: with a bijective dst_idx every destination row is then written).  Scatter form (dst_idx)
+ * otherwise: only addressed rows are written -- the caller zero-fills dst; the destination indices must be distinct.
  * Replaces index_select + the dead-row mask and, in backward, the atomic index_add_ of the [CLS]-tail selection of the
  * variable-length text path (no counterpart in the reference, which runs the padded batch: modules/language/bert.py:26-30). */
 GPS_API int gps_rows_move(int n, long long n_src_rows, long long n_dst_rows, int row_bytes, const void *src, const long long *src_idx,

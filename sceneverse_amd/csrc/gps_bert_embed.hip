@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kThreads) void plan_kernel(int n_seq, int seq_len, 
 }
 // rows of `q` 16-byte words moved between two row arrays of any element type: row r of the launch reads source row
 // (src_idx ? src_idx[r] : r) and writes destination row (dst_idx ? dst_idx[r] : r) when r < *n_live (n_live optional) and both
-// rows exist; with zero_dead the identity-addressed destination rows at or past *n_live are zeroed instead.  One wave per row.
+// rows exist; with zero_dead the destination rows of the launch rows at or past *n_live are zeroed instead.  One wave per row.
 __global__ __launch_bounds__(256) void rows_move_kernel(int n, long long n_src, long long n_dst, int q, const uint4 *__restrict__ src,
                                                         const long long *__restrict__ src_idx, uint4 *__restrict__ dst,
                                                         const long long *__restrict__ dst_idx, const int *__restrict__ n_live,
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(256) void rows_move_kernel(int n, long long n_src, 
   const int live = n_live ? min(n, max(*n_live, 0)) : n;
   for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
     if (r >= live) {
-      if (zero_dead && !dst_idx && r < n_dst)
-        for (int c = lane; c < q; c += 64) dst[(size_t)r * q + c] = make_uint4(0u, 0u, 0u, 0u);
+      const long long z = !zero_dead ? -1 : dst_idx ? dst_idx[r] : (long long)r;
+      if (z >= 0 && z < n_dst)
+        for (int c = lane; c < q; c += 64) dst[(size_t)z * q + c] = make_uint4(0u, 0u, 0u, 0u);
       continue;
     }
     const long long s = src_idx ? src_idx[r] : (long long)r;

@@ -18,7 +18,7 @@ from ..layers.transformers import (TransformerDecoderLayer, TransformerEncoderLa
 from ..utils import calc_pairwise_locs, layer_repeat
 from ..weights import _init_weights_bert
 from ..layers.fused_loc import loc_embed
-from ..layers.fused_norm import add_row
+from ..layers.fused_norm import add_row, broadcast_row
 
 
 _COMPACT_ROWS = True         # False: the joint layers run every padded row, as the reference does (A/B, tests)
@@ -212,7 +212,10 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         T = Lt + obj_embeds.shape[1]
         n = B * T
         dev = txt_embeds.device
-        valid = torch.cat((txt_masks != 0, obj_masks != 0), dim=1).reshape(n)
+        if txt_masks.dtype == torch.bool and obj_masks.dtype == torch.bool:
+            valid = torch.cat((txt_masks, obj_masks), dim=1).reshape(n)                 # one launch
+        else:
+            valid = torch.cat((txt_masks != 0, obj_masks != 0), dim=1).reshape(n)
         i64 = torch.empty(2 * n, dtype=torch.int64, device=dev)
         i32 = torch.empty(B + 2, dtype=torch.int32, device=dev)
         perm, inv, cu, n_live = i64[:n], i64[n:], i32[:B + 1], i32[B + 1:]
@@ -243,7 +246,6 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
     def forward(self, txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks,
                 output_attentions=False, output_hidden_states=False, **kwargs):
         txt_len, obj_len = txt_embeds.shape[1], obj_embeds.shape[1]
-        joint_pad = torch.cat((txt_masks, obj_masks), dim=1).logical_not()
         type_txt = self.token_type_embeddings.weight[0]
         # the same deterministic embeddings are re-added to both streams every layer (ref :154-164) and the
         # streams are concatenated right after: build the joint (B, T, D) addend once and keep the sequence joint
@@ -251,9 +253,10 @@ class UnifiedSpatialCrossEncoderV2(nn.Module):
         # (row-vector additions through add_row: their gradient is a column sum over 3 200 / 5 120 rows, which torch's
         # generic reduction takes 45 - 60 us for)
         obj_extra = add_row(loc_embed(self.loc_layers[0], obj_locs), self.token_type_embeddings.weight[1])
-        txt_extra = add_row(obj_extra.new_zeros((txt_embeds.shape[0], txt_len, obj_extra.shape[-1])), type_txt.to(obj_extra.dtype))
+        txt_extra = broadcast_row(type_txt.to(obj_extra.dtype), (txt_embeds.shape[0], txt_len))
         if self._compact_ok(txt_embeds, obj_embeds):
             return self._forward_compact(txt_embeds, txt_masks, obj_embeds, obj_locs, obj_masks, txt_extra, obj_extra)
+        joint_pad = torch.cat((txt_masks, obj_masks), dim=1).logical_not()
         extra = torch.cat((txt_extra, obj_extra), dim=1)
         joint = torch.cat((txt_embeds, obj_embeds), dim=1)
         # layer l reads joint_l + extra: the first sum is explicit, every later one leaves the previous layer's last

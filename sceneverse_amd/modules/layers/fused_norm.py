@@ -243,6 +243,29 @@ class _AddRow(torch.autograd.Function):
         return dy, column_sum(dy).to(ctx.row_dtype)
 
 
+class _BroadcastRow(torch.autograd.Function):
+    """row (d,) -> (*lead, d) contiguous: one copy launch instead of a zero fill + an add; gradient = column sum."""
+
+    @staticmethod
+    def forward(ctx, row, lead):
+        return row.expand(*lead, row.shape[0]).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return column_sum(dy).to(dy.dtype), None
+
+
+def broadcast_row(row: torch.Tensor, lead) -> torch.Tensor:
+    """`add_row(zeros(*lead, d), row)` without the zeros: the same values, the same (deterministic) row gradient."""
+    lead = tuple(int(v) for v in lead)
+    n = 1
+    for v in lead:
+        n *= v
+    if not (_ENABLED and row.is_cuda and row.dtype == torch.float32 and row.dim() == 1 and row.shape[0] % 4 == 0 and n >= 2):
+        return add_row(row.new_zeros((*lead, row.shape[0])), row)
+    return _BroadcastRow.apply(row, lead)
+
+
 def column_sum(x: torch.Tensor) -> torch.Tensor:
     """Sum over every dimension but the last -> (d,), fp32, deterministic."""
     d = x.shape[-1]

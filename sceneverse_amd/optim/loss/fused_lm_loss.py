@@ -70,11 +70,42 @@ class _PermuteLiveRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         perm, n_valid = ctx.saved_tensors
+        if _rows_move_ok(dy, perm):
+            # one launch: dx[perm[r]] = r < *n_valid ? dy[r] : 0 (perm is a bijection: every row of dx is written)
+            dy = dy.contiguous()
+            dx = torch.empty_like(dy)
+            with torch.cuda.device(dy.device):
+                st = _native.load().gps_rows_move(dy.shape[0], dy.shape[0], dy.shape[0], dy.shape[1] * dy.element_size(),
+                                                  dy.data_ptr(), None, dx.data_ptr(), perm.data_ptr(), n_valid.data_ptr(), 1,
+                                                  torch.cuda.current_stream().cuda_stream)
+            _native.check(st, "rows_move")
+            return dx, None, None
         live = (torch.arange(dy.shape[0], device=dy.device) < n_valid)[:, None]
         dy = torch.where(live, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
         dx = torch.empty_like(dy)
         dx.index_copy_(0, perm, dy)                        # perm is a bijection: every row is written
         return dx, None, None
+
+
+def _rows_move_ok(x: torch.Tensor, idx: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and (x.shape[1] * x.element_size()) % 16 == 0
+            and idx.dtype == torch.int64 and idx.is_contiguous())
+
+
+_ZERO_ROWS = {}
+
+
+def _zero_rows(n: int, d: int, device: torch.device) -> torch.Tensor:
+    """A persistent all-zero (n, d) fp32 tensor (read-only by contract: the zero residual of the head's LayerNorm) -- one
+    allocation + fill per (device, shape) instead of a fill launch per step."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n, d)
+    z = _ZERO_ROWS.get(key)
+    if z is None:
+        with torch.no_grad():
+            z = torch.zeros((n, d), dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():     # (a fill captured into one graph would not have run for the others)
+            _ZERO_ROWS[key] = z
+    return z
 
 
 class _SparseLMLoss(torch.autograd.Function):
@@ -199,6 +230,6 @@ class LazyLMLogits:
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
             y = G.linear_gelu(xs, self.transform.dense, rows_dev=n_valid)
         # LayerNorm(y) through the residual kernel with a zero residual: y fp32 = LN(0 + y) on the live rows
-        zero = torch.zeros((x.shape[0], D), dtype=torch.float32, device=x.device)
+        zero = _zero_rows(x.shape[0], D, x.device)
         h = add_dropout_layer_norm(zero, y, self.transform.LayerNorm, 0.0, False, rows_dev=n_valid)
         return _SparseLMLoss.apply(h, self.weight, self.bias, labels.reshape(-1), int(ignore_index), plan)

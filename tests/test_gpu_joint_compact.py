@@ -141,6 +141,38 @@ def test_select_rows_equals_index_select_with_a_dead_row_mask(dtype):
     assert lib.gps_rows_move(4, 4, 4, 32, None, None, out.data_ptr(), None, None, 0, s) == _native.GPS_ERR_INVALID_ARGUMENT
 
 
+def test_permute_live_rows_gradient_is_one_scatter_with_zeroed_dead_rows():
+    """_PermuteLiveRows (masked-LM head: labelled rows first): the gradient through gps_rows_move's scatter form with
+    zero_dead equals where(live) + index_copy_ -- dead rows arrive as exact zeros even when the incoming rows are NaN."""
+    from sceneverse_amd.optim.loss.fused_lm_loss import _PermuteLiveRows
+    g = torch.Generator().manual_seed(5)
+    for n, D, live in ((3200, 768, 471), (37, 8, 0), (64, 768, 64)):
+        x = torch.randn(n, D, generator=g).to(DEV).requires_grad_(True)
+        perm = torch.randperm(n, generator=g).to(DEV)
+        n_valid = torch.tensor([live], dtype=torch.int32, device=DEV)
+        w = torch.randn(n, D, generator=g).to(DEV)
+        w[live:] = float("nan")                                   # rows the extent-aware kernels never wrote
+        y = _PermuteLiveRows.apply(x, perm, n_valid)
+        assert torch.equal(y, x.detach().index_select(0, perm))
+        (gx,) = torch.autograd.grad(y, x, w)
+        ref = torch.zeros(n, D, device=DEV)
+        ref[perm[:live]] = w[:live]
+        assert torch.equal(gx, ref)
+
+
+def test_broadcast_row_equals_add_row_on_zeros():
+    from sceneverse_amd.modules.layers.fused_norm import add_row, broadcast_row
+    g = torch.Generator().manual_seed(6)
+    row_a = torch.randn(768, generator=g).to(DEV).requires_grad_(True)
+    row_b = row_a.detach().clone().requires_grad_(True)
+    w = torch.randn(64, 50, 768, generator=g).to(DEV)
+    ya = broadcast_row(row_a, (64, 50))
+    yb = add_row(torch.zeros(64, 50, 768, device=DEV), row_b)
+    assert ya.is_contiguous() and torch.equal(ya, yb)
+    (ga,), (gb,) = torch.autograd.grad(ya, row_a, w), torch.autograd.grad(yb, row_b, w)
+    assert torch.equal(ga, gb)
+
+
 def test_gps_model_compact_joint_rows_equal_padded_rows(golden_cpu):
     from oracle.param_fill import fill_params
     from sceneverse_amd.model.build import build_model
