@@ -923,9 +923,24 @@ __global__ __launch_bounds__(kBlock) void cloud_uniform_kernel(int words, const 
   unsigned int diff = 0u;
   if ((words & 3) == 0 && (reinterpret_cast<uintptr_t>(cloud) & 15) == 0) {
     const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
-    for (int i = threadIdx.x; i < words / 4; i += kBlock) {
-      const uint4 v = p4[i];
-      diff |= ((v.x ^ w0) | (v.y ^ w0)) | ((v.z ^ w0) | (v.w ^ w0));
+    const int n4 = words / 4;
+    // [r6] first trip alone: an ordinary object differs from its first word within its first kBlock * 16 bytes and leaves
+    // here having read 4 KB of its 24 KB; only pads (and clouds that start with 4 KB of one word) are read to the end, four
+    // loads in flight per thread (indices clamped, not predicated: a predicated load waits for its own return)
+    if ((int)threadIdx.x < n4) {
+      const uint4 v = p4[threadIdx.x];
+      diff = ((v.x ^ w0) | (v.y ^ w0)) | ((v.z ^ w0) | (v.w ^ w0));
+    }
+    if (__syncthreads_or(diff != 0u)) {
+      if (threadIdx.x == 0) { uniform[obj] = 0; word[obj] = w0; }
+      return;
+    }
+    for (int i = kBlock + (int)threadIdx.x; i < n4; i += 4 * kBlock) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p4[min(i + u * kBlock, n4 - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) diff |= ((v[u].x ^ w0) | (v[u].y ^ w0)) | ((v[u].z ^ w0) | (v[u].w ^ w0));
     }
   } else {
     for (int i = threadIdx.x; i < words; i += kBlock) diff |= p[i] ^ w0;

@@ -185,13 +185,13 @@ def test_single_product_bf16_mode_states_its_error():
     _close(again, want, "PointNetPP after switching back")
 
 
-@pytest.mark.parametrize("pattern", ["mixed", "no_pads", "all_pads", "two_constants", "nearly_constant"])
+@pytest.mark.parametrize("pattern", ["mixed", "no_pads", "all_pads", "two_constants", "nearly_constant", "late_difference"])
 def test_distinct_clouds_only_is_bit_identical_to_every_slot(pattern):
     """modules/layers/pointnet.py: the frozen encoder on the work list of gps_cloud_compact (ordinary objects + one pad
     representative; a pad = a cloud that is one 32-bit word repeated, the word of the first such object -- the reference
     pads with 1.0) against the same encoder on every slot: torch.equal, for batches with pads in the middle, without pads,
     of pads only, with constant clouds of two different values (only the first value's are pads), and with a cloud that
-    differs from the pad in ONE word (an ordinary object)."""
+    differs from the pad in ONE word (an ordinary object; early, late or last word of the cloud)."""
     from sceneverse_amd.modules.layers import pointnet as PN
     from sceneverse_amd.pointnet2 import _ext
     net = _encoder(3)
@@ -206,6 +206,11 @@ def test_distinct_clouds_only_is_bit_identical_to_every_slot(pattern):
     elif pattern == "nearly_constant":
         pcs[[1, 6, 12]] = 1.0
         pcs[6, 100, 4] = 0.5
+    elif pattern == "late_difference":      # the only differing word sits past the uniform test's first trip (4 KB) / is the last one
+        pcs[[1, 6, 12, 15]] = 1.0
+        pcs[6, 900, 2] = 0.5
+        pcs[12, 1023, 5] = 0.5
+        pcs[15, 171, 0] = 0.5               # word 1 026: the first word of the second trip's second load
     pcs = pcs.to(DEV)
     plan = _ext.cloud_compact(pcs)
     words = pcs.view(torch.int32).reshape(pcs.shape[0], -1)
