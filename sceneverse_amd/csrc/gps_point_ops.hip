@@ -126,21 +126,26 @@ __global__ __launch_bounds__(kBlock) void fps_resident_kernel(int b, int n, int 
   // index cast -> expand -> gather, four launches per level, for what is 384 bytes per object)
   float *cen = centres ? centres + (size_t)obj * m * 3 : nullptr;
 
-  float x[R], y[R], z[R];
-  int t[R];  // fp32 bit patterns, see above
+  // [r6] the slots are held as PAIRS (r, r + 1) so that the distance arithmetic is packed fp32 (v_pk_add_f32 /
+  // v_pk_mul_f32: each half individually IEEE-rounded, i.e. the pinned ((dx*dx + dy*dy) + dz*dz) per point; this file is
+  // compiled with -ffp-contract=off): 8 packed + 4 integer instructions per two points instead of 16 + 4.
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int RP = (R + 1) / 2;
+  f2 x[RP], y[RP], z[RP];
+  int t[2 * RP];  // fp32 bit patterns, see above
   constexpr int kNeg1 = (int)0xBF800000u;   // -1.0f
   constexpr int kInit = (int)0x501502F9u;   // 1e10f, src/sampling.cpp:74-76
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
+  for (int r = 0; r < 2 * RP; ++r) {
     // branch-free: out-of-range slots read point 0 and are poisoned like skipped points
-    const int k = fps_point_index(L, r, p, Q);
+    const int k = r < R ? fps_point_index(L, r, p, Q) : -1;
     const bool in = k >= 0 && k < n;
     const int kk = in ? k : 0;
     const float px = ds[kk * 3 + 0], py = ds[kk * 3 + 1], pz = ds[kk * 3 + 2];
     const bool ok = in && !fps_skipped(px, py, pz);
-    x[r] = ok ? px : 1e30f;
-    y[r] = py;
-    z[r] = pz;
+    x[r >> 1][r & 1] = ok ? px : 1e30f;
+    y[r >> 1][r & 1] = py;
+    z[r >> 1][r & 1] = pz;
     t[r] = ok ? kInit : kNeg1;
   }
 
@@ -153,13 +158,18 @@ __global__ __launch_bounds__(kBlock) void fps_resident_kernel(int b, int n, int 
   int mine = 0;  // lane (j & 63) buffers idx j; flushed every 64 rounds with one coalesced store
   for (int j = 1; j < m; ++j) {
     int lane_best = kNeg1;
+    const f2 cx = {x1, x1}, cy = {y1, y1}, cz = {z1, z1};
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float dx = x[r] - x1, dy = y[r] - y1, dz = z[r] - z1;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      const int di = __float_as_int(d);
-      t[r] = di < t[r] ? di : t[r];
-      lane_best = t[r] > lane_best ? t[r] : lane_best;
+    for (int i = 0; i < RP; ++i) {
+      const f2 dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
+      const f2 d = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int r = 2 * i + e;
+        const int di = __float_as_int(d[e]);
+        t[r] = di < t[r] ? di : t[r];
+        lane_best = t[r] > lane_best ? t[r] : lane_best;
+      }
     }
     const int M = wave_max_i32(lane_best);
     const unsigned long long cand = __ballot(lane_best == M);
@@ -174,9 +184,9 @@ __global__ __launch_bounds__(kBlock) void fps_resident_kernel(int b, int n, int 
         if (tr == M) {
           found = true;
           rw = r;
-          x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[r]), Lw));
-          y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[r]), Lw));
-          z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[r]), Lw));
+          x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[r >> 1][r & 1]), Lw));
+          y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y[r >> 1][r & 1]), Lw));
+          z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z[r >> 1][r & 1]), Lw));
         }
       }
     }
