@@ -104,8 +104,7 @@ def _zero_rows(n: int, d: int, device: torch.device) -> torch.Tensor:
         with torch.no_grad():
             z = torch.zeros((n, d), dtype=torch.float32, device=device)
         if not torch.cuda.is_current_stream_capturing():     # (a fill captured into one graph would not have run for the others)
-            if len(_ZERO_ROWS) >= 8:                         # a few batch shapes (train / eval): never an unbounded set
-                _ZERO_ROWS.pop(next(iter(_ZERO_ROWS)))
+            # never evicted: a captured step graph reads the buffer by address on every replay (one entry per batch shape)
             _ZERO_ROWS[key] = z
     return z
 
