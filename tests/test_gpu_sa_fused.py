@@ -185,6 +185,25 @@ def test_single_product_bf16_mode_states_its_error():
     _close(again, want, "PointNetPP after switching back")
 
 
+@pytest.mark.parametrize("b,n,ld", [(7, 1024, 6), (5, 1023, 6), (4, 512, 9), (3, 2, 6), (6, 1500, 6)])
+def test_cloud_compact_copies_every_layout(b, n, ld):
+    """gps_cloud_compact's copy launch: the two-points-per-step form (ld = 6, even n) and the element loop (anything else) write
+    the same xyz / point-major feature blocks as torch indexing, pads dropped."""
+    from sceneverse_amd.pointnet2 import _ext
+    g = torch.Generator().manual_seed(100 * b + ld)
+    pcs = torch.randn(b, n, ld, generator=g)
+    pcs[1] = 1.0
+    if b > 4:
+        pcs[4] = 1.0
+    pcs = pcs.to(DEV)
+    plan = _ext.cloud_compact(pcs)
+    keep = [i for i in range(b) if i not in (1, 4)]
+    n_ord = len(keep)
+    assert plan.scal.tolist()[:2] == [n_ord + 1, n_ord]
+    ids = torch.tensor(keep + [1], device=DEV)
+    assert torch.equal(plan.xyz[:n_ord + 1], pcs[ids][..., 0:3]) and torch.equal(plan.feats_pm[:n_ord + 1], pcs[ids][..., 3:])
+
+
 @pytest.mark.parametrize("pattern", ["mixed", "no_pads", "all_pads", "two_constants", "nearly_constant", "late_difference"])
 def test_distinct_clouds_only_is_bit_identical_to_every_slot(pattern):
     """modules/layers/pointnet.py: the frozen encoder on the work list of gps_cloud_compact (ordinary objects + one pad
